@@ -1,0 +1,109 @@
+"""The oracle against (1) golden vectors produced by the reference's own source text and
+(2) an independent float64 numpy restatement.  CPU only."""
+import glob
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import loss_numpy, loss_oracle, resnet_dilated_oracle, synth
+
+
+def _load(path):
+    z = np.load(path, allow_pickle=False)
+    cfg = {}
+    for k, v in zip(z["cfg_keys"], z["cfg_vals"]):
+        k = str(k)
+        cfg[k] = bool(v) if k.startswith(("use_", "scale_")) else float(v)
+    return z, cfg
+
+
+GOLDENS = sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "loss_ref_*.npz")))
+
+
+def test_goldens_present():
+    assert len(GOLDENS) >= 10
+
+
+@pytest.mark.parametrize("path", GOLDENS, ids=[os.path.basename(p)[9:-4] for p in GOLDENS])
+def test_loss_oracle_matches_reference_goldens(path):
+    z, cfg = _load(path)
+    A = torch.tensor(z["A"], requires_grad=True)
+    B = torch.tensor(z["B"], requires_grad=True)
+    t = lambda k: torch.tensor(z[k])
+    pcl = loss_oracle.PixelwiseContrastiveLoss([int(z["H"]), int(z["W"])], cfg)
+    out = loss_oracle.get_loss(pcl, torch.tensor([int(z["match_type"])]), A, B, t("matches_a"), t("matches_b"),
+                               t("masked_a"), t("masked_b"), t("background_a"), t("background_b"),
+                               t("blind_a"), t("blind_b"))
+    got = np.array([float(o.sum().item()) for o in out])
+    np.testing.assert_allclose(got, z["out"], rtol=1e-6, atol=1e-9)
+    if out[0].requires_grad:
+        out[0].sum().backward()
+        np.testing.assert_allclose(A.grad.numpy(), z["gradA"], rtol=1e-5, atol=1e-8)
+        np.testing.assert_allclose(B.grad.numpy(), z["gradB"], rtol=1e-5, atol=1e-8)
+    if "f7_vec" in z.files:
+        PCL = loss_oracle.PixelwiseContrastiveLoss
+        with torch.no_grad():
+            ml, _, _ = PCL.match_loss(A, B, t("matches_a"), t("matches_b"))
+            vec, hn, _, _ = PCL.non_match_descriptor_loss(A, B, t("masked_a"), t("masked_b"), M=cfg["M_masked"])
+            veci, hni, _, _ = PCL.non_match_descriptor_loss(A, B, t("masked_a"), t("masked_b"), M=cfg["M_masked"],
+                                                            invert=True)
+        np.testing.assert_allclose(ml.numpy(), z["f6_match_loss"], rtol=1e-6)
+        np.testing.assert_allclose(vec.numpy(), z["f7_vec"], rtol=1e-6, atol=1e-9)
+        assert hn == int(z["f7_hard"]) and hni == int(z["f7_hard_invert"])
+        np.testing.assert_allclose(veci.numpy(), z["f7_vec_invert"], rtol=1e-6, atol=1e-9)
+    if "triplet" in z.files:
+        with torch.no_grad():
+            trip = loss_oracle.PixelwiseContrastiveLoss.get_triplet_loss(
+                A, B, t("matches_a"), t("matches_b"), t("triplet_non_matches_a"), t("masked_b"), cfg["alpha_triplet"])
+        np.testing.assert_allclose(trip.numpy(), z["triplet"], rtol=1e-6)
+
+
+@pytest.mark.parametrize("path", [p for p in GOLDENS if "within" in p or "multi" in p],
+                         ids=lambda p: os.path.basename(p)[9:-4])
+def test_numpy_second_opinion_matches_reference_goldens(path):
+    z, cfg = _load(path)
+    if len(z["blind_a"]) > 1:
+        pytest.skip("blind term is not part of `loss`; covered by the torch oracle")
+    lists = {k: z[k] for k in ("matches_a", "matches_b", "masked_a", "masked_b", "background_a", "background_b")}
+    r = loss_numpy.within_scene(z["A"][0], z["B"][0], lists, cfg, int(z["W"]))
+    np.testing.assert_allclose([r["loss"], r["match_loss"], r["masked"], r["background"]], z["out"][:4],
+                               rtol=2e-6, atol=1e-9)
+    np.testing.assert_allclose(r["gradA"], z["gradA"][0], rtol=2e-4, atol=2e-7)
+    np.testing.assert_allclose(r["gradB"], z["gradB"][0], rtol=2e-4, atol=2e-7)
+
+
+def test_backbone_oracle_param_count_and_shapes():
+    # SURVEY.md 8a F1 / BASELINE.md section 2: 21 286 211 params at D=3; 23 573 600 for Resnet50_8s D=32
+    m = resnet_dilated_oracle.build("Resnet34_8s", 3)
+    assert sum(p.numel() for p in m.parameters()) == 21286211
+    keys = list(m.state_dict().keys())
+    assert keys[0] == "resnet34_8s.conv1.weight" and "resnet34_8s.layer3.0.downsample.0.weight" in keys
+    assert "resnet34_8s.fc.bias" in keys
+    # dilation pattern: layer3 d=2 everywhere incl. first block, layer4 d=4, downsample stride 1
+    r = m.resnet34_8s
+    assert r.layer3[0].conv1.dilation == (2, 2) and r.layer3[0].conv1.stride == (1, 1)
+    assert r.layer4[0].conv1.dilation == (4, 4) and r.layer4[2].conv2.padding == (4, 4)
+    assert r.layer3[0].downsample[0].stride == (1, 1) and r.layer2[0].downsample[0].stride == (2, 2)
+    m50 = resnet_dilated_oracle.build("Resnet50_8s", 32)
+    assert sum(p.numel() for p in m50.parameters()) == 23573600
+    x = torch.randn(2, 3, 32, 48)
+    with torch.no_grad():
+        y = m(x)
+    assert y.shape == (2, 3, 32, 48)
+
+
+def test_backbone_oracle_is_seed_deterministic():
+    a = resnet_dilated_oracle.build("Resnet18_8s", 3, seed=0, base_width=8)
+    b = resnet_dilated_oracle.build("Resnet18_8s", 3, seed=0, base_width=8)
+    for (k, v), (_, w) in zip(a.state_dict().items(), b.state_dict().items()):
+        assert torch.equal(v, w), k
+
+
+def test_synth_shapes_and_sentinels():
+    a, b, lists = synth.make_batch(2, 16, 24, 10, 5, 0, seed=1)
+    assert a.shape == (2, 3, 16, 24) and len(lists) == 2
+    assert lists[0]["matches_a"].dtype == torch.int64 and lists[0]["matches_a"].max() < 16 * 24
+    assert loss_oracle.is_empty(lists[0]["background_non_matches_a"])
+    assert loss_oracle.is_empty(lists[0]["blind_non_matches_a"])
