@@ -1,0 +1,206 @@
+/*
+ * dcn_hip.h -- C ABI of libdcn_hip.so: the MI355X (gfx950) implementation of the dense-correspondence
+ * training hot path of RobotLocomotion/pytorch-dense-correspondence.
+ *
+ * The reference has no native code and no FFI of its own: its hot path is Python that calls into
+ * torch.  The entry points below are what a binding for that path replaces;
+ * each cites the reference interface it stands in for (paths relative to the reference root).  The
+ * host-side mirror of the reference's Python API that calls them through ctypes lives in
+ * pytorch-dense-correspondence_amd/ (see INTEGRATION.md for the binding a maintainer would add).
+ *
+ * Conventions
+ *   - plain C: pointers + sizes, no torch / C++ types.  All tensor pointers are DEVICE pointers owned
+ *     by the caller (the PyTorch caching allocator in practice); the library allocates no device
+ *     memory.  Pointer *arrays* (params / grads) are HOST arrays of device pointers.
+ *   - every call is asynchronous on the caller's stream (`hipStream_t` passed as void*), performs no
+ *     host synchronisation and keeps no global state: re-entrant per stream, one process per GPU.
+ *   - return value: 0 on success, negative DCN_E_* otherwise (never throws across the ABI).  The
+ *     Python wrapper raises RuntimeError / ValueError like the reference does
+ *     (dense_correspondence/network/dense_correspondence_network.py:381).
+ *   - layouts: activations are NHWC fp32 (logical [N,C,H,W] in torch.channels_last memory), so the
+ *     reference's own `view(N, D, W*H).permute(0, 2, 1)` (network.py:317-318) of the descriptor map is a
+ *     contiguous [N, H*W, D] tensor.  Convolution weights are [Cout][kh][kw][Cin] (logical OIHW in
+ *     channels_last memory).  Pixel indices are int64 `u + W*v`
+ *     (dense_correspondence/dataset/spartan_dataset_masked.py:1256-1264).
+ */
+#ifndef DCN_HIP_H
+#define DCN_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DCN_OK 0
+#define DCN_E_INVALID (-1)     /* bad argument (shape, null pointer, unsupported architecture name) */
+#define DCN_E_LAUNCH (-2)      /* a kernel launch failed (hipGetLastError != hipSuccess) */
+#define DCN_E_UNSUPPORTED (-3) /* valid request the library does not implement */
+
+/* Build identification: "dcn_hip <version> gfx950" for the shipped library, "... hostemu" for the
+ * test-only host emulation build (tests/hostemu). */
+const char* dcn_version(void);
+
+/* =====================================================================================================
+ * 1. Pixelwise contrastive loss  (kernel K9)
+ *
+ * Replaces, fused into one pass over all pair lists of all image pairs of a step:
+ *   PixelwiseContrastiveLoss.match_loss                  dense_correspondence/loss_functions/pixelwise_contrastive_loss.py:132-167
+ *   PixelwiseContrastiveLoss.non_match_descriptor_loss   ...pixelwise_contrastive_loss.py:171-213
+ *   PixelwiseContrastiveLoss.non_match_loss_descriptor_only / _with_l2_pixel_norm / l2_pixel_loss
+ *                                                        ...pixelwise_contrastive_loss.py:215-352
+ *   loss_composer.get_within_scene_loss / get_different_object_loss / get_same_object_across_scene_loss
+ *                                                        dense_correspondence/loss_functions/loss_composer.py:70-212
+ *   and their autograd (index_select backward == index_add_ into a zeroed [1,HW,D] buffer).
+ *
+ * Pair lists are ragged: for image pair p (0 <= p < num_pairs) and list type t the pairs are
+ * idx_a[offsets[4p+t] .. offsets[4p+t+1]) / idx_b[...] with t = DCN_LIST_*.  An empty list (the
+ * reference's `[-1]` sentinel, dense_correspondence_dataset_masked.py:209-223) has equal offsets.
+ * num_pairs == 1 is exactly one reference iteration; for num_pairs > 1 every pair keeps its own
+ * hard-negative normaliser and `loss = mean_p loss_p` (SURVEY.md section 8a note B).
+ * ===================================================================================================== */
+
+enum { DCN_LIST_MATCH = 0, DCN_LIST_MASKED = 1, DCN_LIST_BACKGROUND = 2, DCN_LIST_BLIND = 3, DCN_NUM_LISTS = 4 };
+
+/* How the per-list sums are composed into `loss` (loss_composer.py). */
+enum {
+    DCN_COMPOSE_WITHIN_SCENE = 0,     /* loss_composer.py:70-143  (also MULTI_OBJECT / SYNTHETIC_MULTI_OBJECT) */
+    DCN_COMPOSE_DIFFERENT_OBJECT = 1, /* loss_composer.py:168-191 blind list only, margin M_background */
+    DCN_COMPOSE_ACROSS_SCENE = 2      /* loss_composer.py:193-212 blind list only, inverted hinge, margin M_masked */
+};
+
+typedef struct dcn_loss_config {
+    float margin[DCN_NUM_LISTS];       /* hinge margin per list type (match entry unused) */
+    int32_t invert[DCN_NUM_LISTS];     /* 1: max(0, d - M)^2 instead of max(0, M - d)^2 (pcl.py:205-208) */
+    int32_t pixel_weight[DCN_NUM_LISTS]; /* 1: weight each term by min(|uv(gt) - uv(b)|, M_pixel)/M_pixel (pcl.py:307-334);
+                                            the list must hold (len/len_match) consecutive entries per match */
+    float m_pixel;
+    int32_t image_width;
+    float match_loss_weight;
+    float non_match_loss_weight;
+    int32_t scale_by_hard_negatives;   /* training.yaml:59 (or scale_by_hard_negatives_DIFFERENT_OBJECT for mode 1) */
+    int32_t compose;                   /* DCN_COMPOSE_* */
+} dcn_loss_config;
+
+/* Bytes of scratch `dcn_contrastive_loss_forward` needs for `num_pairs` image pairs whose longest list
+ * has `max_list_len` entries. */
+size_t dcn_loss_workspace_bytes(int num_pairs, int64_t max_list_len);
+
+/*
+ * Forward.  desc_a / desc_b: [num_pairs, HW, D] contiguous fp32.
+ *   terms      [num_pairs][5] : (loss_p, match_loss, masked_scaled, background_scaled, blind_scaled)  -- the 5-tuple
+ *                               loss_composer.get_loss returns (loss_composer.py:143)
+ *   sums       [num_pairs][4] : raw per-list sums  (match: sum ||a-b||^2; others: sum l_j [*w_j])
+ *   hard_neg   [num_pairs][4] : int32 #{j : l_j != 0} per list (pcl.py:210-211); match entry = list length
+ *   loss       [1]            : mean_p loss_p
+ *   per_term   nullable [offsets[4*num_pairs]] : every pair's own term (match: ||a-b||^2, others l_j) --
+ *                               the vector PixelwiseContrastiveLoss.non_match_descriptor_loss returns
+ *   status     [1] int32      : set to 1 if any index was outside [0, HW) (such pairs are skipped)
+ */
+int dcn_contrastive_loss_forward(const float* desc_a, const float* desc_b, int num_pairs, int64_t hw, int d,
+                                 const int64_t* idx_a, const int64_t* idx_b, const int64_t* offsets_host,
+                                 const int64_t* offsets_dev, const dcn_loss_config* cfg, float* terms, float* sums,
+                                 int32_t* hard_neg, float* loss, float* per_term, int32_t* status, void* workspace,
+                                 void* stream);
+
+/*
+ * Backward of `loss` w.r.t. desc_a / desc_b.  grad_loss: device scalar (the upstream gradient).
+ * grad_a / grad_b [num_pairs, HW, D] are zero-filled by this call and then accumulated into (duplicate
+ * indices are legal and accumulate, correspondence_finder.py:326-328).  `sums` / `hard_neg` are the
+ * forward outputs (read on device; no host round trip for the hard-negative count, unlike
+ * pcl.py:210-211's nonzero()/len()).
+ * pair_grad (nullable, [offsets[4*num_pairs]]): when given, the call instead back-propagates the
+ * per-pair vector `per_term` of the forward: d/d desc of sum_j pair_grad[j] * per_term[j]  (the autograd of the
+ * vector PixelwiseContrastiveLoss.non_match_descriptor_loss returns); grad_loss / sums / hard_neg are ignored.
+ */
+int dcn_contrastive_loss_backward(const float* desc_a, const float* desc_b, int num_pairs, int64_t hw, int d,
+                                  const int64_t* idx_a, const int64_t* idx_b, const int64_t* offsets_host,
+                                  const int64_t* offsets_dev, const dcn_loss_config* cfg, const float* sums,
+                                  const int32_t* hard_neg, const float* grad_loss, const float* pair_grad,
+                                  float* grad_a, float* grad_b, void* stream);
+
+/* =====================================================================================================
+ * 2. Dilated-ResNet FCN backbone  (kernels K1-K8, K10)
+ *
+ * Replaces `self.fcn(img_tensor)` in DenseCorrespondenceNetwork.forward
+ * (dense_correspondence/network/dense_correspondence_network.py:239-263) and its autograd, for
+ * fcn = resnet_dilated.Resnet{18,34,50,101}_8s(num_classes=D) (network.py:373-375; the module itself is
+ * third-party, see oracle/resnet_dilated_oracle.py).
+ *
+ * A plan fixes (architecture, N, H, W, D).  Parameters are passed as a host array of device pointers in
+ * the order dcn_plan_param_name enumerates them, which is the reference checkpoint's state_dict order
+ * (`conv1.weight, bn1.weight, bn1.bias, layer1.0.conv1.weight, ... fc.weight, fc.bias`); BN running
+ * statistics as a second array (`bn1.running_mean, bn1.running_var, layer1.0.bn1.running_mean, ...`).
+ * ===================================================================================================== */
+
+typedef struct dcn_plan dcn_plan;
+
+/* arch: "Resnet18_8s" | "Resnet34_8s" | "Resnet50_8s" | "Resnet101_8s".  base_width = 64 for the real
+ * networks (smaller widths exist for tests).  H and W must be multiples of 8. */
+int dcn_plan_create(const char* arch, int base_width, int n, int h, int w, int d, dcn_plan** out);
+void dcn_plan_destroy(dcn_plan* plan);
+
+int dcn_plan_num_params(const dcn_plan* plan);
+int dcn_plan_num_bn(const dcn_plan* plan);
+/* name (without the "resnet34_8s." prefix) and logical OIHW / [C] shape of parameter i; ndim is 4 or 1. */
+int dcn_plan_param_info(const dcn_plan* plan, int i, char* name, int name_cap, int64_t shape[4], int* ndim);
+/* name prefix ("layer1.0.bn1") and channel count of batch-norm j. */
+int dcn_plan_bn_info(const dcn_plan* plan, int j, char* name, int name_cap, int64_t* channels);
+
+size_t dcn_plan_saved_bytes(const dcn_plan* plan);     /* activations kept from forward to backward */
+size_t dcn_plan_workspace_bytes(const dcn_plan* plan); /* scratch shared by forward and backward */
+double dcn_plan_forward_flops(const dcn_plan* plan);   /* algorithmic conv FLOPs of one forward (2*MAC) */
+
+/*
+ * Forward.  image: [N,3,H,W] fp32 NCHW (what the reference's DataLoader yields, training.py:311-312).
+ * descriptors: [N,H,W,D] fp32 (== logical [N,D,H,W] channels_last).
+ * training != 0: batch statistics over the N images of this call + running-stat update with `momentum`
+ * (nn.BatchNorm2d semantics); training == 0: running statistics.  normalize != 0 applies
+ * network.py:256-259 (per-pixel L2 normalisation over D).
+ * saved may be NULL when training == 0.
+ */
+int dcn_backbone_forward(dcn_plan* plan, const float* image, const float* const* params,
+                         float* const* bn_running, float momentum, float eps, int training, int normalize,
+                         float* descriptors, void* saved, void* workspace, void* stream);
+
+/* Backward.  grad_descriptors: [N,H,W,D]; grads[i] receives dL/d params[i] (overwritten, same layout as
+ * params[i]).  `saved` is the buffer the matching forward filled. */
+int dcn_backbone_backward(dcn_plan* plan, const float* grad_descriptors, const float* const* params,
+                          const void* saved, void* workspace, float* const* grads, void* stream);
+
+/* =====================================================================================================
+ * 3. Individual kernels, exported for unit tests and micro-benchmarks (same conventions).
+ * ===================================================================================================== */
+
+typedef struct dcn_conv_desc {
+    int32_t n, hin, win, cin;   /* input  [n, hin, win, cin] NHWC, cin % 4 == 0 */
+    int32_t hout, wout, cout;   /* output [n, hout, wout, cout], leading dimension ldc >= cout */
+    int32_t kh, kw, stride, pad, dil;
+    int32_t ldc;
+} dcn_conv_desc;
+
+/* out = conv(in, w) [+ bias];  w: [cout][kh][kw][cin].  If bn_partial != NULL also writes per-M-tile
+ * partial sums for batch-norm statistics: bn_partial[tile][2][cout] (sum, sum of squares); the number of
+ * tiles is returned by dcn_conv_num_mtiles. */
+int dcn_conv_forward(const dcn_conv_desc* c, const float* in, const float* w, const float* bias, float* out,
+                     float* bn_partial, void* stream);
+int dcn_conv_num_mtiles(const dcn_conv_desc* c);
+/* din = conv_transpose(dout, w) [+ add];  wt: [cin][kh][kw][cout] (see dcn_transpose_weight). */
+int dcn_conv_dgrad(const dcn_conv_desc* c, const float* dout, const float* wt, const float* add, float* din,
+                   void* stream);
+/* dw[cout][kh][kw][cin] = sum_m dout[m][cout] * in[pix(m,tap)][cin]; slabs: scratch of dcn_conv_wgrad_workspace bytes */
+int dcn_conv_wgrad(const dcn_conv_desc* c, const float* in, const float* dout, float* dw, void* slabs, void* stream);
+size_t dcn_conv_wgrad_workspace(const dcn_conv_desc* c);
+int dcn_transpose_weight(const float* w, float* wt, int cout, int taps, int cin, void* stream);
+
+/* bilinear xS upsample, align_corners=True (F.upsample_bilinear): low [n,hl,wl,ldl] -> out [n,h,w,d] */
+int dcn_upsample_forward(const float* low, int n, int hl, int wl, int ldl, int d, int h, int w, int normalize,
+                         float* out, void* stream);
+int dcn_upsample_backward(const float* gout, int n, int hl, int wl, int ldl, int d, int h, int w, float* glow,
+                          void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DCN_HIP_H */

@@ -1,0 +1,367 @@
+// K9: fused pixelwise-contrastive loss (gather -> L2 distance -> hinge -> wave/block reduction) and its
+// backward (scatter-add), for gfx950.
+//
+// Reference arithmetic being replaced (dense_correspondence/loss_functions/):
+//   pixelwise_contrastive_loss.py:132-167  match_loss                  1/P_m * sum ||A[a_i]-B[b_i]||^2
+//   pixelwise_contrastive_loss.py:171-213  non_match_descriptor_loss   l_j = max(0, M - ||A[a_j]-B[b_j]||_2)^2, #{l_j != 0}
+//   pixelwise_contrastive_loss.py:307-352  l2_pixel_loss               w_j = min(||uv(gt_j)-uv(b_j)||, M_pixel)/M_pixel
+//   loss_composer.py:70-212                composition + hard-negative scaling
+//
+// HBM-bound, latency-dominated gather: one work-item per pixel pair reads its two int64 indices
+// (coalesced), then the two D-float descriptors straight from the [pairs, HW, D] descriptor maps (one
+// contiguous 4*D-byte read each thanks to the channels_last descriptor layout), reduces across the
+// 64-lane wavefront with shuffles, across the workgroup through LDS, and writes ONE partial per
+// workgroup.  A single-workgroup finalize kernel adds the partials in a fixed order in fp64 (run-to-run
+// deterministic forward) and composes the 5-tuple on the device, so the hard-negative count never
+// travels to the host (the reference syncs twice per step at pcl.py:210-211).
+// Algorithmic traffic per pair, fwd+bwd: 2*8 B indices + 2*4D B reads (x2, fwd and bwd) + 2*4D B atomics.
+#include "dcn_common.h"
+
+namespace {
+
+constexpr int kThreads = 256;
+constexpr int kItems = 4;  // pairs per work-item
+constexpr int kPairsPerBlock = kThreads * kItems;
+
+template <int DT> struct Desc {
+    static __device__ __forceinline__ float dist2(const float* a, const float* b, int d_rt, float* diff) {
+        float s = 0.f;
+        if (DT % 4 == 0 && DT > 0) {
+#pragma unroll
+            for (int k = 0; k < DT; k += 4) {
+                const float4 x = *reinterpret_cast<const float4*>(a + k);
+                const float4 y = *reinterpret_cast<const float4*>(b + k);
+                diff[k] = x.x - y.x; diff[k + 1] = x.y - y.y; diff[k + 2] = x.z - y.z; diff[k + 3] = x.w - y.w;
+            }
+#pragma unroll
+            for (int k = 0; k < DT; ++k) s = fmaf(diff[k], diff[k], s);
+        } else if (DT > 0) {
+#pragma unroll
+            for (int k = 0; k < DT; ++k) { diff[k] = a[k] - b[k]; s = fmaf(diff[k], diff[k], s); }
+        } else {
+            for (int k = 0; k < d_rt; ++k) { const float t = a[k] - b[k]; s = fmaf(t, t, s); }
+        }
+        return s;
+    }
+};
+
+__device__ __forceinline__ float pixel_weight(int64_t gt, int64_t nb, int width, float m_pixel) {
+    const float du = (float)((gt % width) - (nb % width));
+    const float dv = (float)((gt / width) - (nb / width));
+    return fminf(sqrtf(du * du + dv * dv), m_pixel) / m_pixel;
+}
+
+// grid = (chunks, 4*num_pairs).  Every workgroup writes its partial, chunks beyond the list's end write zeros.
+template <int DT>
+__global__ void __launch_bounds__(kThreads)
+loss_fwd_kernel(const float* __restrict__ A, const float* __restrict__ B, int64_t hw, int d_rt,
+                const int64_t* __restrict__ idx_a, const int64_t* __restrict__ idx_b,
+                const int64_t* __restrict__ offsets, dcn_loss_config cfg, double* __restrict__ part_sum,
+                int* __restrict__ part_cnt, float* __restrict__ per_term, int* __restrict__ status) {
+    __shared__ double s_sum[kThreads / dcn::kWave];
+    __shared__ int s_cnt[kThreads / dcn::kWave];
+    const int D = DT > 0 ? DT : d_rt;
+    const int seg = blockIdx.y, p = seg >> 2, t = seg & 3;
+    const int64_t beg = offsets[seg], len = offsets[seg + 1] - beg;
+    const int64_t chunk0 = (int64_t)blockIdx.x * kPairsPerBlock;
+    double sum = 0.0;
+    int cnt = 0;
+    if (chunk0 < len) {
+        const float* Ap = A + (int64_t)p * hw * D;
+        const float* Bp = B + (int64_t)p * hw * D;
+        const int64_t mbeg = offsets[4 * p], mlen = offsets[4 * p + 1] - mbeg;
+        const int64_t per = (cfg.pixel_weight[t] && mlen > 0) ? len / mlen : 0;
+        const float M = cfg.margin[t];
+        float acc = 0.f;
+#pragma unroll
+        for (int it = 0; it < kItems; ++it) {
+            const int64_t j = chunk0 + (int64_t)it * kThreads + threadIdx.x;
+            if (j < len) {
+                const int64_t ia = idx_a[beg + j], ib = idx_b[beg + j];
+                float term = 0.f;
+                if (ia < 0 || ib < 0) {
+                    // the reference's `[-1]` "empty list" sentinel (dense_correspondence_dataset_masked.py:209-223)
+                    // left in place by a caller that did not want a host sync to test for it: contributes nothing
+                } else if (ia >= hw || ib >= hw) {
+                    *status = 1;
+                } else {
+                    float diff[DT > 0 ? DT : 1];
+                    const float d2 = Desc<DT>::dist2(Ap + ia * D, Bp + ib * D, d_rt, diff);
+                    if (t == DCN_LIST_MATCH) {
+                        term = d2;
+                        acc += term;
+                    } else {
+                        const float dist = sqrtf(d2);
+                        const float h = fmaxf(cfg.invert[t] ? dist - M : M - dist, 0.f);
+                        term = h * h;
+                        cnt += (term != 0.f) ? 1 : 0;
+                        float w = 1.f;
+                        if (per > 0) {
+                            const int64_t mi = j / per;
+                            w = mi < mlen ? pixel_weight(idx_b[mbeg + mi], ib, cfg.image_width, cfg.m_pixel) : 0.f;
+                        }
+                        acc += term * w;
+                    }
+                }
+                if (per_term) per_term[beg + j] = term;
+            }
+        }
+        sum = (double)acc;
+    }
+    const double bs = dcn::block_sum<kThreads>(sum, s_sum);
+    const int bc = dcn::block_sum<kThreads>(cnt, s_cnt);
+    if (threadIdx.x == 0) {
+        part_sum[(int64_t)seg * gridDim.x + blockIdx.x] = bs;
+        part_cnt[(int64_t)seg * gridDim.x + blockIdx.x] = bc;
+    }
+}
+
+// Scale factors shared by the finalize and the backward kernel (loss_composer.py:107-134, :179-187, :205-211).
+struct PairScales {
+    float match_coef;      // d loss_p / d (sum ||a-b||^2)
+    float nonmatch_coef;   // d loss_p / d (S_masked + S_background)
+    float blind_coef;      // d loss_p / d S_blind
+};
+
+__device__ __forceinline__ PairScales pair_scales(const dcn_loss_config& cfg, const int* h, const int64_t* len) {
+    PairScales s;
+    s.match_coef = 0.f; s.nonmatch_coef = 0.f; s.blind_coef = 0.f;
+    if (cfg.compose == DCN_COMPOSE_WITHIN_SCENE) {
+        s.match_coef = len[0] > 0 ? cfg.match_loss_weight * (float)(1.0 / (double)len[0]) : 0.f;
+        int64_t scale;
+        if (cfg.scale_by_hard_negatives) {
+            scale = (int64_t)h[1] + h[2];
+            if (scale < 1) scale = 1;
+        } else {
+            scale = (len[1] > 1 ? len[1] : 1) + (len[2] > 1 ? len[2] : 1);
+        }
+        s.nonmatch_coef = cfg.non_match_loss_weight * (float)(1.0 / (double)scale);
+    } else {
+        int64_t scale = cfg.scale_by_hard_negatives ? (int64_t)h[3] : len[3];
+        if (scale < 1) scale = 1;
+        s.blind_coef = len[3] > 0 ? (float)(1.0 / (double)scale) : 0.f;
+    }
+    return s;
+}
+
+// One workgroup.  Adds the partials in a fixed order in fp64, composes the 5-tuple per pair and the mean loss.
+__global__ void __launch_bounds__(kThreads)
+loss_finalize_kernel(const double* __restrict__ part_sum, const int* __restrict__ part_cnt, int chunks, int num_pairs,
+                     const int64_t* __restrict__ offsets, dcn_loss_config cfg, float* __restrict__ terms,
+                     float* __restrict__ sums, int* __restrict__ hard_neg, float* __restrict__ loss) {
+    __shared__ double s_sum[kThreads / dcn::kWave];
+    __shared__ int s_cnt[kThreads / dcn::kWave];
+    __shared__ double s_S[4];
+    __shared__ int s_h[4];
+    double total = 0.0;
+    for (int p = 0; p < num_pairs; ++p) {
+        for (int t = 0; t < 4; ++t) {
+            double a = 0.0;
+            int c = 0;
+            const int64_t base = (int64_t)(4 * p + t) * chunks;
+            for (int i = threadIdx.x; i < chunks; i += kThreads) { a += part_sum[base + i]; c += part_cnt[base + i]; }
+            a = dcn::block_sum<kThreads>(a, s_sum);
+            c = dcn::block_sum<kThreads>(c, s_cnt);
+            if (threadIdx.x == 0) { s_S[t] = a; s_h[t] = c; }
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            int64_t len[4];
+            int h[4];
+            for (int t = 0; t < 4; ++t) { len[t] = offsets[4 * p + t + 1] - offsets[4 * p + t]; h[t] = s_h[t]; }
+            h[0] = (int)len[0];
+            const PairScales sc = pair_scales(cfg, h, len);
+            float out[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
+            if (cfg.compose == DCN_COMPOSE_WITHIN_SCENE) {
+                const float match_loss = len[0] > 0 ? (float)(s_S[0] / (double)len[0]) : 0.f;
+                const float Sk = (float)s_S[1], Sg = (float)s_S[2], Sb = (float)s_S[3];
+                int64_t dk, dg, db;
+                if (cfg.scale_by_hard_negatives) {
+                    dk = h[1] > 1 ? h[1] : 1; dg = h[2] > 1 ? h[2] : 1;
+                    db = len[3] > 0 ? (h[3] > 1 ? h[3] : 1) : 1;
+                } else {
+                    dk = len[1] > 1 ? len[1] : 1; dg = len[2] > 1 ? len[2] : 1; db = len[3] > 1 ? len[3] : 1;
+                }
+                out[1] = match_loss;
+                out[2] = Sk / (float)dk;
+                out[3] = Sg / (float)dg;
+                out[4] = Sb / (float)db;
+                out[0] = cfg.match_loss_weight * match_loss + sc.nonmatch_coef * (Sk + Sg);
+            } else {
+                const float Sb = (float)s_S[3];
+                out[0] = sc.blind_coef * Sb;
+                // different_object returns the scaled blind loss, across_scene the raw sum, as 5th element
+                out[4] = cfg.compose == DCN_COMPOSE_DIFFERENT_OBJECT ? out[0] : Sb;
+            }
+            for (int k = 0; k < 5; ++k) terms[5 * p + k] = out[k];
+            for (int t = 0; t < 4; ++t) { sums[4 * p + t] = (float)s_S[t]; hard_neg[4 * p + t] = h[t]; }
+            total += (double)out[0];
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) loss[0] = (float)(total / (double)num_pairs);
+}
+
+// grid = (chunks, 4*num_pairs).  Scatter-adds d loss / d descriptor with hardware fp32 atomics.
+template <int DT>
+__global__ void __launch_bounds__(kThreads)
+loss_bwd_kernel(const float* __restrict__ A, const float* __restrict__ B, int64_t hw, int d_rt, int num_pairs,
+                const int64_t* __restrict__ idx_a, const int64_t* __restrict__ idx_b,
+                const int64_t* __restrict__ offsets, dcn_loss_config cfg, const int* __restrict__ hard_neg,
+                const float* __restrict__ grad_loss, const float* __restrict__ pair_grad,
+                float* __restrict__ gA, float* __restrict__ gB) {
+    const int D = DT > 0 ? DT : d_rt;
+    const int seg = blockIdx.y, p = seg >> 2, t = seg & 3;
+    const int64_t beg = offsets[seg], len = offsets[seg + 1] - beg;
+    const int64_t chunk0 = (int64_t)blockIdx.x * kPairsPerBlock;
+    if (chunk0 >= len) return;
+    int64_t lens[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) lens[k] = offsets[4 * p + k + 1] - offsets[4 * p + k];
+    float coef = 1.f;
+    if (!pair_grad) {
+        int h[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) h[k] = hard_neg[4 * p + k];
+        const PairScales sc = pair_scales(cfg, h, lens);
+        coef = t == DCN_LIST_MATCH ? sc.match_coef : (t == DCN_LIST_BLIND ? sc.blind_coef : sc.nonmatch_coef);
+        if (coef == 0.f) return;
+        coef *= grad_loss[0] / (float)num_pairs;
+    }
+    const float* Ap = A + (int64_t)p * hw * D;
+    const float* Bp = B + (int64_t)p * hw * D;
+    float* gAp = gA + (int64_t)p * hw * D;
+    float* gBp = gB + (int64_t)p * hw * D;
+    const int64_t mbeg = offsets[4 * p], mlen = lens[0];
+    const int64_t per = (cfg.pixel_weight[t] && mlen > 0) ? len / mlen : 0;
+    const float M = cfg.margin[t];
+#pragma unroll
+    for (int it = 0; it < kItems; ++it) {
+        const int64_t j = chunk0 + (int64_t)it * kThreads + threadIdx.x;
+        if (j >= len) continue;
+        const int64_t ia = idx_a[beg + j], ib = idx_b[beg + j];
+        if ((uint64_t)ia >= (uint64_t)hw || (uint64_t)ib >= (uint64_t)hw) continue;
+        const float* a = Ap + ia * D;
+        const float* b = Bp + ib * D;
+        float diff[DT > 0 ? DT : 1];
+        const float d2 = Desc<DT>::dist2(a, b, d_rt, diff);
+        float g;  // d term / d diff = g * diff
+        const float cj = pair_grad ? pair_grad[beg + j] : coef;
+        if (t == DCN_LIST_MATCH) {
+            g = 2.f * cj;
+        } else {
+            const float dist = sqrtf(d2);
+            const float hinge = cfg.invert[t] ? dist - M : M - dist;
+            if (!(hinge > 0.f) || !(dist > 0.f)) continue;  // clamp is flat; d||x||/dx := 0 at x = 0 (torch)
+            float w = 1.f;
+            if (per > 0) {
+                const int64_t mi = j / per;
+                w = mi < mlen ? pixel_weight(idx_b[mbeg + mi], ib, cfg.image_width, cfg.m_pixel) : 0.f;
+            }
+            if (pair_grad) w = 1.f;  // per_term is the unweighted l_j
+            g = (cfg.invert[t] ? 2.f : -2.f) * hinge / dist * w * cj;
+        }
+        if (DT > 0) {
+#pragma unroll
+            for (int k = 0; k < (DT > 0 ? DT : 1); ++k) {
+                const float v = g * diff[k];
+                unsafeAtomicAdd(gAp + ia * D + k, v);
+                unsafeAtomicAdd(gBp + ib * D + k, -v);
+            }
+        } else {
+            for (int k = 0; k < D; ++k) {
+                const float v = g * (a[k] - b[k]);
+                unsafeAtomicAdd(gAp + ia * D + k, v);
+                unsafeAtomicAdd(gBp + ib * D + k, -v);
+            }
+        }
+    }
+}
+
+int chunks_for(int64_t max_list_len) {
+    int64_t c = dcn::ceil_div64(max_list_len > 0 ? max_list_len : 1, kPairsPerBlock);
+    return (int)c;
+}
+
+int64_t max_len(const int64_t* offsets_host, int num_pairs) {
+    int64_t m = 0;
+    for (int s = 0; s < 4 * num_pairs; ++s) {
+        const int64_t l = offsets_host[s + 1] - offsets_host[s];
+        if (l > m) m = l;
+    }
+    return m;
+}
+
+}  // namespace
+
+extern "C" size_t dcn_loss_workspace_bytes(int num_pairs, int64_t max_list_len) {
+    const size_t n = (size_t)4 * (size_t)num_pairs * (size_t)chunks_for(max_list_len);
+    return n * sizeof(double) + n * sizeof(int) + 64;
+}
+
+extern "C" int dcn_contrastive_loss_forward(const float* desc_a, const float* desc_b, int num_pairs, int64_t hw, int d,
+                                            const int64_t* idx_a, const int64_t* idx_b, const int64_t* offsets_host,
+                                            const int64_t* offsets_dev, const dcn_loss_config* cfg, float* terms,
+                                            float* sums, int32_t* hard_neg, float* loss, float* per_term,
+                                            int32_t* status, void* workspace, void* stream) {
+    if (!desc_a || !desc_b || !offsets_host || !offsets_dev || !cfg || !terms || !sums || !hard_neg || !loss ||
+        !status || !workspace || num_pairs < 1 || hw < 1 || d < 1)
+        return DCN_E_INVALID;
+    for (int s = 0; s < 4 * num_pairs; ++s)
+        if (offsets_host[s + 1] < offsets_host[s]) return DCN_E_INVALID;
+    if (offsets_host[4 * num_pairs] > 0 && (!idx_a || !idx_b)) return DCN_E_INVALID;
+    hipStream_t st = (hipStream_t)stream;
+    const int chunks = chunks_for(max_len(offsets_host, num_pairs));
+    const size_t n = (size_t)4 * num_pairs * chunks;
+    double* part_sum = (double*)workspace;
+    int* part_cnt = (int*)(part_sum + n);
+    if (hipMemsetAsync(status, 0, sizeof(int32_t), st) != hipSuccess) return DCN_E_LAUNCH;
+    const dim3 grid(chunks, 4 * num_pairs), block(kThreads);
+#define DCN_LAUNCH_FWD(DT)                                                                                        \
+    hipLaunchKernelGGL((loss_fwd_kernel<DT>), grid, block, 0, st, desc_a, desc_b, hw, d, idx_a, idx_b, offsets_dev, \
+                       *cfg, part_sum, part_cnt, per_term, (int*)status)
+    switch (d) {
+        case 3: DCN_LAUNCH_FWD(3); break;
+        case 4: DCN_LAUNCH_FWD(4); break;
+        case 8: DCN_LAUNCH_FWD(8); break;
+        case 16: DCN_LAUNCH_FWD(16); break;
+        case 32: DCN_LAUNCH_FWD(32); break;
+        default: DCN_LAUNCH_FWD(0); break;
+    }
+#undef DCN_LAUNCH_FWD
+    hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), block, 0, st, part_sum, part_cnt, chunks, num_pairs, offsets_dev,
+                       *cfg, terms, sums, (int*)hard_neg, loss);
+    return dcn::check_launch();
+}
+
+extern "C" int dcn_contrastive_loss_backward(const float* desc_a, const float* desc_b, int num_pairs, int64_t hw, int d,
+                                             const int64_t* idx_a, const int64_t* idx_b, const int64_t* offsets_host,
+                                             const int64_t* offsets_dev, const dcn_loss_config* cfg, const float* sums,
+                                             const int32_t* hard_neg, const float* grad_loss,
+                                             const float* pair_grad, float* grad_a, float* grad_b, void* stream) {
+    (void)sums;
+    if (!desc_a || !desc_b || !offsets_host || !offsets_dev || !cfg || !grad_a || !grad_b || num_pairs < 1 || hw < 1 ||
+        d < 1)
+        return DCN_E_INVALID;
+    if (!pair_grad && (!hard_neg || !grad_loss)) return DCN_E_INVALID;
+    hipStream_t st = (hipStream_t)stream;
+    const size_t bytes = (size_t)num_pairs * (size_t)hw * (size_t)d * sizeof(float);
+    if (hipMemsetAsync(grad_a, 0, bytes, st) != hipSuccess) return DCN_E_LAUNCH;
+    if (hipMemsetAsync(grad_b, 0, bytes, st) != hipSuccess) return DCN_E_LAUNCH;
+    const int64_t ml = max_len(offsets_host, num_pairs);
+    if (ml == 0) return DCN_OK;
+    const dim3 grid(chunks_for(ml), 4 * num_pairs), block(kThreads);
+#define DCN_LAUNCH_BWD(DT)                                                                                         \
+    hipLaunchKernelGGL((loss_bwd_kernel<DT>), grid, block, 0, st, desc_a, desc_b, hw, d, num_pairs, idx_a, idx_b,   \
+                       offsets_dev, *cfg, (const int*)hard_neg, grad_loss, pair_grad, grad_a, grad_b)
+    switch (d) {
+        case 3: DCN_LAUNCH_BWD(3); break;
+        case 4: DCN_LAUNCH_BWD(4); break;
+        case 8: DCN_LAUNCH_BWD(8); break;
+        case 16: DCN_LAUNCH_BWD(16); break;
+        case 32: DCN_LAUNCH_BWD(32); break;
+        default: DCN_LAUNCH_BWD(0); break;
+    }
+#undef DCN_LAUNCH_BWD
+    return dcn::check_launch();
+}

@@ -1,0 +1,179 @@
+"""Host side of kernel K9 (csrc/loss_kernels.hip): ragged pair lists + autograd glue.
+
+The arithmetic is in the HIP kernels; this file only packs index lists, allocates outputs with the
+PyTorch caching allocator and wires ``torch.autograd``.  Reference semantics:
+dense_correspondence/loss_functions/pixelwise_contrastive_loss.py and loss_composer.py.
+"""
+import ctypes
+
+import torch
+
+from . import _lib
+
+LIST_MATCH, LIST_MASKED, LIST_BACKGROUND, LIST_BLIND = 0, 1, 2, 3
+COMPOSE_WITHIN_SCENE, COMPOSE_DIFFERENT_OBJECT, COMPOSE_ACROSS_SCENE = 0, 1, 2
+
+
+def _is_host_sentinel(t):
+    """The reference's empty-list marker ``LongTensor([-1])`` (dense_correspondence_dataset_masked.py:209-223).
+    Only inspected when the tensor lives on the host; a device-resident sentinel is left in place and skipped
+    by the kernel (negative index), which avoids the device->host sync ``is_empty`` costs the reference."""
+    return t is None or t.numel() == 0 or (t.device.type == "cpu" and t.numel() == 1 and int(t[0]) == -1)
+
+
+class PairLists(object):
+    """Concatenated int64 pair lists of ``num_pairs`` image pairs:
+    ``idx_a/idx_b[offsets[4p+t] : offsets[4p+t+1]]`` is list type t (match, masked, background, blind) of pair p.
+    Build once per batch (``from_lists``) -- it is the CSR calling convention of SURVEY.md 8a note B."""
+
+    def __init__(self, idx_a, idx_b, offsets_host):
+        self.idx_a = idx_a
+        self.idx_b = idx_b
+        self.offsets_host = tuple(int(o) for o in offsets_host)
+        self.num_pairs = (len(self.offsets_host) - 1) // 4
+        self._off_c = (ctypes.c_int64 * len(self.offsets_host))(*self.offsets_host)
+        self.offsets_dev = torch.tensor(self.offsets_host, dtype=torch.int64).to(idx_a.device, non_blocking=True)
+        self.max_len = max([self.offsets_host[i + 1] - self.offsets_host[i] for i in range(4 * self.num_pairs)] + [0])
+        self.total = self.offsets_host[-1]
+
+    @staticmethod
+    def from_lists(pairs, device):
+        """pairs: sequence of 8-tuples (matches_a, matches_b, masked_a, masked_b, background_a, background_b,
+        blind_a, blind_b) -- the order loss_composer.get_loss takes them (loss_composer.py:7-12)."""
+        chunks_a, chunks_b, offsets = [], [], [0]
+        for lists in pairs:
+            assert len(lists) == 8
+            for t in range(4):
+                a, b = lists[2 * t], lists[2 * t + 1]
+                if _is_host_sentinel(a) or _is_host_sentinel(b):
+                    offsets.append(offsets[-1])
+                    continue
+                if a.numel() != b.numel():
+                    raise ValueError("pair list %d: a has %d entries, b has %d" % (t, a.numel(), b.numel()))
+                chunks_a.append(a.reshape(-1))
+                chunks_b.append(b.reshape(-1))
+                offsets.append(offsets[-1] + a.numel())
+        if chunks_a:
+            idx_a = torch.cat(chunks_a).to(device=device, dtype=torch.int64)
+            idx_b = torch.cat(chunks_b).to(device=device, dtype=torch.int64)
+        else:
+            idx_a = torch.zeros(1, dtype=torch.int64, device=device)
+            idx_b = torch.zeros(1, dtype=torch.int64, device=device)
+        return PairLists(idx_a.contiguous(), idx_b.contiguous(), offsets)
+
+    def length(self, pair, t):
+        return self.offsets_host[4 * pair + t + 1] - self.offsets_host[4 * pair + t]
+
+
+def make_config(margins, image_width, match_loss_weight=1.0, non_match_loss_weight=1.0, scale_by_hard_negatives=True,
+                compose=COMPOSE_WITHIN_SCENE, invert=(0, 0, 0, 0), pixel_weight=(0, 0, 0, 0), m_pixel=1.0):
+    cfg = _lib.LossConfig()
+    for i in range(4):
+        cfg.margin[i] = float(margins[i])
+        cfg.invert[i] = int(bool(invert[i]))
+        cfg.pixel_weight[i] = int(bool(pixel_weight[i]))
+    cfg.m_pixel = float(m_pixel)
+    cfg.image_width = int(image_width)
+    cfg.match_loss_weight = float(match_loss_weight)
+    cfg.non_match_loss_weight = float(non_match_loss_weight)
+    cfg.scale_by_hard_negatives = int(bool(scale_by_hard_negatives))
+    cfg.compose = int(compose)
+    return cfg
+
+
+def _run_forward(desc_a, desc_b, lists, cfg, want_per_term):
+    lib = _lib.get()
+    _lib.require_device(desc_a, desc_b, lists.idx_a, lists.idx_b)
+    P, HW, D = desc_a.shape
+    if desc_b.shape != desc_a.shape or P != lists.num_pairs:
+        raise ValueError("descriptor maps %s / %s do not match %d pair lists" %
+                         (tuple(desc_a.shape), tuple(desc_b.shape), lists.num_pairs))
+    desc_a = desc_a.contiguous()
+    desc_b = desc_b.contiguous()
+    dev = desc_a.device
+    f32 = dict(dtype=torch.float32, device=dev)
+    terms = torch.empty(P, 5, **f32)
+    sums = torch.empty(P, 4, **f32)
+    hard = torch.empty(P, 4, dtype=torch.int32, device=dev)
+    loss = torch.empty(1, **f32)
+    status = torch.empty(1, dtype=torch.int32, device=dev)
+    per_term = torch.empty(max(lists.total, 1), **f32) if want_per_term else None
+    ws = torch.empty(lib.dcn_loss_workspace_bytes(P, lists.max_len), dtype=torch.uint8, device=dev)
+    rc = lib.dcn_contrastive_loss_forward(
+        _lib.ptr(desc_a), _lib.ptr(desc_b), P, HW, D, _lib.ptr(lists.idx_a), _lib.ptr(lists.idx_b),
+        ctypes.cast(lists._off_c, ctypes.c_void_p), _lib.ptr(lists.offsets_dev), ctypes.byref(cfg),
+        _lib.ptr(terms), _lib.ptr(sums), _lib.ptr(hard), _lib.ptr(loss), _lib.ptr(per_term), _lib.ptr(status),
+        _lib.ptr(ws), _lib.stream_ptr())
+    _lib.check(rc, "dcn_contrastive_loss_forward")
+    return desc_a, desc_b, loss, terms, sums, hard, status, per_term
+
+
+class _ContrastiveLossFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, desc_a, desc_b, lists, cfg, want_per_term):
+        desc_a, desc_b, loss, terms, sums, hard, status, per_term = _run_forward(desc_a, desc_b, lists, cfg,
+                                                                                 want_per_term)
+        ctx.save_for_backward(desc_a, desc_b, sums, hard)
+        ctx.lists = lists
+        ctx.cfg = cfg
+        if want_per_term:
+            ctx.mark_non_differentiable(terms, sums, hard, status, per_term)
+        else:
+            ctx.mark_non_differentiable(terms, sums, hard, status)
+        return loss.reshape(()), terms, sums, hard, status, per_term
+
+    @staticmethod
+    def backward(ctx, grad_loss, *unused):
+        lib = _lib.get()
+        desc_a, desc_b, sums, hard = ctx.saved_tensors
+        lists, cfg = ctx.lists, ctx.cfg
+        P, HW, D = desc_a.shape
+        ga = torch.empty_like(desc_a)
+        gb = torch.empty_like(desc_b)
+        gl = grad_loss.reshape(1).to(torch.float32).contiguous()
+        rc = lib.dcn_contrastive_loss_backward(
+            _lib.ptr(desc_a), _lib.ptr(desc_b), P, HW, D, _lib.ptr(lists.idx_a), _lib.ptr(lists.idx_b),
+            ctypes.cast(lists._off_c, ctypes.c_void_p), _lib.ptr(lists.offsets_dev), ctypes.byref(cfg),
+            _lib.ptr(sums), _lib.ptr(hard), _lib.ptr(gl), None, _lib.ptr(ga), _lib.ptr(gb), _lib.stream_ptr())
+        _lib.check(rc, "dcn_contrastive_loss_backward")
+        return ga, gb, None, None, None
+
+
+class _PerTermFn(torch.autograd.Function):
+    """Differentiable per-pair vector (match: ||a-b||^2, non-match: l_j) -- pcl.py:171-213's first return value."""
+
+    @staticmethod
+    def forward(ctx, desc_a, desc_b, lists, cfg):
+        desc_a, desc_b, loss, terms, sums, hard, status, per_term = _run_forward(desc_a, desc_b, lists, cfg, True)
+        ctx.save_for_backward(desc_a, desc_b)
+        ctx.lists = lists
+        ctx.cfg = cfg
+        ctx.mark_non_differentiable(hard)
+        return per_term[:lists.total], hard
+
+    @staticmethod
+    def backward(ctx, grad_vec, _unused):
+        lib = _lib.get()
+        desc_a, desc_b = ctx.saved_tensors
+        lists, cfg = ctx.lists, ctx.cfg
+        P, HW, D = desc_a.shape
+        ga = torch.empty_like(desc_a)
+        gb = torch.empty_like(desc_b)
+        gv = grad_vec.to(torch.float32).contiguous()
+        rc = lib.dcn_contrastive_loss_backward(
+            _lib.ptr(desc_a), _lib.ptr(desc_b), P, HW, D, _lib.ptr(lists.idx_a), _lib.ptr(lists.idx_b),
+            ctypes.cast(lists._off_c, ctypes.c_void_p), _lib.ptr(lists.offsets_dev), ctypes.byref(cfg),
+            None, None, None, _lib.ptr(gv), _lib.ptr(ga), _lib.ptr(gb), _lib.stream_ptr())
+        _lib.check(rc, "dcn_contrastive_loss_backward(per-term)")
+        return ga, gb, None, None
+
+
+def contrastive_loss(desc_a, desc_b, lists, cfg, want_per_term=False):
+    """Fused forward (+ autograd).  desc_*: [num_pairs, HW, D].  Returns
+    (loss 0-dim, terms [P,5], sums [P,4], hard_neg int32 [P,4], status int32 [1], per_term or None)."""
+    return _ContrastiveLossFn.apply(desc_a, desc_b, lists, cfg, want_per_term)
+
+
+def per_term_losses(desc_a, desc_b, lists, cfg):
+    """(per-pair vector [total], hard_neg int32 [P,4]); the vector is differentiable."""
+    return _PerTermFn.apply(desc_a, desc_b, lists, cfg)

@@ -1,0 +1,280 @@
+// TEST INFRASTRUCTURE ONLY -- NOT PART OF THE PRODUCT.
+//
+// A stand-in <hip/hip_runtime.h> that lets the *unmodified* HIP kernel sources under
+// pytorch-dense-correspondence_amd/csrc/ be compiled for the host (x86-64, ROCm clang++) and
+// executed lane by lane, so that index arithmetic, LDS layouts, MFMA fragment mappings and barrier
+// placement can be checked on a machine that has no GPU.  It is only ever put on the include path
+// by tests/hostemu/build_emu.py; the shipped library is built by hipcc against the real header and
+// never sees this file.  It is slow (thousands of times slower than a CU) and models no caches,
+// no memory ordering and no hazards -- passing here proves logic, not hardware behaviour.
+//
+// Execution model: one OS thread per concurrently running workgroup; inside it every work-item is
+// a cooperative fiber (hand-written x86-64 context switch).  __syncthreads() and the wave-level
+// operations (shuffles, MFMA) are rendezvous points at which fibers yield to one another.
+// Wavefront = 64 lanes.  MFMA fragment maps follow /opt/skills/guides/cdna_hip_programming.md
+// section 3: A[i = l&31][k = l>>5], B[k = l>>5][j = l&31],
+// C/D: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)   (32x32x2 f32)
+// and A[l&15][k = l>>4], B[k = l>>4][l&15], C/D: col = lane&15, row = 4*(lane>>4) + reg (16x16x4 f32).
+#pragma once
+#include <atomic>
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <functional>
+#include <thread>
+#include <vector>
+
+#define __global__
+#define __device__
+#define __host__
+#define __forceinline__ inline __attribute__((always_inline))
+#define __noinline__ __attribute__((noinline))
+#define __shared__ static thread_local
+#define __launch_bounds__(...)
+#define __constant__ static
+
+typedef int hipError_t;
+typedef void* hipStream_t;
+static const hipError_t hipSuccess = 0;
+static const hipError_t hipErrorInvalidValue = 1;
+inline const char* hipGetErrorString(hipError_t e) { return e == 0 ? "hipSuccess(emu)" : "hipError(emu)"; }
+inline hipError_t hipGetLastError() { return hipSuccess; }
+inline hipError_t hipPeekAtLastError() { return hipSuccess; }
+inline hipError_t hipMemsetAsync(void* p, int v, size_t n, hipStream_t) { memset(p, v, n); return hipSuccess; }
+enum hipMemcpyKind { hipMemcpyHostToHost, hipMemcpyHostToDevice, hipMemcpyDeviceToHost, hipMemcpyDeviceToDevice, hipMemcpyDefault };
+inline hipError_t hipMemcpyAsync(void* d, const void* s, size_t n, hipMemcpyKind, hipStream_t) { memmove(d, s, n); return hipSuccess; }
+inline hipError_t hipStreamSynchronize(hipStream_t) { return hipSuccess; }
+inline hipError_t hipDeviceSynchronize() { return hipSuccess; }
+
+struct dim3 {
+    unsigned x, y, z;
+    dim3(unsigned x_ = 1, unsigned y_ = 1, unsigned z_ = 1) : x(x_), y(y_), z(z_) {}
+};
+struct float2 { float x, y; };
+struct float4 { float x, y, z, w; };
+struct int2 { int x, y; };
+struct int4 { int x, y, z, w; };
+struct uint2 { unsigned x, y; };
+struct uint4 { unsigned x, y, z, w; };
+static inline float2 make_float2(float x, float y) { return float2{x, y}; }
+static inline float4 make_float4(float x, float y, float z, float w) { return float4{x, y, z, w}; }
+static inline int2 make_int2(int x, int y) { return int2{x, y}; }
+static inline int4 make_int4(int x, int y, int z, int w) { return int4{x, y, z, w}; }
+
+namespace hipemu {
+
+struct Idx { unsigned x, y, z; };
+extern thread_local Idx t_threadIdx, t_blockIdx, t_blockDim, t_gridDim;
+
+extern "C" void hipemu_switch(void** save_sp, void* new_sp);
+
+enum { RUNNABLE = 0, WAIT_BLOCK = 1, DONE = 2 };
+
+struct Fiber {
+    void* sp = nullptr;
+    char* stack = nullptr;
+    int state = DONE;
+    unsigned tid = 0;
+};
+
+struct WaveState {
+    int arrived = 0;
+    unsigned gen = 0;
+    int lanes = 64;
+    uint64_t buf_a[64];
+    uint64_t buf_b[64];
+};
+
+struct Worker {
+    std::vector<Fiber> fibers;
+    std::vector<WaveState> waves;
+    void* sched_sp = nullptr;
+    int cur = -1;
+    int nthreads = 0;
+    int blk_arrived = 0;
+    unsigned blk_gen = 0;
+    const std::function<void()>* body = nullptr;
+    static const size_t kStack = 192 * 1024;
+};
+extern thread_local Worker* t_worker;
+
+inline void yield_to_scheduler() {
+    Worker* w = t_worker;
+    Fiber& f = w->fibers[w->cur];
+    hipemu_switch(&f.sp, w->sched_sp);
+}
+
+inline void block_barrier() {
+    Worker* w = t_worker;
+    unsigned gen = w->blk_gen;
+    if (++w->blk_arrived == w->nthreads) {
+        w->blk_arrived = 0;
+        w->blk_gen++;
+        for (auto& f : w->fibers) if (f.state == WAIT_BLOCK) f.state = RUNNABLE;
+        return;
+    }
+    Fiber& f = w->fibers[w->cur];
+    f.state = WAIT_BLOCK;
+    while (w->blk_gen == gen) yield_to_scheduler();
+    f.state = RUNNABLE;
+}
+
+inline WaveState& my_wave() { Worker* w = t_worker; return w->waves[w->cur >> 6]; }
+inline int lane_id() { return t_worker->cur & 63; }
+
+inline void wave_barrier() {
+    WaveState& ws = my_wave();
+    unsigned gen = ws.gen;
+    if (++ws.arrived == ws.lanes) { ws.arrived = 0; ws.gen++; return; }
+    while (ws.gen == gen) yield_to_scheduler();
+}
+
+template <class T> inline T wave_exchange(T v, int src_lane) {
+    static_assert(sizeof(T) <= 8, "exchange up to 8 bytes");
+    WaveState& ws = my_wave();
+    uint64_t raw = 0;
+    memcpy(&raw, &v, sizeof(T));
+    ws.buf_a[lane_id()] = raw;
+    wave_barrier();
+    uint64_t got = ws.buf_a[src_lane & 63];
+    if ((src_lane & 63) >= ws.lanes) got = raw;
+    wave_barrier();
+    T out;
+    memcpy(&out, &got, sizeof(T));
+    return out;
+}
+
+void run_grid(dim3 grid, dim3 block, const std::function<void()>& body);
+
+template <class F> inline void launch(dim3 grid, dim3 block, F&& f) {
+    std::function<void()> body(std::forward<F>(f));
+    run_grid(grid, block, body);
+}
+
+}  // namespace hipemu
+
+#define threadIdx (::hipemu::t_threadIdx)
+#define blockIdx (::hipemu::t_blockIdx)
+#define blockDim (::hipemu::t_blockDim)
+#define gridDim (::hipemu::t_gridDim)
+#define warpSize 64
+
+#define hipLaunchKernelGGL(kernel, grid, block, shmem, stream, ...) \
+    ::hipemu::launch((grid), (block), [=]() { kernel(__VA_ARGS__); })
+
+static inline void __syncthreads() { ::hipemu::block_barrier(); }
+static inline void __threadfence() {}
+static inline void __threadfence_block() {}
+
+template <class T> static inline T __shfl_xor(T v, int mask, int width = 64) {
+    int l = ::hipemu::lane_id();
+    return ::hipemu::wave_exchange(v, l ^ mask);
+}
+template <class T> static inline T __shfl_down(T v, unsigned delta, int width = 64) {
+    int l = ::hipemu::lane_id();
+    int src = l + (int)delta;
+    if ((l % width) + (int)delta >= width) src = l;
+    return ::hipemu::wave_exchange(v, src);
+}
+template <class T> static inline T __shfl(T v, int src, int width = 64) {
+    int l = ::hipemu::lane_id();
+    return ::hipemu::wave_exchange(v, (l / width) * width + (src % width));
+}
+static inline unsigned long long __ballot(int pred) {
+    unsigned long long m = 0;
+    for (int i = 0; i < 64; ++i) {
+        int p = ::hipemu::wave_exchange(pred, i);
+        if (p && i < ::hipemu::my_wave().lanes) m |= 1ull << i;
+    }
+    return m;
+}
+
+// ---- atomics (workgroups run on different OS threads) ----
+static inline float atomicAdd(float* p, float v) {
+    uint32_t* ip = reinterpret_cast<uint32_t*>(p);
+    uint32_t old = __atomic_load_n(ip, __ATOMIC_RELAXED);
+    for (;;) {
+        float f;
+        memcpy(&f, &old, 4);
+        float nf = f + v;
+        uint32_t nv;
+        memcpy(&nv, &nf, 4);
+        if (__atomic_compare_exchange_n(ip, &old, nv, false, __ATOMIC_RELAXED, __ATOMIC_RELAXED)) return f;
+    }
+}
+static inline double atomicAdd(double* p, double v) {
+    uint64_t* ip = reinterpret_cast<uint64_t*>(p);
+    uint64_t old = __atomic_load_n(ip, __ATOMIC_RELAXED);
+    for (;;) {
+        double f;
+        memcpy(&f, &old, 8);
+        double nf = f + v;
+        uint64_t nv;
+        memcpy(&nv, &nf, 8);
+        if (__atomic_compare_exchange_n(ip, &old, nv, false, __ATOMIC_RELAXED, __ATOMIC_RELAXED)) return f;
+    }
+}
+static inline int atomicAdd(int* p, int v) { return __atomic_fetch_add(p, v, __ATOMIC_RELAXED); }
+static inline unsigned atomicAdd(unsigned* p, unsigned v) { return __atomic_fetch_add(p, v, __ATOMIC_RELAXED); }
+static inline unsigned long long atomicAdd(unsigned long long* p, unsigned long long v) {
+    return __atomic_fetch_add(p, v, __ATOMIC_RELAXED);
+}
+
+#define unsafeAtomicAdd atomicAdd
+
+// ---- MFMA (f32 in / f32 accumulate), k-ordered fmaf chain like the hardware ----
+typedef float hipemu_f32x16 __attribute__((ext_vector_type(16)));
+typedef float hipemu_f32x4 __attribute__((ext_vector_type(4)));
+
+static inline hipemu_f32x16 hipemu_mfma_32x32x2f32(float a, float b, hipemu_f32x16 c, int, int, int) {
+    using namespace ::hipemu;
+    WaveState& ws = my_wave();
+    int l = lane_id();
+    memcpy(&ws.buf_a[l], &a, 4);
+    memcpy(&ws.buf_b[l], &b, 4);
+    wave_barrier();
+    int col = l & 31;
+    for (int r = 0; r < 16; ++r) {
+        int row = (r & 3) + 8 * (r >> 2) + 4 * (l >> 5);
+        float acc = c[r];
+        for (int k = 0; k < 2; ++k) {
+            float av, bv;
+            memcpy(&av, &ws.buf_a[row + 32 * k], 4);
+            memcpy(&bv, &ws.buf_b[col + 32 * k], 4);
+            acc = fmaf(av, bv, acc);
+        }
+        c[r] = acc;
+    }
+    wave_barrier();
+    return c;
+}
+static inline hipemu_f32x4 hipemu_mfma_16x16x4f32(float a, float b, hipemu_f32x4 c, int, int, int) {
+    using namespace ::hipemu;
+    WaveState& ws = my_wave();
+    int l = lane_id();
+    memcpy(&ws.buf_a[l], &a, 4);
+    memcpy(&ws.buf_b[l], &b, 4);
+    wave_barrier();
+    int col = l & 15;
+    for (int r = 0; r < 4; ++r) {
+        int row = 4 * (l >> 4) + r;
+        float acc = c[r];
+        for (int k = 0; k < 4; ++k) {
+            float av, bv;
+            memcpy(&av, &ws.buf_a[row + 16 * k], 4);
+            memcpy(&bv, &ws.buf_b[col + 16 * k], 4);
+            acc = fmaf(av, bv, acc);
+        }
+        c[r] = acc;
+    }
+    wave_barrier();
+    return c;
+}
+#define __builtin_amdgcn_mfma_f32_32x32x2f32 hipemu_mfma_32x32x2f32
+#define __builtin_amdgcn_mfma_f32_16x16x4f32 hipemu_mfma_16x16x4f32
+#define __builtin_amdgcn_s_setprio(x) ((void)0)
+#define __builtin_amdgcn_sched_barrier(x) ((void)0)
+static inline int hipemu_readfirstlane(int v) { return ::hipemu::wave_exchange(v, 0); }
+#define __builtin_amdgcn_readfirstlane hipemu_readfirstlane
