@@ -137,7 +137,7 @@ int dcn_contrastive_loss_backward(const float* desc_a, const float* desc_b, int 
 typedef struct dcn_plan dcn_plan;
 
 /* arch: "Resnet18_8s" | "Resnet34_8s" | "Resnet50_8s" | "Resnet101_8s".  base_width = 64 for the real
- * networks (smaller widths exist for tests).  H and W must be multiples of 8. */
+ * networks (smaller widths, multiples of 4, exist for tests). */
 int dcn_plan_create(const char* arch, int base_width, int n, int h, int w, int d, dcn_plan** out);
 void dcn_plan_destroy(dcn_plan* plan);
 
@@ -158,7 +158,7 @@ double dcn_plan_forward_flops(const dcn_plan* plan);   /* algorithmic conv FLOPs
  * training != 0: batch statistics over the N images of this call + running-stat update with `momentum`
  * (nn.BatchNorm2d semantics); training == 0: running statistics.  normalize != 0 applies
  * network.py:256-259 (per-pixel L2 normalisation over D).
- * saved may be NULL when training == 0.
+ * saved (dcn_plan_saved_bytes) and workspace (dcn_plan_workspace_bytes) are always required.
  */
 int dcn_backbone_forward(dcn_plan* plan, const float* image, const float* const* params,
                          float* const* bn_running, float momentum, float eps, int training, int normalize,
@@ -192,13 +192,16 @@ int dcn_conv_dgrad(const dcn_conv_desc* c, const float* dout, const float* wt, c
 /* dw[cout][kh][kw][cin] = sum_m dout[m][cout] * in[pix(m,tap)][cin]; slabs: scratch of dcn_conv_wgrad_workspace bytes */
 int dcn_conv_wgrad(const dcn_conv_desc* c, const float* in, const float* dout, float* dw, void* slabs, void* stream);
 size_t dcn_conv_wgrad_workspace(const dcn_conv_desc* c);
-int dcn_transpose_weight(const float* w, float* wt, int cout, int taps, int cin, void* stream);
+/* wt[c][tap][0..ldn) = (w[0..cout)[tap][c], zeros);  ldn >= cout is the row pitch of dout in dcn_conv_dgrad */
+int dcn_transpose_weight(const float* w, float* wt, int cout, int taps, int cin, int ldn, void* stream);
 
 /* bilinear xS upsample, align_corners=True (F.upsample_bilinear): low [n,hl,wl,ldl] -> out [n,h,w,d] */
 int dcn_upsample_forward(const float* low, int n, int hl, int wl, int ldl, int d, int h, int w, int normalize,
                          float* out, void* stream);
+/* glow [n,hl,wl,ldl] (pad channels zeroed); tmp: scratch of dcn_upsample_backward_tmp_bytes(n, hl, w, d) bytes */
 int dcn_upsample_backward(const float* gout, int n, int hl, int wl, int ldl, int d, int h, int w, float* glow,
-                          void* stream);
+                          float* tmp, void* stream);
+size_t dcn_upsample_backward_tmp_bytes(int n, int hl, int w, int d);
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,489 @@
+// Backbone engine: plans and sequences the gfx950 kernels for the dilated-ResNet FCN
+// (`fcn = resnet_dilated.Resnet34_8s(num_classes=D)`, dense_correspondence_network.py:373-375; forward
+// called at network.py:255, backward through loss.backward() at training.py:345).
+//
+// Architecture restated from the published description of the (un-vendored) backbone -- see
+// oracle/resnet_dilated_oracle.py for the statement and its provenance:
+//   conv7x7/2 -> BN -> ReLU -> maxpool3x3/2 -> layer1..4 (BasicBlock or Bottleneck; output stride 8, so
+//   layer3 / layer4 trade their stride for dilation 2 / 4 in every 3x3 conv) -> 1x1 conv (+bias) to D
+//   channels -> bilinear upsample (align_corners=True) back to H x W.
+//
+// Memory plan (sized for 288 GB of HBM3E: nothing is recomputed, nothing is aliased):
+//   saved arena     : NHWC4 input, every conv output x (pre-BN), every BN's (scale, shift, mean, invstd),
+//                     every post-activation tensor y, max-pool argmax          -- kept forward -> backward
+//   workspace arena : 6 activation-gradient buffers, transposed-weight scratch, wgrad split slabs, BN
+//                     partial sums, stem padding buffers, low-resolution descriptor map and its gradient
+// All launches go to the caller's stream; there is no host synchronisation anywhere.
+#include <cstdio>
+#include <string>
+#include <vector>
+
+#include "elementwise_kernels.h"
+
+namespace {
+
+using dcn::ceil_div;
+
+struct ConvL {
+    dcn_conv_desc d;   // as executed (stem: cin padded 3 -> 4)
+    int w = -1, b = -1;  // parameter indices
+    int bn = -1;
+    size_t x = 0;      // conv output offset (floats) in the saved arena
+    int cin_true = 0;
+    int mtiles = 0;
+    std::string name;
+};
+struct BnL {
+    int C = 0, g = -1, b = -1, idx = 0;
+    size_t stats = 0;  // saved arena: scale[C], shift[C], mean[C], invstd[C]
+    int64_t rows = 0;
+    std::string name;
+};
+struct BlockL {
+    int nconv = 2;
+    int conv[3] = {-1, -1, -1};
+    int down = -1;
+    size_t in = 0, mid[2] = {0, 0}, out = 0;
+    int64_t out_rows = 0;
+    int out_c = 0, in_c = 0;
+    int64_t in_rows = 0;
+};
+struct ParamInfo {
+    std::string name;
+    int64_t shape[4];
+    int ndim;
+};
+
+}  // namespace
+
+struct dcn_plan {
+    std::string arch, prefix;
+    int N = 0, H = 0, W = 0, D = 0, Dp = 0, base = 64;
+    bool bottleneck = false;
+    std::vector<ConvL> convs;
+    std::vector<BnL> bns;
+    std::vector<BlockL> blocks;
+    std::vector<ParamInfo> params;
+    int stem = -1, fc = -1;
+    int hl = 0, wl = 0, feat_c = 0;
+    // saved arena offsets (floats)
+    size_t s_in4 = 0, s_stem_y = 0, s_pool = 0, s_argmax = 0, saved_floats = 0;
+    // workspace offsets (floats)
+    size_t w_buf[6] = {0, 0, 0, 0, 0, 0}, w_wt = 0, w_slab = 0, w_part = 0, w_k123 = 0, w_wstem = 0, w_dwstem = 0,
+           w_low = 0, w_glow = 0, w_ups = 0, ws_floats = 0;
+    size_t max_act = 0;
+    double flops = 0;
+};
+
+namespace {
+
+size_t align64(size_t x) { return (x + 63) & ~size_t(63); }
+
+struct Builder {
+    dcn_plan& p;
+    size_t saved = 0;
+    explicit Builder(dcn_plan& pl) : p(pl) {}
+
+    size_t alloc_saved(size_t floats) {
+        const size_t o = saved;
+        saved = align64(saved + floats);
+        return o;
+    }
+    int add_param(const std::string& name, std::initializer_list<int64_t> shape) {
+        ParamInfo pi;
+        pi.name = name;
+        pi.ndim = (int)shape.size();
+        int i = 0;
+        for (int k = 0; k < 4; ++k) pi.shape[k] = 1;
+        for (auto s : shape) pi.shape[i++] = s;
+        p.params.push_back(pi);
+        return (int)p.params.size() - 1;
+    }
+    // returns conv index; registers "<name>.weight"
+    int add_conv(const std::string& name, int n, int hin, int win, int cin, int cout, int k, int stride, int pad, int dil,
+                 bool bias, int ldc = 0) {
+        ConvL c;
+        c.name = name;
+        c.cin_true = cin;
+        c.d.n = n; c.d.hin = hin; c.d.win = win; c.d.cin = (cin + 3) / 4 * 4;
+        c.d.kh = k; c.d.kw = k; c.d.stride = stride; c.d.pad = pad; c.d.dil = dil;
+        c.d.hout = (hin + 2 * pad - dil * (k - 1) - 1) / stride + 1;
+        c.d.wout = (win + 2 * pad - dil * (k - 1) - 1) / stride + 1;
+        c.d.cout = cout;
+        c.d.ldc = ldc ? ldc : cout;
+        c.w = add_param(name + ".weight", {cout, cin, k, k});
+        if (bias) c.b = add_param(name + ".bias", {cout});
+        const int64_t M = (int64_t)n * c.d.hout * c.d.wout;
+        c.mtiles = (int)((M + 127) / 128);
+        p.flops += 2.0 * (double)M * cout * (double)(k * k * cin);
+        p.convs.push_back(c);
+        return (int)p.convs.size() - 1;
+    }
+    int add_bn(const std::string& name, int C, int64_t rows) {
+        BnL b;
+        b.name = name;
+        b.C = C;
+        b.rows = rows;
+        b.g = add_param(name + ".weight", {C});
+        b.b = add_param(name + ".bias", {C});
+        b.idx = (int)p.bns.size();
+        b.stats = alloc_saved((size_t)4 * C);
+        p.bns.push_back(b);
+        return b.idx;
+    }
+    int64_t rows_of(const ConvL& c) const { return (int64_t)c.d.n * c.d.hout * c.d.wout; }
+    void conv_out(int ci) {
+        ConvL& c = p.convs[ci];
+        const size_t fl = (size_t)rows_of(c) * c.d.ldc;
+        c.x = alloc_saved(fl);
+        if (fl > p.max_act) p.max_act = fl;
+    }
+};
+
+int build_plan(dcn_plan& p) {
+    Builder B(p);
+    static const struct { const char* name; bool bott; int layers[4]; const char* prefix; } archs[] = {
+        {"Resnet18_8s", false, {2, 2, 2, 2}, "resnet18_8s"},
+        {"Resnet34_8s", false, {3, 4, 6, 3}, "resnet34_8s"},
+        {"Resnet50_8s", true, {3, 4, 6, 3}, "resnet50_8s"},
+        {"Resnet101_8s", true, {3, 4, 23, 3}, "resnet101_8s"},
+    };
+    const int* layers = nullptr;
+    for (auto& a : archs)
+        if (p.arch == a.name) { layers = a.layers; p.bottleneck = a.bott; p.prefix = a.prefix; }
+    if (!layers) return DCN_E_INVALID;
+    const int N = p.N, w = p.base, exp = p.bottleneck ? 4 : 1;
+    p.Dp = (p.D + 3) / 4 * 4;
+
+    p.s_in4 = B.alloc_saved((size_t)N * p.H * p.W * 4);
+    // stem
+    p.stem = B.add_conv("conv1", N, p.H, p.W, 3, w, 7, 2, 3, 1, false);
+    B.conv_out(p.stem);
+    {
+        ConvL& c = p.convs[p.stem];
+        c.bn = B.add_bn("bn1", w, B.rows_of(c));
+        p.s_stem_y = B.alloc_saved((size_t)B.rows_of(c) * w);
+    }
+    int h = p.convs[p.stem].d.hout, wd = p.convs[p.stem].d.wout;
+    const int hp = (h + 2 - 3) / 2 + 1, wp = (wd + 2 - 3) / 2 + 1;
+    p.s_pool = B.alloc_saved((size_t)N * hp * wp * w);
+    p.s_argmax = B.alloc_saved(((size_t)N * hp * wp * w + 3) / 4);
+    h = hp; wd = wp;
+    size_t cur = p.s_pool;
+    int inplanes = w, cur_stride = 4, cur_dil = 1;
+    for (int li = 0; li < 4; ++li) {
+        const int planes = w << li;
+        int stride = li == 0 ? 1 : 2;
+        for (int bi = 0; bi < layers[li]; ++bi) {
+            const std::string bname = "layer" + std::to_string(li + 1) + "." + std::to_string(bi);
+            BlockL blk;
+            blk.in = cur;
+            blk.in_c = inplanes;
+            blk.in_rows = (int64_t)N * h * wd;
+            int bstride = 1;
+            bool need_down = false;
+            if (bi == 0 && (stride != 1 || inplanes != planes * exp)) {
+                need_down = true;
+                if (cur_stride == 8) { cur_dil *= stride; }
+                else { cur_stride *= stride; bstride = stride; }
+            }
+            const int dil = cur_dil;
+            // NB: like the reference's _make_layer, the first block of a layer already uses the layer's dilation
+            if (!p.bottleneck) {
+                blk.nconv = 2;
+                blk.conv[0] = B.add_conv(bname + ".conv1", N, h, wd, inplanes, planes, 3, bstride, dil, dil, false);
+                B.conv_out(blk.conv[0]);
+                const ConvL c0 = p.convs[blk.conv[0]];
+                p.convs[blk.conv[0]].bn = B.add_bn(bname + ".bn1", planes, B.rows_of(c0));
+                blk.mid[0] = B.alloc_saved((size_t)B.rows_of(c0) * planes);
+                blk.conv[1] = B.add_conv(bname + ".conv2", N, c0.d.hout, c0.d.wout, planes, planes, 3, 1, dil, dil, false);
+                B.conv_out(blk.conv[1]);
+                p.convs[blk.conv[1]].bn = B.add_bn(bname + ".bn2", planes, B.rows_of(p.convs[blk.conv[1]]));
+            } else {
+                blk.nconv = 3;
+                blk.conv[0] = B.add_conv(bname + ".conv1", N, h, wd, inplanes, planes, 1, 1, 0, 1, false);
+                B.conv_out(blk.conv[0]);
+                const ConvL c0 = p.convs[blk.conv[0]];
+                p.convs[blk.conv[0]].bn = B.add_bn(bname + ".bn1", planes, B.rows_of(c0));
+                blk.mid[0] = B.alloc_saved((size_t)B.rows_of(c0) * planes);
+                blk.conv[1] = B.add_conv(bname + ".conv2", N, h, wd, planes, planes, 3, bstride, dil, dil, false);
+                B.conv_out(blk.conv[1]);
+                const ConvL c1 = p.convs[blk.conv[1]];
+                p.convs[blk.conv[1]].bn = B.add_bn(bname + ".bn2", planes, B.rows_of(c1));
+                blk.mid[1] = B.alloc_saved((size_t)B.rows_of(c1) * planes);
+                blk.conv[2] = B.add_conv(bname + ".conv3", N, c1.d.hout, c1.d.wout, planes, planes * 4, 1, 1, 0, 1, false);
+                B.conv_out(blk.conv[2]);
+                p.convs[blk.conv[2]].bn = B.add_bn(bname + ".bn3", planes * 4, B.rows_of(p.convs[blk.conv[2]]));
+            }
+            const ConvL last = p.convs[blk.conv[blk.nconv - 1]];
+            if (need_down) {
+                blk.down = B.add_conv(bname + ".downsample.0", N, h, wd, inplanes, planes * exp, 1, bstride, 0, 1, false);
+                B.conv_out(blk.down);
+                p.convs[blk.down].bn = B.add_bn(bname + ".downsample.1", planes * exp, B.rows_of(p.convs[blk.down]));
+            }
+            blk.out_rows = B.rows_of(last);
+            blk.out_c = planes * exp;
+            blk.out = B.alloc_saved((size_t)blk.out_rows * blk.out_c);
+            if ((size_t)blk.out_rows * blk.out_c > p.max_act) p.max_act = (size_t)blk.out_rows * blk.out_c;
+            p.blocks.push_back(blk);
+            cur = blk.out;
+            h = last.d.hout; wd = last.d.wout;
+            inplanes = planes * exp;
+        }
+    }
+    p.hl = h; p.wl = wd; p.feat_c = inplanes;
+    p.fc = B.add_conv("fc", N, h, wd, inplanes, p.D, 1, 1, 0, 1, true, p.Dp);
+    p.saved_floats = B.saved;
+    {
+        const size_t in4 = (size_t)N * p.H * p.W * 4;
+        if (in4 > p.max_act) p.max_act = in4;
+    }
+
+    // ---- workspace
+    size_t ws = 0;
+    auto alloc = [&](size_t fl) { const size_t o = ws; ws = align64(ws + fl); return o; };
+    for (int i = 0; i < 6; ++i) p.w_buf[i] = alloc(p.max_act);
+    size_t max_w = 0, max_slab = 0, max_part = 0;
+    int max_c = 4;
+    for (const ConvL& c : p.convs) {
+        const size_t welems = (size_t)c.d.ldc * c.d.kh * c.d.kw * c.d.cin;
+        if (welems > max_w) max_w = welems;
+        const size_t sl = dcn_conv_wgrad_workspace(&c.d) / sizeof(float);
+        if (sl > max_slab) max_slab = sl;
+        const size_t pf = (size_t)c.mtiles * 2 * c.d.cout;
+        if (pf > max_part) max_part = pf;
+        if (c.d.cout > max_c) max_c = c.d.cout;
+    }
+    for (const BnL& b : p.bns) {
+        const size_t pb = (size_t)dcn::bn_bwd_chunks(b.rows) * 2 * b.C;
+        if (pb > max_part) max_part = pb;
+    }
+    p.w_wt = alloc(max_w);
+    p.w_slab = alloc(max_slab);
+    p.w_part = alloc(max_part);
+    p.w_k123 = alloc((size_t)3 * max_c);
+    p.w_wstem = alloc((size_t)p.base * 49 * 4);
+    p.w_dwstem = alloc((size_t)p.base * 49 * 4);
+    p.w_low = alloc((size_t)N * p.hl * p.wl * p.Dp);
+    p.w_glow = alloc((size_t)N * p.hl * p.wl * p.Dp);
+    p.w_ups = alloc(dcn::upsample_bwd_tmp_bytes(N, p.hl, p.W, p.D) / sizeof(float));
+    p.ws_floats = ws;
+    return DCN_OK;
+}
+
+// column sums of a [rows][ld] matrix (fc bias gradient): one workgroup per column, fixed-order reduction
+__global__ void __launch_bounds__(256)
+colsum_kernel(const float* __restrict__ m, int64_t rows, int ld, float* __restrict__ out) {
+    __shared__ double s[4];
+    double a = 0.0;
+    for (int64_t r = threadIdx.x; r < rows; r += 256) a += (double)m[r * ld + blockIdx.x];
+    a = dcn::block_sum<256>(a, s);
+    if (threadIdx.x == 0) out[blockIdx.x] = (float)a;
+}
+
+#define DCN_TRY(expr)                    \
+    do {                                 \
+        const int rc__ = (expr);         \
+        if (rc__ != DCN_OK) return rc__; \
+    } while (0)
+
+struct Run {
+    dcn_plan& p;
+    const float* const* params;
+    float* saved;
+    float* ws;
+    hipStream_t st;
+
+    float* S(size_t off) const { return saved + off; }
+    float* Wk(size_t off) const { return ws + off; }
+    const float* P(int i) const { return params[i]; }
+
+    // conv + BN statistics -> scale/shift in the saved arena
+    int conv_bn(const ConvL& c, const float* in, const float* w, float* const* bn_running, float momentum, float eps,
+                int training) {
+        float* part = training ? Wk(p.w_part) : nullptr;
+        DCN_TRY(dcn_conv_forward(&c.d, in, w, nullptr, S(c.x), part, st));
+        const BnL& b = p.bns[c.bn];
+        float* stats = S(b.stats);
+        float* rm = bn_running ? bn_running[2 * b.idx] : nullptr;
+        float* rv = bn_running ? bn_running[2 * b.idx + 1] : nullptr;
+        if (!training && (!rm || !rv)) return DCN_E_INVALID;
+        dcn::launch_bn_finalize(part, c.mtiles, b.C, (double)b.rows, P(b.g), P(b.b), rm, rv, momentum, eps, training,
+                                stats, stats + b.C, stats + 2 * b.C, stats + 3 * b.C, st);
+        return DCN_OK;
+    }
+};
+
+}  // namespace
+
+extern "C" int dcn_plan_create(const char* arch, int base_width, int n, int h, int w, int d, dcn_plan** out) {
+    if (!arch || !out || n < 1 || h < 8 || w < 8 || d < 1 || base_width < 4 || (base_width % 4))
+        return DCN_E_INVALID;
+    dcn_plan* p = new dcn_plan();
+    p->arch = arch; p->N = n; p->H = h; p->W = w; p->D = d; p->base = base_width;
+    const int rc = build_plan(*p);
+    if (rc != DCN_OK) { delete p; return rc; }
+    *out = p;
+    return DCN_OK;
+}
+extern "C" void dcn_plan_destroy(dcn_plan* plan) { delete plan; }
+extern "C" int dcn_plan_num_params(const dcn_plan* plan) { return plan ? (int)plan->params.size() : DCN_E_INVALID; }
+extern "C" int dcn_plan_num_bn(const dcn_plan* plan) { return plan ? (int)plan->bns.size() : DCN_E_INVALID; }
+extern "C" int dcn_plan_param_info(const dcn_plan* plan, int i, char* name, int name_cap, int64_t shape[4], int* ndim) {
+    if (!plan || i < 0 || i >= (int)plan->params.size() || !name || name_cap < 2 || !shape || !ndim) return DCN_E_INVALID;
+    const ParamInfo& pi = plan->params[i];
+    snprintf(name, (size_t)name_cap, "%s", pi.name.c_str());
+    for (int k = 0; k < 4; ++k) shape[k] = pi.shape[k];
+    *ndim = pi.ndim;
+    return DCN_OK;
+}
+extern "C" int dcn_plan_bn_info(const dcn_plan* plan, int j, char* name, int name_cap, int64_t* channels) {
+    if (!plan || j < 0 || j >= (int)plan->bns.size() || !name || name_cap < 2 || !channels) return DCN_E_INVALID;
+    snprintf(name, (size_t)name_cap, "%s", plan->bns[j].name.c_str());
+    *channels = plan->bns[j].C;
+    return DCN_OK;
+}
+extern "C" size_t dcn_plan_saved_bytes(const dcn_plan* plan) { return plan ? plan->saved_floats * sizeof(float) : 0; }
+extern "C" size_t dcn_plan_workspace_bytes(const dcn_plan* plan) { return plan ? plan->ws_floats * sizeof(float) : 0; }
+extern "C" double dcn_plan_forward_flops(const dcn_plan* plan) { return plan ? plan->flops : 0.0; }
+
+extern "C" int dcn_backbone_forward(dcn_plan* plan, const float* image, const float* const* params,
+                                    float* const* bn_running, float momentum, float eps, int training, int normalize,
+                                    float* descriptors, void* saved, void* workspace, void* stream) {
+    if (!plan || !image || !params || !descriptors || !saved || !workspace) return DCN_E_INVALID;
+    dcn_plan& p = *plan;
+    Run R{p, params, (float*)saved, (float*)workspace, (hipStream_t)stream};
+    hipStream_t st = R.st;
+    const int N = p.N;
+
+    // stem: NCHW(3) -> NHWC(4), weight [w][7][7][3] -> [w][7][7][4]
+    dcn::launch_nchw3_to_nhwc4(image, R.S(p.s_in4), N, p.H * p.W, st);
+    const ConvL& stem = p.convs[p.stem];
+    dcn::launch_pad_c3_to_c4(R.P(stem.w), R.Wk(p.w_wstem), (int64_t)p.base * 49, st);
+    DCN_TRY(R.conv_bn(stem, R.S(p.s_in4), R.Wk(p.w_wstem), bn_running, momentum, eps, training));
+    {
+        const BnL& b = p.bns[stem.bn];
+        const float* s = R.S(b.stats);
+        dcn::launch_bn_apply(R.S(stem.x), s, s + b.C, nullptr, nullptr, nullptr, 1, R.S(p.s_stem_y), b.C, b.rows, st);
+        const int hp = (stem.d.hout + 2 - 3) / 2 + 1, wp = (stem.d.wout + 2 - 3) / 2 + 1;
+        dcn::launch_maxpool_fwd(R.S(p.s_stem_y), R.S(p.s_pool), (unsigned char*)R.S(p.s_argmax), N, stem.d.hout,
+                                stem.d.wout, hp, wp, b.C, st);
+    }
+    for (const BlockL& blk : p.blocks) {
+        const float* in = R.S(blk.in);
+        const float* cur = in;
+        for (int i = 0; i < blk.nconv; ++i) {
+            const ConvL& c = p.convs[blk.conv[i]];
+            DCN_TRY(R.conv_bn(c, cur, R.P(c.w), bn_running, momentum, eps, training));
+            if (i + 1 < blk.nconv) {
+                const BnL& b = p.bns[c.bn];
+                const float* s = R.S(b.stats);
+                dcn::launch_bn_apply(R.S(c.x), s, s + b.C, nullptr, nullptr, nullptr, 1, R.S(blk.mid[i]), b.C, b.rows, st);
+                cur = R.S(blk.mid[i]);
+            }
+        }
+        const ConvL& last = p.convs[blk.conv[blk.nconv - 1]];
+        const BnL& bl = p.bns[last.bn];
+        const float* sl = R.S(bl.stats);
+        if (blk.down >= 0) {
+            const ConvL& dc = p.convs[blk.down];
+            DCN_TRY(R.conv_bn(dc, in, R.P(dc.w), bn_running, momentum, eps, training));
+            const float* sd = R.S(p.bns[dc.bn].stats);
+            dcn::launch_bn_apply(R.S(last.x), sl, sl + bl.C, R.S(dc.x), sd, sd + bl.C, 1, R.S(blk.out), bl.C, bl.rows, st);
+        } else {
+            dcn::launch_bn_apply(R.S(last.x), sl, sl + bl.C, in, nullptr, nullptr, 1, R.S(blk.out), bl.C, bl.rows, st);
+        }
+    }
+    // scoring layer (1x1 conv + bias) into the padded low-resolution map, then bilinear upsample
+    const ConvL& fc = p.convs[p.fc];
+    const size_t low_bytes = (size_t)N * p.hl * p.wl * p.Dp * sizeof(float);
+    if (hipMemsetAsync(R.Wk(p.w_low), 0, low_bytes, st) != hipSuccess) return DCN_E_LAUNCH;
+    DCN_TRY(dcn_conv_forward(&fc.d, R.S(p.blocks.back().out), R.P(fc.w), R.P(fc.b), R.Wk(p.w_low), nullptr, st));
+    dcn::launch_upsample_fwd(R.Wk(p.w_low), N, p.hl, p.wl, p.Dp, p.D, p.H, p.W, normalize, descriptors, st);
+    return dcn::check_launch();
+}
+
+extern "C" int dcn_backbone_backward(dcn_plan* plan, const float* grad_descriptors, const float* const* params,
+                                     const void* saved, void* workspace, float* const* grads, void* stream) {
+    if (!plan || !grad_descriptors || !params || !saved || !workspace || !grads) return DCN_E_INVALID;
+    dcn_plan& p = *plan;
+    Run R{p, params, (float*)saved, (float*)workspace, (hipStream_t)stream};
+    hipStream_t st = R.st;
+    const int N = p.N;
+    float* part = R.Wk(p.w_part);
+    float* k123 = R.Wk(p.w_k123);
+    float* wt = R.Wk(p.w_wt);
+    float* slab = R.Wk(p.w_slab);
+
+    // BN backward of conv c's batch norm: dy (+ optional relu mask from relu_out) -> dx; g_out optional
+    auto bn_bwd = [&](const ConvL& c, const float* dy, const float* relu_out, float* dx, float* g_out) {
+        const BnL& b = p.bns[c.bn];
+        const float* s = R.S(b.stats);
+        dcn::launch_bn_bwd(dy, relu_out, R.S(c.x), s + 2 * b.C, s + 3 * b.C, R.P(b.g), b.C, b.rows, part, grads[b.g],
+                           grads[b.b], k123, dx, g_out, st);
+    };
+    auto wgrad = [&](const ConvL& c, const float* in, const float* dx, float* dw) -> int {
+        return dcn_conv_wgrad(&c.d, in, dx, dw, slab, st);
+    };
+    auto dgrad = [&](const ConvL& c, const float* dx, const float* add, float* din) -> int {
+        DCN_TRY(dcn_transpose_weight(R.P(c.w), wt, c.d.cout, c.d.kh * c.d.kw, c.d.cin, c.d.ldc, st));
+        return dcn_conv_dgrad(&c.d, dx, wt, add, din, st);
+    };
+
+    // ---- upsample + scoring layer
+    float* glow = R.Wk(p.w_glow);
+    dcn::launch_upsample_bwd(grad_descriptors, N, p.hl, p.wl, p.Dp, p.D, p.H, p.W, R.Wk(p.w_ups), glow, st);
+    const ConvL& fc = p.convs[p.fc];
+    const float* feat = R.S(p.blocks.back().out);
+    DCN_TRY(wgrad(fc, feat, glow, grads[fc.w]));
+    hipLaunchKernelGGL(colsum_kernel, dim3(p.D), dim3(256), 0, st, (const float*)glow, (int64_t)N * p.hl * p.wl, p.Dp,
+                       grads[fc.b]);
+    float* dout = R.Wk(p.w_buf[0]);   // gradient w.r.t. the current block's output
+    float* dnext = R.Wk(p.w_buf[1]);  // gradient w.r.t. its input (swapped after every block)
+    float* gbuf = R.Wk(p.w_buf[2]);   // relu-masked dout (residual branch)
+    float* dxa = R.Wk(p.w_buf[3]);
+    float* dxb = R.Wk(p.w_buf[4]);
+    float* dpart = R.Wk(p.w_buf[5]);
+    DCN_TRY(dgrad(fc, glow, nullptr, dout));
+
+    for (int bi = (int)p.blocks.size() - 1; bi >= 0; --bi) {
+        const BlockL& blk = p.blocks[bi];
+        const float* in = R.S(blk.in);
+        // last conv's BN: relu mask from the block output, emits g for the identity branch
+        const ConvL& last = p.convs[blk.conv[blk.nconv - 1]];
+        bn_bwd(last, dout, R.S(blk.out), dxa, gbuf);
+        float* dx = dxa;
+        float* dy = dxb;
+        for (int i = blk.nconv - 1; i >= 0; --i) {
+            const ConvL& c = p.convs[blk.conv[i]];
+            const float* cin = i == 0 ? in : R.S(blk.mid[i - 1]);
+            DCN_TRY(wgrad(c, cin, dx, grads[c.w]));
+            if (i > 0) {
+                DCN_TRY(dgrad(c, dx, nullptr, dy));  // dy = grad w.r.t. mid[i-1]
+                const ConvL& prev = p.convs[blk.conv[i - 1]];
+                bn_bwd(prev, dy, R.S(blk.mid[i - 1]), dx, nullptr);  // dx reused: grad w.r.t. prev conv output
+            } else if (blk.down >= 0) {
+                DCN_TRY(dgrad(c, dx, nullptr, dpart));
+            } else {
+                DCN_TRY(dgrad(c, dx, gbuf, dnext));  // + identity gradient
+            }
+        }
+        if (blk.down >= 0) {
+            const ConvL& dc = p.convs[blk.down];
+            bn_bwd(dc, gbuf, nullptr, dxa, nullptr);
+            DCN_TRY(wgrad(dc, in, dxa, grads[dc.w]));
+            DCN_TRY(dgrad(dc, dxa, dpart, dnext));
+        }
+        float* t = dout; dout = dnext; dnext = t;
+    }
+    // ---- max pool, stem
+    const ConvL& stem = p.convs[p.stem];
+    const BnL& sb = p.bns[stem.bn];
+    const int hp = (stem.d.hout + 2 - 3) / 2 + 1, wp = (stem.d.wout + 2 - 3) / 2 + 1;
+    dcn::launch_maxpool_bwd(dout, (const unsigned char*)R.S(p.s_argmax), dnext, N, stem.d.hout, stem.d.wout, hp, wp, sb.C,
+                            st);
+    bn_bwd(stem, dnext, R.S(p.s_stem_y), dxa, nullptr);
+    DCN_TRY(wgrad(stem, R.S(p.s_in4), dxa, R.Wk(p.w_dwstem)));
+    dcn::launch_unpad_c4_to_c3(R.Wk(p.w_dwstem), grads[stem.w], (int64_t)p.base * 49, st);
+    return dcn::check_launch();
+}

@@ -1,0 +1,37 @@
+// Host launchers of the HBM-bound kernels (elementwise_kernels.hip), used by the backbone engine.
+#pragma once
+#include "dcn_common.h"
+
+namespace dcn {
+
+void launch_nchw3_to_nhwc4(const float* img, float* out, int n, int hw, hipStream_t st);
+void launch_pad_c3_to_c4(const float* w, float* wp, int64_t rows, hipStream_t st);
+void launch_unpad_c4_to_c3(const float* wp, float* w, int64_t rows, hipStream_t st);
+void launch_pad_rows(const float* src, float* dst, int64_t rows, int d, int ld, hipStream_t st);
+
+// batch norm: partial[tiles][2][C] (sum, sum of squares) -> scale/shift (+ saved mean/invstd, running update)
+void launch_bn_finalize(const float* partial, int tiles, int C, double count, const float* gamma, const float* beta,
+                        float* rmean, float* rvar, float momentum, float eps, int training, float* scale, float* shift,
+                        float* save_mean, float* save_invstd, hipStream_t st);
+// y = [relu](x*s1 + b1 + (res ? (s2 ? res*s2 + b2 : res) : 0))
+void launch_bn_apply(const float* x, const float* s1, const float* b1, const float* res, const float* s2,
+                     const float* b2, int relu, float* y, int C, int64_t rows, hipStream_t st);
+int bn_bwd_chunks(int64_t rows);
+// partial: bn_bwd_chunks(rows)*2*C floats, k123: 3*C floats.  g_out (nullable) receives the relu-masked dy.
+void launch_bn_bwd(const float* dy, const float* relu_out, const float* x, const float* mean, const float* invstd,
+                   const float* gamma, int C, int64_t rows, float* partial, float* dgamma, float* dbeta, float* k123,
+                   float* dx, float* g_out, hipStream_t st);
+void launch_add(const float* a, const float* b, float* out, int64_t n, hipStream_t st);
+
+void launch_maxpool_fwd(const float* in, float* out, unsigned char* argmax, int n, int hin, int win, int hout,
+                        int wout, int C, hipStream_t st);
+void launch_maxpool_bwd(const float* gout, const unsigned char* argmax, float* gin, int n, int hin, int win, int hout,
+                        int wout, int C, hipStream_t st);
+
+void launch_upsample_fwd(const float* low, int n, int hl, int wl, int ldl, int d, int h, int w, int normalize,
+                         float* out, hipStream_t st);
+size_t upsample_bwd_tmp_bytes(int n, int hl, int w, int d);
+void launch_upsample_bwd(const float* gout, int n, int hl, int wl, int ldl, int d, int h, int w, float* tmp,
+                         float* glow, hipStream_t st);
+
+}  // namespace dcn

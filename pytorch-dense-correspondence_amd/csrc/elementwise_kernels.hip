@@ -1,0 +1,508 @@
+// K2 / K7 / K8 / K10 and layout helpers: the HBM-bound kernels around the convolutions (gfx950).
+// All activations are NHWC fp32 with C % 4 == 0, so every work-item moves float4 (16 B/lane, 1 KiB per
+// wave-instruction).  Reductions are two-stage and fixed-order (run-to-run deterministic), accumulated
+// in fp64 in the tiny finalize kernels.
+//
+//   batch norm (train):  mean/var over N*H*W of one forward call, eps 1e-5, momentum 0.1, unbiased running var
+//                        == torch.nn.BatchNorm2d as the [NOT IN TREE] backbone uses it
+//   max pool 3x3/2 pad 1 (first maximum in window scan order wins, like ATen's CPU kernel)
+//   bilinear upsample, align_corners=True  == F.upsample_bilinear (called from Resnet34_8s.forward [NOT IN TREE])
+//   optional per-pixel L2 normalisation of the descriptor (dense_correspondence_network.py:256-259)
+#include "elementwise_kernels.h"
+
+namespace dcn {
+
+// ---------------------------------------------------------------------------------------------- layout
+__global__ void __launch_bounds__(256)
+nchw3_to_nhwc4_kernel(const float* __restrict__ img, float* __restrict__ out, int hw, int64_t total) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;  // over n*hw
+    if (i >= total) return;
+    const int64_t n = i / hw, p = i - n * hw;
+    const float* s = img + n * 3 * hw + p;
+    reinterpret_cast<float4*>(out)[i] = make_float4(s[0], s[hw], s[2 * (int64_t)hw], 0.f);
+}
+
+// wp[o][tap][4] = (w[o][tap][0..2], 0)   and back (gradient): w[o][tap][c] = wp[o][tap][c], c < 3
+__global__ void __launch_bounds__(256)
+pad_c3_to_c4_kernel(const float* __restrict__ w, float* __restrict__ wp, int64_t rows) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= rows) return;
+    reinterpret_cast<float4*>(wp)[i] = make_float4(w[3 * i], w[3 * i + 1], w[3 * i + 2], 0.f);
+}
+__global__ void __launch_bounds__(256)
+unpad_c4_to_c3_kernel(const float* __restrict__ wp, float* __restrict__ w, int64_t rows) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= rows) return;
+    const float4 v = reinterpret_cast<const float4*>(wp)[i];
+    w[3 * i] = v.x; w[3 * i + 1] = v.y; w[3 * i + 2] = v.z;
+}
+
+// pads rows of [rows][d] to [rows][ld] with zeros (fc weight -> ld = round_up(d, 4))
+__global__ void __launch_bounds__(256)
+pad_rows_kernel(const float* __restrict__ src, float* __restrict__ dst, int64_t rows, int d, int ld) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= rows * ld) return;
+    const int64_t r = i / ld;
+    const int c = (int)(i - r * ld);
+    dst[i] = c < d ? src[r * d + c] : 0.f;
+}
+
+// ---------------------------------------------------------------------------------------------- batch norm
+// partial[tile][2][C] -> per-channel sums (fp64), then scale/shift + saved statistics + running update.
+__global__ void __launch_bounds__(256)
+bn_finalize_kernel(const float* __restrict__ partial, int tiles, int C, double count, const float* __restrict__ gamma,
+                   const float* __restrict__ beta, float* __restrict__ running_mean, float* __restrict__ running_var,
+                   float momentum, float eps, int training, float* __restrict__ scale, float* __restrict__ shift,
+                   float* __restrict__ save_mean, float* __restrict__ save_invstd) {
+    __shared__ double s_sum[4][64];
+    __shared__ double s_sq[4][64];
+    const int cl = threadIdx.x & 63, part = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + cl;
+    double a = 0.0, b = 0.0;
+    if (training && c < C) {
+        for (int t = part; t < tiles; t += 4) {
+            a += (double)partial[((int64_t)t * 2 + 0) * C + c];
+            b += (double)partial[((int64_t)t * 2 + 1) * C + c];
+        }
+    }
+    s_sum[part][cl] = a;
+    s_sq[part][cl] = b;
+    __syncthreads();
+    if (part != 0 || c >= C) return;
+    double mean, var;
+    if (training) {
+        a = s_sum[0][cl] + s_sum[1][cl] + s_sum[2][cl] + s_sum[3][cl];
+        b = s_sq[0][cl] + s_sq[1][cl] + s_sq[2][cl] + s_sq[3][cl];
+        mean = a / count;
+        var = b / count - mean * mean;
+        if (var < 0.0) var = 0.0;
+        if (running_mean) {
+            const double unbiased = count > 1.0 ? var * count / (count - 1.0) : var;
+            running_mean[c] = (float)((1.0 - momentum) * (double)running_mean[c] + momentum * mean);
+            running_var[c] = (float)((1.0 - momentum) * (double)running_var[c] + momentum * unbiased);
+        }
+    } else {
+        mean = (double)running_mean[c];
+        var = (double)running_var[c];
+    }
+    const float invstd = (float)(1.0 / sqrt(var + (double)eps));
+    const float sc = gamma[c] * invstd;
+    scale[c] = sc;
+    shift[c] = beta[c] - (float)mean * sc;
+    if (save_mean) { save_mean[c] = (float)mean; save_invstd[c] = invstd; }
+}
+
+// y = [relu]( x*s1 + b1 + (res ? (s2 ? res*s2 + b2 : res) : 0) )
+__global__ void __launch_bounds__(256)
+bn_apply_kernel(const float* __restrict__ x, const float* __restrict__ s1, const float* __restrict__ b1,
+                const float* __restrict__ res, const float* __restrict__ s2, const float* __restrict__ b2, int relu,
+                float* __restrict__ y, int c4n, int64_t total4) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total4; i += (int64_t)gridDim.x * 256) {
+        const int c = (int)(i % c4n) * 4;
+        const float4 v = reinterpret_cast<const float4*>(x)[i];
+        const float4 s = *reinterpret_cast<const float4*>(s1 + c);
+        const float4 b = *reinterpret_cast<const float4*>(b1 + c);
+        float4 o = make_float4(v.x * s.x + b.x, v.y * s.y + b.y, v.z * s.z + b.z, v.w * s.w + b.w);
+        if (res) {
+            float4 r = reinterpret_cast<const float4*>(res)[i];
+            if (s2) {
+                const float4 t = *reinterpret_cast<const float4*>(s2 + c);
+                const float4 u = *reinterpret_cast<const float4*>(b2 + c);
+                r = make_float4(r.x * t.x + u.x, r.y * t.y + u.y, r.z * t.z + u.z, r.w * t.w + u.w);
+            }
+            o.x += r.x; o.y += r.y; o.z += r.z; o.w += r.w;
+        }
+        if (relu) { o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f); }
+        reinterpret_cast<float4*>(y)[i] = o;
+    }
+}
+
+// Backward reduction.  g = relu_out ? (relu_out > 0 ? dy : 0) : dy.
+// partial[chunk][2][C] = ( sum g , sum g * (x - mean) * invstd ) over the chunk's rows.
+// work-item (c4 = tid & 15, rl = tid >> 4): 16 channel quads x 16 row lanes; grid = (C/64 groups, chunks).
+__global__ void __launch_bounds__(256)
+bn_bwd_reduce_kernel(const float* __restrict__ dy, const float* __restrict__ relu_out, const float* __restrict__ x,
+                     const float* __restrict__ mean, const float* __restrict__ invstd, int C, int64_t rows,
+                     int rows_per_chunk, float* __restrict__ partial) {
+    __shared__ float4 s_g[16][16];
+    __shared__ float4 s_gx[16][16];
+    const int c4 = threadIdx.x & 15, rl = threadIdx.x >> 4;
+    const int c = blockIdx.x * 64 + c4 * 4;
+    float4 ag = make_float4(0.f, 0.f, 0.f, 0.f), agx = ag;
+    if (c < C) {
+        const float4 mu = *reinterpret_cast<const float4*>(mean + c);
+        const float4 is = *reinterpret_cast<const float4*>(invstd + c);
+        const int64_t r0 = (int64_t)blockIdx.y * rows_per_chunk;
+        int64_t r1 = r0 + rows_per_chunk;
+        if (r1 > rows) r1 = rows;
+        for (int64_t r = r0 + rl; r < r1; r += 16) {
+            const int64_t o = r * C + c;
+            float4 g = *reinterpret_cast<const float4*>(dy + o);
+            if (relu_out) {
+                const float4 y = *reinterpret_cast<const float4*>(relu_out + o);
+                g.x = y.x > 0.f ? g.x : 0.f; g.y = y.y > 0.f ? g.y : 0.f;
+                g.z = y.z > 0.f ? g.z : 0.f; g.w = y.w > 0.f ? g.w : 0.f;
+            }
+            const float4 v = *reinterpret_cast<const float4*>(x + o);
+            ag.x += g.x; ag.y += g.y; ag.z += g.z; ag.w += g.w;
+            agx.x = fmaf(g.x, (v.x - mu.x) * is.x, agx.x); agx.y = fmaf(g.y, (v.y - mu.y) * is.y, agx.y);
+            agx.z = fmaf(g.z, (v.z - mu.z) * is.z, agx.z); agx.w = fmaf(g.w, (v.w - mu.w) * is.w, agx.w);
+        }
+    }
+    s_g[rl][c4] = ag;
+    s_gx[rl][c4] = agx;
+    __syncthreads();
+    if (rl == 0 && c < C) {
+        for (int i = 1; i < 16; ++i) {
+            const float4 a = s_g[i][c4], b = s_gx[i][c4];
+            ag.x += a.x; ag.y += a.y; ag.z += a.z; ag.w += a.w;
+            agx.x += b.x; agx.y += b.y; agx.z += b.z; agx.w += b.w;
+        }
+        float* p = partial + ((int64_t)blockIdx.y * 2) * C + c;
+        *reinterpret_cast<float4*>(p) = ag;
+        *reinterpret_cast<float4*>(p + C) = agx;
+    }
+}
+
+// partial[chunk][2][C] -> dgamma, dbeta and the coefficients of the apply pass:
+//   dx = k1 * (g - k2 - xhat * k3),  k1 = gamma*invstd, k2 = sum_g / M, k3 = sum_gx / M
+__global__ void __launch_bounds__(256)
+bn_bwd_finalize_kernel(const float* __restrict__ partial, int chunks, int C, double count,
+                       const float* __restrict__ gamma, const float* __restrict__ invstd, float* __restrict__ dgamma,
+                       float* __restrict__ dbeta, float* __restrict__ k1, float* __restrict__ k2,
+                       float* __restrict__ k3) {
+    __shared__ double s_a[4][64];
+    __shared__ double s_b[4][64];
+    const int cl = threadIdx.x & 63, part = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + cl;
+    double a = 0.0, b = 0.0;
+    if (c < C) {
+        for (int t = part; t < chunks; t += 4) {
+            a += (double)partial[((int64_t)t * 2 + 0) * C + c];
+            b += (double)partial[((int64_t)t * 2 + 1) * C + c];
+        }
+    }
+    s_a[part][cl] = a;
+    s_b[part][cl] = b;
+    __syncthreads();
+    if (part != 0 || c >= C) return;
+    a = s_a[0][cl] + s_a[1][cl] + s_a[2][cl] + s_a[3][cl];
+    b = s_b[0][cl] + s_b[1][cl] + s_b[2][cl] + s_b[3][cl];
+    dbeta[c] = (float)a;
+    dgamma[c] = (float)b;
+    k1[c] = gamma[c] * invstd[c];
+    k2[c] = (float)(a / count);
+    k3[c] = (float)(b / count);
+}
+
+// dx = k1*(g - k2 - (x-mean)*invstd*k3); optionally also writes g (the relu-masked upstream gradient) for the
+// residual branch.
+__global__ void __launch_bounds__(256)
+bn_bwd_apply_kernel(const float* __restrict__ dy, const float* __restrict__ relu_out, const float* __restrict__ x,
+                    const float* __restrict__ mean, const float* __restrict__ invstd, const float* __restrict__ k1,
+                    const float* __restrict__ k2, const float* __restrict__ k3, float* __restrict__ dx,
+                    float* __restrict__ g_out, int c4n, int64_t total4) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total4; i += (int64_t)gridDim.x * 256) {
+        const int c = (int)(i % c4n) * 4;
+        float4 g = reinterpret_cast<const float4*>(dy)[i];
+        if (relu_out) {
+            const float4 y = reinterpret_cast<const float4*>(relu_out)[i];
+            g.x = y.x > 0.f ? g.x : 0.f; g.y = y.y > 0.f ? g.y : 0.f;
+            g.z = y.z > 0.f ? g.z : 0.f; g.w = y.w > 0.f ? g.w : 0.f;
+        }
+        const float4 v = reinterpret_cast<const float4*>(x)[i];
+        const float4 mu = *reinterpret_cast<const float4*>(mean + c);
+        const float4 is = *reinterpret_cast<const float4*>(invstd + c);
+        const float4 a = *reinterpret_cast<const float4*>(k1 + c);
+        const float4 b = *reinterpret_cast<const float4*>(k2 + c);
+        const float4 d = *reinterpret_cast<const float4*>(k3 + c);
+        float4 o;
+        o.x = a.x * (g.x - b.x - (v.x - mu.x) * is.x * d.x);
+        o.y = a.y * (g.y - b.y - (v.y - mu.y) * is.y * d.y);
+        o.z = a.z * (g.z - b.z - (v.z - mu.z) * is.z * d.z);
+        o.w = a.w * (g.w - b.w - (v.w - mu.w) * is.w * d.w);
+        reinterpret_cast<float4*>(dx)[i] = o;
+        if (g_out) reinterpret_cast<float4*>(g_out)[i] = g;
+    }
+}
+
+// out = a + b
+__global__ void __launch_bounds__(256)
+add_kernel(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ out, int64_t total4) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total4; i += (int64_t)gridDim.x * 256) {
+        const float4 u = reinterpret_cast<const float4*>(a)[i], v = reinterpret_cast<const float4*>(b)[i];
+        reinterpret_cast<float4*>(out)[i] = make_float4(u.x + v.x, u.y + v.y, u.z + v.z, u.w + v.w);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------- max pool 3x3 / 2 / pad 1
+__global__ void __launch_bounds__(256)
+maxpool_fwd_kernel(const float* __restrict__ in, float* __restrict__ out, unsigned char* __restrict__ argmax, int hin,
+                   int win, int hout, int wout, int c4n, int64_t total4) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;  // over n*hout*wout*c4n
+    if (i >= total4) return;
+    const int c4 = (int)(i % c4n);
+    int64_t pix = i / c4n;
+    const int ox = (int)(pix % wout); pix /= wout;
+    const int oy = (int)(pix % hout);
+    const int64_t n = pix / hout;
+    float4 best = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+    int bx = -1, by = -1, bz = -1, bw = -1;
+    for (int r = 0; r < 3; ++r) {
+        const int iy = oy * 2 - 1 + r;
+        if (iy < 0 || iy >= hin) continue;
+        for (int s = 0; s < 3; ++s) {
+            const int ix = ox * 2 - 1 + s;
+            if (ix < 0 || ix >= win) continue;
+            const float4 v = reinterpret_cast<const float4*>(in)[((n * hin + iy) * win + ix) * c4n + c4];
+            const int t = r * 3 + s;
+            if (v.x > best.x || bx < 0 || v.x != v.x) { best.x = v.x; bx = t; }
+            if (v.y > best.y || by < 0 || v.y != v.y) { best.y = v.y; by = t; }
+            if (v.z > best.z || bz < 0 || v.z != v.z) { best.z = v.z; bz = t; }
+            if (v.w > best.w || bw < 0 || v.w != v.w) { best.w = v.w; bw = t; }
+        }
+    }
+    reinterpret_cast<float4*>(out)[i] = best;
+    if (argmax) {
+        unsigned char* a = argmax + i * 4;
+        a[0] = (unsigned char)bx; a[1] = (unsigned char)by; a[2] = (unsigned char)bz; a[3] = (unsigned char)bw;
+    }
+}
+
+// gather form: every input element collects from the (<= 4) windows that contain it
+__global__ void __launch_bounds__(256)
+maxpool_bwd_kernel(const float* __restrict__ gout, const unsigned char* __restrict__ argmax, float* __restrict__ gin,
+                   int hin, int win, int hout, int wout, int c4n, int64_t total4) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;  // over n*hin*win*c4n
+    if (i >= total4) return;
+    const int c4 = (int)(i % c4n);
+    int64_t pix = i / c4n;
+    const int ix = (int)(pix % win); pix /= win;
+    const int iy = (int)(pix % hin);
+    const int64_t n = pix / hin;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int oy = iy / 2; oy <= (iy + 1) / 2; ++oy) {
+        if (oy >= hout) continue;
+        const int r = iy - (oy * 2 - 1);
+        if (r < 0 || r > 2) continue;
+        for (int ox = ix / 2; ox <= (ix + 1) / 2; ++ox) {
+            if (ox >= wout) continue;
+            const int s = ix - (ox * 2 - 1);
+            if (s < 0 || s > 2) continue;
+            const int t = r * 3 + s;
+            const int64_t o = ((n * hout + oy) * wout + ox) * c4n + c4;
+            const float4 g = reinterpret_cast<const float4*>(gout)[o];
+            const unsigned char* a = argmax + o * 4;
+            if (a[0] == t) acc.x += g.x;
+            if (a[1] == t) acc.y += g.y;
+            if (a[2] == t) acc.z += g.z;
+            if (a[3] == t) acc.w += g.w;
+        }
+    }
+    reinterpret_cast<float4*>(gin)[i] = acc;
+}
+
+// ---------------------------------------------------------------------------------------------- bilinear upsample
+__device__ __forceinline__ void src_index(int dst, float scale, int in_size, int& i0, int& i1, float& l1) {
+    const float s = scale * (float)dst;  // align_corners=True: scale = (in-1)/(out-1)
+    i0 = (int)s;
+    if (i0 > in_size - 1) i0 = in_size - 1;
+    i1 = i0 < in_size - 1 ? i0 + 1 : i0;
+    l1 = s - (float)i0;
+}
+
+// one work-item per output pixel; low-res rows have pitch ldl (>= d)
+__global__ void __launch_bounds__(256)
+upsample_fwd_kernel(const float* __restrict__ low, int hl, int wl, int ldl, int d, int h, int w, float sh, float sw,
+                    int normalize, float* __restrict__ out, int64_t total) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;  // over n*h*w
+    if (i >= total) return;
+    const int x = (int)(i % w);
+    const int64_t t = i / w;
+    const int y = (int)(t % h);
+    const int64_t n = t / h;
+    int y0, y1, x0, x1;
+    float ly, lx;
+    src_index(y, sh, hl, y0, y1, ly);
+    src_index(x, sw, wl, x0, x1, lx);
+    const float hy = 1.f - ly, hx = 1.f - lx;
+    const float* p00 = low + ((n * hl + y0) * wl + x0) * ldl;
+    const float* p01 = low + ((n * hl + y0) * wl + x1) * ldl;
+    const float* p10 = low + ((n * hl + y1) * wl + x0) * ldl;
+    const float* p11 = low + ((n * hl + y1) * wl + x1) * ldl;
+    float* o = out + i * d;
+    if (!normalize) {
+        for (int k = 0; k < d; ++k) o[k] = hy * (hx * p00[k] + lx * p01[k]) + ly * (hx * p10[k] + lx * p11[k]);
+    } else {
+        float ss = 0.f;
+        for (int k = 0; k < d; ++k) {
+            const float v = hy * (hx * p00[k] + lx * p01[k]) + ly * (hx * p10[k] + lx * p11[k]);
+            ss = fmaf(v, v, ss);
+        }
+        const float nrm = sqrtf(ss);
+        for (int k = 0; k < d; ++k)
+            o[k] = (hy * (hx * p00[k] + lx * p01[k]) + ly * (hx * p10[k] + lx * p11[k])) / nrm;
+    }
+}
+
+// backward, separable and gather-form (deterministic).  pass 1: tmp[n][iy][x][d] = sum_y wy(y, iy) * gout[n][y][x][d]
+__global__ void __launch_bounds__(256)
+upsample_bwd_rows_kernel(const float* __restrict__ gout, int hl, int d, int h, int w, float sh, float* __restrict__ tmp,
+                         int64_t total) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;  // over n*hl*w*d
+    if (i >= total) return;
+    const int64_t wd = (int64_t)w * d;
+    const int64_t xd = i % wd;
+    const int64_t t = i / wd;
+    const int iy = (int)(t % hl);
+    const int64_t n = t / hl;
+    const float inv = sh > 0.f ? 1.f / sh : 0.f;
+    int ylo = (int)floorf(((float)iy - 1.f) * inv) - 1, yhi = (int)ceilf(((float)iy + 1.f) * inv) + 1;
+    if (ylo < 0) ylo = 0;
+    if (yhi > h - 1 || sh <= 0.f) yhi = h - 1;
+    float acc = 0.f;
+    for (int y = ylo; y <= yhi; ++y) {
+        int y0, y1;
+        float ly;
+        src_index(y, sh, hl, y0, y1, ly);
+        float wgt = 0.f;
+        if (y0 == iy) wgt += 1.f - ly;
+        if (y1 == iy) wgt += ly;
+        if (wgt != 0.f) acc = fmaf(wgt, gout[(n * h + y) * wd + xd], acc);
+    }
+    tmp[i] = acc;
+}
+// pass 2: glow[n][iy][ix][0..ldl) = sum_x wx(x, ix) * tmp[n][iy][x][k]  (k >= d -> 0)
+__global__ void __launch_bounds__(256)
+upsample_bwd_cols_kernel(const float* __restrict__ tmp, int hl, int wl, int ldl, int d, int w, float sw,
+                         float* __restrict__ glow, int64_t total) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;  // over n*hl*wl*ldl
+    if (i >= total) return;
+    const int k = (int)(i % ldl);
+    const int64_t t = i / ldl;
+    const int ix = (int)(t % wl);
+    const int64_t row = t / wl;  // n*hl + iy
+    if (k >= d) { glow[i] = 0.f; return; }
+    const float inv = sw > 0.f ? 1.f / sw : 0.f;
+    int xlo = (int)floorf(((float)ix - 1.f) * inv) - 1, xhi = (int)ceilf(((float)ix + 1.f) * inv) + 1;
+    if (xlo < 0) xlo = 0;
+    if (xhi > w - 1 || sw <= 0.f) xhi = w - 1;
+    float acc = 0.f;
+    for (int x = xlo; x <= xhi; ++x) {
+        int x0, x1;
+        float lx;
+        src_index(x, sw, wl, x0, x1, lx);
+        float wgt = 0.f;
+        if (x0 == ix) wgt += 1.f - lx;
+        if (x1 == ix) wgt += lx;
+        if (wgt != 0.f) acc = fmaf(wgt, tmp[(row * w + x) * d + k], acc);
+    }
+    glow[i] = acc;
+}
+
+// ---------------------------------------------------------------------------------------------- host launchers
+static inline unsigned blocks_for(int64_t n, int cap = 0) {
+    int64_t b = ceil_div64(n, 256);
+    if (cap > 0 && b > cap) b = cap;
+    if (b < 1) b = 1;
+    return (unsigned)b;
+}
+constexpr int kGridCap = 256 * 8;  // grid-stride kernels: 8 workgroups per CU
+
+void launch_nchw3_to_nhwc4(const float* img, float* out, int n, int hw, hipStream_t st) {
+    const int64_t total = (int64_t)n * hw;
+    hipLaunchKernelGGL(nchw3_to_nhwc4_kernel, dim3(blocks_for(total)), dim3(256), 0, st, img, out, hw, total);
+}
+void launch_pad_c3_to_c4(const float* w, float* wp, int64_t rows, hipStream_t st) {
+    hipLaunchKernelGGL(pad_c3_to_c4_kernel, dim3(blocks_for(rows)), dim3(256), 0, st, w, wp, rows);
+}
+void launch_unpad_c4_to_c3(const float* wp, float* w, int64_t rows, hipStream_t st) {
+    hipLaunchKernelGGL(unpad_c4_to_c3_kernel, dim3(blocks_for(rows)), dim3(256), 0, st, wp, w, rows);
+}
+void launch_pad_rows(const float* src, float* dst, int64_t rows, int d, int ld, hipStream_t st) {
+    hipLaunchKernelGGL(pad_rows_kernel, dim3(blocks_for(rows * ld)), dim3(256), 0, st, src, dst, rows, d, ld);
+}
+void launch_bn_finalize(const float* partial, int tiles, int C, double count, const float* gamma, const float* beta,
+                        float* rmean, float* rvar, float momentum, float eps, int training, float* scale, float* shift,
+                        float* save_mean, float* save_invstd, hipStream_t st) {
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3(ceil_div(C, 64)), dim3(256), 0, st, partial, tiles, C, count, gamma,
+                       beta, rmean, rvar, momentum, eps, training, scale, shift, save_mean, save_invstd);
+}
+void launch_bn_apply(const float* x, const float* s1, const float* b1, const float* res, const float* s2,
+                     const float* b2, int relu, float* y, int C, int64_t rows, hipStream_t st) {
+    const int64_t total4 = rows * (C / 4);
+    hipLaunchKernelGGL(bn_apply_kernel, dim3(blocks_for(total4, kGridCap)), dim3(256), 0, st, x, s1, b1, res, s2, b2,
+                       relu, y, C / 4, total4);
+}
+int bn_bwd_chunks(int64_t rows) {
+    int64_t chunks = ceil_div64(rows, 512);
+    if (chunks > 512) chunks = 512;
+    if (chunks < 1) chunks = 1;
+    return (int)chunks;
+}
+void launch_bn_bwd(const float* dy, const float* relu_out, const float* x, const float* mean, const float* invstd,
+                   const float* gamma, int C, int64_t rows, float* partial, float* dgamma, float* dbeta, float* k123,
+                   float* dx, float* g_out, hipStream_t st) {
+    const int chunks = bn_bwd_chunks(rows);
+    const int rpc = (int)ceil_div64(rows, chunks);
+    hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(ceil_div(C, 64), chunks), dim3(256), 0, st, dy, relu_out, x, mean,
+                       invstd, C, rows, rpc, partial);
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(ceil_div(C, 64)), dim3(256), 0, st, (const float*)partial, chunks, C,
+                       (double)rows, gamma, invstd, dgamma, dbeta, k123, k123 + C, k123 + 2 * C);
+    const int64_t total4 = rows * (C / 4);
+    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(blocks_for(total4, kGridCap)), dim3(256), 0, st, dy, relu_out, x, mean,
+                       invstd, (const float*)k123, (const float*)(k123 + C), (const float*)(k123 + 2 * C), dx, g_out,
+                       C / 4, total4);
+}
+void launch_add(const float* a, const float* b, float* out, int64_t n, hipStream_t st) {
+    hipLaunchKernelGGL(add_kernel, dim3(blocks_for(n / 4, kGridCap)), dim3(256), 0, st, a, b, out, n / 4);
+}
+void launch_maxpool_fwd(const float* in, float* out, unsigned char* argmax, int n, int hin, int win, int hout,
+                        int wout, int C, hipStream_t st) {
+    const int64_t total4 = (int64_t)n * hout * wout * (C / 4);
+    hipLaunchKernelGGL(maxpool_fwd_kernel, dim3(blocks_for(total4)), dim3(256), 0, st, in, out, argmax, hin, win, hout,
+                       wout, C / 4, total4);
+}
+void launch_maxpool_bwd(const float* gout, const unsigned char* argmax, float* gin, int n, int hin, int win, int hout,
+                        int wout, int C, hipStream_t st) {
+    const int64_t total4 = (int64_t)n * hin * win * (C / 4);
+    hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(blocks_for(total4)), dim3(256), 0, st, gout, argmax, gin, hin, win,
+                       hout, wout, C / 4, total4);
+}
+static inline float ac_scale(int in, int out) { return out > 1 ? (float)(in - 1) / (float)(out - 1) : 0.f; }
+void launch_upsample_fwd(const float* low, int n, int hl, int wl, int ldl, int d, int h, int w, int normalize,
+                         float* out, hipStream_t st) {
+    const int64_t total = (int64_t)n * h * w;
+    hipLaunchKernelGGL(upsample_fwd_kernel, dim3(blocks_for(total)), dim3(256), 0, st, low, hl, wl, ldl, d, h, w,
+                       ac_scale(hl, h), ac_scale(wl, w), normalize, out, total);
+}
+size_t upsample_bwd_tmp_bytes(int n, int hl, int w, int d) { return (size_t)n * hl * w * d * sizeof(float); }
+void launch_upsample_bwd(const float* gout, int n, int hl, int wl, int ldl, int d, int h, int w, float* tmp,
+                         float* glow, hipStream_t st) {
+    const int64_t t1 = (int64_t)n * hl * w * d;
+    hipLaunchKernelGGL(upsample_bwd_rows_kernel, dim3(blocks_for(t1)), dim3(256), 0, st, gout, hl, d, h, w,
+                       ac_scale(hl, h), tmp, t1);
+    const int64_t t2 = (int64_t)n * hl * wl * ldl;
+    hipLaunchKernelGGL(upsample_bwd_cols_kernel, dim3(blocks_for(t2)), dim3(256), 0, st, (const float*)tmp, hl, wl, ldl,
+                       d, w, ac_scale(wl, w), glow, t2);
+}
+
+}  // namespace dcn
+
+extern "C" int dcn_upsample_forward(const float* low, int n, int hl, int wl, int ldl, int d, int h, int w, int normalize,
+                                    float* out, void* stream) {
+    if (!low || !out || n < 1 || hl < 1 || wl < 1 || d < 1 || ldl < d || h < 1 || w < 1) return DCN_E_INVALID;
+    dcn::launch_upsample_fwd(low, n, hl, wl, ldl, d, h, w, normalize, out, (hipStream_t)stream);
+    return dcn::check_launch();
+}
+
+extern "C" size_t dcn_upsample_backward_tmp_bytes(int n, int hl, int w, int d) {
+    return dcn::upsample_bwd_tmp_bytes(n, hl, w, d);
+}
+
+extern "C" int dcn_upsample_backward(const float* gout, int n, int hl, int wl, int ldl, int d, int h, int w, float* glow,
+                                     float* tmp, void* stream) {
+    if (!gout || !glow || !tmp || n < 1 || hl < 1 || wl < 1 || d < 1 || ldl < d || h < 1 || w < 1) return DCN_E_INVALID;
+    dcn::launch_upsample_bwd(gout, n, hl, wl, ldl, d, h, w, tmp, glow, (hipStream_t)stream);
+    return dcn::check_launch();
+}

@@ -55,10 +55,12 @@ SYMBOLS = {
     "dcn_conv_dgrad": (c_int, [ctypes.POINTER(ConvDesc), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "dcn_conv_wgrad": (c_int, [ctypes.POINTER(ConvDesc), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "dcn_conv_wgrad_workspace": (c_size_t, [ctypes.POINTER(ConvDesc)]),
-    "dcn_transpose_weight": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
+    "dcn_transpose_weight": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     "dcn_upsample_forward": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p,
                                      c_void_p]),
-    "dcn_upsample_backward": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
+    "dcn_upsample_backward": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p,
+                                      c_void_p]),
+    "dcn_upsample_backward_tmp_bytes": (c_size_t, [c_int, c_int, c_int, c_int]),
 }
 
 ERRORS = {-1: "DCN_E_INVALID (bad argument)", -2: "DCN_E_LAUNCH (kernel launch failed)",

@@ -1,0 +1,139 @@
+"""Host side of the backbone engine (csrc/backbone_engine.hip): plan cache + autograd glue.
+
+The network arithmetic (convolutions, batch norm, pooling, upsampling, every gradient) runs in the HIP
+kernels; this file allocates buffers with the PyTorch caching allocator, builds the pointer tables the
+C ABI takes and hooks the two C calls into ``torch.autograd``.
+"""
+import ctypes
+
+import torch
+
+from . import _lib
+
+
+class Plan(object):
+    """dcn_plan for (arch, base_width, N, H, W, D); owns the parameter / batch-norm name tables."""
+
+    def __init__(self, arch, base_width, n, h, w, d):
+        lib = _lib.get()
+        handle = ctypes.c_void_p()
+        rc = lib.dcn_plan_create(arch.encode(), base_width, n, h, w, d, ctypes.byref(handle))
+        if rc != 0:
+            raise ValueError("dcn_hip: cannot plan %s (base %d) for input [%d,3,%d,%d], D=%d: %s" %
+                             (arch, base_width, n, h, w, d, _lib.ERRORS.get(rc, rc)))
+        self.handle = handle
+        self.key = (arch, base_width, n, h, w, d)
+        self.n, self.h, self.w, self.d = n, h, w, d
+        self.param_names, self.param_shapes = [], []
+        buf = ctypes.create_string_buffer(256)
+        shape = (ctypes.c_int64 * 4)()
+        ndim = ctypes.c_int()
+        for i in range(lib.dcn_plan_num_params(handle)):
+            _lib.check(lib.dcn_plan_param_info(handle, i, buf, 256, shape, ctypes.byref(ndim)), "dcn_plan_param_info")
+            self.param_names.append(buf.value.decode())
+            self.param_shapes.append(tuple(int(shape[k]) for k in range(ndim.value)))
+        self.bn_names, self.bn_channels = [], []
+        ch = ctypes.c_int64()
+        for j in range(lib.dcn_plan_num_bn(handle)):
+            _lib.check(lib.dcn_plan_bn_info(handle, j, buf, 256, ctypes.byref(ch)), "dcn_plan_bn_info")
+            self.bn_names.append(buf.value.decode())
+            self.bn_channels.append(int(ch.value))
+        self.saved_bytes = int(lib.dcn_plan_saved_bytes(handle))
+        self.workspace_bytes = int(lib.dcn_plan_workspace_bytes(handle))
+        self.forward_flops = float(lib.dcn_plan_forward_flops(handle))
+        # flat gradient layout (one buffer -> one RCCL all-reduce)
+        self.param_numel = [int(torch.Size(s).numel()) for s in self.param_shapes]
+        self.grad_offsets = [0]
+        for nmel in self.param_numel:
+            self.grad_offsets.append(self.grad_offsets[-1] + nmel)
+
+    def __del__(self):
+        try:
+            _lib.get().dcn_plan_destroy(self.handle)
+        except Exception:
+            pass
+
+
+_PLANS = {}
+
+
+def get_plan(arch, base_width, n, h, w, d):
+    key = (arch, base_width, n, h, w, d)
+    p = _PLANS.get(key)
+    if p is None:
+        p = _PLANS[key] = Plan(*key)
+    return p
+
+
+def _kernel_layout(p):
+    """Conv weights are consumed as [Cout][kh][kw][Cin] == logical OIHW in channels_last memory."""
+    if p.dim() == 4:
+        return p.contiguous(memory_format=torch.channels_last)
+    return p.contiguous()
+
+
+def _grad_views(flat, plan):
+    views = []
+    for i, shape in enumerate(plan.param_shapes):
+        v = flat[plan.grad_offsets[i]:plan.grad_offsets[i + 1]]
+        if len(shape) == 4:
+            o, c, kh, kw = shape
+            v = v.view(o, kh, kw, c).permute(0, 3, 1, 2)
+        views.append(v)
+    return views
+
+
+class _BackboneFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, image, plan, bn_running, training, normalize, momentum, eps, *params):
+        lib = _lib.get()
+        _lib.require_device(image, *params)
+        if image.dim() != 4 or image.shape[1] != 3 or image.dtype != torch.float32:
+            raise ValueError("expected a float32 [N,3,H,W] image batch, got %s %s" % (tuple(image.shape), image.dtype))
+        if tuple(image.shape) != (plan.n, 3, plan.h, plan.w):
+            raise ValueError("plan %s does not match input %s" % (plan.key, tuple(image.shape)))
+        if normalize and training and any(p.requires_grad for p in params):
+            raise NotImplementedError("dcn_hip: backward through normalize=True descriptors is not implemented yet")
+        image = image.contiguous()
+        dev = image.device
+        kparams = [_kernel_layout(p.detach()) for p in params]
+        pptr = (ctypes.c_void_p * len(kparams))(*[p.data_ptr() for p in kparams])
+        rptr = (ctypes.c_void_p * len(bn_running))(*[b.data_ptr() for b in bn_running])
+        desc = torch.empty((plan.n, plan.h, plan.w, plan.d), dtype=torch.float32, device=dev)
+        saved = torch.empty(plan.saved_bytes, dtype=torch.uint8, device=dev)
+        ws = torch.empty(plan.workspace_bytes, dtype=torch.uint8, device=dev)
+        rc = lib.dcn_backbone_forward(plan.handle, _lib.ptr(image), pptr, rptr, float(momentum), float(eps),
+                                      int(bool(training)), int(bool(normalize)), _lib.ptr(desc), _lib.ptr(saved),
+                                      _lib.ptr(ws), _lib.stream_ptr())
+        _lib.check(rc, "dcn_backbone_forward")
+        ctx.plan = plan
+        ctx.saved_arena = saved
+        ctx.kparams = kparams
+        ctx.trained = bool(training)
+        # logical [N,D,H,W] over NHWC memory == torch.channels_last
+        return desc.permute(0, 3, 1, 2)
+
+    @staticmethod
+    def backward(ctx, grad_desc):
+        lib = _lib.get()
+        plan = ctx.plan
+        if not ctx.trained:
+            raise RuntimeError("dcn_hip: backward through an eval-mode forward is not supported")
+        g = grad_desc.permute(0, 2, 3, 1).contiguous()  # NHWC; no copy when grad is channels_last
+        dev = g.device
+        ws = torch.empty(plan.workspace_bytes, dtype=torch.uint8, device=dev)
+        flat = torch.empty(plan.grad_offsets[-1], dtype=torch.float32, device=dev)
+        base = flat.data_ptr()
+        gptr = (ctypes.c_void_p * len(plan.param_numel))(*[base + 4 * o for o in plan.grad_offsets[:-1]])
+        pptr = (ctypes.c_void_p * len(ctx.kparams))(*[p.data_ptr() for p in ctx.kparams])
+        rc = lib.dcn_backbone_backward(plan.handle, _lib.ptr(g), pptr, _lib.ptr(ctx.saved_arena), _lib.ptr(ws), gptr,
+                                       _lib.stream_ptr())
+        _lib.check(rc, "dcn_backbone_backward")
+        ctx.saved_arena = None
+        return (None, None, None, None, None, None, None) + tuple(_grad_views(flat, plan))
+
+
+def backbone_forward(image, plan, params, bn_running, training, normalize=False, momentum=0.1, eps=1e-5):
+    """image [N,3,H,W] -> descriptors, logical [N,D,H,W] in channels_last memory.
+    ``params`` / ``bn_running`` follow ``plan.param_names`` / ``plan.bn_names`` (running_mean, running_var per BN)."""
+    return _BackboneFn.apply(image, plan, bn_running, training, normalize, momentum, eps, *params)

@@ -1,0 +1,3 @@
+"""Import-name shim for the reference's un-vendored submodule ``external/pytorch-segmentation-detection``
+(imported at dense_correspondence/network/dense_correspondence_network.py:16).  Only the piece on the
+training hot path exists here: ``models.resnet_dilated`` backed by the gfx950 kernels."""

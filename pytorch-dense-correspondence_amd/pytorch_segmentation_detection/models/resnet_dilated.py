@@ -1,0 +1,120 @@
+"""``resnet_dilated.Resnet{18,34,50,101}_8s`` -- the names the reference resolves with
+``getattr(resnet_dilated, config["backbone"]["resnet_name"])(num_classes=D)``
+(dense_correspondence/network/dense_correspondence_network.py:373-375).
+
+Each class is an ``nn.Module`` whose parameters / buffers carry the reference checkpoints' names
+(``resnet34_8s.layer1.0.conv1.weight`` ...), so ``optim.Adam(dcn.parameters())``, ``state_dict()``,
+``.cuda()``, ``.train()/.eval()`` behave as with the original (training.py:144,245,510).  ``forward`` does not
+run any torch operator on the activations: it hands the parameter pointers to the MI355X backbone
+engine (dcn_hip / csrc/backbone_engine.hip).  There is no CPU path."""
+import math
+
+import torch
+import torch.nn as nn
+
+from dcn_hip import backbone as _bb
+
+
+class _Node(nn.Module):
+    """Parameter container (never executed on its own)."""
+
+    def forward(self, *a, **k):
+        raise RuntimeError("this sub-module only holds parameters; call the top-level Resnet*_8s module "
+                           "(the whole network runs as one fused MI355X engine call)")
+
+
+def _child(parent, name):
+    if name not in parent._modules:
+        parent.add_module(name, _Node())
+    return parent._modules[name]
+
+
+class _DilatedResnet8s(nn.Module):
+    arch = None
+    attr = None
+
+    def __init__(self, num_classes=1000, base_width=64):
+        super(_DilatedResnet8s, self).__init__()
+        self.num_classes = int(num_classes)
+        self.base_width = int(base_width)
+        probe = _bb.get_plan(self.arch, self.base_width, 1, 32, 32, self.num_classes)  # names/shapes only
+        self._param_names = list(probe.param_names)
+        self._bn_names = list(probe.bn_names)
+        trunk = _Node()
+        setattr(self, self.attr, trunk)
+        for name, shape in zip(probe.param_names, probe.param_shapes):
+            parts = name.split(".")
+            node = trunk
+            for p in parts[:-1]:
+                node = _child(node, p)
+            t = torch.empty(shape, dtype=torch.float32)
+            if len(shape) == 4:
+                t = t.contiguous(memory_format=torch.channels_last)  # the kernels' [Cout][kh][kw][Cin]
+            node.register_parameter(parts[-1], nn.Parameter(t))
+        for name, ch in zip(probe.bn_names, probe.bn_channels):
+            node = trunk
+            for p in name.split("."):
+                node = _child(node, p)
+            node.register_buffer("running_mean", torch.zeros(ch))
+            node.register_buffer("running_var", torch.ones(ch))
+            node.register_buffer("num_batches_tracked", torch.tensor(0, dtype=torch.long))
+        self.bn_momentum = 0.1
+        self.bn_eps = 1e-5
+        self.reset_parameters()
+
+    def reset_parameters(self):
+        """He-normal (fan-out) convs, BN (1, 0), scoring layer N(0, 0.01) / bias 0 -- what the original does before
+        it loads ImageNet weights (not downloadable offline)."""
+        trunk = getattr(self, self.attr)
+        bn_set = set(self._bn_names)
+        with torch.no_grad():
+            for name in self._param_names:
+                p = trunk.get_parameter(name)
+                owner, leaf = name.rsplit(".", 1)
+                if owner == "fc":
+                    if leaf == "weight":
+                        p.normal_(0, 0.01)
+                    else:
+                        p.zero_()
+                elif owner in bn_set:
+                    p.fill_(1.0) if leaf == "weight" else p.zero_()
+                else:
+                    o, c, kh, kw = p.shape
+                    p.normal_(0, math.sqrt(2.0 / (kh * kw * o)))
+
+    def _tables(self):
+        trunk = getattr(self, self.attr)
+        params = [trunk.get_parameter(n) for n in self._param_names]
+        running, tracked = [], []
+        for n in self._bn_names:
+            node = trunk.get_submodule(n)
+            running += [node.running_mean, node.running_var]
+            tracked.append(node.num_batches_tracked)
+        return params, running, tracked
+
+    def forward(self, x, normalize=False):
+        n, _, h, w = x.shape
+        plan = _bb.get_plan(self.arch, self.base_width, int(n), int(h), int(w), self.num_classes)
+        params, running, tracked = self._tables()
+        if self.training:
+            torch._foreach_add_(tracked, 1)
+        return _bb.backbone_forward(x, plan, params, running, self.training, normalize, self.bn_momentum, self.bn_eps)
+
+    def forward_flops(self, n, h, w):
+        return _bb.get_plan(self.arch, self.base_width, int(n), int(h), int(w), self.num_classes).forward_flops
+
+
+class Resnet18_8s(_DilatedResnet8s):
+    arch, attr = "Resnet18_8s", "resnet18_8s"
+
+
+class Resnet34_8s(_DilatedResnet8s):
+    arch, attr = "Resnet34_8s", "resnet34_8s"
+
+
+class Resnet50_8s(_DilatedResnet8s):
+    arch, attr = "Resnet50_8s", "resnet50_8s"
+
+
+class Resnet101_8s(_DilatedResnet8s):
+    arch, attr = "Resnet101_8s", "resnet101_8s"

@@ -223,6 +223,8 @@ static inline unsigned long long atomicAdd(unsigned long long* p, unsigned long 
 }
 
 #define unsafeAtomicAdd atomicAdd
+template <class T> static inline T min(T a, T b) { return a < b ? a : b; }
+template <class T> static inline T max(T a, T b) { return a > b ? a : b; }
 
 // ---- MFMA (f32 in / f32 accumulate), k-ordered fmaf chain like the hardware ----
 typedef float hipemu_f32x16 __attribute__((ext_vector_type(16)));
