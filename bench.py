@@ -1,0 +1,238 @@
+#!/usr/bin/env python3
+"""Training throughput of the dense-correspondence hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+One step = one pass of the reference's training iteration (dense_correspondence/training/training.py:325-346)
+over one synthetic batch already resident in HBM:
+    zero grads -> dcn.forward(img_a) -> dcn.forward(img_b) -> process_network_output x2 ->
+    loss_composer (match + masked + background non-match lists, hard-negative scaling) -> backward ->
+    gradient all-reduce (RCCL, N > 1) -> Adam step (lr 1e-4, weight decay 1e-4, training.yaml:3,6).
+Workload at N = 1: BASELINE.json configs[1] -- B = 4 image pairs (8 images / step), 640x480, D = 3,
+Resnet34_8s, 5000 match + 2500 masked + 2500 background non-match pixel pairs per image pair.  For N > 1 every
+rank runs that same per-GPU workload on its own pairs (weak scaling, BN statistics per rank: the reference has no
+SyncBN); `value` is the whole-job images / second.
+
+Prints ONE JSON line on rank 0 (contract in the task description) with `roofline` (dominant kernel =
+conv_gemm_kernel, fp32 MFMA; algorithmic FLOPs and per-launch durations from HIP events recorded by the engine
+on the launch stream) and `cpu_baseline` (the oracle's step on this box's host cores, bounded sample).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+PKG = os.path.join(ROOT, "pytorch-dense-correspondence_amd")
+for _p in (ROOT, PKG):
+    if _p not in sys.path:
+        sys.path.insert(0, _p)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+# synthetic-input constants.  Kept here so the measured path never imports `oracle`;
+# tests/test_synth_consistency.py checks they equal oracle/synth.py.
+DEFAULT_IMAGE_MEAN = [0.5573105812072754, 0.37420374155044556, 0.37020164728164673]
+DEFAULT_IMAGE_STD_DEV = [0.24336038529872894, 0.2987397611141205, 0.31875079870224]
+LOSS_CONFIG = {"M_masked": 0.5, "M_background": 0.5, "M_pixel": 50, "match_loss_weight": 1.0,
+               "non_match_loss_weight": 1.0, "use_l2_pixel_loss_on_masked_non_matches": False,
+               "use_l2_pixel_loss_on_background_non_matches": False, "scale_by_hard_negatives": True,
+               "scale_by_hard_negatives_DIFFERENT_OBJECT": True, "alpha_triplet": 0.1}
+WORKLOADS = {
+    "config2": dict(B=4, H=480, W=640, D=3, Pm=5000, Pk=2500, Pg=2500, backbone="Resnet34_8s",
+                    desc="BASELINE configs[1]: B=4 pairs 640x480 D=3 Resnet34_8s 5000/2500/2500 pairs"),
+    "config1": dict(B=1, H=480, W=640, D=3, Pm=1000, Pk=500, Pg=500, backbone="Resnet34_8s",
+                    desc="BASELINE configs[0]: B=1 pair 640x480 D=3 Resnet34_8s 1000/500/500 pairs"),
+    "config3": dict(B=32, H=480, W=640, D=16, Pm=10000, Pk=50000, Pg=50000, backbone="Resnet34_8s",
+                    desc="BASELINE configs[2]: B=32 pairs 640x480 D=16 Resnet34_8s 10000/50000/50000 pairs"),
+    "config4": dict(B=8, H=480, W=640, D=3, Pm=5000, Pk=2500, Pg=2500, backbone="Resnet34_8s",
+                    desc="BASELINE configs[3] per-GPU share: B=8 pairs 640x480 D=3 Resnet34_8s"),
+    "tiny": dict(B=1, H=96, W=128, D=3, Pm=500, Pk=250, Pg=250, backbone="Resnet34_8s", desc="smoke-size workload"),
+}
+FP32_MFMA_PEAK_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 256 CUs @ 2.4 GHz
+
+
+def make_batch(B, H, W, Pm, Pk, Pg, seed):
+    """Seeded synthetic batch: mean/std-normalised uniform images, uniformly drawn int64 pixel pairs."""
+    gen = torch.Generator().manual_seed(seed)
+    mean = torch.tensor(DEFAULT_IMAGE_MEAN).view(1, 3, 1, 1)
+    std = torch.tensor(DEFAULT_IMAGE_STD_DEV).view(1, 3, 1, 1)
+    img_a = (torch.rand(B, 3, H, W, generator=gen) - mean) / std
+    img_b = (torch.rand(B, 3, H, W, generator=gen) - mean) / std
+    lists = []
+    for _ in range(B):
+        d = {}
+        for name, n in (("matches", Pm), ("masked_non_matches", Pk), ("background_non_matches", Pg)):
+            for side in ("a", "b"):
+                d[name + "_" + side] = (torch.randint(0, H * W, (n,), generator=gen, dtype=torch.int64) if n > 0
+                                        else torch.tensor([-1], dtype=torch.int64))
+        d["blind_non_matches_a"] = torch.tensor([-1], dtype=torch.int64)
+        d["blind_non_matches_b"] = torch.tensor([-1], dtype=torch.int64)
+        lists.append(d)
+    return img_a, img_b, lists
+
+
+def as_tuples(lists):
+    keys = ("matches_a", "matches_b", "masked_non_matches_a", "masked_non_matches_b", "background_non_matches_a",
+            "background_non_matches_b", "blind_non_matches_a", "blind_non_matches_b")
+    return [tuple(L[k] for k in keys) for L in lists]
+
+
+def cpu_baseline(wl, steps, warmup):
+    """The oracle's training step (oracle/step.py, the CPU restatement of the reference) on this box's host cores.
+    Bounded sample: ONE image pair of the workload's shapes."""
+    from oracle import resnet_dilated_oracle, step as ostep, synth
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    model = resnet_dilated_oracle.build(wl["backbone"], wl["D"], seed=0)
+    model.train()
+    img_a, img_b, lists = synth.make_batch(1, wl["H"], wl["W"], wl["Pm"], wl["Pk"], wl["Pg"], seed=1)
+    sec = ostep.time_cpu_step(model, img_a, img_b, lists, synth.LOSS_CONFIG, steps=steps, warmup=warmup)
+    return {"value": 2.0 / sec, "unit": "images/s", "cores": cores, "kind": "port",
+            "sample": "oracle (py3 CPU restatement of training.py:325-346, torch %s, fp32) on 1 image pair of the "
+                      "workload's shapes (%dx%d, D=%d, %d/%d/%d pairs), %d warm-up + median of %d steps, %.2f s/step"
+                      % (torch.__version__.split("+")[0], wl["W"], wl["H"], wl["D"], wl["Pm"], wl["Pk"], wl["Pg"],
+                         warmup, steps, sec)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--workload", default="config2", choices=sorted(WORKLOADS))
+    ap.add_argument("--batch", type=int, default=0, help="override image pairs per GPU per step")
+    ap.add_argument("--cpu-baseline-steps", type=int, default=3, help="0 disables the CPU baseline leg")
+    ap.add_argument("--profile-steps", type=int, default=3, help="extra steps with per-launch HIP events (roofline)")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the dense-correspondence hot path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    from dcn_hip import _lib, backbone as bb
+    from dcn_hip.distributed import FlatGradients, broadcast_module
+    from dcn_hip.loss import PairLists
+    from dense_correspondence.loss_functions import loss_composer
+    from dense_correspondence.loss_functions.pixelwise_contrastive_loss import PixelwiseContrastiveLoss
+    from dense_correspondence.network.dense_correspondence_network import DenseCorrespondenceNetwork
+    info = _lib.library_info()
+    assert not info["hostemu"], "bench.py must run the gfx950 library"
+
+    wl = dict(WORKLOADS[args.workload])
+    if args.batch:
+        wl["B"] = args.batch
+    B, H, W, D = wl["B"], wl["H"], wl["W"], wl["D"]
+    torch.manual_seed(0)
+    cfg = {"descriptor_dimension": D, "image_width": W, "image_height": H,
+           "backbone": {"model_class": "Resnet", "resnet_name": wl["backbone"]}}
+    dcn = DenseCorrespondenceNetwork.from_config(cfg, load_stored_params=False)  # .cuda().train() like network.py:435
+    dcn.to(dev)
+    broadcast_module(dcn)
+    pcl = PixelwiseContrastiveLoss(image_shape=dcn.image_shape, config=LOSS_CONFIG)
+    grads = FlatGradients(dcn)
+    opt = torch.optim.Adam(dcn.parameters(), lr=1.0e-4, weight_decay=1.0e-4)
+    img_a, img_b, lists = make_batch(B, H, W, wl["Pm"], wl["Pk"], wl["Pg"], seed=1 + rank)
+    img_a, img_b = img_a.to(dev), img_b.to(dev)
+    pair_lists = PairLists.from_lists(as_tuples(lists), dev)
+    match_type = 0  # SINGLE_OBJECT_WITHIN_SCENE
+
+    def step(it):
+        grads.zero_()
+        if it % 250 == 0 and it > 0:  # training.yaml:4-5 step decay
+            for g in opt.param_groups:
+                g["lr"] *= 0.9
+        pa = dcn.process_network_output(dcn.forward(img_a), B)
+        pb = dcn.process_network_output(dcn.forward(img_b), B)
+        loss, terms, hard = loss_composer.get_loss_batched(pcl, match_type, pa, pb, pair_lists)
+        loss.backward()
+        grads.all_reduce_mean()
+        opt.step()
+        return loss
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for it in range(args.warmup):
+        loss = step(it)
+    fence()
+    t0 = time.perf_counter()
+    for it in range(args.steps):
+        loss = step(args.warmup + it)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    final_loss = float(loss.item())
+
+    # ---- roofline of the dominant kernel: extra steps, every conv_gemm / conv_wgrad launch bracketed by HIP events
+    roofline = None
+    if args.profile_steps > 0:
+        plan = bb.get_plan(wl["backbone"], 64, B, H, W, D)
+        plan.profile_begin()
+        for it in range(args.profile_steps):
+            step(args.warmup + args.steps + it)
+        prof = plan.profile_end()
+        ms, n, fl = prof["conv_gemm"]
+        wms, wn, wfl = prof["conv_wgrad"]
+        if n > 0 and ms > 0:
+            achieved = fl / (ms * 1e-3) / 1e12
+            roofline = {"bound": "mfma", "kernel": "conv_gemm_kernel (fp32 v_mfma_f32_32x32x2_f32; forward + dgrad)",
+                        "achieved": achieved, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                        "frac": achieved / FP32_MFMA_PEAK_TFLOPS, "traffic": None,
+                        "launches_per_step": n / args.profile_steps, "avg_launch_us": 1e3 * ms / n,
+                        "algorithmic_gflop_per_launch": fl / n / 1e9,
+                        "kernel_ms_per_step": ms / args.profile_steps,
+                        "conv_wgrad": {"achieved": (wfl / (wms * 1e-3) / 1e12) if wms > 0 else None,
+                                       "frac": (wfl / (wms * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS) if wms > 0 else None,
+                                       "launches_per_step": wn / args.profile_steps,
+                                       "avg_launch_us": (1e3 * wms / wn) if wn else None,
+                                       "kernel_ms_per_step": wms / args.profile_steps}}
+
+    if rank == 0:
+        images_per_step = 2 * B * world
+        ms_per_step = 1e3 * elapsed / args.steps
+        out = {"metric": "training images/sec, 640x480 D=3 ResNet34-8s" if args.workload in ("config1", "config2", "config4")
+               else "training images/sec (%s)" % args.workload,
+               "value": images_per_step * args.steps / elapsed, "unit": "images/s", "n_gpus": world,
+               "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
+               "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+               "config": {"workload": wl["desc"], "pairs_per_gpu": B, "images_per_step": images_per_step,
+                          "image": "%dx%d" % (W, H), "descriptor_dim": D, "backbone": wl["backbone"],
+                          "pixel_pairs_per_image_pair": [wl["Pm"], wl["Pk"], wl["Pg"]],
+                          "optimizer": "Adam lr 1e-4 wd 1e-4", "parallelism": "dp%d" % world,
+                          "library": info["version"], "final_loss": final_loss,
+                          "train_gflop_per_image": 3 * bb.get_plan(wl["backbone"], 64, B, H, W, D).forward_flops / B / 1e9},
+               "roofline": roofline}
+        if world == 1 and args.cpu_baseline_steps > 0:
+            out["cpu_baseline"] = cpu_baseline(wl, args.cpu_baseline_steps, 1)
+        else:
+            out["cpu_baseline"] = None
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

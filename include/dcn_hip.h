@@ -67,7 +67,10 @@ enum { DCN_LIST_MATCH = 0, DCN_LIST_MASKED = 1, DCN_LIST_BACKGROUND = 2, DCN_LIS
 enum {
     DCN_COMPOSE_WITHIN_SCENE = 0,     /* loss_composer.py:70-143  (also MULTI_OBJECT / SYNTHETIC_MULTI_OBJECT) */
     DCN_COMPOSE_DIFFERENT_OBJECT = 1, /* loss_composer.py:168-191 blind list only, margin M_background */
-    DCN_COMPOSE_ACROSS_SCENE = 2      /* loss_composer.py:193-212 blind list only, inverted hinge, margin M_masked */
+    DCN_COMPOSE_ACROSS_SCENE = 2,     /* loss_composer.py:193-212 blind list only, inverted hinge, margin M_masked */
+    DCN_COMPOSE_RAW_SUMS = 3          /* loss = match_weight * S_match + non_match_weight * (S_masked + S_background + S_blind):
+                                         the un-normalised sums the PixelwiseContrastiveLoss building blocks return
+                                         (pixelwise_contrastive_loss.py:271-304) */
 };
 
 typedef struct dcn_loss_config {
@@ -163,6 +166,16 @@ double dcn_plan_forward_flops(const dcn_plan* plan);   /* algorithmic conv FLOPs
 int dcn_backbone_forward(dcn_plan* plan, const float* image, const float* const* params,
                          float* const* bn_running, float momentum, float eps, int training, int normalize,
                          float* descriptors, void* saved, void* workspace, void* stream);
+
+/*
+ * Launch-level timing of the two matrix-core kernels (for bench.py's roofline): between begin and end every
+ * conv_gemm_kernel (forward + dgrad; category 0) and conv_wgrad_kernel (category 1) launch made through this
+ * plan is bracketed by hipEventRecord on the caller's stream.  `end` synchronises on the recorded events and
+ * returns, per category, the summed kernel milliseconds, the number of launches and the algorithmic FLOPs
+ * (2 * MACs of the convolution being computed, padding not counted).
+ */
+int dcn_plan_profile_begin(dcn_plan* plan);
+int dcn_plan_profile_end(dcn_plan* plan, double ms[2], int64_t launches[2], double flops[2]);
 
 /* Backward.  grad_descriptors: [N,H,W,D]; grads[i] receives dL/d params[i] (overwritten, same layout as
  * params[i]).  `saved` is the buffer the matching forward filled. */

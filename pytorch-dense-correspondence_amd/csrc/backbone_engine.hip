@@ -25,6 +25,7 @@ namespace {
 using dcn::ceil_div;
 
 struct ConvL {
+    double flops = 0;  // algorithmic 2*MAC of the forward convolution
     dcn_conv_desc d;   // as executed (stem: cin padded 3 -> 4)
     int w = -1, b = -1;  // parameter indices
     int bn = -1;
@@ -73,6 +74,12 @@ struct dcn_plan {
            w_low = 0, w_glow = 0, w_ups = 0, ws_floats = 0;
     size_t max_act = 0;
     double flops = 0;
+    // optional launch-level timing (dcn_plan_profile_begin/end)
+    bool prof_on = false;
+    std::vector<hipEvent_t> prof_ev;   // start/stop pairs
+    std::vector<int> prof_cat;
+    std::vector<double> prof_flops;
+    size_t prof_used = 0;
 };
 
 namespace {
@@ -115,7 +122,8 @@ struct Builder {
         if (bias) c.b = add_param(name + ".bias", {cout});
         const int64_t M = (int64_t)n * c.d.hout * c.d.wout;
         c.mtiles = (int)((M + 127) / 128);
-        p.flops += 2.0 * (double)M * cout * (double)(k * k * cin);
+        c.flops = 2.0 * (double)M * cout * (double)(k * k * cin);
+        p.flops += c.flops;
         p.convs.push_back(c);
         return (int)p.convs.size() - 1;
     }
@@ -294,6 +302,25 @@ struct Run {
     float* ws;
     hipStream_t st;
 
+    // bracket one matrix-core launch with events when profiling is on
+    template <class F> int timed(int cat, double flops, F&& launch) {
+        if (!p.prof_on) return launch();
+        if (p.prof_used + 2 > p.prof_ev.size()) {
+            hipEvent_t a, b;
+            if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) return DCN_E_LAUNCH;
+            p.prof_ev.push_back(a);
+            p.prof_ev.push_back(b);
+        }
+        hipEvent_t e0 = p.prof_ev[p.prof_used], e1 = p.prof_ev[p.prof_used + 1];
+        p.prof_used += 2;
+        p.prof_cat.push_back(cat);
+        p.prof_flops.push_back(flops);
+        hipEventRecord(e0, st);
+        const int rc = launch();
+        hipEventRecord(e1, st);
+        return rc;
+    }
+
     float* S(size_t off) const { return saved + off; }
     float* Wk(size_t off) const { return ws + off; }
     const float* P(int i) const { return params[i]; }
@@ -302,7 +329,7 @@ struct Run {
     int conv_bn(const ConvL& c, const float* in, const float* w, float* const* bn_running, float momentum, float eps,
                 int training) {
         float* part = training ? Wk(p.w_part) : nullptr;
-        DCN_TRY(dcn_conv_forward(&c.d, in, w, nullptr, S(c.x), part, st));
+        DCN_TRY(timed(0, c.flops, [&] { return dcn_conv_forward(&c.d, in, w, nullptr, S(c.x), part, st); }));
         const BnL& b = p.bns[c.bn];
         float* stats = S(b.stats);
         float* rm = bn_running ? bn_running[2 * b.idx] : nullptr;
@@ -326,7 +353,38 @@ extern "C" int dcn_plan_create(const char* arch, int base_width, int n, int h, i
     *out = p;
     return DCN_OK;
 }
-extern "C" void dcn_plan_destroy(dcn_plan* plan) { delete plan; }
+extern "C" void dcn_plan_destroy(dcn_plan* plan) {
+    if (!plan) return;
+    for (hipEvent_t e : plan->prof_ev) hipEventDestroy(e);
+    delete plan;
+}
+extern "C" int dcn_plan_profile_begin(dcn_plan* plan) {
+    if (!plan) return DCN_E_INVALID;
+    plan->prof_on = true;
+    plan->prof_used = 0;
+    plan->prof_cat.clear();
+    plan->prof_flops.clear();
+    return DCN_OK;
+}
+extern "C" int dcn_plan_profile_end(dcn_plan* plan, double ms[2], int64_t launches[2], double flops[2]) {
+    if (!plan || !ms || !launches || !flops) return DCN_E_INVALID;
+    plan->prof_on = false;
+    for (int c = 0; c < 2; ++c) { ms[c] = 0; launches[c] = 0; flops[c] = 0; }
+    for (size_t i = 0; i < plan->prof_cat.size(); ++i) {
+        hipEvent_t e0 = plan->prof_ev[2 * i], e1 = plan->prof_ev[2 * i + 1];
+        if (hipEventSynchronize(e1) != hipSuccess) return DCN_E_LAUNCH;
+        float t = 0.f;
+        if (hipEventElapsedTime(&t, e0, e1) != hipSuccess) return DCN_E_LAUNCH;
+        const int c = plan->prof_cat[i];
+        ms[c] += (double)t;
+        launches[c] += 1;
+        flops[c] += plan->prof_flops[i];
+    }
+    plan->prof_used = 0;
+    plan->prof_cat.clear();
+    plan->prof_flops.clear();
+    return DCN_OK;
+}
 extern "C" int dcn_plan_num_params(const dcn_plan* plan) { return plan ? (int)plan->params.size() : DCN_E_INVALID; }
 extern "C" int dcn_plan_num_bn(const dcn_plan* plan) { return plan ? (int)plan->bns.size() : DCN_E_INVALID; }
 extern "C" int dcn_plan_param_info(const dcn_plan* plan, int i, char* name, int name_cap, int64_t shape[4], int* ndim) {
@@ -398,7 +456,9 @@ extern "C" int dcn_backbone_forward(dcn_plan* plan, const float* image, const fl
     const ConvL& fc = p.convs[p.fc];
     const size_t low_bytes = (size_t)N * p.hl * p.wl * p.Dp * sizeof(float);
     if (hipMemsetAsync(R.Wk(p.w_low), 0, low_bytes, st) != hipSuccess) return DCN_E_LAUNCH;
-    DCN_TRY(dcn_conv_forward(&fc.d, R.S(p.blocks.back().out), R.P(fc.w), R.P(fc.b), R.Wk(p.w_low), nullptr, st));
+    DCN_TRY(R.timed(0, fc.flops, [&] {
+        return dcn_conv_forward(&fc.d, R.S(p.blocks.back().out), R.P(fc.w), R.P(fc.b), R.Wk(p.w_low), nullptr, st);
+    }));
     dcn::launch_upsample_fwd(R.Wk(p.w_low), N, p.hl, p.wl, p.Dp, p.D, p.H, p.W, normalize, descriptors, st);
     return dcn::check_launch();
 }
@@ -423,11 +483,11 @@ extern "C" int dcn_backbone_backward(dcn_plan* plan, const float* grad_descripto
                            grads[b.b], k123, dx, g_out, st);
     };
     auto wgrad = [&](const ConvL& c, const float* in, const float* dx, float* dw) -> int {
-        return dcn_conv_wgrad(&c.d, in, dx, dw, slab, st);
+        return R.timed(1, c.flops, [&] { return dcn_conv_wgrad(&c.d, in, dx, dw, slab, st); });
     };
     auto dgrad = [&](const ConvL& c, const float* dx, const float* add, float* din) -> int {
         DCN_TRY(dcn_transpose_weight(R.P(c.w), wt, c.d.cout, c.d.kh * c.d.kw, c.d.cin, c.d.ldc, st));
-        return dcn_conv_dgrad(&c.d, dx, wt, add, din, st);
+        return R.timed(0, c.flops, [&] { return dcn_conv_dgrad(&c.d, dx, wt, add, din, st); });
     };
 
     // ---- upsample + scoring layer

@@ -136,6 +136,10 @@ __device__ __forceinline__ PairScales pair_scales(const dcn_loss_config& cfg, co
             scale = (len[1] > 1 ? len[1] : 1) + (len[2] > 1 ? len[2] : 1);
         }
         s.nonmatch_coef = cfg.non_match_loss_weight * (float)(1.0 / (double)scale);
+    } else if (cfg.compose == DCN_COMPOSE_RAW_SUMS) {
+        s.match_coef = cfg.match_loss_weight;
+        s.nonmatch_coef = cfg.non_match_loss_weight;
+        s.blind_coef = cfg.non_match_loss_weight;
     } else {
         int64_t scale = cfg.scale_by_hard_negatives ? (int64_t)h[3] : len[3];
         if (scale < 1) scale = 1;
@@ -187,6 +191,9 @@ loss_finalize_kernel(const double* __restrict__ part_sum, const int* __restrict_
                 out[3] = Sg / (float)dg;
                 out[4] = Sb / (float)db;
                 out[0] = cfg.match_loss_weight * match_loss + sc.nonmatch_coef * (Sk + Sg);
+            } else if (cfg.compose == DCN_COMPOSE_RAW_SUMS) {
+                out[1] = (float)s_S[0]; out[2] = (float)s_S[1]; out[3] = (float)s_S[2]; out[4] = (float)s_S[3];
+                out[0] = sc.match_coef * out[1] + sc.nonmatch_coef * (out[2] + out[3] + out[4]);
             } else {
                 const float Sb = (float)s_S[3];
                 out[0] = sc.blind_coef * Sb;

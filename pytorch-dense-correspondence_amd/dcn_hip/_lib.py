@@ -9,6 +9,7 @@ DEFAULT_PATH = os.path.join(HERE, "libdcn_hip.so")
 
 _lib = None
 _info = {"path": None, "version": None, "hostemu": False}
+_reset_hooks = []  # callables run when a different library is loaded (drops cached plan handles)
 
 c_void_p, c_int, c_int64, c_size_t, c_float, c_char_p = (ctypes.c_void_p, ctypes.c_int, ctypes.c_int64,
                                                          ctypes.c_size_t, ctypes.c_float, ctypes.c_char_p)
@@ -47,6 +48,9 @@ SYMBOLS = {
     "dcn_plan_saved_bytes": (c_size_t, [c_void_p]),
     "dcn_plan_workspace_bytes": (c_size_t, [c_void_p]),
     "dcn_plan_forward_flops": (ctypes.c_double, [c_void_p]),
+    "dcn_plan_profile_begin": (c_int, [c_void_p]),
+    "dcn_plan_profile_end": (c_int, [c_void_p, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(c_int64),
+                                     ctypes.POINTER(ctypes.c_double)]),
     "dcn_backbone_forward": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_float, c_int, c_int, c_void_p,
                                      c_void_p, c_void_p, c_void_p]),
     "dcn_backbone_backward": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
@@ -83,6 +87,8 @@ def load(path=None):
         fn.restype = res
         fn.argtypes = args
     ver = lib.dcn_version().decode()
+    for hook in _reset_hooks:
+        hook()
     _lib = lib
     _info.update(path=p, version=ver, hostemu=("hostemu" in ver))
     return _lib

@@ -45,7 +45,18 @@ class Plan(object):
         self.param_numel = [int(torch.Size(s).numel()) for s in self.param_shapes]
         self.grad_offsets = [0]
         for nmel in self.param_numel:
-            self.grad_offsets.append(self.grad_offsets[-1] + nmel)
+            self.grad_offsets.append((self.grad_offsets[-1] + nmel + 3) // 4 * 4)  # keep every gradient 16-B aligned
+
+    def profile_begin(self):
+        _lib.check(_lib.get().dcn_plan_profile_begin(self.handle), "dcn_plan_profile_begin")
+
+    def profile_end(self):
+        """-> {"conv_gemm": (ms, launches, flops), "conv_wgrad": (...)} since profile_begin (synchronises)."""
+        ms = (ctypes.c_double * 2)()
+        n = (ctypes.c_int64 * 2)()
+        fl = (ctypes.c_double * 2)()
+        _lib.check(_lib.get().dcn_plan_profile_end(self.handle, ms, n, fl), "dcn_plan_profile_end")
+        return {"conv_gemm": (ms[0], int(n[0]), fl[0]), "conv_wgrad": (ms[1], int(n[1]), fl[1])}
 
     def __del__(self):
         try:
@@ -55,6 +66,7 @@ class Plan(object):
 
 
 _PLANS = {}
+_lib._reset_hooks.append(_PLANS.clear)
 
 
 def get_plan(arch, base_width, n, h, w, d):
@@ -75,7 +87,7 @@ def _kernel_layout(p):
 def _grad_views(flat, plan):
     views = []
     for i, shape in enumerate(plan.param_shapes):
-        v = flat[plan.grad_offsets[i]:plan.grad_offsets[i + 1]]
+        v = flat[plan.grad_offsets[i]:plan.grad_offsets[i] + plan.param_numel[i]]
         if len(shape) == 4:
             o, c, kh, kw = shape
             v = v.view(o, kh, kw, c).permute(0, 3, 1, 2)

@@ -11,7 +11,7 @@ import torch
 from . import _lib
 
 LIST_MATCH, LIST_MASKED, LIST_BACKGROUND, LIST_BLIND = 0, 1, 2, 3
-COMPOSE_WITHIN_SCENE, COMPOSE_DIFFERENT_OBJECT, COMPOSE_ACROSS_SCENE = 0, 1, 2
+COMPOSE_WITHIN_SCENE, COMPOSE_DIFFERENT_OBJECT, COMPOSE_ACROSS_SCENE, COMPOSE_RAW_SUMS = 0, 1, 2, 3
 
 
 def _is_host_sentinel(t):

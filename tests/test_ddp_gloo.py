@@ -1,0 +1,88 @@
+"""Multi-GPU path on CPU: world_size 2, gloo.  Every rank runs the step on its own image pairs (kernels
+host-emulated), FlatGradients averages with one all-reduce; the result must equal the oracle run per shard with
+averaged gradients (BN statistics are per rank, no SyncBN)."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from helpers import rel_err
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HIPEMU_THREADS="2")
+    torch.set_num_threads(2)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from helpers import use_emulation_library
+    use_emulation_library()
+    from dcn_hip.distributed import FlatGradients, broadcast_module
+    from dense_correspondence.loss_functions import loss_composer
+    from dense_correspondence.loss_functions.pixelwise_contrastive_loss import PixelwiseContrastiveLoss
+    from oracle import resnet_dilated_oracle as orc, step as ostep, synth
+    from pytorch_segmentation_detection.models import resnet_dilated as prod
+    H, W, D, B = 32, 32, 3, 1
+    torch.manual_seed(100 + rank)  # different init per rank: the broadcast must fix that
+    m = prod.Resnet18_8s(num_classes=D, base_width=8)
+    if rank == 0:
+        m.load_state_dict(orc.build("Resnet18_8s", D, seed=0, base_width=8).state_dict())
+    broadcast_module(m, src=0)
+    grads = FlatGradients(m)
+    m.train()
+    img_a, img_b, lists = synth.make_batch(B, H, W, 40, 20, 20, seed=1 + rank)
+    pcl = PixelwiseContrastiveLoss([H, W], synth.LOSS_CONFIG)
+    grads.zero_()
+    pa = m(img_a).permute(0, 2, 3, 1).reshape(B, H * W, D)
+    pb = m(img_b).permute(0, 2, 3, 1).reshape(B, H * W, D)
+    L = lists[0]
+    tup = [(L["matches_a"], L["matches_b"], L["masked_non_matches_a"], L["masked_non_matches_b"],
+            L["background_non_matches_a"], L["background_non_matches_b"], L["blind_non_matches_a"],
+            L["blind_non_matches_b"])]
+    loss, _, _ = loss_composer.get_loss_batched(pcl, 0, pa, pb, tup)
+    loss.backward()
+    grads.all_reduce_mean()
+    # oracle: both shards on this rank, averaged
+    ref = None
+    for r in range(world):
+        o = orc.build("Resnet18_8s", D, seed=0, base_width=8)
+        o.train()
+        ia, ib, ls = synth.make_batch(B, H, W, 40, 20, 20, seed=1 + r)
+        lo = ostep.forward_loss(o, ia, ib, ls, synth.LOSS_CONFIG)[0]
+        lo.backward()
+        g = torch.cat([p.grad.reshape(-1) for p in o.parameters()])
+        ref = g if ref is None else ref + g
+    ref = ref / world
+    mine = torch.cat([p.grad.contiguous().reshape(-1) for p in m.parameters()])
+    gathered = [torch.zeros_like(mine) for _ in range(world)]
+    dist.all_gather(gathered, mine)
+    q.put((rank, rel_err(mine, ref), float((gathered[0] - gathered[1]).abs().max()),
+           all(p.grad.data_ptr() >= grads.flat.data_ptr() for p in m.parameters())))
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+def test_two_rank_gradient_average_matches_oracle():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=540) for _ in procs]
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    for rank, err, spread, views in res:
+        assert err < 5e-4, (rank, err)
+        assert spread == 0.0, "ranks disagree after the all-reduce"
+        assert views

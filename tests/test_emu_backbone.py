@@ -1,0 +1,92 @@
+"""The whole backbone engine (plan -> forward -> backward; every kernel, through the C ABI, host-emulated)
+against the oracle on narrow networks.  The oracle itself is float32, so the yard-stick is a float64 copy of
+it: the engine must be as close to the float64 truth as the float32 oracle is (x3 + 1e-5)."""
+import copy
+
+import pytest
+import torch
+
+from helpers import rel_err, use_emulation_library
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _lib():
+    return use_emulation_library()
+
+
+def _pair(arch, D, bw, seed=0):
+    from oracle import resnet_dilated_oracle as orc
+    from pytorch_segmentation_detection.models import resnet_dilated as prod
+    o = orc.build(arch, D, seed=seed, base_width=bw)
+    m = getattr(prod, arch)(num_classes=D, base_width=bw)
+    m.load_state_dict(o.state_dict(), strict=True)
+    return m, o
+
+
+@pytest.mark.parametrize("arch,bw,shape,D", [
+    ("Resnet18_8s", 8, (2, 32, 40), 3),
+    ("Resnet34_8s", 8, (2, 32, 40), 3),
+    ("Resnet34_8s", 16, (1, 40, 24), 16),
+    ("Resnet50_8s", 8, (2, 32, 40), 5),
+])
+def test_forward_backward_vs_oracle(arch, bw, shape, D):
+    N, H, W = shape
+    m, o = _pair(arch, D, bw)
+    o64 = copy.deepcopy(o).double()
+    g = torch.Generator().manual_seed(11)
+    x = torch.randn(N, 3, H, W, generator=g)
+    gy = torch.randn(N, D, H, W, generator=g)
+    m.train(); o.train(); o64.train()
+    y = m(x)
+    assert y.shape == (N, D, H, W) and y.is_contiguous(memory_format=torch.channels_last)
+    yo, y64 = o(x), o64(x.double())
+    tol = 3 * rel_err(yo, y64) + 1e-5
+    assert rel_err(y, y64) < tol, (rel_err(y, y64), tol)
+    (y * gy).sum().backward(); (yo * gy).sum().backward(); (y64 * gy.double()).sum().backward()
+    for (k, p), (_, po), (_, p6) in zip(m.named_parameters(), o.named_parameters(), o64.named_parameters()):
+        tol = 3 * rel_err(po.grad, p6.grad) + 2e-5
+        assert rel_err(p.grad, p6.grad) < tol, (k, rel_err(p.grad, p6.grad), tol)
+    # BN running statistics / counters follow nn.BatchNorm2d
+    for (k, b), (_, bo) in zip(m.named_buffers(), o.named_buffers()):
+        assert rel_err(b.float(), bo.float()) < 1e-4 or float((b.float() - bo.float()).abs().max()) < 1e-5, k
+
+
+def test_real_width_resnet34_small_image():
+    """The real Resnet34_8s (base width 64, 21.3 M parameters): exercises full 128x128 tiles, multiple N tiles,
+    K = 4608 reductions and the split-K wgrad path."""
+    m, o = _pair("Resnet34_8s", 3, 64)
+    assert sum(p.numel() for p in m.parameters()) == 21286211
+    assert list(m.state_dict().keys()) == list(o.state_dict().keys())
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(1, 3, 32, 32, generator=g)
+    gy = torch.randn(1, 3, 32, 32, generator=g)
+    m.train(); o.train()
+    y, yo = m(x), o(x)
+    assert rel_err(y, yo) < 1e-4
+    (y * gy).sum().backward(); (yo * gy).sum().backward()
+    worst = max(rel_err(p.grad, po.grad) for p, po in zip(m.parameters(), o.parameters()))
+    assert worst < 2e-3, worst   # 16 output pixels per BN: ill-conditioned, the float32 oracle is no better
+
+
+def test_eval_mode_uses_running_statistics():
+    m, o = _pair("Resnet18_8s", 3, 8)
+    g = torch.Generator().manual_seed(2)
+    x = torch.randn(2, 3, 32, 32, generator=g)
+    m.train(); o.train()
+    with torch.no_grad():
+        for _ in range(2):
+            m(x); o(x)
+    m.eval(); o.eval()
+    with torch.no_grad():
+        assert rel_err(m(x), o(x)) < 2e-5
+    assert int(m.resnet18_8s.bn1.num_batches_tracked) == 2
+
+
+def test_container_nodes_refuse_to_run_and_cpu_guard():
+    from dcn_hip import _lib
+    m, _ = _pair("Resnet18_8s", 3, 8)
+    with pytest.raises(RuntimeError):
+        m.resnet18_8s.layer1(torch.zeros(1))
+    with pytest.raises(ValueError):
+        m(torch.zeros(1, 4, 32, 32))
+    assert _lib.is_hostemu()   # (the shipped library rejects CPU tensors: see test_abi.py)

@@ -1,0 +1,117 @@
+"""Individual gfx950 kernels through the C ABI (kernels compiled for the host, tests/hostemu) against plain
+PyTorch fp32 on CPU: fp32-MFMA implicit-GEMM convolution (forward / dgrad / wgrad incl. the fused BN partial
+sums), bilinear upsample and its backward.  The MFMA fragment maps, LDS images and index arithmetic executed
+here are the ones that run on the GPU."""
+import ctypes
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+from helpers import rel_err, use_emulation_library
+
+
+@pytest.fixture(scope="module")
+def L():
+    return use_emulation_library()
+
+
+CONV_CASES = [
+    # n, hin, win, cin, cout, k, stride, pad, dil
+    (1, 8, 10, 8, 16, 3, 1, 1, 1),
+    (2, 9, 7, 4, 12, 7, 2, 3, 1),       # stem-like: cin padded to 4, K = 196 (ragged K tile)
+    (1, 12, 10, 16, 24, 3, 2, 1, 1),    # layer2.0.conv1-like stride 2 (transposed-gather dgrad)
+    (1, 12, 10, 16, 24, 1, 2, 0, 1),    # 1x1 / 2 downsample
+    (1, 10, 12, 20, 136, 3, 1, 2, 2),   # dilation 2, two N tiles, ragged channels
+    (2, 9, 9, 32, 8, 3, 1, 4, 4),       # dilation 4 with halo larger than the image border
+    (3, 7, 7, 8, 8, 3, 1, 1, 1),        # M = 147 rows: two M tiles, second one ragged
+]
+
+
+@pytest.mark.parametrize("case", CONV_CASES, ids=[str(c) for c in CONV_CASES])
+def test_conv_forward_dgrad_wgrad(L, case):
+    lib = L.get()
+    n, hin, win, cin, cout, k, stride, pad, dil = case
+    hout = (hin + 2 * pad - dil * (k - 1) - 1) // stride + 1
+    wout = (win + 2 * pad - dil * (k - 1) - 1) // stride + 1
+    d = L.ConvDesc(n, hin, win, cin, hout, wout, cout, k, k, stride, pad, dil, cout)
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(n, cin, hin, win, generator=g, requires_grad=True)
+    w = (torch.randn(cout, cin, k, k, generator=g) * 0.1).requires_grad_(True)
+    x_nhwc = x.detach().permute(0, 2, 3, 1).contiguous()
+    w_k = w.detach().permute(0, 2, 3, 1).contiguous()
+    out = torch.full((n, hout, wout, cout), float("nan"))
+    mt = lib.dcn_conv_num_mtiles(ctypes.byref(d))
+    assert mt == (n * hout * wout + 127) // 128
+    part = torch.full((mt, 2, cout), float("nan"))
+    assert lib.dcn_conv_forward(ctypes.byref(d), L.ptr(x_nhwc), L.ptr(w_k), None, L.ptr(out), L.ptr(part), None) == 0
+    ref = F.conv2d(x, w, None, stride, pad, dil)
+    refn = ref.detach().permute(0, 2, 3, 1)
+    assert rel_err(out, refn) < 2e-6
+    assert rel_err(part.sum(0)[0], refn.sum((0, 1, 2))) < 5e-6
+    assert rel_err(part.sum(0)[1], (refn ** 2).sum((0, 1, 2))) < 5e-6
+    dout = torch.randn(n, hout, wout, cout, generator=g)
+    ref.backward(dout.permute(0, 3, 1, 2))
+    wt = torch.empty(cin, k * k, cout)
+    assert lib.dcn_transpose_weight(L.ptr(w_k), L.ptr(wt), cout, k * k, cin, cout, None) == 0
+    assert torch.equal(wt, w_k.reshape(cout, k * k, cin).permute(2, 1, 0))
+    add = torch.randn(n, hin, win, cin, generator=g)
+    din = torch.full((n, hin, win, cin), float("nan"))
+    assert lib.dcn_conv_dgrad(ctypes.byref(d), L.ptr(dout), L.ptr(wt), L.ptr(add), L.ptr(din), None) == 0
+    assert rel_err(din, x.grad.permute(0, 2, 3, 1) + add) < 3e-6
+    dw = torch.full((cout, k, k, cin), float("nan"))
+    slab = torch.empty(max(lib.dcn_conv_wgrad_workspace(ctypes.byref(d)), 4) // 4)
+    assert lib.dcn_conv_wgrad(ctypes.byref(d), L.ptr(x_nhwc), L.ptr(dout), L.ptr(dw), L.ptr(slab), None) == 0
+    assert rel_err(dw, w.grad.permute(0, 2, 3, 1)) < 3e-6
+
+
+def test_conv_scoring_layer_shape(L):
+    """fc: 1x1 conv to D=3 channels with bias, output rows padded to 4 floats (what the upsample kernel reads)."""
+    lib = L.get()
+    n, h, w_, cin, D, ld = 1, 13, 17, 64, 3, 4
+    d = L.ConvDesc(n, h, w_, cin, h, w_, D, 1, 1, 1, 0, 1, ld)
+    g = torch.Generator().manual_seed(1)
+    x = torch.randn(n, cin, h, w_, generator=g)
+    w = torch.randn(D, cin, 1, 1, generator=g) * 0.1
+    b = torch.randn(D, generator=g)
+    out = torch.zeros(n, h, w_, ld)
+    assert lib.dcn_conv_forward(ctypes.byref(d), L.ptr(x.permute(0, 2, 3, 1).contiguous()),
+                                L.ptr(w.permute(0, 2, 3, 1).contiguous()), L.ptr(b), L.ptr(out), None, None) == 0
+    assert rel_err(out[..., :D], F.conv2d(x, w, b).permute(0, 2, 3, 1)) < 2e-6
+    assert float(out[..., D:].abs().max()) == 0.0
+
+
+def test_conv_rejects_bad_arguments(L):
+    lib = L.get()
+    d = L.ConvDesc(1, 8, 8, 6, 8, 8, 8, 3, 3, 1, 1, 1, 8)   # cin not a multiple of 4
+    t = torch.zeros(4096)
+    assert lib.dcn_conv_forward(ctypes.byref(d), L.ptr(t), L.ptr(t), None, L.ptr(t), None, None) == -1
+    d = L.ConvDesc(1, 8, 8, 8, 8, 8, 8, 3, 3, 1, 1, 1, 8)
+    assert lib.dcn_conv_forward(ctypes.byref(d), None, L.ptr(t), None, L.ptr(t), None, None) == -1
+
+
+@pytest.mark.parametrize("shape", [(2, 4, 5, 3, 32, 40), (1, 3, 3, 16, 24, 24), (1, 6, 8, 5, 41, 59)])
+def test_upsample_forward_backward(L, shape):
+    lib = L.get()
+    n, hl, wl, D, H, W = shape
+    ld = (D + 3) // 4 * 4
+    g = torch.Generator().manual_seed(2)
+    low = torch.randn(n, D, hl, wl, generator=g, requires_grad=True)
+    lowp = torch.zeros(n, hl, wl, ld)
+    lowp[..., :D] = low.detach().permute(0, 2, 3, 1)
+    out = torch.empty(n, H, W, D)
+    assert lib.dcn_upsample_forward(L.ptr(lowp), n, hl, wl, ld, D, H, W, 0, L.ptr(out), None) == 0
+    ref = F.interpolate(low, size=(H, W), mode="bilinear", align_corners=True)
+    assert rel_err(out, ref.detach().permute(0, 2, 3, 1)) < 2e-6
+    gout = torch.randn(n, H, W, D, generator=g)
+    ref.backward(gout.permute(0, 3, 1, 2))
+    glow = torch.full((n, hl, wl, ld), float("nan"))
+    tmp = torch.empty(lib.dcn_upsample_backward_tmp_bytes(n, hl, W, D) // 4)
+    assert lib.dcn_upsample_backward(L.ptr(gout), n, hl, wl, ld, D, H, W, L.ptr(glow), L.ptr(tmp), None) == 0
+    assert rel_err(glow[..., :D], low.grad.permute(0, 2, 3, 1)) < 3e-6
+    assert float(glow[..., D:].abs().sum()) == 0.0
+    # K10: fused per-pixel L2 normalisation (network.py:256-259)
+    outn = torch.empty(n, H, W, D)
+    assert lib.dcn_upsample_forward(L.ptr(lowp), n, hl, wl, ld, D, H, W, 1, L.ptr(outn), None) == 0
+    r = ref.detach()
+    assert rel_err(outn, (r / r.norm(2, 1, keepdim=True)).permute(0, 2, 3, 1)) < 3e-6

@@ -1,0 +1,151 @@
+"""Loss kernels (K9) through the C ABI -- kernels compiled for the host (tests/hostemu) -- against
+(1) the golden vectors produced by the reference's own source and (2) the oracle on seeded inputs.
+CPU only; the same checks run on the real gfx950 build in test_gpu_parity.py."""
+import glob
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from helpers import lists_from_golden, load_golden_loss, rel_err, use_emulation_library
+
+GOLDENS = sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "loss_ref_*.npz")))
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _lib():
+    return use_emulation_library()
+
+
+@pytest.mark.parametrize("path", GOLDENS, ids=[os.path.basename(p)[9:-4] for p in GOLDENS])
+def test_composer_matches_reference_goldens(path):
+    from dense_correspondence.loss_functions import loss_composer
+    from dense_correspondence.loss_functions.pixelwise_contrastive_loss import PixelwiseContrastiveLoss
+    z, cfg = load_golden_loss(path)
+    A = torch.tensor(z["A"], requires_grad=True)
+    B = torch.tensor(z["B"], requires_grad=True)
+    pcl = PixelwiseContrastiveLoss([int(z["H"]), int(z["W"])], cfg)
+    out = loss_composer.get_loss(pcl, torch.tensor([int(z["match_type"])]), A, B, *lists_from_golden(z))
+    got = np.array([float(o.sum().item()) for o in out])
+    np.testing.assert_allclose(got, z["out"], rtol=2e-6, atol=1e-9)   # tolerance 1e-4 required; we hold 2e-6
+    out[0].backward()
+    assert rel_err(A.grad, z["gradA"]) < 1e-5 and rel_err(B.grad, z["gradB"]) < 1e-5
+
+
+def test_building_blocks_match_reference_goldens():
+    """F6 / F7 / F8 called one by one, as pcl.py exposes them."""
+    from dense_correspondence.loss_functions.pixelwise_contrastive_loss import PixelwiseContrastiveLoss as PCL
+    z, cfg = load_golden_loss([p for p in GOLDENS if p.endswith("within_d16.npz")][0])
+    A = torch.tensor(z["A"], requires_grad=True)
+    B = torch.tensor(z["B"])
+    ma, mb, ka, kb = [torch.tensor(z[k]) for k in ("matches_a", "matches_b", "masked_a", "masked_b")]
+    ml, da, db = PCL.match_loss(A, B, ma, mb)
+    np.testing.assert_allclose(ml.item(), z["f6_match_loss"], rtol=2e-6)
+    assert da.shape == (1, len(ma), 16)
+    vec, hn, _, _ = PCL.non_match_descriptor_loss(A, B, ka, kb, M=cfg["M_masked"])
+    np.testing.assert_allclose(vec.detach().numpy(), z["f7_vec"], rtol=1e-5, atol=1e-8)  # (M - d)^2 near the margin amplifies 1-ulp differences of d
+    assert hn == int(z["f7_hard"])
+    veci, hni, _, _ = PCL.non_match_descriptor_loss(A, B, ka, kb, M=cfg["M_masked"], invert=True)
+    np.testing.assert_allclose(veci.detach().numpy(), z["f7_vec_invert"], rtol=1e-5, atol=1e-8)
+    assert hni == int(z["f7_hard_invert"])
+    # the vector is differentiable, like the reference's
+    w = torch.linspace(0.5, 1.5, len(ka))
+    (vec * w).sum().backward()
+    A2 = torch.tensor(z["A"], requires_grad=True)
+    from oracle import loss_oracle
+    v2, _, _, _ = loss_oracle.PixelwiseContrastiveLoss.non_match_descriptor_loss(A2, B, ka, kb, M=cfg["M_masked"])
+    (v2 * w).sum().backward()
+    assert rel_err(A.grad, A2.grad) < 1e-5
+    pcl = PCL([int(z["H"]), int(z["W"])], cfg)
+    s, h = pcl.non_match_loss_descriptor_only(A, B, ka, kb, M_descriptor=cfg["M_masked"])
+    np.testing.assert_allclose(s.item(), z["f7_vec"].sum(), rtol=2e-6)
+    assert h == int(z["f7_hard"])
+    trip = PCL.get_triplet_loss(A, B, ma, mb, torch.tensor(z["triplet_non_matches_a"]), kb, cfg["alpha_triplet"])
+    np.testing.assert_allclose(trip.item(), z["triplet"], rtol=1e-6)
+    orig = pcl.get_loss_original(A, B, ma, mb, ka, kb)
+    np.testing.assert_allclose([o.item() for o in orig], z["original_loss"], rtol=1e-6)
+
+
+def test_batched_ragged_lists_vs_oracle():
+    """B = 3 pairs with different list lengths, an empty background list, duplicates, a device-side sentinel."""
+    from dense_correspondence.loss_functions import loss_composer
+    from dense_correspondence.loss_functions.pixelwise_contrastive_loss import PixelwiseContrastiveLoss
+    from oracle import loss_oracle, synth
+    H, W, D, B = 24, 32, 5, 3
+    g = torch.Generator().manual_seed(7)
+    A = ((torch.rand(B, H * W, D, generator=g) * 2 - 1) * 0.3).requires_grad_(True)
+    Bt = ((torch.rand(B, H * W, D, generator=g) * 2 - 1) * 0.3).requires_grad_(True)
+    sizes = [(50, 1100, 70), (1, 3, 2), (2049, 5, 1025)]   # crosses the 1024-pairs-per-workgroup chunk boundary
+    lists = []
+    for pm, pk, pg in sizes:
+        L = synth.make_index_lists(1, H * W, pm, pk, pg, g)[0]
+        lists.append((L["matches_a"], L["matches_b"], L["masked_non_matches_a"], L["masked_non_matches_b"],
+                      L["background_non_matches_a"], L["background_non_matches_b"],
+                      L["blind_non_matches_a"], L["blind_non_matches_b"]))
+    pcl = PixelwiseContrastiveLoss([H, W], synth.LOSS_CONFIG)
+    loss, terms, hard = loss_composer.get_loss_batched(pcl, 0, A, Bt, lists)
+    loss.backward()
+    A2 = A.detach().clone().requires_grad_(True)
+    B2 = Bt.detach().clone().requires_grad_(True)
+    opcl = loss_oracle.PixelwiseContrastiveLoss([H, W], synth.LOSS_CONFIG)
+    tot = 0
+    for b in range(B):
+        out = loss_oracle.get_loss(opcl, torch.tensor([0]), A2[b:b + 1], B2[b:b + 1], *lists[b])
+        tot = tot + out[0]
+        np.testing.assert_allclose(terms[b].numpy(), [float(o.sum()) for o in out], rtol=3e-6, atol=1e-9)
+    (tot / B).backward()
+    assert abs(loss.item() - (tot / B).item()) <= 3e-6 * abs(tot.item() / B)
+    assert rel_err(A.grad, A2.grad) < 1e-5 and rel_err(Bt.grad, B2.grad) < 1e-5
+
+
+def test_empty_lists_vs_numpy_oracle():
+    """Empty masked / background lists (the reference itself would crash in index_select on the `[-1]` sentinel,
+    so the independent numpy statement is the checker) -- also with the sentinel left on the 'device'."""
+    from dcn_hip import loss as K
+    from oracle import loss_numpy, synth
+    H, W, D = 16, 16, 3
+    g = torch.Generator().manual_seed(3)
+    A = ((torch.rand(1, H * W, D, generator=g) * 2 - 1) * 0.3).requires_grad_(True)
+    B = ((torch.rand(1, H * W, D, generator=g) * 2 - 1) * 0.3).requires_grad_(True)
+    ma = torch.randint(0, H * W, (40,), generator=g)
+    mb = torch.randint(0, H * W, (40,), generator=g)
+    ka = torch.randint(0, H * W, (30,), generator=g)
+    kb = torch.randint(0, H * W, (30,), generator=g)
+    sentinel = torch.tensor([-1])
+    lists = K.PairLists.from_lists([(ma, mb, ka, kb, sentinel, sentinel, None, None)], "cpu")
+    assert lists.length(0, K.LIST_BACKGROUND) == 0
+    c = synth.LOSS_CONFIG
+    cfg = K.make_config([0, c["M_masked"], c["M_background"], c["M_masked"]], W)
+    loss = K.contrastive_loss(A, B, lists, cfg)[0]
+    loss.backward()
+    ref = loss_numpy.within_scene(A.detach()[0].numpy(), B.detach()[0].numpy(),
+                                  dict(matches_a=ma, matches_b=mb, masked_a=ka, masked_b=kb,
+                                       background_a=[-1], background_b=[-1]), c, W)
+    np.testing.assert_allclose(loss.item(), ref["loss"], rtol=3e-6)
+    assert rel_err(A.grad[0], ref["gradA"]) < 1e-5
+    # a sentinel that was NOT stripped on the host (as if it lived on the GPU): the kernel skips negative indices
+    raw = K.PairLists(torch.cat([ma, ka, sentinel]), torch.cat([mb, kb, sentinel]), [0, 40, 70, 70, 71])
+    loss2, terms2 = K.contrastive_loss(A.detach(), B.detach(), raw, cfg)[:2]
+    np.testing.assert_allclose(loss2.item(), loss.item(), rtol=1e-7)
+    assert terms2[0, 4].item() == 0.0
+
+
+def test_index_out_of_range_sets_status_and_is_skipped():
+    from dcn_hip import loss as K
+    A = torch.rand(1, 100, 3)
+    B = torch.rand(1, 100, 3)
+    good = torch.tensor([1, 2, 3])
+    bad = torch.tensor([1, 100, 3])   # 100 == HW is out of range
+    lists = K.PairLists.from_lists([(good, bad, None, None, None, None, None, None)], "cpu")
+    cfg = K.make_config([0, .5, .5, .5], 10)
+    out = K.contrastive_loss(A, B, lists, cfg)
+    assert int(out[4]) == 1
+    ref = ((A[0, [1, 3]] - B[0, [1, 3]]) ** 2).sum() / 3
+    np.testing.assert_allclose(out[0].item(), ref.item(), rtol=1e-6)
+
+
+def test_mismatched_lists_raise():
+    from dcn_hip import loss as K
+    with pytest.raises(ValueError):
+        K.PairLists.from_lists([(torch.tensor([1, 2]), torch.tensor([1]), None, None, None, None, None, None)], "cpu")

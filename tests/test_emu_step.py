@@ -1,0 +1,108 @@
+"""One full reference training step (training.py:325-346) through the drop-in API --
+DenseCorrespondenceNetwork.from_config -> forward x2 -> process_network_output -> loss_composer.get_loss ->
+backward -> Adam -- against the oracle's step, on a narrow network (kernels host-emulated; CPU only)."""
+import pytest
+import torch
+
+from helpers import rel_err, use_emulation_library
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _lib():
+    return use_emulation_library()
+
+
+FC_SCALE = 4.0
+
+
+def _make(arch="Resnet18_8s", D=3, H=32, W=48, bw=8):
+    import pytorch_segmentation_detection.models.resnet_dilated as rd
+    from dense_correspondence.network.dense_correspondence_network import DenseCorrespondenceNetwork
+    from oracle import resnet_dilated_oracle as orc
+
+    class Narrow(getattr(rd, arch)):   # from_config passes only num_classes (network.py:375)
+        def __init__(self, num_classes):
+            super(Narrow, self).__init__(num_classes=num_classes, base_width=bw)
+    rd.NarrowTestNet = Narrow
+    Narrow.arch, Narrow.attr = getattr(rd, arch).arch, getattr(rd, arch).attr
+    cfg = {"descriptor_dimension": D, "image_width": W, "image_height": H, "normalize": False,
+           "backbone": {"model_class": "Resnet", "resnet_name": "NarrowTestNet"}}
+    dcn = DenseCorrespondenceNetwork.from_config(cfg, load_stored_params=False)
+    o = orc.build(arch, D, seed=0, base_width=bw)
+    dcn.fcn.load_state_dict(o.state_dict())
+    return dcn, o
+
+
+def test_api_surface_and_state_dict_keys():
+    dcn, o = _make()
+    assert dcn.training and dcn.descriptor_dimension == 3 and dcn.image_shape == [32, 48]
+    keys = list(dcn.state_dict().keys())
+    assert keys[0] == "_fcn.resnet18_8s.conv1.weight" and "_fcn.resnet18_8s.fc.bias" in keys
+    assert [k[5:] for k in keys] == list(o.state_dict().keys())
+    x = torch.randn(1, 3, 32, 48)
+    y = dcn.forward(x)
+    p = dcn.process_network_output(y, 1)
+    assert p.shape == (1, 32 * 48, 3) and p.is_contiguous()
+    # same values as the reference's view/permute on an NCHW tensor
+    ref = y.contiguous().view(1, 3, 48 * 32).permute(0, 2, 1)
+    assert torch.equal(p, ref)
+    s = dcn.forward_single_image_tensor(x[0])
+    assert s.shape == (32, 48, 3)
+    with pytest.raises(ValueError):
+        dcn.path_to_network_params_folder
+    uv, diff, norm = dcn.find_best_match((3, 4), s.detach().numpy(), s.detach().numpy())
+    assert uv == (3, 4) and diff == 0.0 and norm.shape == (32, 48)
+
+
+@pytest.mark.parametrize("B", [1, 2])
+def test_training_step_matches_oracle(B):
+    from dense_correspondence.loss_functions import loss_composer
+    from dense_correspondence.loss_functions.pixelwise_contrastive_loss import PixelwiseContrastiveLoss
+    from oracle import step as ostep, synth
+    H, W, D = 32, 48, 3
+    dcn, o = _make(D=D, H=H, W=W)
+    img_a, img_b, lists = synth.make_batch(B, H, W, 60, 30, 30, seed=1)
+    # untrained descriptors are tiny -> every non-match is a hard negative; scale the fc layer so both hinge sides occur
+    with torch.no_grad():
+        for net in (dcn.fcn.resnet18_8s, o.resnet18_8s):
+            net.fc.weight.mul_(FC_SCALE)
+    o.train(); dcn.train()
+    opt_o = torch.optim.Adam(o.parameters(), lr=1e-4, weight_decay=1e-4)
+    opt_m = torch.optim.Adam(dcn.parameters(), lr=1e-4, weight_decay=1e-4)
+    pcl = PixelwiseContrastiveLoss(image_shape=dcn.image_shape, config=synth.LOSS_CONFIG)
+    for it in range(2):
+        loss_o, terms_o, da_o, db_o = ostep.train_step(o, opt_o, img_a, img_b, lists, synth.LOSS_CONFIG)
+        opt_m.zero_grad()
+        pa = dcn.process_network_output(dcn.forward(img_a), B)
+        pb = dcn.process_network_output(dcn.forward(img_b), B)
+        if B == 1:
+            L = lists[0]
+            loss, ml, mk, bg, bl = loss_composer.get_loss(
+                pcl, torch.tensor([0]), pa, pb, L["matches_a"], L["matches_b"], L["masked_non_matches_a"],
+                L["masked_non_matches_b"], L["background_non_matches_a"], L["background_non_matches_b"],
+                L["blind_non_matches_a"], L["blind_non_matches_b"])
+            assert abs(ml.item() - terms_o[0][1].item()) <= 1e-4 * abs(terms_o[0][1].item())
+            assert abs(mk.item() - terms_o[0][2].item()) <= 1e-4 * abs(terms_o[0][2].item()) + 1e-9
+            assert abs(bg.item() - terms_o[0][3].item()) <= 1e-4 * abs(terms_o[0][3].item()) + 1e-9
+            assert bl.item() == 0.0
+            if it == 0:   # the hinge must be exercised on both sides for this test to mean anything
+                hn = loss_composer.get_loss_batched(pcl, 0, pa.detach(), pb.detach(), [tuple(
+                    L[k] for k in ("matches_a", "matches_b", "masked_non_matches_a", "masked_non_matches_b",
+                                   "background_non_matches_a", "background_non_matches_b",
+                                   "blind_non_matches_a", "blind_non_matches_b"))])[2]
+                assert 0 < int(hn[0, 1]) < 30, hn
+        else:
+            tup = [(L["matches_a"], L["matches_b"], L["masked_non_matches_a"], L["masked_non_matches_b"],
+                    L["background_non_matches_a"], L["background_non_matches_b"], L["blind_non_matches_a"],
+                    L["blind_non_matches_b"]) for L in lists]
+            loss, terms, hard = loss_composer.get_loss_batched(pcl, 0, pa, pb, tup)
+        assert rel_err(pa.detach().reshape(B, H, W, D).permute(0, 3, 1, 2), da_o) < 1e-4
+        assert abs(loss.item() - loss_o.item()) <= 1e-4 * abs(loss_o.item()), (it, loss.item(), loss_o.item())
+        loss.backward()
+        opt_m.step()
+        for (k, p), (_, po) in zip(dcn.fcn.named_parameters(), o.named_parameters()):
+            # fc.bias has a mathematically zero gradient (the loss only sees descriptor differences): pure round-off
+            tol = 2e-3 * float(po.grad.abs().max()) + 1e-6
+            assert float((p.grad - po.grad).abs().max()) < tol, (it, k, rel_err(p.grad, po.grad))
+            # Adam's first updates are lr * sign(g): a gradient that is ~0 may pick the other sign, 2 * lr apart
+            assert float((p - po).abs().max()) < 2.5e-4, (it, k)

@@ -1,0 +1,298 @@
+"""Parity tests proper: the gfx950 library on a real MI355X, through the C ABI, against
+ (1) the golden vectors made from the reference's own loss source   (tests/golden/loss_ref_*.npz)
+ (2) the oracle (CPU, fp32) on the same seeded inputs at sizes it finishes in seconds
+ (3) the committed config-1 oracle fixture                           (tests/golden/config1_oracle.npz)
+ (4) size-independent properties at BASELINE's full sizes (determinism, a<->b symmetry, zero-sum gradients).
+Tolerance: 1e-4 relative on descriptor maps and loss (BASELINE.json north_star); integer outputs exact."""
+import ctypes
+import glob
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from helpers import lists_from_golden, load_golden_loss, rel_err, use_gfx950_library
+
+pytestmark = pytest.mark.gpu
+GOLDEN_DIR = os.path.join(os.path.dirname(__file__), "golden")
+GOLDENS = sorted(glob.glob(os.path.join(GOLDEN_DIR, "loss_ref_*.npz")))
+TOL = 1e-4
+
+
+@pytest.fixture(scope="module")
+def L():
+    lib = use_gfx950_library()
+    assert torch.cuda.is_available()
+    info = lib.library_info()
+    assert info["path"].endswith("libdcn_hip.so") and "gfx950" in info["version"] and not info["hostemu"]
+    return lib
+
+
+def _tuple(Ld, dev):
+    keys = ("matches_a", "matches_b", "masked_non_matches_a", "masked_non_matches_b", "background_non_matches_a",
+            "background_non_matches_b", "blind_non_matches_a", "blind_non_matches_b")
+    return tuple(Ld[k].to(dev) for k in keys)
+
+
+# ------------------------------------------------------------------------------------------------ loss (K9)
+@pytest.mark.parametrize("path", GOLDENS, ids=[os.path.basename(p)[9:-4] for p in GOLDENS])
+def test_loss_matches_reference_goldens(L, path):
+    from dense_correspondence.loss_functions import loss_composer
+    from dense_correspondence.loss_functions.pixelwise_contrastive_loss import PixelwiseContrastiveLoss
+    z, cfg = load_golden_loss(path)
+    A = torch.tensor(z["A"], device="cuda", requires_grad=True)
+    B = torch.tensor(z["B"], device="cuda", requires_grad=True)
+    pcl = PixelwiseContrastiveLoss([int(z["H"]), int(z["W"])], cfg)
+    out = loss_composer.get_loss(pcl, torch.tensor([int(z["match_type"])]), A, B, *lists_from_golden(z, "cuda"))
+    got = np.array([float(o.sum().item()) for o in out])
+    np.testing.assert_allclose(got, z["out"], rtol=5e-6, atol=1e-9)
+    out[0].backward()
+    assert rel_err(A.grad.cpu(), z["gradA"]) < 1e-5 and rel_err(B.grad.cpu(), z["gradB"]) < 1e-5
+
+
+def test_loss_building_blocks_on_gpu(L):
+    from dense_correspondence.loss_functions.pixelwise_contrastive_loss import PixelwiseContrastiveLoss as PCL
+    z, cfg = load_golden_loss(os.path.join(GOLDEN_DIR, "loss_ref_within_d16.npz"))
+    A = torch.tensor(z["A"], device="cuda", requires_grad=True)
+    B = torch.tensor(z["B"], device="cuda")
+    ma, mb, ka, kb = [torch.tensor(z[k], device="cuda") for k in ("matches_a", "matches_b", "masked_a", "masked_b")]
+    ml, _, _ = PCL.match_loss(A, B, ma, mb)
+    np.testing.assert_allclose(ml.item(), z["f6_match_loss"], rtol=5e-6)
+    vec, hn, _, _ = PCL.non_match_descriptor_loss(A, B, ka, kb, M=cfg["M_masked"])
+    np.testing.assert_allclose(vec.detach().cpu().numpy(), z["f7_vec"], rtol=1e-5, atol=1e-8)
+    assert hn == int(z["f7_hard"])
+
+
+def test_loss_config3_scale_vs_oracle_and_properties(L):
+    """BASELINE config 3 list sizes (10 000 match + 50 000 + 50 000 non-match per pair, D = 16, HW = 307 200),
+    2 pairs: oracle comparison + symmetry + zero-sum gradient + run-to-run determinism of the forward."""
+    from dense_correspondence.loss_functions import loss_composer
+    from dense_correspondence.loss_functions.pixelwise_contrastive_loss import PixelwiseContrastiveLoss
+    from oracle import loss_oracle, synth
+    H, W, D, B = 480, 640, 16, 2
+    g = torch.Generator().manual_seed(3)
+    A = ((torch.rand(B, H * W, D, generator=g) * 2 - 1) * 0.12)
+    Bd = ((torch.rand(B, H * W, D, generator=g) * 2 - 1) * 0.12)
+    lists = synth.make_index_lists(B, H * W, 10000, 50000, 50000, g)
+    Ac, Bc = A.cuda().requires_grad_(True), Bd.cuda().requires_grad_(True)
+    pcl = PixelwiseContrastiveLoss([H, W], synth.LOSS_CONFIG)
+    tup = [_tuple(Ld, "cuda") for Ld in lists]
+    loss, terms, hard = loss_composer.get_loss_batched(pcl, 0, Ac, Bc, tup)
+    loss.backward()
+    loss_again = loss_composer.get_loss_batched(pcl, 0, Ac.detach(), Bc.detach(), tup)[0]
+    assert loss_again.item() == loss.item(), "forward reduction must be run-to-run deterministic"
+    A2, B2 = A.clone().requires_grad_(True), Bd.clone().requires_grad_(True)
+    opcl = loss_oracle.PixelwiseContrastiveLoss([H, W], synth.LOSS_CONFIG)
+    tot = 0
+    for b in range(B):
+        out = loss_oracle.get_loss(opcl, torch.tensor([0]), A2[b:b + 1], B2[b:b + 1], *_tuple(lists[b], "cpu"))
+        tot = tot + out[0]
+        np.testing.assert_allclose(terms[b].cpu().numpy(), [float(o.sum()) for o in out], rtol=TOL)
+        hk = int(hard[b, 1])
+        vec, hn, _, _ = loss_oracle.PixelwiseContrastiveLoss.non_match_descriptor_loss(
+            A2[b:b + 1], B2[b:b + 1], lists[b]["masked_non_matches_a"], lists[b]["masked_non_matches_b"], M=0.5)
+        assert abs(hk - hn) <= 2, (hk, hn)   # tie band: pairs with |M - d| ~ 1e-7 may flip
+        assert 0 < hk < 50000
+    (tot / B).backward()
+    assert abs(loss.item() - (tot / B).item()) <= TOL * abs((tot / B).item())
+    assert rel_err(Ac.grad.cpu(), A2.grad) < TOL and rel_err(Bc.grad.cpu(), B2.grad) < TOL
+    # property: every pair contributes +g to A and -g to B
+    assert float((Ac.grad.sum(1) + Bc.grad.sum(1)).abs().max()) < 1e-5 * float(Ac.grad.abs().sum(1).max())
+    # property: swapping the roles of a and b leaves the loss unchanged
+    swapped = [tuple(t[i ^ 1] for i in range(8)) for t in tup]
+    loss_sw = loss_composer.get_loss_batched(pcl, 0, Bc.detach(), Ac.detach(), swapped)[0]
+    assert abs(loss_sw.item() - loss.item()) <= 1e-6 * abs(loss.item())
+
+
+# ------------------------------------------------------------------------------------------------ conv kernels
+GPU_CONV_CASES = [
+    (2, 9, 7, 4, 12, 7, 2, 3, 1),
+    (1, 12, 10, 16, 24, 3, 2, 1, 1),
+    (1, 10, 12, 20, 136, 3, 1, 2, 2),
+    (2, 30, 40, 64, 64, 3, 1, 1, 1),       # layer1-like
+    (1, 60, 80, 256, 256, 3, 1, 2, 2),     # layer3 shape
+    (1, 60, 80, 512, 512, 3, 1, 4, 4),     # layer4 shape: 59 % of the network's FLOPs
+    (1, 60, 80, 256, 512, 1, 1, 0, 1),     # layer4 downsample
+    (1, 120, 160, 64, 128, 1, 2, 0, 1),    # layer2 downsample, stride 2
+]
+
+
+@pytest.mark.parametrize("case", GPU_CONV_CASES, ids=[str(c) for c in GPU_CONV_CASES])
+def test_conv_kernels_vs_torch_cpu(L, case):
+    lib = L.get()
+    n, hin, win, cin, cout, k, stride, pad, dil = case
+    hout = (hin + 2 * pad - dil * (k - 1) - 1) // stride + 1
+    wout = (win + 2 * pad - dil * (k - 1) - 1) // stride + 1
+    d = L.ConvDesc(n, hin, win, cin, hout, wout, cout, k, k, stride, pad, dil, cout)
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(n, cin, hin, win, generator=g, requires_grad=True)
+    w = (torch.randn(cout, cin, k, k, generator=g) * (1.0 / (cin * k * k) ** 0.5)).requires_grad_(True)
+    dout = torch.randn(n, hout, wout, cout, generator=g)
+    ref = F.conv2d(x, w, None, stride, pad, dil)
+    ref.backward(dout.permute(0, 3, 1, 2))
+    refn = ref.detach().permute(0, 2, 3, 1)
+    xg = x.detach().permute(0, 2, 3, 1).contiguous().cuda()
+    wg = w.detach().permute(0, 2, 3, 1).contiguous().cuda()
+    out = torch.full((n, hout, wout, cout), float("nan"), device="cuda")
+    mt = lib.dcn_conv_num_mtiles(ctypes.byref(d))
+    part = torch.full((mt, 2, cout), float("nan"), device="cuda")
+    st = L.stream_ptr()
+    assert lib.dcn_conv_forward(ctypes.byref(d), L.ptr(xg), L.ptr(wg), None, L.ptr(out), L.ptr(part), st) == 0
+    assert rel_err(out.cpu(), refn) < 1e-5
+    assert rel_err(part.sum(0)[0].cpu(), refn.sum((0, 1, 2))) < 2e-5
+    assert rel_err(part.sum(0)[1].cpu(), (refn ** 2).sum((0, 1, 2))) < 2e-5
+    wt = torch.empty(cin, k * k, cout, device="cuda")
+    assert lib.dcn_transpose_weight(L.ptr(wg), L.ptr(wt), cout, k * k, cin, cout, st) == 0
+    add = torch.randn(n, hin, win, cin, generator=g)
+    din = torch.full((n, hin, win, cin), float("nan"), device="cuda")
+    dg = dout.cuda()
+    addg = add.cuda()
+    assert lib.dcn_conv_dgrad(ctypes.byref(d), L.ptr(dg), L.ptr(wt), L.ptr(addg), L.ptr(din), st) == 0
+    assert rel_err(din.cpu(), x.grad.permute(0, 2, 3, 1) + add) < 1e-5
+    dw = torch.full((cout, k, k, cin), float("nan"), device="cuda")
+    slab = torch.empty(max(lib.dcn_conv_wgrad_workspace(ctypes.byref(d)), 4) // 4, device="cuda")
+    assert lib.dcn_conv_wgrad(ctypes.byref(d), L.ptr(xg), L.ptr(dg), L.ptr(dw), L.ptr(slab), st) == 0
+    assert rel_err(dw.cpu(), w.grad.permute(0, 2, 3, 1)) < 1e-5
+    # deterministic: same bits on a second run (fixed-order split reduction, no float atomics)
+    dw2 = torch.empty_like(dw)
+    assert lib.dcn_conv_wgrad(ctypes.byref(d), L.ptr(xg), L.ptr(dg), L.ptr(dw2), L.ptr(slab), st) == 0
+    assert torch.equal(dw, dw2)
+
+
+# ------------------------------------------------------------------------------------------------ backbone + step
+def _dcn_and_oracle(arch, D, H, W):
+    from dense_correspondence.network.dense_correspondence_network import DenseCorrespondenceNetwork
+    from oracle import resnet_dilated_oracle
+    cfg = {"descriptor_dimension": D, "image_width": W, "image_height": H,
+           "backbone": {"model_class": "Resnet", "resnet_name": arch}}
+    dcn = DenseCorrespondenceNetwork.from_config(cfg, load_stored_params=False)
+    o = resnet_dilated_oracle.build(arch, D, seed=0)
+    dcn.fcn.load_state_dict(o.state_dict())
+    assert next(dcn.parameters()).is_cuda and dcn.training
+    return dcn, o
+
+
+def _gpu_step(dcn, img_a, img_b, lists, B):
+    from dense_correspondence.loss_functions import loss_composer
+    from dense_correspondence.loss_functions.pixelwise_contrastive_loss import PixelwiseContrastiveLoss
+    from oracle import synth
+    pcl = PixelwiseContrastiveLoss(image_shape=dcn.image_shape, config=synth.LOSS_CONFIG)
+    ya = dcn.forward(img_a.cuda())
+    yb = dcn.forward(img_b.cuda())
+    pa, pb = dcn.process_network_output(ya, B), dcn.process_network_output(yb, B)
+    assert pa.is_contiguous()
+    loss, terms, hard = loss_composer.get_loss_batched(pcl, 0, pa, pb, [_tuple(Ld, "cuda") for Ld in lists])
+    return loss, terms, hard, ya, yb
+
+
+def test_config1_full_size_vs_committed_oracle_fixture(L):
+    """BASELINE config 1 at full size (1 pair, 640x480, D=3, Resnet34_8s): descriptor maps, loss terms and every
+    parameter gradient against the committed oracle fixture -- no oracle run needed on the GPU box."""
+    from oracle import synth
+    z = np.load(os.path.join(GOLDEN_DIR, "config1_oracle.npz"))
+    c = synth.CONFIGS[1]
+    dcn, _ = _dcn_and_oracle(c["backbone"], c["D"], c["H"], c["W"])
+    img_a, img_b, lists = synth.make_batch(c["B"], c["H"], c["W"], c["Pm"], c["Pk"], c["Pg"], seed=1)
+    loss, terms, hard, ya, yb = _gpu_step(dcn, img_a, img_b, lists, c["B"])
+    scale = float(z["desc_a_absmax"])
+    assert float((ya.detach().cpu()[:, :, ::16, ::16] - torch.tensor(z["desc_a"])).abs().max()) < TOL * scale
+    assert float((yb.detach().cpu()[:, :, ::16, ::16] - torch.tensor(z["desc_b"])).abs().max()) < TOL * scale
+    np.testing.assert_allclose(terms[0].cpu().numpy(), z["terms"], rtol=TOL, atol=1e-9)
+    assert abs(loss.item() - float(z["loss"])) <= TOL * abs(float(z["loss"]))
+    loss.backward()
+    torch.cuda.synchronize()
+    names = [str(s) for s in z["grad_names"]]
+    params = dict(dcn.fcn.named_parameters())
+    worst = 0.0
+    for i, k in enumerate(names):
+        gq = params[k].grad.detach().cpu()
+        nrm = float(gq.double().norm())
+        ref = float(z["grad_norms"][i])
+        if k.endswith("fc.bias"):
+            continue   # mathematically zero (the loss only sees descriptor differences): round-off only
+        worst = max(worst, abs(nrm - ref) / max(ref, 1e-30))
+        flat = gq.reshape(-1)
+        idx = torch.linspace(0, flat.numel() - 1, 8).long()
+        assert float((flat[idx] - torch.tensor(z["grad_samples"][i])).abs().max()) < 2e-3 * float(gq.abs().max()) + 1e-7, k
+    assert worst < 1e-3, worst
+    assert rel_err(dcn.fcn.resnet34_8s.bn1.running_mean.cpu(), z["running_mean_bn1"]) < 1e-5
+
+
+def test_config1_full_size_vs_live_oracle(L):
+    """Same configuration against the oracle run live on the host cores (takes a few seconds)."""
+    from oracle import step as ostep, synth
+    c = synth.CONFIGS[1]
+    dcn, o = _dcn_and_oracle(c["backbone"], c["D"], c["H"], c["W"])
+    img_a, img_b, lists = synth.make_batch(c["B"], c["H"], c["W"], c["Pm"], c["Pk"], c["Pg"], seed=1)
+    o.train()
+    loss_o, terms_o, da_o, db_o = ostep.forward_loss(o, img_a, img_b, lists, synth.LOSS_CONFIG)
+    loss_o.backward()
+    loss, terms, hard, ya, yb = _gpu_step(dcn, img_a, img_b, lists, c["B"])
+    loss.backward()
+    assert rel_err(ya.detach().cpu(), da_o) < TOL and rel_err(yb.detach().cpu(), db_o) < TOL
+    assert abs(loss.item() - loss_o.item()) <= TOL * abs(loss_o.item())
+    for (k, p), (_, po) in zip(dcn.fcn.named_parameters(), o.named_parameters()):
+        tol = 2e-3 * float(po.grad.abs().max()) + 1e-7
+        assert float((p.grad.cpu() - po.grad).abs().max()) < tol, (k, rel_err(p.grad.cpu(), po.grad))
+
+
+def test_batched_step_small_images_vs_oracle(L):
+    """B = 3 pairs (BN statistics over 3 images per call), D = 16, 96x128 images, with Adam."""
+    from oracle import step as ostep, synth
+    H, W, D, B = 96, 128, 16, 3
+    dcn, o = _dcn_and_oracle("Resnet34_8s", D, H, W)
+    img_a, img_b, lists = synth.make_batch(B, H, W, 300, 200, 200, seed=4)
+    opt_o = torch.optim.Adam(o.parameters(), lr=1e-4, weight_decay=1e-4)
+    opt = torch.optim.Adam(dcn.parameters(), lr=1e-4, weight_decay=1e-4)
+    o.train()
+    for it in range(2):
+        loss_o, _, da_o, _ = ostep.train_step(o, opt_o, img_a, img_b, lists, synth.LOSS_CONFIG)
+        opt.zero_grad()
+        loss, terms, hard, ya, yb = _gpu_step(dcn, img_a, img_b, lists, B)
+        loss.backward()
+        opt.step()
+        assert rel_err(ya.detach().cpu(), da_o) < TOL, it
+        assert abs(loss.item() - loss_o.item()) <= TOL * abs(loss_o.item()), it
+
+
+def test_resnet50_8s_forward_backward_vs_oracle(L):
+    """Bottleneck family (BASELINE config 5's backbone) at a small size, D = 32."""
+    import copy
+    H, W, D = 64, 64, 32
+    dcn, o = _dcn_and_oracle("Resnet50_8s", D, H, W)
+    o64 = copy.deepcopy(o).double()
+    g = torch.Generator().manual_seed(9)
+    x = torch.randn(2, 3, H, W, generator=g)
+    gy = torch.randn(2, D, H, W, generator=g)
+    o.train(); o64.train()
+    y = dcn.forward(x.cuda())
+    yo, y64 = o(x), o64(x.double())
+    assert rel_err(y.detach().cpu(), y64) < 3 * rel_err(yo, y64) + 1e-5
+    (y * gy.cuda()).sum().backward(); (yo * gy).sum().backward(); (y64 * gy.double()).sum().backward()
+    for (k, p), (_, po), (_, p6) in zip(dcn.fcn.named_parameters(), o.named_parameters(), o64.named_parameters()):
+        assert rel_err(p.grad.cpu(), p6.grad) < 3 * rel_err(po.grad, p6.grad) + 2e-5, k
+
+
+def test_config2_full_size_properties(L):
+    """BASELINE config 2 (B = 4 pairs, 640x480): too slow for the CPU oracle in a unit test, so properties:
+    bitwise run-to-run determinism of the forward, finite outputs, eval-mode idempotence, gradient flat buffer."""
+    from dcn_hip.distributed import FlatGradients
+    from oracle import synth
+    c = synth.CONFIGS[2]
+    dcn, _ = _dcn_and_oracle(c["backbone"], c["D"], c["H"], c["W"])
+    grads = FlatGradients(dcn)
+    img_a, img_b, lists = synth.make_batch(c["B"], c["H"], c["W"], c["Pm"], c["Pk"], c["Pg"], seed=1)
+    dcn.eval()
+    with torch.no_grad():
+        y1 = dcn.forward(img_a.cuda())
+        y2 = dcn.forward(img_a.cuda())
+    assert torch.equal(y1, y2) and torch.isfinite(y1).all()
+    dcn.train()
+    loss, terms, hard, ya, yb = _gpu_step(dcn, img_a, img_b, lists, c["B"])
+    loss.backward()
+    assert torch.isfinite(grads.flat).all() and float(grads.flat.abs().max()) > 0
+    assert ya.shape == (4, 3, 480, 640) and ya.is_contiguous(memory_format=torch.channels_last)
+    assert (hard[:, 1] <= c["Pk"]).all() and (hard[:, 0] == c["Pm"]).all()
+    assert abs(float(terms[:, 0].mean()) - loss.item()) <= 1e-6 * abs(loss.item())
