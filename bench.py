@@ -86,13 +86,14 @@ def cpu_baseline(wl, steps, warmup):
     """The oracle's training step (oracle/step.py, the CPU restatement of the reference) on this box's host cores.
     Bounded sample: ONE image pair of the workload's shapes."""
     from oracle import resnet_dilated_oracle, step as ostep, synth
-    cores = os.cpu_count() or 1
-    torch.set_num_threads(cores)
+    # torch's default intra-op thread count (it respects the container's CPU affinity / quota); forcing
+    # os.cpu_count() threads on a cgroup-limited box oversubscribes it by orders of magnitude
+    cores = torch.get_num_threads()
     model = resnet_dilated_oracle.build(wl["backbone"], wl["D"], seed=0)
     model.train()
     img_a, img_b, lists = synth.make_batch(1, wl["H"], wl["W"], wl["Pm"], wl["Pk"], wl["Pg"], seed=1)
     sec = ostep.time_cpu_step(model, img_a, img_b, lists, synth.LOSS_CONFIG, steps=steps, warmup=warmup)
-    return {"value": 2.0 / sec, "unit": "images/s", "cores": cores, "kind": "port",
+    return {"value": 2.0 / sec, "unit": "images/s", "cores": cores, "host_logical_cpus": os.cpu_count(), "kind": "port",
             "sample": "oracle (py3 CPU restatement of training.py:325-346, torch %s, fp32) on 1 image pair of the "
                       "workload's shapes (%dx%d, D=%d, %d/%d/%d pairs), %d warm-up + median of %d steps, %.2f s/step"
                       % (torch.__version__.split("+")[0], wl["W"], wl["H"], wl["D"], wl["Pm"], wl["Pk"], wl["Pg"],

@@ -61,11 +61,16 @@ def time_cpu_step(model, img_a, img_b, lists, loss_config, steps=3, warmup=1, lr
     opt = torch.optim.Adam(model.parameters(), lr=lr, weight_decay=weight_decay)
     model.train()
     ts = []
+    budget_s = 30.0  # bounded sample: stop adding steps once ~30 s of CPU work have been spent
+    spent = 0.0
     for i in range(warmup + steps):
         t0 = time.perf_counter()
         train_step(model, opt, img_a, img_b, lists, loss_config)
         t1 = time.perf_counter()
-        if i >= warmup:
+        spent += t1 - t0
+        if i >= warmup or spent > budget_s:
             ts.append(t1 - t0)
+        if spent > budget_s:
+            break
     ts.sort()
     return ts[len(ts) // 2]

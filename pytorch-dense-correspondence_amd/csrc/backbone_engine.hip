@@ -121,7 +121,7 @@ struct Builder {
         c.w = add_param(name + ".weight", {cout, cin, k, k});
         if (bias) c.b = add_param(name + ".bias", {cout});
         const int64_t M = (int64_t)n * c.d.hout * c.d.wout;
-        c.mtiles = (int)((M + 127) / 128);
+        c.mtiles = dcn_conv_num_mtiles(&c.d);  // M tiles of the forward kernel == rows of its BN partial sums
         c.flops = 2.0 * (double)M * cout * (double)(k * k * cin);
         p.flops += c.flops;
         p.convs.push_back(c);

@@ -21,13 +21,32 @@
 //   16-lane ds_read_b128 groups hit 16 distinct 16-byte slots (conflict-free).
 //   wgrad LDS image: [pixel][128 channels], fragments by ds_read_b64 (lane i holds channels 2i, 2i+1 of
 //   pixel 2q + (lane >> 5)): 64 consecutive dwords per half-wave, conflict-free without padding.
+#include <cstdlib>
+
 #include "dcn_common.h"
 
 namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-constexpr int BM = 128, BN = 128, BK = 16, LDK = BK + 4, NT = 256;
+constexpr int NT = 256;
+
+// Division by a launch-invariant positive integer without the ~25-instruction software divide:
+// q = (umulhi(n, mul) + n) >> shr, exact for 0 <= n < 2^31 (round-up method; mul = floor(2^32 (2^shr - d) / d) + 1).
+struct FastDiv {
+    uint32_t mul, shr;
+    int d;
+};
+FastDiv make_fastdiv(int d) {
+    FastDiv f;
+    f.d = d;
+    uint32_t s = 0;
+    while ((1u << s) < (uint32_t)d) ++s;
+    f.shr = s;
+    f.mul = (uint32_t)((((uint64_t)1 << 32) * (((uint64_t)1 << s) - (uint64_t)d)) / (uint64_t)d) + 1u;
+    return f;
+}
+__device__ __forceinline__ int fdiv(int n, const FastDiv& f) { return (int)((__umulhi((uint32_t)n, f.mul) + (uint32_t)n) >> f.shr); }
 
 struct GemmConv {
     const float* src;   // [n, hs, ws, cs] NHWC
@@ -36,7 +55,8 @@ struct GemmConv {
     const float* add;   // [M][ldc] or null
     float* dst;         // [M][ldc]
     float* bn_partial;  // [mtiles][2][cd] or null
-    int hs, ws, cs, hd, wd, cd, kh, kw, stride, pad, dil, ldc, M, K, transposed, mtiles, ntiles;
+    int hs, ws, cs, hd, wd, cd, kh, kw, stride, sshift, pad, dil, ldc, M, K, transposed, mtiles, ntiles;
+    FastDiv div_hw, div_w, div_cs, div_kw;
 };
 
 // bijective XCD-aware remap: consecutive logical tiles (sharing an M tile) land on the same XCD / L2
@@ -45,124 +65,193 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
     return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + local;
 }
 
-__global__ void __launch_bounds__(NT)
+// TN: 32-column MFMA tiles per wavefront (2 -> 128-wide workgroup tile, 1 -> 64-wide for Cout <= 64 layers).
+// BK: K elements staged per barrier.  All gather arithmetic is branch-free (selects + clamped addresses), so the
+// compiler can issue next-tile address math, global loads and LDS traffic in the shadow of the 64-cycle MFMAs.
+// WM: wavefronts along M (2 -> 2x2 wave grid, 1 -> 1x4).  Workgroup tile = (32*TM*WM) x (32*TN*(4/WM)).
+template <int WM, int TM, int TN, int BK, bool TR>
+__global__ void __launch_bounds__(NT, (TM * TN == 4 ? 3 : 1))   // 64x64 wave tile: cap at 168 registers -> 3 waves / SIMD
 conv_gemm_kernel(GemmConv p) {
-    __shared__ __attribute__((aligned(16))) float lds[2 * (BM + BN) * LDK];
-    constexpr int kStage = (BM + BN) * LDK;
+    constexpr int WN = 4 / WM, BM = 32 * TM * WM, BN = 32 * TN * WN, LDK = BK + 4, KQ = BK / 4, ROWS = NT / KQ, PA = (BM + ROWS - 1) / ROWS,
+                  PB = (BN + ROWS - 1) / ROWS, kStage = (BM + BN) * LDK;
+    __shared__ __attribute__((aligned(16))) float lds[2 * kStage];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const int wm_ = wv >> 1, wn_ = wv & 1;
+    const int wm_ = WM == 2 ? (wv >> 1) : 0, wn_ = WM == 2 ? (wv & 1) : wv;
     const int tile = xcd_remap(blockIdx.x, p.mtiles * p.ntiles);
     const int mt = tile / p.ntiles, nt = tile - mt * p.ntiles;
     const int m0 = mt * BM, n0 = nt * BN;
 
-    // ---- per-thread gather coordinates: this thread stages rows r0, r0+64 (A and B) at k-quad kq
-    const int kq = tid & 3, r0 = tid >> 2;
-    int by[2], bx[2], pixbase[2];
+    // ---- per-thread gather coordinates: this thread stages rows r0 + ROWS*j at k-quad kq
+    const int kq = tid % KQ, r0 = tid / KQ;
+    int by[PA], bx[PA], pixbase[PA];
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int m = m0 + r0 + 64 * j;
-        if (m < p.M) {
-            const int hw = p.hd * p.wd;
-            const int img = m / hw, rem = m - img * hw;
-            const int y = rem / p.wd, x = rem - y * p.wd;
-            by[j] = p.transposed ? y + p.pad : y * p.stride - p.pad;
-            bx[j] = p.transposed ? x + p.pad : x * p.stride - p.pad;
-            pixbase[j] = img * p.hs * p.ws;
-        } else {
-            by[j] = -(1 << 28); bx[j] = -(1 << 28); pixbase[j] = 0;
-        }
+    for (int j = 0; j < PA; ++j) {
+        const int m = m0 + r0 + ROWS * j;
+        const int mm = m < p.M ? m : 0;  // (v_cndmask, not a branch)
+        const int img = fdiv(mm, p.div_hw), rem = mm - img * p.div_hw.d;
+        const int y = fdiv(rem, p.div_w), x = rem - y * p.div_w.d;
+        by[j] = TR ? y + p.pad : y * p.stride - p.pad;
+        bx[j] = TR ? x + p.pad : x * p.stride - p.pad;
+        if (m >= p.M || r0 + ROWS * j >= BM) by[j] = -(1 << 28);
+        pixbase[j] = img * p.hs * p.ws;
+    }
+    int wrow[PB];      // element offset of this thread's weight row (0 when the row is out of range)
+    unsigned wokm = 0;
+#pragma unroll
+    for (int j = 0; j < PB; ++j) {
+        const int n = n0 + r0 + ROWS * j;
+        const bool ok = (n < p.cd) & ((r0 + ROWS * j) < BN);
+        wokm |= (ok ? 1u : 0u) << j;
+        wrow[j] = (ok ? n : 0) * p.K + kq * 4;
     }
     const int nk = (p.K + BK - 1) / BK;
-    float4 ra[2], rb[2];
+    const int smask = p.stride - 1;
+    float4 ra[PA], rb[PB];
+    unsigned okm = 0;  // validity bits of the tile held in ra / rb (applied when it is written to LDS, AFTER the MFMAs:
+                       // selecting on freshly loaded data here would put the load latency in front of the MFMA block)
 
     auto load_tile = [&](int kt) {
         const int k = kt * BK + kq * 4;
         const bool kval = k < p.K;
-        const int tap = k / p.cs, c = k - tap * p.cs;
-        const int r = tap / p.kw, s = tap - r * p.kw;
+        const int kk = kval ? k : 0;
+        const int tap = fdiv(kk, p.div_cs), c = kk - tap * p.cs;
+        const int r = fdiv(tap, p.div_kw), s = tap - r * p.kw;
+        const int dy = r * p.dil, dx = s * p.dil;
+        okm = 0;
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
+        for (int j = 0; j < PA; ++j) {
             int sy, sx;
             bool ok = kval;
-            if (p.transposed) {
-                const int ny = by[j] - r * p.dil, nx = bx[j] - s * p.dil;
-                sy = ny / p.stride; sx = nx / p.stride;
-                ok = ok && ny >= 0 && nx >= 0 && (sy * p.stride == ny) && (sx * p.stride == nx);
+            if (TR) {
+                const int ny = by[j] - dy, nx = bx[j] - dx;
+                ok = ok & ((ny | nx) >= 0) & (((ny | nx) & smask) == 0);
+                sy = ny >> p.sshift; sx = nx >> p.sshift;
             } else {
-                sy = by[j] + r * p.dil; sx = bx[j] + s * p.dil;
-                ok = ok && sy >= 0 && sx >= 0;
+                sy = by[j] + dy; sx = bx[j] + dx;
             }
-            ok = ok && sy < p.hs && sx < p.ws;
-            if (ok) {
-                const int64_t off = (int64_t)(pixbase[j] + sy * p.ws + sx) * p.cs + c;
-                ra[j] = *reinterpret_cast<const float4*>(p.src + off);
-            } else {
-                ra[j] = make_float4(0.f, 0.f, 0.f, 0.f);
-            }
-            const int n = n0 + r0 + 64 * j;
-            if (kval && n < p.cd) rb[j] = *reinterpret_cast<const float4*>(p.wm + (int64_t)n * p.K + k);
-            else rb[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+            ok = ok & ((unsigned)sy < (unsigned)p.hs) & ((unsigned)sx < (unsigned)p.ws);
+            int off = (pixbase[j] + sy * p.ws + sx) * p.cs + c;
+            off = ok ? off : 0;
+            ra[j] = *reinterpret_cast<const float4*>(p.src + off);
+            okm |= (ok ? 1u : 0u) << j;
+        }
+#pragma unroll
+        for (int j = 0; j < PB; ++j) {
+            const bool ok = kval & (((wokm >> j) & 1u) != 0);
+            rb[j] = *reinterpret_cast<const float4*>(p.wm + (ok ? wrow[j] + kt * BK : 0));
+            okm |= (ok ? 1u : 0u) << (16 + j);
         }
     };
     auto store_tile = [&](int stage) {
         float* a = lds + stage * kStage;
         float* b = a + BM * LDK;
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            *reinterpret_cast<float4*>(a + (r0 + 64 * j) * LDK + kq * 4) = ra[j];
-            *reinterpret_cast<float4*>(b + (r0 + 64 * j) * LDK + kq * 4) = rb[j];
+        for (int j = 0; j < PA; ++j) {
+            const bool ok = (okm >> j) & 1u;
+            const float4 v = ra[j];
+            if (BM % ROWS == 0 || r0 + ROWS * j < BM)
+                *reinterpret_cast<float4*>(a + (r0 + ROWS * j) * LDK + kq * 4) =
+                    make_float4(ok ? v.x : 0.f, ok ? v.y : 0.f, ok ? v.z : 0.f, ok ? v.w : 0.f);
+        }
+#pragma unroll
+        for (int j = 0; j < PB; ++j) {
+            const bool ok = (okm >> (16 + j)) & 1u;
+            const float4 v = rb[j];
+            if (BN % ROWS == 0 || r0 + ROWS * j < BN)
+                *reinterpret_cast<float4*>(b + (r0 + ROWS * j) * LDK + kq * 4) =
+                    make_float4(ok ? v.x : 0.f, ok ? v.y : 0.f, ok ? v.z : 0.f, ok ? v.w : 0.f);
         }
     };
 
-    f32x16 acc[2][2];
+    f32x16 acc[TM][TN];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < TN; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
+    // ---- software-pipelined main loop (one barrier per K tile, two LDS stages, global loads one full tile ahead)
+    //   phase A: MFMAs on fragment set F0 | in their shadow: ds_read F1 (second half of this tile), zero-fill selects
+    //            + ds_write of tile kt+1 (its global loads were issued a whole iteration ago) into the other stage
+    //   barrier: everybody has written stage nxt / finished reading stage cur's first half
+    //   phase B: MFMAs on F1 | in their shadow: address math + global loads of tile kt+2, ds_read of tile kt+1's F0
+    // so that a lone wavefront per SIMD (few workgroups per CU at small batch) still keeps the matrix pipe fed.
+    static_assert(BK == 16, "the pipelined loop is written for two 8-deep fragment groups per K tile");
+    const int fi = lane & 31, fh = lane >> 5;
+    const int a_off = (wm_ * 32 * TM + fi) * LDK + 4 * fh;
+    const int b_off = BM * LDK + (wn_ * 32 * TN + fi) * LDK + 4 * fh;
+    float fa[2][TM][4], fb[2][TN][4];
+    auto read_frags = [&](int stage, int ks, int set) {
+        const float* a = lds + stage * kStage + a_off + ks * 8;
+        const float* b = lds + stage * kStage + b_off + ks * 8;
+#pragma unroll
+        for (int t = 0; t < TM; ++t) {
+            const float4 v = *reinterpret_cast<const float4*>(a + t * 32 * LDK);
+            fa[set][t][0] = v.x; fa[set][t][1] = v.y; fa[set][t][2] = v.z; fa[set][t][3] = v.w;
+        }
+#pragma unroll
+        for (int t = 0; t < TN; ++t) {
+            const float4 v = *reinterpret_cast<const float4*>(b + t * 32 * LDK);
+            fb[set][t][0] = v.x; fb[set][t][1] = v.y; fb[set][t][2] = v.z; fb[set][t][3] = v.w;
+        }
+    };
+    auto mfma_steps = [&](int set, int j0, int j1) {
+#pragma unroll
+        for (int j = j0; j < j1; ++j)
+#pragma unroll
+            for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+                for (int tn = 0; tn < TN; ++tn)
+                    acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[set][tm][j], fb[set][tn][j], acc[tm][tn], 0, 0, 0);
+    };
+
+    // The loop body is branch-free (tile indices are clamped instead of guarded: the extra tile loaded / staged in
+    // the last iterations is never consumed) so that each phase is ONE scheduling region, and
+    // sched_group_barrier pins the interleave "1 MFMA, a few VALU/LDS/VMEM instructions" inside it.
+    constexpr int kMfmaPerPhase = 4 * TM * TN;
     load_tile(0);
     store_tile(0);
+    load_tile(nk > 1 ? 1 : 0);
     __syncthreads();
-    const int fi = lane & 31, fh = lane >> 5;
+    read_frags(0, 0, 0);
     for (int kt = 0; kt < nk; ++kt) {
         const int cur = kt & 1;
-        if (kt + 1 < nk) load_tile(kt + 1);
-        const float* a = lds + cur * kStage + (wm_ * 64 + fi) * LDK + 4 * fh;
-        const float* b = lds + cur * kStage + BM * LDK + (wn_ * 64 + fi) * LDK + 4 * fh;
+        // ---- phase A: MFMAs on F0 | ds_read F1, stage tile kt+1 into the other LDS buffer
+        read_frags(cur, 1, 1);
+        store_tile(cur ^ 1);
+        mfma_steps(0, 0, 4);
 #pragma unroll
-        for (int ks = 0; ks < BK / 8; ++ks) {
-            const float4 a0 = *reinterpret_cast<const float4*>(a + ks * 8);
-            const float4 a1 = *reinterpret_cast<const float4*>(a + 32 * LDK + ks * 8);
-            const float4 b0 = *reinterpret_cast<const float4*>(b + ks * 8);
-            const float4 b1 = *reinterpret_cast<const float4*>(b + 32 * LDK + ks * 8);
-            const float av[2][4] = {{a0.x, a0.y, a0.z, a0.w}, {a1.x, a1.y, a1.z, a1.w}};
-            const float bv[2][4] = {{b0.x, b0.y, b0.z, b0.w}, {b1.x, b1.y, b1.z, b1.w}};
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[0][j], bv[0][j], acc[0][0], 0, 0, 0);
-                acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[0][j], bv[1][j], acc[0][1], 0, 0, 0);
-                acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[1][j], bv[0][j], acc[1][0], 0, 0, 0);
-                acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[1][j], bv[1][j], acc[1][1], 0, 0, 0);
-            }
+        for (int i = 0; i < kMfmaPerPhase; ++i) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);          // 1 MFMA
+            __builtin_amdgcn_sched_group_barrier(0x306, 48 / kMfmaPerPhase + 1, 0);  // VALU | SALU | DS
         }
-        if (kt + 1 < nk) store_tile(cur ^ 1);
         __syncthreads();
+        // ---- phase B: MFMAs on F1 | address math + global loads of tile kt+2, ds_read of tile kt+1's F0
+        load_tile(kt + 2 < nk ? kt + 2 : nk - 1);
+        read_frags(cur ^ 1, 0, 0);
+        mfma_steps(1, 0, 4);
+#pragma unroll
+        for (int i = 0; i < kMfmaPerPhase; ++i) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);          // 1 MFMA
+            __builtin_amdgcn_sched_group_barrier(0x126, 112 / kMfmaPerPhase + 1, 0);  // VALU | SALU | VMEM read | DS read
+        }
     }
+    __syncthreads();  // the epilogue reuses the LDS tile as reduction scratch
 
     // ---- epilogue: C/D fragment -> NHWC rows (32 consecutive channels per half-wave = 128 B segments)
-    float csum[2] = {0.f, 0.f}, csq[2] = {0.f, 0.f};
+    float csum[TN], csq[TN];
 #pragma unroll
-    for (int tn = 0; tn < 2; ++tn) {
-        const int col = n0 + wn_ * 64 + tn * 32 + fi;
+    for (int tn = 0; tn < TN; ++tn) {
+        csum[tn] = 0.f; csq[tn] = 0.f;
+        const int col = n0 + wn_ * 32 * TN + tn * 32 + fi;
         const bool cok = col < p.cd;
         const float bv = (p.bias && cok) ? p.bias[col] : 0.f;
 #pragma unroll
-        for (int tm = 0; tm < 2; ++tm) {
+        for (int tm = 0; tm < TM; ++tm) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int row = m0 + wm_ * 64 + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh;
+                const int row = m0 + wm_ * 32 * TM + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh;
                 float v = acc[tm][tn][r] + bv;
                 if (cok && row < p.M) {
                     const int64_t o = (int64_t)row * p.ldc + col;
@@ -176,24 +265,63 @@ conv_gemm_kernel(GemmConv p) {
     }
     if (p.bn_partial) {
         // rows >= M and columns >= cd are exactly zero in acc (zero-filled fragments), so no masking is needed
-        float* red = lds;  // [2 (wm)][2 (sum, sq)][128]
+        float* red = lds;  // [2 (wm)][2 (sum, sq)][BN]
 #pragma unroll
-        for (int tn = 0; tn < 2; ++tn) {
+        for (int tn = 0; tn < TN; ++tn) {
             csum[tn] += __shfl_xor(csum[tn], 32, 64);
             csq[tn] += __shfl_xor(csq[tn], 32, 64);
             if (fh == 0) {
-                red[(wm_ * 2 + 0) * BN + wn_ * 64 + tn * 32 + fi] = csum[tn];
-                red[(wm_ * 2 + 1) * BN + wn_ * 64 + tn * 32 + fi] = csq[tn];
+                red[(wm_ * 2 + 0) * BN + wn_ * 32 * TN + tn * 32 + fi] = csum[tn];
+                red[(wm_ * 2 + 1) * BN + wn_ * 32 * TN + tn * 32 + fi] = csq[tn];
             }
         }
         __syncthreads();
         if (tid < BN && n0 + tid < p.cd) {
-            const float s = red[(0 * 2 + 0) * BN + tid] + red[(1 * 2 + 0) * BN + tid];
-            const float q = red[(0 * 2 + 1) * BN + tid] + red[(1 * 2 + 1) * BN + tid];
+            const float s = red[(0 * 2 + 0) * BN + tid] + (WM == 2 ? red[(1 * 2 + 0) * BN + tid] : 0.f);
+            const float q = red[(0 * 2 + 1) * BN + tid] + (WM == 2 ? red[(1 * 2 + 1) * BN + tid] : 0.f);
             p.bn_partial[((int64_t)mt * 2 + 0) * p.cd + n0 + tid] = s;
             p.bn_partial[((int64_t)mt * 2 + 1) * p.cd + n0 + tid] = q;
         }
     }
+}
+
+// Tile-shape choice (fp32 MFMA is slow enough that load balance across the 256 CUs matters more than tile reuse):
+//   N tile  64 when the layer has at most 64 output channels (no MFMA work on padding), else 128
+//   M tile  128, or 64 when 128-row tiles would give the chip fewer than ~3 workgroups per CU (tail effect)
+int gemm_tile_m(int M, int cd) {
+    if (const char* e = getenv("DCN_GEMM_TILE_M")) {  // tuning / test override
+        const int v = atoi(e);
+        if (v == 32 || v == 64 || v == 128) return (v == 32 && cd <= 64) ? 64 : v;
+    }
+    const int ntiles = dcn::ceil_div(cd, cd <= 64 ? 64 : 128);
+    return dcn::ceil_div(M, 128) * ntiles < 3 * 256 ? 64 : 128;
+}
+
+int launch_gemm(GemmConv& p, hipStream_t st) {
+    if (p.stride != 1 && p.stride != 2 && p.stride != 4) return DCN_E_UNSUPPORTED;
+    p.sshift = p.stride == 1 ? 0 : (p.stride == 2 ? 1 : 2);
+    p.div_hw = make_fastdiv(p.hd * p.wd);
+    p.div_w = make_fastdiv(p.wd);
+    p.div_cs = make_fastdiv(p.cs);
+    p.div_kw = make_fastdiv(p.kw);
+    // 32-bit element offsets inside the kernel
+    if ((int64_t)p.M / (p.hd * p.wd) * p.hs * p.ws * p.cs >= ((int64_t)1 << 31) || (int64_t)p.cd * p.K >= ((int64_t)1 << 31))
+        return DCN_E_UNSUPPORTED;
+    const bool narrow = p.cd <= 64;
+    const int bm = gemm_tile_m(p.M, p.cd);
+    p.mtiles = dcn::ceil_div(p.M, bm);
+    p.ntiles = dcn::ceil_div(p.cd, narrow ? 64 : 128);
+    const dim3 grid(p.mtiles * p.ntiles), block(NT);
+#define DCN_GEMM(WM, TM, TN)                                                                                  \
+    do {                                                                                                      \
+        if (p.transposed) hipLaunchKernelGGL((conv_gemm_kernel<WM, TM, TN, 16, true>), grid, block, 0, st, p); \
+        else hipLaunchKernelGGL((conv_gemm_kernel<WM, TM, TN, 16, false>), grid, block, 0, st, p);             \
+    } while (0)
+    if (bm == 32) DCN_GEMM(1, 1, 1);                                   //  32 x 128, waves 1x4
+    else if (bm == 64) { if (narrow) DCN_GEMM(2, 1, 1); else DCN_GEMM(2, 1, 2); }   //  64 x 64 | 64 x 128
+    else { if (narrow) DCN_GEMM(2, 2, 1); else DCN_GEMM(2, 2, 2); }                 // 128 x 64 | 128 x 128
+#undef DCN_GEMM
+    return dcn::check_launch();
 }
 
 // ------------------------------------------------------------------------------------------- wgrad
@@ -205,6 +333,7 @@ struct WgradConv {
     float* slab;        // [splits][cout][K]
     int hin, win, cin, hout, wout, cout, kh, kw, stride, pad, dil, ldo, M, K, splits, rows_per_split, ntiles_n,
         ntiles_k;
+    FastDiv div_hw, div_w, div_cin, div_kw;
 };
 
 __global__ void __launch_bounds__(NT)
@@ -226,28 +355,32 @@ conv_wgrad_kernel(WgradConv p) {
     const bool nval = ncol < p.ldo;          // dout rows are padded to ldo (multiple of 4) with zeros
     const int kcol = j0 + c4 * 4;
     const bool kval = kcol < p.K;
-    const int tap = kcol / p.cin, cc = kcol - tap * p.cin;
-    const int tr = tap / p.kw, ts = tap - tr * p.kw;
-    const int hw = p.hout * p.wout;
+    const int kc0 = kval ? kcol : 0;
+    const int tap = fdiv(kc0, p.div_cin), cc = kc0 - tap * p.cin;
+    const int tr = fdiv(tap, p.div_kw), ts = tap - tr * p.kw;
+    const int oy = tr * p.dil - p.pad, ox = ts * p.dil - p.pad;
     float4 rd[2], rx[2];
+    unsigned okm = 0;
 
+    // branch-free (clamped addresses; the zero-fill selects are applied when the tile is written to LDS, after the
+    // MFMA block) so the loads are issued early and complete in the shadow of the MFMAs
     auto load_tile = [&](int m_base) {
+        okm = 0;
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             const int m = m_base + p0 + 8 * j;
-            rd[j] = make_float4(0.f, 0.f, 0.f, 0.f);
-            rx[j] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (m < m_end) {
-                if (nval) rd[j] = *reinterpret_cast<const float4*>(p.dout + (int64_t)m * p.ldo + ncol);
-                if (kval) {
-                    const int img = m / hw, rem = m - img * hw;
-                    const int y = rem / p.wout, x = rem - y * p.wout;
-                    const int sy = y * p.stride - p.pad + tr * p.dil, sx = x * p.stride - p.pad + ts * p.dil;
-                    if (sy >= 0 && sy < p.hin && sx >= 0 && sx < p.win)
-                        rx[j] = *reinterpret_cast<const float4*>(
-                            p.in + ((int64_t)(img * p.hin + sy) * p.win + sx) * p.cin + cc);
-                }
-            }
+            const bool mval = m < m_end;
+            const int mm = mval ? m : 0;
+            const bool dok = mval && nval;
+            rd[j] = *reinterpret_cast<const float4*>(p.dout + (dok ? mm * p.ldo + ncol : 0));
+            const int img = fdiv(mm, p.div_hw), rem = mm - img * p.div_hw.d;
+            const int y = fdiv(rem, p.div_w), x = rem - y * p.div_w.d;
+            const int sy = y * p.stride + oy, sx = x * p.stride + ox;
+            const bool ok = mval && kval && (unsigned)sy < (unsigned)p.hin && (unsigned)sx < (unsigned)p.win;
+            int off = ((img * p.hin + sy) * p.win + sx) * p.cin + cc;
+            off = ok ? off : 0;
+            rx[j] = *reinterpret_cast<const float4*>(p.in + off);
+            okm |= ((dok ? 1u : 0u) << j) | ((ok ? 1u : 0u) << (8 + j));
         }
     };
     auto store_tile = [&](int stage) {
@@ -255,8 +388,12 @@ conv_wgrad_kernel(WgradConv p) {
         float* x = d + WK * 128;
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
-            *reinterpret_cast<float4*>(d + (p0 + 8 * j) * 128 + c4 * 4) = rd[j];
-            *reinterpret_cast<float4*>(x + (p0 + 8 * j) * 128 + c4 * 4) = rx[j];
+            const bool dok = (okm >> j) & 1u, ok = (okm >> (8 + j)) & 1u;
+            const float4 dv = rd[j], xv = rx[j];
+            *reinterpret_cast<float4*>(d + (p0 + 8 * j) * 128 + c4 * 4) =
+                make_float4(dok ? dv.x : 0.f, dok ? dv.y : 0.f, dok ? dv.z : 0.f, dok ? dv.w : 0.f);
+            *reinterpret_cast<float4*>(x + (p0 + 8 * j) * 128 + c4 * 4) =
+                make_float4(ok ? xv.x : 0.f, ok ? xv.y : 0.f, ok ? xv.z : 0.f, ok ? xv.w : 0.f);
         }
     };
 
@@ -363,7 +500,8 @@ bool valid_desc(const dcn_conv_desc* c) {
 
 extern "C" int dcn_conv_num_mtiles(const dcn_conv_desc* c) {
     if (!valid_desc(c)) return DCN_E_INVALID;
-    return dcn::ceil_div(c->n * c->hout * c->wout, BM);
+    const int M = c->n * c->hout * c->wout;
+    return dcn::ceil_div(M, gemm_tile_m(M, c->cout));
 }
 
 extern "C" int dcn_conv_forward(const dcn_conv_desc* c, const float* in, const float* w, const float* bias, float* out,
@@ -374,9 +512,7 @@ extern "C" int dcn_conv_forward(const dcn_conv_desc* c, const float* in, const f
     p.hs = c->hin; p.ws = c->win; p.cs = c->cin; p.hd = c->hout; p.wd = c->wout; p.cd = c->cout;
     p.kh = c->kh; p.kw = c->kw; p.stride = c->stride; p.pad = c->pad; p.dil = c->dil; p.ldc = c->ldc;
     p.M = c->n * c->hout * c->wout; p.K = c->kh * c->kw * c->cin; p.transposed = 0;
-    p.mtiles = dcn::ceil_div(p.M, BM); p.ntiles = dcn::ceil_div(p.cd, BN);
-    hipLaunchKernelGGL(conv_gemm_kernel, dim3(p.mtiles * p.ntiles), dim3(NT), 0, (hipStream_t)stream, p);
-    return dcn::check_launch();
+    return launch_gemm(p, (hipStream_t)stream);
 }
 
 // The description is the FORWARD convolution's; dout is [n,hout,wout,ld = c->ldc], din is [n,hin,win,cin].
@@ -389,9 +525,7 @@ extern "C" int dcn_conv_dgrad(const dcn_conv_desc* c, const float* dout, const f
     p.hd = c->hin; p.wd = c->win; p.cd = c->cin;
     p.kh = c->kh; p.kw = c->kw; p.stride = c->stride; p.pad = c->pad; p.dil = c->dil; p.ldc = c->cin;
     p.M = c->n * c->hin * c->win; p.K = c->kh * c->kw * c->ldc; p.transposed = 1;
-    p.mtiles = dcn::ceil_div(p.M, BM); p.ntiles = dcn::ceil_div(p.cd, BN);
-    hipLaunchKernelGGL(conv_gemm_kernel, dim3(p.mtiles * p.ntiles), dim3(NT), 0, (hipStream_t)stream, p);
-    return dcn::check_launch();
+    return launch_gemm(p, (hipStream_t)stream);
 }
 
 extern "C" size_t dcn_conv_wgrad_workspace(const dcn_conv_desc* c) {
@@ -404,6 +538,9 @@ extern "C" size_t dcn_conv_wgrad_workspace(const dcn_conv_desc* c) {
 extern "C" int dcn_conv_wgrad(const dcn_conv_desc* c, const float* in, const float* dout, float* dw, void* slabs,
                               void* stream) {
     if (!valid_desc(c) || !in || !dout || !dw || !slabs || (c->ldc % 4) != 0) return DCN_E_INVALID;
+    if ((int64_t)c->n * c->hin * c->win * c->cin >= ((int64_t)1 << 31) ||
+        (int64_t)c->n * c->hout * c->wout * c->ldc >= ((int64_t)1 << 31))
+        return DCN_E_UNSUPPORTED;  // 32-bit element offsets inside the kernel
     WgradConv p;
     p.in = in; p.dout = dout;
     p.hin = c->hin; p.win = c->win; p.cin = c->cin; p.hout = c->hout; p.wout = c->wout; p.cout = c->cout;
@@ -411,6 +548,8 @@ extern "C" int dcn_conv_wgrad(const dcn_conv_desc* c, const float* in, const flo
     p.M = c->n * c->hout * c->wout; p.K = c->kh * c->kw * c->cin;
     p.splits = wgrad_splits(c, &p.rows_per_split);
     p.ntiles_n = dcn::ceil_div(c->cout, 128); p.ntiles_k = dcn::ceil_div(p.K, 128);
+    p.div_hw = make_fastdiv(c->hout * c->wout); p.div_w = make_fastdiv(c->wout);
+    p.div_cin = make_fastdiv(c->cin); p.div_kw = make_fastdiv(c->kw);
     p.slab = p.splits == 1 ? dw : (float*)slabs;
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(conv_wgrad_kernel, dim3(p.ntiles_n * p.ntiles_k * p.splits), dim3(NT), 0, st, p);

@@ -229,6 +229,7 @@ static inline unsigned long long atomicAdd(unsigned long long* p, unsigned long 
 }
 
 #define unsafeAtomicAdd atomicAdd
+static inline unsigned __umulhi(unsigned a, unsigned b) { return (unsigned)(((unsigned long long)a * b) >> 32); }
 template <class T> static inline T min(T a, T b) { return a < b ? a : b; }
 template <class T> static inline T max(T a, T b) { return a > b ? a : b; }
 
@@ -284,5 +285,6 @@ static inline hipemu_f32x4 hipemu_mfma_16x16x4f32(float a, float b, hipemu_f32x4
 #define __builtin_amdgcn_mfma_f32_16x16x4f32 hipemu_mfma_16x16x4f32
 #define __builtin_amdgcn_s_setprio(x) ((void)0)
 #define __builtin_amdgcn_sched_barrier(x) ((void)0)
+#define __builtin_amdgcn_sched_group_barrier(a, b, c) ((void)0)
 static inline int hipemu_readfirstlane(int v) { return ::hipemu::wave_exchange(v, 0); }
 #define __builtin_amdgcn_readfirstlane hipemu_readfirstlane

@@ -1,0 +1,101 @@
+#!/usr/bin/env python3
+"""Per-shape micro-benchmark of the matrix-core kernels through the C ABI (GPU only): every distinct convolution
+of Resnet34_8s at a given batch, forward / dgrad / wgrad, timed with events on the launch stream.
+    python tools/conv_bench.py [--n 4] [--reps 10]
+Prints TFLOP/s (algorithmic) and the fraction of the fp32-MFMA peak (157.3 TF)."""
+import argparse
+import ctypes
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "pytorch-dense-correspondence_amd"))
+import torch  # noqa: E402
+from dcn_hip import _lib  # noqa: E402
+
+SHAPES = [  # name, count in the net, hin, win, cin, cout, k, stride, pad, dil
+    ("stem 7x7/2 3(4)->64", 1, 480, 640, 4, 64, 7, 2, 3, 1),
+    ("layer1 3x3 64->64", 6, 120, 160, 64, 64, 3, 1, 1, 1),
+    ("layer2.0 3x3/2 64->128", 1, 120, 160, 64, 128, 3, 2, 1, 1),
+    ("layer2 3x3 128->128", 7, 60, 80, 128, 128, 3, 1, 1, 1),
+    ("layer2 down 1x1/2 64->128", 1, 120, 160, 64, 128, 1, 2, 0, 1),
+    ("layer3.0 3x3 d2 128->256", 1, 60, 80, 128, 256, 3, 1, 2, 2),
+    ("layer3 3x3 d2 256->256", 11, 60, 80, 256, 256, 3, 1, 2, 2),
+    ("layer3 down 1x1 128->256", 1, 60, 80, 128, 256, 1, 1, 0, 1),
+    ("layer4.0 3x3 d4 256->512", 1, 60, 80, 256, 512, 3, 1, 4, 4),
+    ("layer4 3x3 d4 512->512", 5, 60, 80, 512, 512, 3, 1, 4, 4),
+    ("layer4 down 1x1 256->512", 1, 60, 80, 256, 512, 1, 1, 0, 1),
+]
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--n", type=int, default=4)
+    ap.add_argument("--reps", type=int, default=10)
+    ap.add_argument("--json", default="")
+    ap.add_argument("--only", default="", help="substring filter on the shape name")
+    ap.add_argument("--kinds", default="fwd,dgrad,wgrad")
+    a = ap.parse_args()
+    lib = _lib.get()
+    dev = torch.device("cuda")
+    st = _lib.stream_ptr()
+    rows = []
+    tot = {"fwd": [0.0, 0.0], "dgrad": [0.0, 0.0], "wgrad": [0.0, 0.0]}
+    for name, count, hin, win, cin, cout, k, stride, pad, dil in SHAPES:
+        if a.only and a.only not in name:
+            continue
+        n = a.n
+        hout = (hin + 2 * pad - dil * (k - 1) - 1) // stride + 1
+        wout = (win + 2 * pad - dil * (k - 1) - 1) // stride + 1
+        d = _lib.ConvDesc(n, hin, win, cin, hout, wout, cout, k, k, stride, pad, dil, cout)
+        x = torch.randn(n, hin, win, cin, device=dev)
+        w = torch.randn(cout, k, k, cin, device=dev) * 0.05
+        wt = torch.randn(cin, k, k, cout, device=dev) * 0.05
+        y = torch.empty(n, hout, wout, cout, device=dev)
+        dy = torch.randn(n, hout, wout, cout, device=dev)
+        dx = torch.empty_like(x)
+        dw = torch.empty_like(w)
+        part = torch.empty(lib.dcn_conv_num_mtiles(ctypes.byref(d)), 2, cout, device=dev)
+        slab = torch.empty(max(lib.dcn_conv_wgrad_workspace(ctypes.byref(d)), 4) // 4, device=dev)
+        flops = 2.0 * n * hout * wout * cout * k * k * (3 if cin == 4 else cin)
+        calls = {
+            "fwd": lambda: lib.dcn_conv_forward(ctypes.byref(d), _lib.ptr(x), _lib.ptr(w), None, _lib.ptr(y), _lib.ptr(part), st),
+            "dgrad": lambda: lib.dcn_conv_dgrad(ctypes.byref(d), _lib.ptr(dy), _lib.ptr(wt), None, _lib.ptr(dx), st),
+            "wgrad": lambda: lib.dcn_conv_wgrad(ctypes.byref(d), _lib.ptr(x), _lib.ptr(dy), _lib.ptr(dw), _lib.ptr(slab), st),
+        }
+        row = {"shape": name, "count": count, "gflop": flops / 1e9}
+        for kind in ("fwd", "dgrad", "wgrad"):
+            row[kind + "_us"] = float("nan")
+            row[kind + "_tf"] = float("nan")
+        for kind, fn in calls.items():
+            if kind not in a.kinds.split(","):
+                continue
+            for _ in range(2):
+                assert fn() == 0
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(a.reps):
+                fn()
+            e1.record()
+            torch.cuda.synchronize()
+            ms = e0.elapsed_time(e1) / a.reps
+            row[kind + "_us"] = 1e3 * ms
+            row[kind + "_tf"] = flops / (ms * 1e-3) / 1e12
+            if not (kind == "dgrad" and cin == 4):
+                tot[kind][0] += count * ms
+                tot[kind][1] += count * flops
+        rows.append(row)
+        print("%-28s x%-2d %7.2f GF | fwd %7.1f us %6.1f TF | dgrad %7.1f us %6.1f TF | wgrad %7.1f us %6.1f TF" %
+              (name, count, row["gflop"], row["fwd_us"], row["fwd_tf"], row["dgrad_us"], row["dgrad_tf"],
+               row["wgrad_us"], row["wgrad_tf"]), flush=True)
+    for kind, (ms, fl) in tot.items():
+        if ms <= 0:
+            continue
+        print("net total %-6s %8.2f ms  %6.1f TF/s  (%.1f%% of fp32 MFMA peak)" % (kind, ms, fl / ms / 1e9, fl / ms / 1e9 / 1.573))
+    if a.json:
+        json.dump({"n": a.n, "rows": rows}, open(a.json, "w"), indent=1)
+
+
+if __name__ == "__main__":
+    main()
