@@ -82,13 +82,26 @@ def as_tuples(lists):
     return [tuple(L[k] for k in keys) for L in lists]
 
 
+def usable_cpus():
+    """Host cores this process may really use: min(affinity mask, cgroup CPU quota).  (os.cpu_count() reports the
+    machine's logical CPUs -- 256 on the GPU box -- while the container is capped by cgroup cpu.max; running torch
+    with more threads than the quota oversubscribes it by an order of magnitude.)"""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return max(1, n)
+
+
 def cpu_baseline(wl, steps, warmup):
     """The oracle's training step (oracle/step.py, the CPU restatement of the reference) on this box's host cores.
     Bounded sample: ONE image pair of the workload's shapes."""
     from oracle import resnet_dilated_oracle, step as ostep, synth
-    # torch's default intra-op thread count (it respects the container's CPU affinity / quota); forcing
-    # os.cpu_count() threads on a cgroup-limited box oversubscribes it by orders of magnitude
-    cores = torch.get_num_threads()
+    cores = usable_cpus()
+    torch.set_num_threads(cores)
     model = resnet_dilated_oracle.build(wl["backbone"], wl["D"], seed=0)
     model.train()
     img_a, img_b, lists = synth.make_batch(1, wl["H"], wl["W"], wl["Pm"], wl["Pk"], wl["Pg"], seed=1)

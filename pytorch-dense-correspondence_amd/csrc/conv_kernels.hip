@@ -371,12 +371,12 @@ conv_wgrad_kernel(WgradConv p) {
             const int m = m_base + p0 + 8 * j;
             const bool mval = m < m_end;
             const int mm = mval ? m : 0;
-            const bool dok = mval && nval;
+            const bool dok = mval & nval;
             rd[j] = *reinterpret_cast<const float4*>(p.dout + (dok ? mm * p.ldo + ncol : 0));
             const int img = fdiv(mm, p.div_hw), rem = mm - img * p.div_hw.d;
             const int y = fdiv(rem, p.div_w), x = rem - y * p.div_w.d;
             const int sy = y * p.stride + oy, sx = x * p.stride + ox;
-            const bool ok = mval && kval && (unsigned)sy < (unsigned)p.hin && (unsigned)sx < (unsigned)p.win;
+            const bool ok = mval & kval & ((unsigned)sy < (unsigned)p.hin) & ((unsigned)sx < (unsigned)p.win);
             int off = ((img * p.hin + sy) * p.win + sx) * p.cin + cc;
             off = ok ? off : 0;
             rx[j] = *reinterpret_cast<const float4*>(p.in + off);
@@ -407,27 +407,55 @@ conv_wgrad_kernel(WgradConv p) {
 
     const int fi = lane & 31, fh = lane >> 5;
     const int nsteps = (m_end - m_begin + WK - 1) / WK;
+    // Software-pipelined like the gather-GEMM kernel: two fragment sets (pixel pairs 0-3 / 4-7 of a 16-pixel step),
+    // one barrier per step, global loads a full step ahead, branch-free body + sched_group_barrier interleave.
+    const int d_off = fh * 128 + wm_ * 64 + 2 * fi;
+    const int x_off = WK * 128 + fh * 128 + wn_ * 64 + 2 * fi;
+    float2 fd[2][4], fx[2][4];
+    auto read_frags = [&](int stage, int half, int set) {
+        const float* d = lds + stage * 2 * WK * 128 + d_off + half * 8 * 128;
+        const float* x = lds + stage * 2 * WK * 128 + x_off + half * 8 * 128;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            fd[set][q] = *reinterpret_cast<const float2*>(d + 2 * q * 128);
+            fx[set][q] = *reinterpret_cast<const float2*>(x + 2 * q * 128);
+        }
+    };
+    auto mfma_steps = [&](int set) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(fd[set][q].x, fx[set][q].x, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(fd[set][q].x, fx[set][q].y, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(fd[set][q].y, fx[set][q].x, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(fd[set][q].y, fx[set][q].y, acc[1][1], 0, 0, 0);
+        }
+    };
     if (nsteps > 0) {
         load_tile(m_begin);
         store_tile(0);
-    }
-    __syncthreads();
-    for (int st = 0; st < nsteps; ++st) {
-        const int cur = st & 1;
-        if (st + 1 < nsteps) load_tile(m_begin + (st + 1) * WK);
-        const float* d = lds + cur * 2 * WK * 128 + fh * 128 + wm_ * 64 + 2 * fi;
-        const float* x = lds + cur * 2 * WK * 128 + WK * 128 + fh * 128 + wn_ * 64 + 2 * fi;
-#pragma unroll
-        for (int q = 0; q < WK / 2; ++q) {
-            const float2 a = *reinterpret_cast<const float2*>(d + 2 * q * 128);
-            const float2 b = *reinterpret_cast<const float2*>(x + 2 * q * 128);
-            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b.x, acc[0][0], 0, 0, 0);
-            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b.y, acc[0][1], 0, 0, 0);
-            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b.x, acc[1][0], 0, 0, 0);
-            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b.y, acc[1][1], 0, 0, 0);
-        }
-        if (st + 1 < nsteps) store_tile(cur ^ 1);
+        load_tile(m_begin + (nsteps > 1 ? WK : 0));
         __syncthreads();
+        read_frags(0, 0, 0);
+        for (int st = 0; st < nsteps; ++st) {
+            const int cur = st & 1;
+            read_frags(cur, 1, 1);
+            store_tile(cur ^ 1);
+            mfma_steps(0);
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x306, 3, 0);
+            }
+            __syncthreads();
+            load_tile(m_begin + (st + 2 < nsteps ? st + 2 : nsteps - 1) * WK);
+            read_frags(cur ^ 1, 0, 0);
+            mfma_steps(1);
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x126, 6, 0);
+            }
+        }
     }
     // fragment (tm, r) <-> output channel n0 + wm*64 + 2*row_r + tm ; (tn, lane) <-> k column j0 + wn*64 + 2*fi + tn
     float* out = p.slab + (int64_t)split * p.cout * p.K;

@@ -54,13 +54,13 @@ bn_finalize_kernel(const float* __restrict__ partial, int tiles, int C, double c
                    const float* __restrict__ beta, float* __restrict__ running_mean, float* __restrict__ running_var,
                    float momentum, float eps, int training, float* __restrict__ scale, float* __restrict__ shift,
                    float* __restrict__ save_mean, float* __restrict__ save_invstd) {
-    __shared__ double s_sum[4][64];
-    __shared__ double s_sq[4][64];
-    const int cl = threadIdx.x & 63, part = threadIdx.x >> 6;
-    const int c = blockIdx.x * 64 + cl;
+    __shared__ double s_sum[16][16];
+    __shared__ double s_sq[16][16];
+    const int cl = threadIdx.x & 15, part = threadIdx.x >> 4;
+    const int c = blockIdx.x * 16 + cl;
     double a = 0.0, b = 0.0;
     if (training && c < C) {
-        for (int t = part; t < tiles; t += 4) {
+        for (int t = part; t < tiles; t += 16) {
             a += (double)partial[((int64_t)t * 2 + 0) * C + c];
             b += (double)partial[((int64_t)t * 2 + 1) * C + c];
         }
@@ -71,8 +71,8 @@ bn_finalize_kernel(const float* __restrict__ partial, int tiles, int C, double c
     if (part != 0 || c >= C) return;
     double mean, var;
     if (training) {
-        a = s_sum[0][cl] + s_sum[1][cl] + s_sum[2][cl] + s_sum[3][cl];
-        b = s_sq[0][cl] + s_sq[1][cl] + s_sq[2][cl] + s_sq[3][cl];
+        a = 0.0; b = 0.0;
+        for (int i = 0; i < 16; ++i) { a += s_sum[i][cl]; b += s_sq[i][cl]; }  // fixed order
         mean = a / count;
         var = b / count - mean * mean;
         if (var < 0.0) var = 0.0;
@@ -425,7 +425,7 @@ void launch_pad_rows(const float* src, float* dst, int64_t rows, int d, int ld, 
 void launch_bn_finalize(const float* partial, int tiles, int C, double count, const float* gamma, const float* beta,
                         float* rmean, float* rvar, float momentum, float eps, int training, float* scale, float* shift,
                         float* save_mean, float* save_invstd, hipStream_t st) {
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3(ceil_div(C, 64)), dim3(256), 0, st, partial, tiles, C, count, gamma,
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3(ceil_div(C, 16)), dim3(256), 0, st, partial, tiles, C, count, gamma,
                        beta, rmean, rvar, momentum, eps, training, scale, shift, save_mean, save_invstd);
 }
 void launch_bn_apply(const float* x, const float* s1, const float* b1, const float* res, const float* s2,

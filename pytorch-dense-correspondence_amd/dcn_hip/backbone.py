@@ -119,6 +119,8 @@ class _BackboneFn(torch.autograd.Function):
                                       _lib.ptr(ws), _lib.stream_ptr())
         _lib.check(rc, "dcn_backbone_forward")
         ctx.plan = plan
+        ctx.grad_sink = getattr(bn_running, "grad_sink", None)
+        ctx.grad_probe = (params[0], params[-1])  # to verify at backward time that .grad still aliases the sink
         ctx.saved_arena = saved
         ctx.kparams = kparams
         ctx.trained = bool(training)
@@ -142,10 +144,28 @@ class _BackboneFn(torch.autograd.Function):
                                        _lib.stream_ptr())
         _lib.check(rc, "dcn_backbone_backward")
         ctx.saved_arena = None
+        sink = ctx.grad_sink
+        first, last = ctx.grad_probe
+        aliased = (sink is not None and sink.numel() == flat.numel() and first.grad is not None and
+                   last.grad is not None and first.grad.data_ptr() == sink.data_ptr() and
+                   last.grad.data_ptr() == sink.data_ptr() + 4 * plan.grad_offsets[-2])
+        if aliased:
+            # the parameters' .grad are views of ONE flat buffer with this very layout (dcn_hip.distributed.FlatGradients):
+            # accumulate with a single kernel instead of ~110 autograd AccumulateGrad launches
+            sink.add_(flat)
+            return (None,) * (7 + len(plan.param_numel))
         return (None, None, None, None, None, None, None) + tuple(_grad_views(flat, plan))
 
 
-def backbone_forward(image, plan, params, bn_running, training, normalize=False, momentum=0.1, eps=1e-5):
+class _RunningList(list):
+    """bn running-statistic tensors + an optional flat gradient sink (non-tensor payload of the autograd call)."""
+    grad_sink = None
+
+
+def backbone_forward(image, plan, params, bn_running, training, normalize=False, momentum=0.1, eps=1e-5, grad_sink=None):
     """image [N,3,H,W] -> descriptors, logical [N,D,H,W] in channels_last memory.
-    ``params`` / ``bn_running`` follow ``plan.param_names`` / ``plan.bn_names`` (running_mean, running_var per BN)."""
-    return _BackboneFn.apply(image, plan, bn_running, training, normalize, momentum, eps, *params)
+    ``params`` / ``bn_running`` follow ``plan.param_names`` / ``plan.bn_names`` (running_mean, running_var per BN).
+    ``grad_sink``: flat fp32 buffer laid out like ``plan.grad_offsets`` that the parameters' ``.grad`` alias."""
+    rl = _RunningList(bn_running)
+    rl.grad_sink = grad_sink
+    return _BackboneFn.apply(image, plan, rl, training, normalize, momentum, eps, *params)

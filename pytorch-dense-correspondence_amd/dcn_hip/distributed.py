@@ -20,11 +20,14 @@ class FlatGradients(object):
         if not self.params:
             raise ValueError("module has no trainable parameters")
         dev = self.params[0].device
-        total = sum(p.numel() for p in self.params)
-        self.flat = torch.zeros(total, dtype=torch.float32, device=dev)
-        self.group = process_group
-        off = 0
+        # every gradient starts 16-byte aligned: the same layout the backbone engine writes (Plan.grad_offsets), so its
+        # backward can add its whole flat result into this buffer with one kernel
+        offsets = [0]
         for p in self.params:
+            offsets.append((offsets[-1] + p.numel() + 3) // 4 * 4)
+        self.flat = torch.zeros(offsets[-1], dtype=torch.float32, device=dev)
+        self.group = process_group
+        for p, off in zip(self.params, offsets):
             n = p.numel()
             chunk = self.flat[off:off + n]
             if p.dim() == 4 and p.is_contiguous(memory_format=torch.channels_last) and not p.is_contiguous():
@@ -33,7 +36,10 @@ class FlatGradients(object):
             else:
                 view = chunk.view(p.shape)
             p.grad = view
-            off += n
+        # let the fused backbone (a module that owns ALL of these parameters) accumulate straight into the buffer
+        owners = [m for m in module.modules() if hasattr(m, "_param_names")]
+        if len(owners) == 1 and sum(p.numel() for p in owners[0].parameters()) == sum(p.numel() for p in self.params):
+            owners[0]._flat_grad_sink = self.flat
 
     def zero_(self):
         """optimizer.zero_grad() equivalent that keeps the views alive (use instead of set_to_none=True)."""

@@ -98,7 +98,9 @@ class _DilatedResnet8s(nn.Module):
         params, running, tracked = self._tables()
         if self.training:
             torch._foreach_add_(tracked, 1)
-        return _bb.backbone_forward(x, plan, params, running, self.training, normalize, self.bn_momentum, self.bn_eps)
+        sink = getattr(self, "_flat_grad_sink", None)
+        return _bb.backbone_forward(x, plan, params, running, self.training, normalize, self.bn_momentum, self.bn_eps,
+                                    grad_sink=sink)
 
     def forward_flops(self, n, h, w):
         return _bb.get_plan(self.arch, self.base_width, int(n), int(h), int(w), self.num_classes).forward_flops
