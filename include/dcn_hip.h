@@ -196,12 +196,15 @@ typedef struct dcn_conv_desc {
 /* out = conv(in, w) [+ bias];  w: [cout][kh][kw][cin].  If bn_partial != NULL also writes per-M-tile
  * partial sums for batch-norm statistics: bn_partial[tile][2][cout] (sum, sum of squares); the number of
  * tiles is returned by dcn_conv_num_mtiles. */
+/* workspace (nullable): dcn_conv_gemm_workspace(c, dgrad) bytes; enables the stream-K work split used when the layer
+ * has too few output tiles to load all 256 CUs evenly (small batch). */
 int dcn_conv_forward(const dcn_conv_desc* c, const float* in, const float* w, const float* bias, float* out,
-                     float* bn_partial, void* stream);
+                     float* bn_partial, void* workspace, void* stream);
+size_t dcn_conv_gemm_workspace(const dcn_conv_desc* c, int dgrad);
 int dcn_conv_num_mtiles(const dcn_conv_desc* c);
 /* din = conv_transpose(dout, w) [+ add];  wt: [cin][kh][kw][cout] (see dcn_transpose_weight). */
 int dcn_conv_dgrad(const dcn_conv_desc* c, const float* dout, const float* wt, const float* add, float* din,
-                   void* stream);
+                   void* workspace, void* stream);
 /* dw[cout][kh][kw][cin] = sum_m dout[m][cout] * in[pix(m,tap)][cin]; slabs: scratch of dcn_conv_wgrad_workspace bytes */
 int dcn_conv_wgrad(const dcn_conv_desc* c, const float* in, const float* dout, float* dw, void* slabs, void* stream);
 size_t dcn_conv_wgrad_workspace(const dcn_conv_desc* c);

@@ -71,7 +71,7 @@ struct dcn_plan {
     size_t s_in4 = 0, s_stem_y = 0, s_pool = 0, s_argmax = 0, saved_floats = 0;
     // workspace offsets (floats)
     size_t w_buf[6] = {0, 0, 0, 0, 0, 0}, w_wt = 0, w_slab = 0, w_part = 0, w_k123 = 0, w_wstem = 0, w_dwstem = 0,
-           w_low = 0, w_glow = 0, w_ups = 0, ws_floats = 0;
+           w_low = 0, w_glow = 0, w_ups = 0, w_sk = 0, ws_floats = 0;
     size_t max_act = 0;
     double flops = 0;
     // optional launch-level timing (dcn_plan_profile_begin/end)
@@ -251,13 +251,17 @@ int build_plan(dcn_plan& p) {
     size_t ws = 0;
     auto alloc = [&](size_t fl) { const size_t o = ws; ws = align64(ws + fl); return o; };
     for (int i = 0; i < 6; ++i) p.w_buf[i] = alloc(p.max_act);
-    size_t max_w = 0, max_slab = 0, max_part = 0;
+    size_t max_w = 0, max_slab = 0, max_part = 0, max_sk = 0;
     int max_c = 4;
     for (const ConvL& c : p.convs) {
         const size_t welems = (size_t)c.d.ldc * c.d.kh * c.d.kw * c.d.cin;
         if (welems > max_w) max_w = welems;
         const size_t sl = dcn_conv_wgrad_workspace(&c.d) / sizeof(float);
         if (sl > max_slab) max_slab = sl;
+        for (int dg = 0; dg < 2; ++dg) {
+            const size_t sk = dcn_conv_gemm_workspace(&c.d, dg) / sizeof(float);
+            if (sk > max_sk) max_sk = sk;
+        }
         const size_t pf = (size_t)c.mtiles * 2 * c.d.cout;
         if (pf > max_part) max_part = pf;
         if (c.d.cout > max_c) max_c = c.d.cout;
@@ -268,6 +272,7 @@ int build_plan(dcn_plan& p) {
     }
     p.w_wt = alloc(max_w);
     p.w_slab = alloc(max_slab);
+    p.w_sk = alloc(max_sk);
     p.w_part = alloc(max_part);
     p.w_k123 = alloc((size_t)3 * max_c);
     p.w_wstem = alloc((size_t)p.base * 49 * 4);
@@ -329,7 +334,7 @@ struct Run {
     int conv_bn(const ConvL& c, const float* in, const float* w, float* const* bn_running, float momentum, float eps,
                 int training) {
         float* part = training ? Wk(p.w_part) : nullptr;
-        DCN_TRY(timed(0, c.flops, [&] { return dcn_conv_forward(&c.d, in, w, nullptr, S(c.x), part, st); }));
+        DCN_TRY(timed(0, c.flops, [&] { return dcn_conv_forward(&c.d, in, w, nullptr, S(c.x), part, Wk(p.w_sk), st); }));
         const BnL& b = p.bns[c.bn];
         float* stats = S(b.stats);
         float* rm = bn_running ? bn_running[2 * b.idx] : nullptr;
@@ -457,7 +462,8 @@ extern "C" int dcn_backbone_forward(dcn_plan* plan, const float* image, const fl
     const size_t low_bytes = (size_t)N * p.hl * p.wl * p.Dp * sizeof(float);
     if (hipMemsetAsync(R.Wk(p.w_low), 0, low_bytes, st) != hipSuccess) return DCN_E_LAUNCH;
     DCN_TRY(R.timed(0, fc.flops, [&] {
-        return dcn_conv_forward(&fc.d, R.S(p.blocks.back().out), R.P(fc.w), R.P(fc.b), R.Wk(p.w_low), nullptr, st);
+        return dcn_conv_forward(&fc.d, R.S(p.blocks.back().out), R.P(fc.w), R.P(fc.b), R.Wk(p.w_low), nullptr,
+                                R.Wk(p.w_sk), st);
     }));
     dcn::launch_upsample_fwd(R.Wk(p.w_low), N, p.hl, p.wl, p.Dp, p.D, p.H, p.W, normalize, descriptors, st);
     return dcn::check_launch();
@@ -487,7 +493,7 @@ extern "C" int dcn_backbone_backward(dcn_plan* plan, const float* grad_descripto
     };
     auto dgrad = [&](const ConvL& c, const float* dx, const float* add, float* din) -> int {
         DCN_TRY(dcn_transpose_weight(R.P(c.w), wt, c.d.cout, c.d.kh * c.d.kw, c.d.cin, c.d.ldc, st));
-        return R.timed(0, c.flops, [&] { return dcn_conv_dgrad(&c.d, dx, wt, add, din, st); });
+        return R.timed(0, c.flops, [&] { return dcn_conv_dgrad(&c.d, dx, wt, add, din, R.Wk(p.w_sk), st); });
     };
 
     // ---- upsample + scoring layer

@@ -55,8 +55,9 @@ struct GemmConv {
     const float* add;   // [M][ldc] or null
     float* dst;         // [M][ldc]
     float* bn_partial;  // [mtiles][2][cd] or null
-    int hs, ws, cs, hd, wd, cd, kh, kw, stride, sshift, pad, dil, ldc, M, K, transposed, mtiles, ntiles;
-    FastDiv div_hw, div_w, div_cs, div_kw;
+    float* sk_partial;  // stream-K: [2 * workgroups][BM*BN] parked accumulators (fragment order)
+    int hs, ws, cs, hd, wd, cd, kh, kw, stride, sshift, pad, dil, ldc, M, K, transposed, mtiles, ntiles, sk_units;
+    FastDiv div_hw, div_w, div_cs, div_kw, div_nt, div_nk;
 };
 
 // bijective XCD-aware remap: consecutive logical tiles (sharing an M tile) land on the same XCD / L2
@@ -65,20 +66,79 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
     return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + local;
 }
 
-// TN: 32-column MFMA tiles per wavefront (2 -> 128-wide workgroup tile, 1 -> 64-wide for Cout <= 64 layers).
-// BK: K elements staged per barrier.  All gather arithmetic is branch-free (selects + clamped addresses), so the
-// compiler can issue next-tile address math, global loads and LDS traffic in the shadow of the 64-cycle MFMAs.
-// WM: wavefronts along M (2 -> 2x2 wave grid, 1 -> 1x4).  Workgroup tile = (32*TM*WM) x (32*TN*(4/WM)).
-template <int WM, int TM, int TN, int BK, bool TR>
-__global__ void __launch_bounds__(NT, (TM * TN == 4 ? 3 : 1))   // 64x64 wave tile: cap at 168 registers -> 3 waves / SIMD
-conv_gemm_kernel(GemmConv p) {
-    constexpr int WN = 4 / WM, BM = 32 * TM * WM, BN = 32 * TN * WN, LDK = BK + 4, KQ = BK / 4, ROWS = NT / KQ, PA = (BM + ROWS - 1) / ROWS,
-                  PB = (BN + ROWS - 1) / ROWS, kStage = (BM + BN) * LDK;
-    __shared__ __attribute__((aligned(16))) float lds[2 * kStage];
+// ---- geometry shared by the gather-GEMM kernel and its stream-K fix-up kernel
+// WM: wavefronts along M (2 -> 2x2 wave grid, 1 -> 1x4).  TM / TN: 32x32 MFMA tiles per wavefront.
+// Workgroup tile = (32*TM*WM) x (32*TN*(4/WM)).  BK: K elements staged per barrier.
+template <int WM, int TM, int TN, int BK> struct GemmGeo {
+    static constexpr int WN = 4 / WM, BM = 32 * TM * WM, BN = 32 * TN * WN, LDK = BK + 4, KQ = BK / 4, ROWS = NT / KQ,
+                         PA = (BM + ROWS - 1) / ROWS, PB = (BN + ROWS - 1) / ROWS, kStage = (BM + BN) * LDK,
+                         kSlotFloats = BM * BN;
+};
+
+// Epilogue: C/D fragments -> NHWC rows (32 consecutive channels per half-wave = 128 B segments), + bias, + residual
+// gradient, + per-M-tile batch-norm partial sums (fixed order).  `red` = at least 4*BN floats of LDS, free to use.
+template <int WM, int TM, int TN, int BK>
+__device__ __forceinline__ void gemm_epilogue(const GemmConv& p, f32x16 (&acc)[TM][TN], int mt, int nt, float* red) {
+    using G = GemmGeo<WM, TM, TN, BK>;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int wm_ = WM == 2 ? (wv >> 1) : 0, wn_ = WM == 2 ? (wv & 1) : wv;
-    const int tile = xcd_remap(blockIdx.x, p.mtiles * p.ntiles);
-    const int mt = tile / p.ntiles, nt = tile - mt * p.ntiles;
+    const int fi = lane & 31, fh = lane >> 5;
+    const int m0 = mt * G::BM, n0 = nt * G::BN;
+    float csum[TN], csq[TN];
+#pragma unroll
+    for (int tn = 0; tn < TN; ++tn) {
+        csum[tn] = 0.f; csq[tn] = 0.f;
+        const int col = n0 + wn_ * 32 * TN + tn * 32 + fi;
+        const bool cok = col < p.cd;
+        const float bv = (p.bias && cok) ? p.bias[col] : 0.f;
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = m0 + wm_ * 32 * TM + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh;
+                float v = acc[tm][tn][r] + bv;
+                if (cok && row < p.M) {
+                    const int64_t o = (int64_t)row * p.ldc + col;
+                    if (p.add) v += p.add[o];
+                    p.dst[o] = v;
+                }
+                csum[tn] += acc[tm][tn][r];
+                csq[tn] = fmaf(acc[tm][tn][r], acc[tm][tn][r], csq[tn]);
+            }
+        }
+    }
+    if (p.bn_partial) {
+        // rows >= M and columns >= cd are exactly zero in acc (zero-filled fragments), so no masking is needed
+#pragma unroll
+        for (int tn = 0; tn < TN; ++tn) {
+            csum[tn] += __shfl_xor(csum[tn], 32, 64);
+            csq[tn] += __shfl_xor(csq[tn], 32, 64);
+            if (fh == 0) {
+                red[(wm_ * 2 + 0) * G::BN + wn_ * 32 * TN + tn * 32 + fi] = csum[tn];
+                red[(wm_ * 2 + 1) * G::BN + wn_ * 32 * TN + tn * 32 + fi] = csq[tn];
+            }
+        }
+        __syncthreads();
+        if (tid < G::BN && n0 + tid < p.cd) {
+            const float s = red[(0 * 2 + 0) * G::BN + tid] + (WM == 2 ? red[(1 * 2 + 0) * G::BN + tid] : 0.f);
+            const float q = red[(0 * 2 + 1) * G::BN + tid] + (WM == 2 ? red[(1 * 2 + 1) * G::BN + tid] : 0.f);
+            p.bn_partial[((int64_t)mt * 2 + 0) * p.cd + n0 + tid] = s;
+            p.bn_partial[((int64_t)mt * 2 + 1) * p.cd + n0 + tid] = q;
+        }
+    }
+}
+
+// One (tile, K range) segment: K tiles [k0, k1) of output tile `tile`.  A full range ends in the epilogue, a partial
+// one (stream-K) parks the raw accumulators in `slot` (fragment order: fully coalesced) for the fix-up kernel.
+// All gather arithmetic is branch-free (selects + clamped addresses); the main loop is software-pipelined.
+template <int WM, int TM, int TN, int BK, bool TR>
+__device__ __forceinline__ void gemm_segment(const GemmConv& p, float* lds, int tile, int k0, int k1, int nk, float* slot) {
+    using G = GemmGeo<WM, TM, TN, BK>;
+    constexpr int BM = G::BM, BN = G::BN, LDK = G::LDK, KQ = G::KQ, ROWS = G::ROWS, PA = G::PA, PB = G::PB,
+                  kStage = G::kStage;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int wm_ = WM == 2 ? (wv >> 1) : 0, wn_ = WM == 2 ? (wv & 1) : wv;
+    const int mt = fdiv(tile, p.div_nt), nt = tile - mt * p.ntiles;
     const int m0 = mt * BM, n0 = nt * BN;
 
     // ---- per-thread gather coordinates: this thread stages rows r0 + ROWS*j at k-quad kq
@@ -104,7 +164,6 @@ conv_gemm_kernel(GemmConv p) {
         wokm |= (ok ? 1u : 0u) << j;
         wrow[j] = (ok ? n : 0) * p.K + kq * 4;
     }
-    const int nk = (p.K + BK - 1) / BK;
     const int smask = p.stride - 1;
     float4 ra[PA], rb[PB];
     unsigned okm = 0;  // validity bits of the tile held in ra / rb (applied when it is written to LDS, AFTER the MFMAs:
@@ -177,6 +236,9 @@ conv_gemm_kernel(GemmConv p) {
     //   barrier: everybody has written stage nxt / finished reading stage cur's first half
     //   phase B: MFMAs on F1 | in their shadow: address math + global loads of tile kt+2, ds_read of tile kt+1's F0
     // so that a lone wavefront per SIMD (few workgroups per CU at small batch) still keeps the matrix pipe fed.
+    // The loop body is branch-free (tile indices are clamped instead of guarded: the extra tile loaded / staged in
+    // the last iterations is never consumed) so that each phase is ONE scheduling region, and
+    // sched_group_barrier pins the interleave "1 MFMA, a few VALU/LDS/VMEM instructions" inside it.
     static_assert(BK == 16, "the pipelined loop is written for two 8-deep fragment groups per K tile");
     const int fi = lane & 31, fh = lane >> 5;
     const int a_off = (wm_ * 32 * TM + fi) * LDK + 4 * fh;
@@ -196,93 +258,121 @@ conv_gemm_kernel(GemmConv p) {
             fb[set][t][0] = v.x; fb[set][t][1] = v.y; fb[set][t][2] = v.z; fb[set][t][3] = v.w;
         }
     };
-    auto mfma_steps = [&](int set, int j0, int j1) {
+    auto mfma_steps = [&](int set) {
 #pragma unroll
-        for (int j = j0; j < j1; ++j)
+        for (int j = 0; j < 4; ++j)
 #pragma unroll
             for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
                 for (int tn = 0; tn < TN; ++tn)
                     acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[set][tm][j], fb[set][tn][j], acc[tm][tn], 0, 0, 0);
     };
-
-    // The loop body is branch-free (tile indices are clamped instead of guarded: the extra tile loaded / staged in
-    // the last iterations is never consumed) so that each phase is ONE scheduling region, and
-    // sched_group_barrier pins the interleave "1 MFMA, a few VALU/LDS/VMEM instructions" inside it.
     constexpr int kMfmaPerPhase = 4 * TM * TN;
-    load_tile(0);
+    load_tile(k0);
     store_tile(0);
-    load_tile(nk > 1 ? 1 : 0);
+    load_tile(k0 + 1 < k1 ? k0 + 1 : k0);
     __syncthreads();
     read_frags(0, 0, 0);
-    for (int kt = 0; kt < nk; ++kt) {
-        const int cur = kt & 1;
-        // ---- phase A: MFMAs on F0 | ds_read F1, stage tile kt+1 into the other LDS buffer
+    for (int kt = k0; kt < k1; ++kt) {
+        const int cur = (kt - k0) & 1;
+        // ---- phase A
         read_frags(cur, 1, 1);
         store_tile(cur ^ 1);
-        mfma_steps(0, 0, 4);
+        mfma_steps(0);
 #pragma unroll
         for (int i = 0; i < kMfmaPerPhase; ++i) {
-            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);          // 1 MFMA
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                       // 1 MFMA
             __builtin_amdgcn_sched_group_barrier(0x306, 48 / kMfmaPerPhase + 1, 0);  // VALU | SALU | DS
         }
         __syncthreads();
-        // ---- phase B: MFMAs on F1 | address math + global loads of tile kt+2, ds_read of tile kt+1's F0
-        load_tile(kt + 2 < nk ? kt + 2 : nk - 1);
+        // ---- phase B
+        load_tile(kt + 2 < k1 ? kt + 2 : k1 - 1);
         read_frags(cur ^ 1, 0, 0);
-        mfma_steps(1, 0, 4);
+        mfma_steps(1);
 #pragma unroll
         for (int i = 0; i < kMfmaPerPhase; ++i) {
-            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);          // 1 MFMA
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                        // 1 MFMA
             __builtin_amdgcn_sched_group_barrier(0x126, 112 / kMfmaPerPhase + 1, 0);  // VALU | SALU | VMEM read | DS read
         }
     }
-    __syncthreads();  // the epilogue reuses the LDS tile as reduction scratch
+    __syncthreads();  // LDS is reused below (reduction scratch) / by the next segment
 
-    // ---- epilogue: C/D fragment -> NHWC rows (32 consecutive channels per half-wave = 128 B segments)
-    float csum[TN], csq[TN];
+    if (k0 == 0 && k1 == nk) {
+        gemm_epilogue<WM, TM, TN, BK>(p, acc, mt, nt, lds);
+    } else {
+        float* o = slot + wv * (TM * TN * 16 * 64) + lane;
 #pragma unroll
-    for (int tn = 0; tn < TN; ++tn) {
-        csum[tn] = 0.f; csq[tn] = 0.f;
-        const int col = n0 + wn_ * 32 * TN + tn * 32 + fi;
-        const bool cok = col < p.cd;
-        const float bv = (p.bias && cok) ? p.bias[col] : 0.f;
+        for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
-        for (int tm = 0; tm < TM; ++tm) {
+            for (int tn = 0; tn < TN; ++tn)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = m0 + wm_ * 32 * TM + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh;
-                float v = acc[tm][tn][r] + bv;
-                if (cok && row < p.M) {
-                    const int64_t o = (int64_t)row * p.ldc + col;
-                    if (p.add) v += p.add[o];
-                    p.dst[o] = v;
-                }
-                csum[tn] += acc[tm][tn][r];
-                csq[tn] = fmaf(acc[tm][tn][r], acc[tm][tn][r], csq[tn]);
-            }
+                for (int r = 0; r < 16; ++r) o[((tm * TN + tn) * 16 + r) * 64] = acc[tm][tn][r];
+    }
+}
+
+// Data-parallel form: one workgroup per output tile.
+// Stream-K form (SK): the tiles x K-tiles iteration space is cut into equal contiguous ranges, one per workgroup, so
+// that all 256 CUs finish together even when the layer has too few tiles to fill them evenly (small batch); tiles that
+// end up split across workgroups are completed by conv_gemm_fixup_kernel.
+template <int WM, int TM, int TN, int BK, bool TR, bool SK>
+__global__ void __launch_bounds__(NT, (TM * TN == 4 ? 3 : 1))   // 64x64 wave tile: cap at 168 registers -> 3 waves / SIMD
+conv_gemm_kernel(GemmConv p) {
+    using G = GemmGeo<WM, TM, TN, BK>;
+    __shared__ __attribute__((aligned(16))) float lds[2 * G::kStage];
+    const int nk = (p.K + BK - 1) / BK;
+    if (!SK) {
+        gemm_segment<WM, TM, TN, BK, TR>(p, lds, xcd_remap(blockIdx.x, p.mtiles * p.ntiles), 0, nk, nk, nullptr);
+    } else {
+        const int g = xcd_remap(blockIdx.x, gridDim.x);  // neighbouring unit ranges on the same XCD (shared L2 lines)
+        int u = g * p.sk_units;
+        const int total = p.mtiles * p.ntiles * nk;
+        const int u_end = min(total, u + p.sk_units);
+        bool first = true;
+        while (u < u_end) {
+            const int tile = fdiv(u, p.div_nk), k0 = u - tile * nk;
+            const int k1 = min(nk, k0 + (u_end - u));
+            gemm_segment<WM, TM, TN, BK, TR>(p, lds, tile, k0, k1, nk,
+                                             p.sk_partial + (int64_t)(2 * g + (first ? 0 : 1)) * G::kSlotFloats);
+            u += k1 - k0;
+            first = false;
+            __syncthreads();  // the epilogue's reduction scratch lives in the LDS tile the next segment overwrites
         }
     }
-    if (p.bn_partial) {
-        // rows >= M and columns >= cd are exactly zero in acc (zero-filled fragments), so no masking is needed
-        float* red = lds;  // [2 (wm)][2 (sum, sq)][BN]
+}
+
+// Completes the tiles that stream-K split: adds the parked accumulators in workgroup order (deterministic) and runs
+// the normal epilogue.  One workgroup per tile; tiles computed whole by a single workgroup return at once.
+template <int WM, int TM, int TN, int BK>
+__global__ void __launch_bounds__(NT)
+conv_gemm_fixup_kernel(GemmConv p) {
+    using G = GemmGeo<WM, TM, TN, BK>;
+    __shared__ float red[4 * G::BN];
+    const int nk = (p.K + BK - 1) / BK;
+    const int tile = blockIdx.x;
+    const int ua = tile * nk, ub = ua + nk - 1;
+    const int ga = ua / p.sk_units, gb = ub / p.sk_units;
+    if (ga == gb) return;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    f32x16 acc[TM][TN];
 #pragma unroll
-        for (int tn = 0; tn < TN; ++tn) {
-            csum[tn] += __shfl_xor(csum[tn], 32, 64);
-            csq[tn] += __shfl_xor(csq[tn], 32, 64);
-            if (fh == 0) {
-                red[(wm_ * 2 + 0) * BN + wn_ * 32 * TN + tn * 32 + fi] = csum[tn];
-                red[(wm_ * 2 + 1) * BN + wn_ * 32 * TN + tn * 32 + fi] = csq[tn];
-            }
-        }
-        __syncthreads();
-        if (tid < BN && n0 + tid < p.cd) {
-            const float s = red[(0 * 2 + 0) * BN + tid] + (WM == 2 ? red[(1 * 2 + 0) * BN + tid] : 0.f);
-            const float q = red[(0 * 2 + 1) * BN + tid] + (WM == 2 ? red[(1 * 2 + 1) * BN + tid] : 0.f);
-            p.bn_partial[((int64_t)mt * 2 + 0) * p.cd + n0 + tid] = s;
-            p.bn_partial[((int64_t)mt * 2 + 1) * p.cd + n0 + tid] = q;
-        }
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    for (int g = ga; g <= gb; ++g) {
+        const int first_tile = (g * p.sk_units) / nk;  // the tile this workgroup's FIRST segment belongs to
+        const float* o = p.sk_partial + (int64_t)(2 * g + (first_tile == tile ? 0 : 1)) * G::kSlotFloats +
+                         wv * (TM * TN * 16 * 64) + lane;
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+            for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[tm][tn][r] += o[((tm * TN + tn) * 16 + r) * 64];
     }
+    const int mt = tile / p.ntiles, nt = tile - mt * p.ntiles;
+    gemm_epilogue<WM, TM, TN, BK>(p, acc, mt, nt, red);
 }
 
 // Tile-shape choice (fp32 MFMA is slow enough that load balance across the 256 CUs matters more than tile reuse):
@@ -297,7 +387,44 @@ int gemm_tile_m(int M, int cd) {
     return dcn::ceil_div(M, 128) * ntiles < 3 * 256 ? 64 : 128;
 }
 
-int launch_gemm(GemmConv& p, hipStream_t st) {
+// Stream-K decision.  With one workgroup per tile the chip processes ceil(tiles / 256) "rounds"; when the last round
+// is mostly empty (small batch: a few hundred tiles) the equal-work split recovers the idle CUs.
+struct GemmShape {
+    int bm, bn, mtiles, ntiles, nk, sk_wgs, sk_units;
+    bool narrow, sk;
+    size_t ws_bytes;
+};
+GemmShape gemm_shape(int M, int cd, int K) {
+    GemmShape g;
+    g.narrow = cd <= 64;
+    g.bm = gemm_tile_m(M, cd);
+    g.bn = g.bm == 32 ? 128 : (g.narrow ? 64 : 128);
+    g.mtiles = dcn::ceil_div(M, g.bm);
+    g.ntiles = dcn::ceil_div(cd, g.bn);
+    g.nk = dcn::ceil_div(K, 16);
+    const int tiles = g.mtiles * g.ntiles;
+    const double rounds = tiles / 256.0;
+    const double waste = 1.0 - rounds / (double)(int)(rounds + 0.999999);
+    g.sk = tiles < 8 * 256 && waste > 0.08 && g.nk >= 32;  // short K loops (1x1 convs) do not amortise the fix-up pass
+    int wgs = 512;
+    if (const char* e = getenv("DCN_GEMM_SK")) {  // tuning / test override: 0 = off, 1 = as decided, N > 1 = force N workgroups
+        const int v = atoi(e);
+        if (v == 0) g.sk = false;
+        if (v > 1) { g.sk = g.nk >= 2; wgs = v; }
+    }
+    g.sk_wgs = 0; g.sk_units = 0; g.ws_bytes = 0;
+    if (g.sk) {
+        const int64_t total = (int64_t)tiles * g.nk;
+        if (total >= ((int64_t)1 << 30)) { g.sk = false; return g; }
+        if (wgs > total / 2) wgs = (int)(total / 2) > 0 ? (int)(total / 2) : 1;  // at least two K tiles per workgroup
+        g.sk_units = (int)((total + wgs - 1) / wgs);
+        g.sk_wgs = (int)((total + g.sk_units - 1) / g.sk_units);
+        g.ws_bytes = (size_t)2 * g.sk_wgs * g.bm * g.bn * sizeof(float);
+    }
+    return g;
+}
+
+int launch_gemm(GemmConv& p, void* workspace, hipStream_t st) {
     if (p.stride != 1 && p.stride != 2 && p.stride != 4) return DCN_E_UNSUPPORTED;
     p.sshift = p.stride == 1 ? 0 : (p.stride == 2 ? 1 : 2);
     p.div_hw = make_fastdiv(p.hd * p.wd);
@@ -307,19 +434,29 @@ int launch_gemm(GemmConv& p, hipStream_t st) {
     // 32-bit element offsets inside the kernel
     if ((int64_t)p.M / (p.hd * p.wd) * p.hs * p.ws * p.cs >= ((int64_t)1 << 31) || (int64_t)p.cd * p.K >= ((int64_t)1 << 31))
         return DCN_E_UNSUPPORTED;
-    const bool narrow = p.cd <= 64;
-    const int bm = gemm_tile_m(p.M, p.cd);
-    p.mtiles = dcn::ceil_div(p.M, bm);
-    p.ntiles = dcn::ceil_div(p.cd, narrow ? 64 : 128);
-    const dim3 grid(p.mtiles * p.ntiles), block(NT);
-#define DCN_GEMM(WM, TM, TN)                                                                                  \
-    do {                                                                                                      \
-        if (p.transposed) hipLaunchKernelGGL((conv_gemm_kernel<WM, TM, TN, 16, true>), grid, block, 0, st, p); \
-        else hipLaunchKernelGGL((conv_gemm_kernel<WM, TM, TN, 16, false>), grid, block, 0, st, p);             \
+    const GemmShape g = gemm_shape(p.M, p.cd, p.K);
+    const bool sk = g.sk && workspace != nullptr;
+    p.mtiles = g.mtiles;
+    p.ntiles = g.ntiles;
+    p.div_nt = make_fastdiv(g.ntiles);
+    p.div_nk = make_fastdiv(g.nk);
+    p.sk_units = sk ? g.sk_units : 0;
+    p.sk_partial = sk ? (float*)workspace : nullptr;
+    const dim3 grid(sk ? g.sk_wgs : g.mtiles * g.ntiles), fgrid(g.mtiles * g.ntiles), block(NT);
+#define DCN_GEMM(WM, TM, TN)                                                                                          \
+    do {                                                                                                              \
+        if (sk) {                                                                                                     \
+            if (p.transposed) hipLaunchKernelGGL((conv_gemm_kernel<WM, TM, TN, 16, true, true>), grid, block, 0, st, p); \
+            else hipLaunchKernelGGL((conv_gemm_kernel<WM, TM, TN, 16, false, true>), grid, block, 0, st, p);           \
+            hipLaunchKernelGGL((conv_gemm_fixup_kernel<WM, TM, TN, 16>), fgrid, block, 0, st, p);                      \
+        } else {                                                                                                      \
+            if (p.transposed) hipLaunchKernelGGL((conv_gemm_kernel<WM, TM, TN, 16, true, false>), grid, block, 0, st, p); \
+            else hipLaunchKernelGGL((conv_gemm_kernel<WM, TM, TN, 16, false, false>), grid, block, 0, st, p);          \
+        }                                                                                                             \
     } while (0)
-    if (bm == 32) DCN_GEMM(1, 1, 1);                                   //  32 x 128, waves 1x4
-    else if (bm == 64) { if (narrow) DCN_GEMM(2, 1, 1); else DCN_GEMM(2, 1, 2); }   //  64 x 64 | 64 x 128
-    else { if (narrow) DCN_GEMM(2, 2, 1); else DCN_GEMM(2, 2, 2); }                 // 128 x 64 | 128 x 128
+    if (g.bm == 32) DCN_GEMM(1, 1, 1);                                     //  32 x 128, waves 1x4
+    else if (g.bm == 64) { if (g.narrow) DCN_GEMM(2, 1, 1); else DCN_GEMM(2, 1, 2); }   //  64 x 64 | 64 x 128
+    else { if (g.narrow) DCN_GEMM(2, 2, 1); else DCN_GEMM(2, 2, 2); }                   // 128 x 64 | 128 x 128
 #undef DCN_GEMM
     return dcn::check_launch();
 }
@@ -528,24 +665,29 @@ bool valid_desc(const dcn_conv_desc* c) {
 
 extern "C" int dcn_conv_num_mtiles(const dcn_conv_desc* c) {
     if (!valid_desc(c)) return DCN_E_INVALID;
-    const int M = c->n * c->hout * c->wout;
-    return dcn::ceil_div(M, gemm_tile_m(M, c->cout));
+    return gemm_shape(c->n * c->hout * c->wout, c->cout, c->kh * c->kw * c->cin).mtiles;
+}
+
+extern "C" size_t dcn_conv_gemm_workspace(const dcn_conv_desc* c, int dgrad) {
+    if (!valid_desc(c)) return 0;
+    if (dgrad) return gemm_shape(c->n * c->hin * c->win, c->cin, c->kh * c->kw * c->ldc).ws_bytes;
+    return gemm_shape(c->n * c->hout * c->wout, c->cout, c->kh * c->kw * c->cin).ws_bytes;
 }
 
 extern "C" int dcn_conv_forward(const dcn_conv_desc* c, const float* in, const float* w, const float* bias, float* out,
-                                float* bn_partial, void* stream) {
+                                float* bn_partial, void* workspace, void* stream) {
     if (!valid_desc(c) || !in || !w || !out) return DCN_E_INVALID;
     GemmConv p;
     p.src = in; p.wm = w; p.bias = bias; p.add = nullptr; p.dst = out; p.bn_partial = bn_partial;
     p.hs = c->hin; p.ws = c->win; p.cs = c->cin; p.hd = c->hout; p.wd = c->wout; p.cd = c->cout;
     p.kh = c->kh; p.kw = c->kw; p.stride = c->stride; p.pad = c->pad; p.dil = c->dil; p.ldc = c->ldc;
     p.M = c->n * c->hout * c->wout; p.K = c->kh * c->kw * c->cin; p.transposed = 0;
-    return launch_gemm(p, (hipStream_t)stream);
+    return launch_gemm(p, workspace, (hipStream_t)stream);
 }
 
 // The description is the FORWARD convolution's; dout is [n,hout,wout,ld = c->ldc], din is [n,hin,win,cin].
 extern "C" int dcn_conv_dgrad(const dcn_conv_desc* c, const float* dout, const float* wt, const float* add, float* din,
-                              void* stream) {
+                              void* workspace, void* stream) {
     if (!valid_desc(c) || !dout || !wt || !din || (c->ldc % 4) != 0) return DCN_E_INVALID;
     GemmConv p;
     p.src = dout; p.wm = wt; p.bias = nullptr; p.add = add; p.dst = din; p.bn_partial = nullptr;
@@ -553,7 +695,7 @@ extern "C" int dcn_conv_dgrad(const dcn_conv_desc* c, const float* dout, const f
     p.hd = c->hin; p.wd = c->win; p.cd = c->cin;
     p.kh = c->kh; p.kw = c->kw; p.stride = c->stride; p.pad = c->pad; p.dil = c->dil; p.ldc = c->cin;
     p.M = c->n * c->hin * c->win; p.K = c->kh * c->kw * c->ldc; p.transposed = 1;
-    return launch_gemm(p, (hipStream_t)stream);
+    return launch_gemm(p, workspace, (hipStream_t)stream);
 }
 
 extern "C" size_t dcn_conv_wgrad_workspace(const dcn_conv_desc* c) {

@@ -54,9 +54,11 @@ SYMBOLS = {
     "dcn_backbone_forward": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_float, c_int, c_int, c_void_p,
                                      c_void_p, c_void_p, c_void_p]),
     "dcn_backbone_backward": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
-    "dcn_conv_forward": (c_int, [ctypes.POINTER(ConvDesc), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "dcn_conv_forward": (c_int, [ctypes.POINTER(ConvDesc), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                 c_void_p]),
+    "dcn_conv_gemm_workspace": (c_size_t, [ctypes.POINTER(ConvDesc), c_int]),
     "dcn_conv_num_mtiles": (c_int, [ctypes.POINTER(ConvDesc)]),
-    "dcn_conv_dgrad": (c_int, [ctypes.POINTER(ConvDesc), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "dcn_conv_dgrad": (c_int, [ctypes.POINTER(ConvDesc), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "dcn_conv_wgrad": (c_int, [ctypes.POINTER(ConvDesc), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "dcn_conv_wgrad_workspace": (c_size_t, [ctypes.POINTER(ConvDesc)]),
     "dcn_transpose_weight": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),

@@ -51,6 +51,20 @@ def test_forward_backward_vs_oracle(arch, bw, shape, D):
         assert rel_err(b.float(), bo.float()) < 1e-4 or float((b.float() - bo.float()).abs().max()) < 1e-5, k
 
 
+def test_forward_backward_with_stream_k_forced(monkeypatch):
+    """Same network with every gather-GEMM launch forced through the stream-K split + fix-up path (engine workspace)."""
+    monkeypatch.setenv("DCN_GEMM_SK", "5")
+    m, o = _pair("Resnet18_8s", 3, 8)
+    g = torch.Generator().manual_seed(11)
+    x = torch.randn(2, 3, 32, 40, generator=g)
+    gy = torch.randn(2, 3, 32, 40, generator=g)
+    m.train(); o.train()
+    y, yo = m(x), o(x)
+    assert rel_err(y, yo) < 2e-5
+    (y * gy).sum().backward(); (yo * gy).sum().backward()
+    assert max(rel_err(p.grad, po.grad) for p, po in zip(m.parameters(), o.parameters())) < 1e-4
+
+
 def test_real_width_resnet34_small_image():
     """The real Resnet34_8s (base width 64, 21.3 M parameters): exercises full 128x128 tiles, multiple N tiles,
     K = 4608 reductions and the split-K wgrad path."""

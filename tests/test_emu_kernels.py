@@ -28,10 +28,12 @@ CONV_CASES = [
 ]
 
 
-@pytest.mark.parametrize("tile_m", ["32", "64", "128"])
+@pytest.mark.parametrize("tile_m,sk", [("32", "0"), ("64", "0"), ("128", "0"), ("32", "3"), ("64", "5"), ("128", "2"),
+                                       ("64", "7")])
 @pytest.mark.parametrize("case", CONV_CASES, ids=[str(c) for c in CONV_CASES])
-def test_conv_forward_dgrad_wgrad(L, case, tile_m, monkeypatch):
+def test_conv_forward_dgrad_wgrad(L, case, tile_m, sk, monkeypatch):
     monkeypatch.setenv("DCN_GEMM_TILE_M", tile_m)   # every workgroup-tile height of the gather-GEMM kernel
+    monkeypatch.setenv("DCN_GEMM_SK", sk)           # 0: one workgroup per tile; N: stream-K over N workgroups
     lib = L.get()
     n, hin, win, cin, cout, k, stride, pad, dil = case
     hout = (hin + 2 * pad - dil * (k - 1) - 1) // stride + 1
@@ -46,7 +48,11 @@ def test_conv_forward_dgrad_wgrad(L, case, tile_m, monkeypatch):
     mt = lib.dcn_conv_num_mtiles(ctypes.byref(d))
     assert mt in [(n * hout * wout + b - 1) // b for b in (32, 64, 128)]
     part = torch.full((mt, 2, cout), float("nan"))
-    assert lib.dcn_conv_forward(ctypes.byref(d), L.ptr(x_nhwc), L.ptr(w_k), None, L.ptr(out), L.ptr(part), None) == 0
+    ws_f = torch.empty(max(lib.dcn_conv_gemm_workspace(ctypes.byref(d), 0), 4) // 4)
+    ws_d = torch.empty(max(lib.dcn_conv_gemm_workspace(ctypes.byref(d), 1), 4) // 4)
+    if sk != "0" and k > 1:
+        assert ws_f.numel() > 1 and ws_d.numel() > 1   # stream-K really is exercised (K spans >= 2 K tiles)
+    assert lib.dcn_conv_forward(ctypes.byref(d), L.ptr(x_nhwc), L.ptr(w_k), None, L.ptr(out), L.ptr(part), L.ptr(ws_f), None) == 0
     ref = F.conv2d(x, w, None, stride, pad, dil)
     refn = ref.detach().permute(0, 2, 3, 1)
     assert rel_err(out, refn) < 2e-6
@@ -59,7 +65,7 @@ def test_conv_forward_dgrad_wgrad(L, case, tile_m, monkeypatch):
     assert torch.equal(wt, w_k.reshape(cout, k * k, cin).permute(2, 1, 0))
     add = torch.randn(n, hin, win, cin, generator=g)
     din = torch.full((n, hin, win, cin), float("nan"))
-    assert lib.dcn_conv_dgrad(ctypes.byref(d), L.ptr(dout), L.ptr(wt), L.ptr(add), L.ptr(din), None) == 0
+    assert lib.dcn_conv_dgrad(ctypes.byref(d), L.ptr(dout), L.ptr(wt), L.ptr(add), L.ptr(din), L.ptr(ws_d), None) == 0
     assert rel_err(din, x.grad.permute(0, 2, 3, 1) + add) < 3e-6
     dw = torch.full((cout, k, k, cin), float("nan"))
     slab = torch.empty(max(lib.dcn_conv_wgrad_workspace(ctypes.byref(d)), 4) // 4)
@@ -78,7 +84,7 @@ def test_conv_scoring_layer_shape(L):
     b = torch.randn(D, generator=g)
     out = torch.zeros(n, h, w_, ld)
     assert lib.dcn_conv_forward(ctypes.byref(d), L.ptr(x.permute(0, 2, 3, 1).contiguous()),
-                                L.ptr(w.permute(0, 2, 3, 1).contiguous()), L.ptr(b), L.ptr(out), None, None) == 0
+                                L.ptr(w.permute(0, 2, 3, 1).contiguous()), L.ptr(b), L.ptr(out), None, None, None) == 0
     assert rel_err(out[..., :D], F.conv2d(x, w, b).permute(0, 2, 3, 1)) < 2e-6
     assert float(out[..., D:].abs().max()) == 0.0
 
@@ -87,9 +93,9 @@ def test_conv_rejects_bad_arguments(L):
     lib = L.get()
     d = L.ConvDesc(1, 8, 8, 6, 8, 8, 8, 3, 3, 1, 1, 1, 8)   # cin not a multiple of 4
     t = torch.zeros(4096)
-    assert lib.dcn_conv_forward(ctypes.byref(d), L.ptr(t), L.ptr(t), None, L.ptr(t), None, None) == -1
+    assert lib.dcn_conv_forward(ctypes.byref(d), L.ptr(t), L.ptr(t), None, L.ptr(t), None, None, None) == -1
     d = L.ConvDesc(1, 8, 8, 8, 8, 8, 8, 3, 3, 1, 1, 1, 8)
-    assert lib.dcn_conv_forward(ctypes.byref(d), None, L.ptr(t), None, L.ptr(t), None, None) == -1
+    assert lib.dcn_conv_forward(ctypes.byref(d), None, L.ptr(t), None, L.ptr(t), None, None, None) == -1
 
 
 @pytest.mark.parametrize("shape", [(2, 4, 5, 3, 32, 40), (1, 3, 3, 16, 24, 24), (1, 6, 8, 5, 41, 59)])

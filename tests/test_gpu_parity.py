@@ -139,7 +139,9 @@ def test_conv_kernels_vs_torch_cpu(L, case):
     mt = lib.dcn_conv_num_mtiles(ctypes.byref(d))
     part = torch.full((mt, 2, cout), float("nan"), device="cuda")
     st = L.stream_ptr()
-    assert lib.dcn_conv_forward(ctypes.byref(d), L.ptr(xg), L.ptr(wg), None, L.ptr(out), L.ptr(part), st) == 0
+    ws_f = torch.empty(max(lib.dcn_conv_gemm_workspace(ctypes.byref(d), 0), 4) // 4, device="cuda")
+    ws_d = torch.empty(max(lib.dcn_conv_gemm_workspace(ctypes.byref(d), 1), 4) // 4, device="cuda")
+    assert lib.dcn_conv_forward(ctypes.byref(d), L.ptr(xg), L.ptr(wg), None, L.ptr(out), L.ptr(part), L.ptr(ws_f), st) == 0
     assert rel_err(out.cpu(), refn) < 1e-5
     assert rel_err(part.sum(0)[0].cpu(), refn.sum((0, 1, 2))) < 2e-5
     assert rel_err(part.sum(0)[1].cpu(), (refn ** 2).sum((0, 1, 2))) < 2e-5
@@ -149,7 +151,7 @@ def test_conv_kernels_vs_torch_cpu(L, case):
     din = torch.full((n, hin, win, cin), float("nan"), device="cuda")
     dg = dout.cuda()
     addg = add.cuda()
-    assert lib.dcn_conv_dgrad(ctypes.byref(d), L.ptr(dg), L.ptr(wt), L.ptr(addg), L.ptr(din), st) == 0
+    assert lib.dcn_conv_dgrad(ctypes.byref(d), L.ptr(dg), L.ptr(wt), L.ptr(addg), L.ptr(din), L.ptr(ws_d), st) == 0
     assert rel_err(din.cpu(), x.grad.permute(0, 2, 3, 1) + add) < 1e-5
     dw = torch.full((cout, k, k, cin), float("nan"), device="cuda")
     slab = torch.empty(max(lib.dcn_conv_wgrad_workspace(ctypes.byref(d)), 4) // 4, device="cuda")
@@ -275,7 +277,7 @@ def test_batched_step_small_images_vs_oracle(L):
 def test_resnet50_8s_forward_backward_vs_oracle(L):
     """Bottleneck family (BASELINE config 5's backbone) at a small size, D = 32."""
     import copy
-    H, W, D = 64, 64, 32
+    H, W, D = 128, 160, 32    # 2 x 16 x 20 = 640 samples per batch-norm channel in layer3/4
     dcn, o = _dcn_and_oracle("Resnet50_8s", D, H, W)
     o64 = copy.deepcopy(o).double()
     g = torch.Generator().manual_seed(9)
@@ -288,7 +290,7 @@ def test_resnet50_8s_forward_backward_vs_oracle(L):
     (y * gy.cuda()).sum().backward(); (yo * gy).sum().backward(); (y64 * gy.double()).sum().backward()
     for (k, p), (_, po), (_, p6) in zip(dcn.fcn.named_parameters(), o.named_parameters(), o64.named_parameters()):
         l2 = lambda g: float((g.double().cpu() - p6.grad).norm() / p6.grad.norm().clamp_min(1e-30))
-        assert l2(p.grad) < 5 * l2(po.grad) + 1e-3, (k, l2(p.grad), l2(po.grad))
+        assert l2(p.grad) < 5 * l2(po.grad) + 2e-3, (k, l2(p.grad), l2(po.grad))
 
 
 def test_config2_full_size_properties(L):

@@ -59,9 +59,11 @@ def main():
         part = torch.empty(lib.dcn_conv_num_mtiles(ctypes.byref(d)), 2, cout, device=dev)
         slab = torch.empty(max(lib.dcn_conv_wgrad_workspace(ctypes.byref(d)), 4) // 4, device=dev)
         flops = 2.0 * n * hout * wout * cout * k * k * (3 if cin == 4 else cin)
+        wsf = torch.empty(max(lib.dcn_conv_gemm_workspace(ctypes.byref(d), 0), 4) // 4, device=dev)
+        wsd = torch.empty(max(lib.dcn_conv_gemm_workspace(ctypes.byref(d), 1), 4) // 4, device=dev)
         calls = {
-            "fwd": lambda: lib.dcn_conv_forward(ctypes.byref(d), _lib.ptr(x), _lib.ptr(w), None, _lib.ptr(y), _lib.ptr(part), st),
-            "dgrad": lambda: lib.dcn_conv_dgrad(ctypes.byref(d), _lib.ptr(dy), _lib.ptr(wt), None, _lib.ptr(dx), st),
+            "fwd": lambda: lib.dcn_conv_forward(ctypes.byref(d), _lib.ptr(x), _lib.ptr(w), None, _lib.ptr(y), _lib.ptr(part), _lib.ptr(wsf), st),
+            "dgrad": lambda: lib.dcn_conv_dgrad(ctypes.byref(d), _lib.ptr(dy), _lib.ptr(wt), None, _lib.ptr(dx), _lib.ptr(wsd), st),
             "wgrad": lambda: lib.dcn_conv_wgrad(ctypes.byref(d), _lib.ptr(x), _lib.ptr(dy), _lib.ptr(dw), _lib.ptr(slab), st),
         }
         row = {"shape": name, "count": count, "gflop": flops / 1e9}
