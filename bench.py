@@ -122,6 +122,7 @@ def main():
     ap.add_argument("--batch", type=int, default=0, help="override image pairs per GPU per step")
     ap.add_argument("--cpu-baseline-steps", type=int, default=3, help="0 disables the CPU baseline leg")
     ap.add_argument("--profile-steps", type=int, default=3, help="extra steps with per-launch HIP events (roofline)")
+    ap.add_argument("--force-dist", action="store_true", help="initialise RCCL even with one rank (smoke-tests the collective path)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -133,9 +134,14 @@ def main():
         raise SystemExit("bench.py needs an MI355X: the dense-correspondence hot path has no CPU fallback")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    use_dist = world > 1 or args.force_dist
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        dist.barrier()
+        import ctypes
+        ctypes.CDLL(None).fflush(None)  # RCCL's version banner sits in the C stdio buffer: emit it now, not after the JSON line
 
     from dcn_hip import _lib, backbone as bb
     from dcn_hip.distributed import FlatGradients, broadcast_module
@@ -178,7 +184,7 @@ def main():
         return loss
 
     def fence():
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -189,11 +195,11 @@ def main():
     for it in range(args.steps):
         loss = step(args.warmup + it)
     torch.cuda.synchronize()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -223,6 +229,36 @@ def main():
                                        "avg_launch_us": (1e3 * wms / wn) if wn else None,
                                        "kernel_ms_per_step": wms / args.profile_steps}}
 
+    # ---- HBM roofline of the loss gather (K9): forward + backward of the fused contrastive loss alone, on the
+    # descriptor maps of the last step, timed with events on the launch stream
+    loss_roof = None
+    if args.profile_steps > 0:
+        with torch.no_grad():
+            da = dcn.process_network_output(dcn.forward(img_a), B).detach().contiguous()
+            db = dcn.process_network_output(dcn.forward(img_b), B).detach().contiguous()
+        da.requires_grad_(True)
+        db.requires_grad_(True)
+        reps = 20
+        for _ in range(3):
+            l = loss_composer.get_loss_batched(pcl, match_type, da, db, pair_lists)[0]
+            l.backward()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            l = loss_composer.get_loss_batched(pcl, match_type, da, db, pair_lists)[0]
+            l.backward()
+        e1.record()
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / reps
+        npairs = pair_lists.total
+        pair_bytes = (16 * D + 16) * npairs              # 2 descriptor reads + 2 int64 indices + 2 gradient accumulations
+        fill_bytes = 2 * B * H * W * D * 4               # zero-fill of the two dense gradient maps
+        loss_roof = {"bound": "hbm", "kernel": "loss_fwd_kernel + loss_finalize_kernel + loss_bwd_kernel (+ memset)",
+                     "achieved": (pair_bytes + fill_bytes) / (ms * 1e-3) / 1e9, "peak": 8000.0, "unit": "GB/s",
+                     "frac": (pair_bytes + fill_bytes) / (ms * 1e-3) / 1e9 / 8000.0, "us_per_call": 1e3 * ms,
+                     "pixel_pairs": npairs, "algorithmic_bytes": {"pairs": pair_bytes, "zero_fill": fill_bytes},
+                     "note": "latency-bound at this size: %d random %d-byte gathers per call" % (2 * npairs, 4 * D)}
+
     if rank == 0:
         images_per_step = 2 * B * world
         ms_per_step = 1e3 * elapsed / args.steps
@@ -237,13 +273,13 @@ def main():
                           "optimizer": "Adam lr 1e-4 wd 1e-4", "parallelism": "dp%d" % world,
                           "library": info["version"], "final_loss": final_loss,
                           "train_gflop_per_image": 3 * bb.get_plan(wl["backbone"], 64, B, H, W, D).forward_flops / B / 1e9},
-               "roofline": roofline}
+               "roofline": roofline, "roofline_loss_gather": loss_roof}
         if world == 1 and args.cpu_baseline_steps > 0:
             out["cpu_baseline"] = cpu_baseline(wl, args.cpu_baseline_steps, 1)
         else:
             out["cpu_baseline"] = None
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -473,30 +473,36 @@ struct WgradConv {
     FastDiv div_hw, div_w, div_cin, div_kw;
 };
 
+// WM = 2: workgroup tile 128 output channels x 128 K columns (2x2 wavefronts);
+// WM = 1:                  64 output channels x 256 K columns (1x4) -- layers with <= 64 output channels (stem, layer1)
+//                          would otherwise spend half of their MFMAs on zero rows.
+template <int WM>
 __global__ void __launch_bounds__(NT)
 conv_wgrad_kernel(WgradConv p) {
-    __shared__ __attribute__((aligned(16))) float lds[2 * 2 * WK * 128];
+    constexpr int DW = 64 * WM, XW = 64 * (4 / WM), DQ = DW / 4, XQ = XW / 4, DR = NT / DQ, XR = NT / XQ, PD = WK / DR,
+                  PX = WK / XR, kStage = WK * (DW + XW);
+    __shared__ __attribute__((aligned(16))) float lds[2 * kStage];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const int wm_ = wv >> 1, wn_ = wv & 1;
+    const int wm_ = WM == 2 ? (wv >> 1) : 0, wn_ = WM == 2 ? (wv & 1) : wv;
     const int tiles = p.ntiles_n * p.ntiles_k;
     const int bid = xcd_remap(blockIdx.x, tiles * p.splits);
     const int split = bid / tiles, tile = bid - split * tiles;
     const int tn_ = tile / p.ntiles_k, tk_ = tile - tn_ * p.ntiles_k;
-    const int n0 = tn_ * 128, j0 = tk_ * 128;
+    const int n0 = tn_ * DW, j0 = tk_ * XW;
     const int m_begin = split * p.rows_per_split;
     const int m_end = min(p.M, m_begin + p.rows_per_split);
 
-    // this thread stages channel quad c4 of pixel rows p0, p0 + 8
-    const int c4 = tid & 31, p0 = tid >> 5;
-    const int ncol = n0 + c4 * 4;
+    // this thread stages channel quad dc4 of dout pixel rows dp0 + DR*j, and K-column quad xc4 of input rows xp0 + XR*j
+    const int dc4 = tid % DQ, dp0 = tid / DQ, xc4 = tid % XQ, xp0 = tid / XQ;
+    const int ncol = n0 + dc4 * 4;
     const bool nval = ncol < p.ldo;          // dout rows are padded to ldo (multiple of 4) with zeros
-    const int kcol = j0 + c4 * 4;
+    const int kcol = j0 + xc4 * 4;
     const bool kval = kcol < p.K;
     const int kc0 = kval ? kcol : 0;
     const int tap = fdiv(kc0, p.div_cin), cc = kc0 - tap * p.cin;
     const int tr = fdiv(tap, p.div_kw), ts = tap - tr * p.kw;
     const int oy = tr * p.dil - p.pad, ox = ts * p.dil - p.pad;
-    float4 rd[2], rx[2];
+    float4 rd[PD], rx[PX];
     unsigned okm = 0;
 
     // branch-free (clamped addresses; the zero-fill selects are applied when the tile is written to LDS, after the
@@ -504,12 +510,17 @@ conv_wgrad_kernel(WgradConv p) {
     auto load_tile = [&](int m_base) {
         okm = 0;
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int m = m_base + p0 + 8 * j;
+        for (int j = 0; j < PD; ++j) {
+            const int m = m_base + dp0 + DR * j;
+            const bool dok = (m < m_end) & nval;
+            rd[j] = *reinterpret_cast<const float4*>(p.dout + (dok ? m * p.ldo + ncol : 0));
+            okm |= (dok ? 1u : 0u) << j;
+        }
+#pragma unroll
+        for (int j = 0; j < PX; ++j) {
+            const int m = m_base + xp0 + XR * j;
             const bool mval = m < m_end;
             const int mm = mval ? m : 0;
-            const bool dok = mval & nval;
-            rd[j] = *reinterpret_cast<const float4*>(p.dout + (dok ? mm * p.ldo + ncol : 0));
             const int img = fdiv(mm, p.div_hw), rem = mm - img * p.div_hw.d;
             const int y = fdiv(rem, p.div_w), x = rem - y * p.div_w.d;
             const int sy = y * p.stride + oy, sx = x * p.stride + ox;
@@ -517,19 +528,24 @@ conv_wgrad_kernel(WgradConv p) {
             int off = ((img * p.hin + sy) * p.win + sx) * p.cin + cc;
             off = ok ? off : 0;
             rx[j] = *reinterpret_cast<const float4*>(p.in + off);
-            okm |= ((dok ? 1u : 0u) << j) | ((ok ? 1u : 0u) << (8 + j));
+            okm |= (ok ? 1u : 0u) << (8 + j);
         }
     };
     auto store_tile = [&](int stage) {
-        float* d = lds + stage * 2 * WK * 128;
-        float* x = d + WK * 128;
+        float* d = lds + stage * kStage;
+        float* x = d + WK * DW;
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const bool dok = (okm >> j) & 1u, ok = (okm >> (8 + j)) & 1u;
-            const float4 dv = rd[j], xv = rx[j];
-            *reinterpret_cast<float4*>(d + (p0 + 8 * j) * 128 + c4 * 4) =
+        for (int j = 0; j < PD; ++j) {
+            const bool dok = (okm >> j) & 1u;
+            const float4 dv = rd[j];
+            *reinterpret_cast<float4*>(d + (dp0 + DR * j) * DW + dc4 * 4) =
                 make_float4(dok ? dv.x : 0.f, dok ? dv.y : 0.f, dok ? dv.z : 0.f, dok ? dv.w : 0.f);
-            *reinterpret_cast<float4*>(x + (p0 + 8 * j) * 128 + c4 * 4) =
+        }
+#pragma unroll
+        for (int j = 0; j < PX; ++j) {
+            const bool ok = (okm >> (8 + j)) & 1u;
+            const float4 xv = rx[j];
+            *reinterpret_cast<float4*>(x + (xp0 + XR * j) * XW + xc4 * 4) =
                 make_float4(ok ? xv.x : 0.f, ok ? xv.y : 0.f, ok ? xv.z : 0.f, ok ? xv.w : 0.f);
         }
     };
@@ -546,16 +562,16 @@ conv_wgrad_kernel(WgradConv p) {
     const int nsteps = (m_end - m_begin + WK - 1) / WK;
     // Software-pipelined like the gather-GEMM kernel: two fragment sets (pixel pairs 0-3 / 4-7 of a 16-pixel step),
     // one barrier per step, global loads a full step ahead, branch-free body + sched_group_barrier interleave.
-    const int d_off = fh * 128 + wm_ * 64 + 2 * fi;
-    const int x_off = WK * 128 + fh * 128 + wn_ * 64 + 2 * fi;
+    const int d_off = fh * DW + wm_ * 64 + 2 * fi;
+    const int x_off = WK * DW + fh * XW + wn_ * 64 + 2 * fi;
     float2 fd[2][4], fx[2][4];
     auto read_frags = [&](int stage, int half, int set) {
-        const float* d = lds + stage * 2 * WK * 128 + d_off + half * 8 * 128;
-        const float* x = lds + stage * 2 * WK * 128 + x_off + half * 8 * 128;
+        const float* d = lds + stage * kStage + d_off + half * 8 * DW;
+        const float* x = lds + stage * kStage + x_off + half * 8 * XW;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            fd[set][q] = *reinterpret_cast<const float2*>(d + 2 * q * 128);
-            fx[set][q] = *reinterpret_cast<const float2*>(x + 2 * q * 128);
+            fd[set][q] = *reinterpret_cast<const float2*>(d + 2 * q * DW);
+            fx[set][q] = *reinterpret_cast<const float2*>(x + 2 * q * XW);
         }
     };
     auto mfma_steps = [&](int set) {
@@ -643,12 +659,15 @@ transpose_weight_kernel(const float* __restrict__ w, float* __restrict__ wt, int
 
 int wgrad_splits(const dcn_conv_desc* c, int* rows_per_split) {
     const int M = c->n * c->hout * c->wout, K = c->kh * c->kw * c->cin;
-    const int tiles = dcn::ceil_div(c->cout, 128) * dcn::ceil_div(K, 128);
-    // aim for ~4 workgroup waves over 256 CUs x 2 resident workgroups, at least 8 reduction steps per workgroup
+    const bool narrow = c->cout <= 64;
+    const int tiles = dcn::ceil_div(c->cout, narrow ? 64 : 128) * dcn::ceil_div(K, narrow ? 256 : 128);
+    // aim for ~8 workgroups per CU, at least 8 reduction steps per workgroup
     int splits = dcn::ceil_div(2048, tiles);
     const int max_by_rows = (M / (8 * WK)) > 1 ? (M / (8 * WK)) : 1;
     if (splits > max_by_rows) splits = max_by_rows;
-    if (splits > 64) splits = 64;
+    // the partial slabs are written and read back once; narrow layers (few, small tiles) may split further
+    const int cap = narrow ? 256 : 64;
+    if (splits > cap) splits = cap;
     if (splits < 1) splits = 1;
     int rps = dcn::ceil_div(dcn::ceil_div(M, splits), WK) * WK;
     splits = dcn::ceil_div(M, rps);
@@ -717,12 +736,14 @@ extern "C" int dcn_conv_wgrad(const dcn_conv_desc* c, const float* in, const flo
     p.kh = c->kh; p.kw = c->kw; p.stride = c->stride; p.pad = c->pad; p.dil = c->dil; p.ldo = c->ldc;
     p.M = c->n * c->hout * c->wout; p.K = c->kh * c->kw * c->cin;
     p.splits = wgrad_splits(c, &p.rows_per_split);
-    p.ntiles_n = dcn::ceil_div(c->cout, 128); p.ntiles_k = dcn::ceil_div(p.K, 128);
+    const bool narrow = c->cout <= 64;
+    p.ntiles_n = dcn::ceil_div(c->cout, narrow ? 64 : 128); p.ntiles_k = dcn::ceil_div(p.K, narrow ? 256 : 128);
     p.div_hw = make_fastdiv(c->hout * c->wout); p.div_w = make_fastdiv(c->wout);
     p.div_cin = make_fastdiv(c->cin); p.div_kw = make_fastdiv(c->kw);
     p.slab = p.splits == 1 ? dw : (float*)slabs;
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(conv_wgrad_kernel, dim3(p.ntiles_n * p.ntiles_k * p.splits), dim3(NT), 0, st, p);
+    if (narrow) hipLaunchKernelGGL(conv_wgrad_kernel<1>, dim3(p.ntiles_n * p.ntiles_k * p.splits), dim3(NT), 0, st, p);
+    else hipLaunchKernelGGL(conv_wgrad_kernel<2>, dim3(p.ntiles_n * p.ntiles_k * p.splits), dim3(NT), 0, st, p);
     if (p.splits > 1) {
         const int64_t n4 = (int64_t)c->cout * p.K / 4;
         hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)dcn::ceil_div64(n4, 256)), dim3(256), 0, st,
