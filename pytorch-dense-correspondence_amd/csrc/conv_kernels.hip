@@ -631,9 +631,19 @@ __global__ void __launch_bounds__(256)
 wgrad_reduce_kernel(const float* __restrict__ slab, float* __restrict__ dw, int64_t n4, int splits) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= n4) return;
-    float4 a = reinterpret_cast<const float4*>(slab)[i];
-    for (int s = 1; s < splits; ++s) {
-        const float4 b = reinterpret_cast<const float4*>(slab)[(int64_t)s * n4 + i];
+    const float4* src = reinterpret_cast<const float4*>(slab) + i;
+    float4 a = src[0];
+    int s = 1;
+    for (; s + 4 <= splits; s += 4) {  // four loads in flight; the additions keep the fixed order s = 1, 2, 3, ...
+        const float4 b0 = src[(int64_t)s * n4], b1 = src[(int64_t)(s + 1) * n4], b2 = src[(int64_t)(s + 2) * n4],
+                     b3 = src[(int64_t)(s + 3) * n4];
+        a.x += b0.x; a.y += b0.y; a.z += b0.z; a.w += b0.w;
+        a.x += b1.x; a.y += b1.y; a.z += b1.z; a.w += b1.w;
+        a.x += b2.x; a.y += b2.y; a.z += b2.z; a.w += b2.w;
+        a.x += b3.x; a.y += b3.y; a.z += b3.z; a.w += b3.w;
+    }
+    for (; s < splits; ++s) {
+        const float4 b = src[(int64_t)s * n4];
         a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
     }
     reinterpret_cast<float4*>(dw)[i] = a;

@@ -435,8 +435,9 @@ void launch_bn_apply(const float* x, const float* s1, const float* b1, const flo
                        relu, y, C / 4, total4);
 }
 int bn_bwd_chunks(int64_t rows) {
-    int64_t chunks = ceil_div64(rows, 512);
-    if (chunks > 512) chunks = 512;
+    // enough row chunks that even a 64-channel layer launches >= ~1000 workgroups (HBM-bound pass: fill all 256 CUs)
+    int64_t chunks = ceil_div64(rows, 64);
+    if (chunks > 1024) chunks = 1024;
     if (chunks < 1) chunks = 1;
     return (int)chunks;
 }
