@@ -178,9 +178,9 @@ int dcn_plan_profile_begin(dcn_plan* plan);
 int dcn_plan_profile_end(dcn_plan* plan, double ms[2], int64_t launches[2], double flops[2]);
 
 /* Backward.  grad_descriptors: [N,H,W,D]; grads[i] receives dL/d params[i] (overwritten, same layout as
- * params[i]).  `saved` is the buffer the matching forward filled. */
+ * params[i]).  `saved` is the buffer the matching forward filled; `normalize` must be the forward's flag. */
 int dcn_backbone_backward(dcn_plan* plan, const float* grad_descriptors, const float* const* params,
-                          const void* saved, void* workspace, float* const* grads, void* stream);
+                          const void* saved, void* workspace, float* const* grads, int normalize, void* stream);
 
 /* =====================================================================================================
  * 3. Individual kernels, exported for unit tests and micro-benchmarks (same conventions).
@@ -218,6 +218,24 @@ int dcn_upsample_forward(const float* low, int n, int hl, int wl, int ldl, int d
 int dcn_upsample_backward(const float* gout, int n, int hl, int wl, int ldl, int d, int h, int w, float* glow,
                           float* tmp, void* stream);
 size_t dcn_upsample_backward_tmp_bytes(int n, int hl, int w, int d);
+
+/* =====================================================================================================
+ * 4. Best-match search over a descriptor image (evaluation / heat-map side)
+ *
+ * Replaces DenseCorrespondenceNetwork.find_best_match / find_best_match_for_descriptor
+ * (dense_correspondence/network/dense_correspondence_network.py:488-550: numpy
+ * `sqrt(sum(square(res_b - d), axis=2))` + argmin, once per query) for Q queries in one pass.
+ *   res        [HW][D] fp32 descriptor image (the [H,W,D] tensor forward_single_image_tensor returns)
+ *   queries    [Q][D]
+ *   mask       nullable [HW] uint8: only pixels with mask != 0 are candidates
+ *   best_idx   [Q] int64 flat index u + W*v of the first minimum (np.argmin order); -1 if the mask is empty
+ *   best_dist  [Q] the distance at best_idx
+ *   norm_diffs nullable [Q][HW]: the full distance images
+ *   workspace  dcn_find_best_match_workspace(Q) bytes
+ * ===================================================================================================== */
+int dcn_find_best_match(const float* res, int64_t hw, int d, const float* queries, int q, const unsigned char* mask,
+                        int64_t* best_idx, float* best_dist, float* norm_diffs, void* workspace, void* stream);
+size_t dcn_find_best_match_workspace(int q);
 
 #ifdef __cplusplus
 }

@@ -68,10 +68,10 @@ struct dcn_plan {
     int stem = -1, fc = -1;
     int hl = 0, wl = 0, feat_c = 0;
     // saved arena offsets (floats)
-    size_t s_in4 = 0, s_stem_y = 0, s_pool = 0, s_argmax = 0, saved_floats = 0;
+    size_t s_in4 = 0, s_stem_y = 0, s_pool = 0, s_argmax = 0, s_low = 0, saved_floats = 0;
     // workspace offsets (floats)
     size_t w_buf[6] = {0, 0, 0, 0, 0, 0}, w_wt = 0, w_slab = 0, w_part = 0, w_k123 = 0, w_wstem = 0, w_dwstem = 0,
-           w_low = 0, w_glow = 0, w_ups = 0, w_sk = 0, ws_floats = 0;
+           w_glow = 0, w_ups = 0, w_sk = 0, w_gnorm = 0, ws_floats = 0;
     size_t max_act = 0;
     double flops = 0;
     // optional launch-level timing (dcn_plan_profile_begin/end)
@@ -241,6 +241,7 @@ int build_plan(dcn_plan& p) {
     }
     p.hl = h; p.wl = wd; p.feat_c = inplanes;
     p.fc = B.add_conv("fc", N, h, wd, inplanes, p.D, 1, 1, 0, 1, true, p.Dp);
+    p.s_low = B.alloc_saved((size_t)N * h * wd * p.Dp);  // low-resolution descriptor map (needed by the normalise backward)
     p.saved_floats = B.saved;
     {
         const size_t in4 = (size_t)N * p.H * p.W * 4;
@@ -277,8 +278,8 @@ int build_plan(dcn_plan& p) {
     p.w_k123 = alloc((size_t)3 * max_c);
     p.w_wstem = alloc((size_t)p.base * 49 * 4);
     p.w_dwstem = alloc((size_t)p.base * 49 * 4);
-    p.w_low = alloc((size_t)N * p.hl * p.wl * p.Dp);
     p.w_glow = alloc((size_t)N * p.hl * p.wl * p.Dp);
+    p.w_gnorm = alloc((size_t)N * p.H * p.W * p.D);
     p.w_ups = alloc(dcn::upsample_bwd_tmp_bytes(N, p.hl, p.W, p.D) / sizeof(float));
     p.ws_floats = ws;
     return DCN_OK;
@@ -460,17 +461,18 @@ extern "C" int dcn_backbone_forward(dcn_plan* plan, const float* image, const fl
     // scoring layer (1x1 conv + bias) into the padded low-resolution map, then bilinear upsample
     const ConvL& fc = p.convs[p.fc];
     const size_t low_bytes = (size_t)N * p.hl * p.wl * p.Dp * sizeof(float);
-    if (hipMemsetAsync(R.Wk(p.w_low), 0, low_bytes, st) != hipSuccess) return DCN_E_LAUNCH;
+    if (hipMemsetAsync(R.S(p.s_low), 0, low_bytes, st) != hipSuccess) return DCN_E_LAUNCH;
     DCN_TRY(R.timed(0, fc.flops, [&] {
-        return dcn_conv_forward(&fc.d, R.S(p.blocks.back().out), R.P(fc.w), R.P(fc.b), R.Wk(p.w_low), nullptr,
+        return dcn_conv_forward(&fc.d, R.S(p.blocks.back().out), R.P(fc.w), R.P(fc.b), R.S(p.s_low), nullptr,
                                 R.Wk(p.w_sk), st);
     }));
-    dcn::launch_upsample_fwd(R.Wk(p.w_low), N, p.hl, p.wl, p.Dp, p.D, p.H, p.W, normalize, descriptors, st);
+    dcn::launch_upsample_fwd(R.S(p.s_low), N, p.hl, p.wl, p.Dp, p.D, p.H, p.W, normalize, descriptors, st);
     return dcn::check_launch();
 }
 
 extern "C" int dcn_backbone_backward(dcn_plan* plan, const float* grad_descriptors, const float* const* params,
-                                     const void* saved, void* workspace, float* const* grads, void* stream) {
+                                     const void* saved, void* workspace, float* const* grads, int normalize,
+                                     void* stream) {
     if (!plan || !grad_descriptors || !params || !saved || !workspace || !grads) return DCN_E_INVALID;
     dcn_plan& p = *plan;
     Run R{p, params, (float*)saved, (float*)workspace, (hipStream_t)stream};
@@ -498,6 +500,10 @@ extern "C" int dcn_backbone_backward(dcn_plan* plan, const float* grad_descripto
 
     // ---- upsample + scoring layer
     float* glow = R.Wk(p.w_glow);
+    if (normalize) {  // network.py:256-259 was fused into the forward upsample: undo it first
+        dcn::launch_normalize_bwd(R.S(p.s_low), N, p.hl, p.wl, p.Dp, p.D, p.H, p.W, grad_descriptors, R.Wk(p.w_gnorm), st);
+        grad_descriptors = R.Wk(p.w_gnorm);
+    }
     dcn::launch_upsample_bwd(grad_descriptors, N, p.hl, p.wl, p.Dp, p.D, p.H, p.W, R.Wk(p.w_ups), glow, st);
     const ConvL& fc = p.convs[p.fc];
     const float* feat = R.S(p.blocks.back().out);

@@ -31,6 +31,9 @@ void launch_maxpool_bwd(const float* gout, const unsigned char* argmax, float* g
 void launch_upsample_fwd(const float* low, int n, int hl, int wl, int ldl, int d, int h, int w, int normalize,
                          float* out, hipStream_t st);
 size_t upsample_bwd_tmp_bytes(int n, int hl, int w, int d);
+// gv = gradient w.r.t. the un-normalised upsampled map, given gout = gradient w.r.t. the L2-normalised one
+void launch_normalize_bwd(const float* low, int n, int hl, int wl, int ldl, int d, int h, int w, const float* gout,
+                          float* gv, hipStream_t st);
 void launch_upsample_bwd(const float* gout, int n, int hl, int wl, int ldl, int d, int h, int w, float* tmp,
                          float* glow, hipStream_t st);
 

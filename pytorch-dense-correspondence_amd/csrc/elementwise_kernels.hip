@@ -345,6 +345,40 @@ upsample_fwd_kernel(const float* __restrict__ low, int hl, int wl, int ldl, int 
     }
 }
 
+// backward of the fused L2 normalisation y = v / ||v||:  g' = (g - y (y . g)) / ||v||, v re-interpolated from `low`
+__global__ void __launch_bounds__(256)
+normalize_bwd_kernel(const float* __restrict__ low, int hl, int wl, int ldl, int d, int h, int w, float sh, float sw,
+                     const float* __restrict__ gout, float* __restrict__ gv, int64_t total) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;  // over n*h*w
+    if (i >= total) return;
+    const int x = (int)(i % w);
+    const int64_t t = i / w;
+    const int y = (int)(t % h);
+    const int64_t n = t / h;
+    int y0, y1, x0, x1;
+    float ly, lx;
+    src_index(y, sh, hl, y0, y1, ly);
+    src_index(x, sw, wl, x0, x1, lx);
+    const float hy = 1.f - ly, hx = 1.f - lx;
+    const float* p00 = low + ((n * hl + y0) * wl + x0) * ldl;
+    const float* p01 = low + ((n * hl + y0) * wl + x1) * ldl;
+    const float* p10 = low + ((n * hl + y1) * wl + x0) * ldl;
+    const float* p11 = low + ((n * hl + y1) * wl + x1) * ldl;
+    const float* g = gout + i * d;
+    float ss = 0.f, dot = 0.f;
+    for (int k = 0; k < d; ++k) {
+        const float v = hy * (hx * p00[k] + lx * p01[k]) + ly * (hx * p10[k] + lx * p11[k]);
+        ss = fmaf(v, v, ss);
+        dot = fmaf(v, g[k], dot);
+    }
+    const float nrm = sqrtf(ss), inv = 1.f / nrm;
+    dot *= inv;  // y . g
+    for (int k = 0; k < d; ++k) {
+        const float v = hy * (hx * p00[k] + lx * p01[k]) + ly * (hx * p10[k] + lx * p11[k]);
+        gv[i * d + k] = (g[k] - v * inv * dot) * inv;
+    }
+}
+
 // backward, separable and gather-form (deterministic).  pass 1: tmp[n][iy][x][d] = sum_y wy(y, iy) * gout[n][y][x][d]
 __global__ void __launch_bounds__(256)
 upsample_bwd_rows_kernel(const float* __restrict__ gout, int hl, int d, int h, int w, float sh, float* __restrict__ tmp,
@@ -478,6 +512,12 @@ void launch_upsample_fwd(const float* low, int n, int hl, int wl, int ldl, int d
                        ac_scale(hl, h), ac_scale(wl, w), normalize, out, total);
 }
 size_t upsample_bwd_tmp_bytes(int n, int hl, int w, int d) { return (size_t)n * hl * w * d * sizeof(float); }
+void launch_normalize_bwd(const float* low, int n, int hl, int wl, int ldl, int d, int h, int w, const float* gout,
+                          float* gv, hipStream_t st) {
+    const int64_t total = (int64_t)n * h * w;
+    hipLaunchKernelGGL(normalize_bwd_kernel, dim3(blocks_for(total)), dim3(256), 0, st, low, hl, wl, ldl, d, h, w,
+                       ac_scale(hl, h), ac_scale(wl, w), gout, gv, total);
+}
 void launch_upsample_bwd(const float* gout, int n, int hl, int wl, int ldl, int d, int h, int w, float* tmp,
                          float* glow, hipStream_t st) {
     const int64_t t1 = (int64_t)n * hl * w * d;

@@ -1,0 +1,93 @@
+// Best-match search over a dense descriptor image ("next" row 1) -- the evaluation-side hot loop
+//   norm_diffs = sqrt(sum(square(res_b - descriptor), axis=2));  argmin      (dense_correspondence_network.py:517-523, :541-547)
+// which the reference runs in numpy on the CPU once per query pixel (100 full-image scans per image pair,
+// evaluation.py:932-950).  Here ALL queries of an image are answered by one pass over the descriptor image:
+// HBM-bound, algorithmic traffic = HW * D * 4 bytes once (+ Q * HW * 4 when the distance images are requested).
+// One work-item per pixel keeps its descriptor in registers and loops over the queries (LDS broadcast reads);
+// per query: wave64 shuffle min-reduction of the packed key (dist2 bits << 32 | pixel index) -> one 64-bit atomicMin
+// per wavefront.  The key order makes ties resolve to the smallest index, exactly like np.argmin.
+#include "dcn_common.h"
+
+namespace {
+
+constexpr int kMT = 256;    // work-items (pixels) per workgroup
+constexpr int kQT = 32;     // queries staged in LDS at a time
+constexpr int kMaxD = 64;
+
+template <int DT>
+__global__ void __launch_bounds__(kMT)
+best_match_kernel(const float* __restrict__ res, int64_t hw, int d_rt, const float* __restrict__ queries, int nq,
+                  const unsigned char* __restrict__ mask, unsigned long long* __restrict__ best,
+                  float* __restrict__ norm_diffs) {
+    __shared__ float sq[kQT * kMaxD];
+    const int D = DT > 0 ? DT : d_rt;
+    const int64_t pix = (int64_t)blockIdx.x * kMT + threadIdx.x;
+    const bool in = pix < hw;
+    const bool cand = in && (!mask || mask[pix] != 0);
+    float v[DT > 0 ? DT : kMaxD];
+#pragma unroll
+    for (int k = 0; k < (DT > 0 ? DT : kMaxD); ++k) v[k] = (in && k < D) ? res[pix * D + k] : 0.f;
+    for (int q0 = 0; q0 < nq; q0 += kQT) {
+        const int qn = min(kQT, nq - q0);
+        __syncthreads();
+        for (int i = threadIdx.x; i < qn * D; i += kMT) sq[i] = queries[(int64_t)q0 * D + i];
+        __syncthreads();
+        for (int q = 0; q < qn; ++q) {
+            float d2 = 0.f;
+#pragma unroll
+            for (int k = 0; k < (DT > 0 ? DT : kMaxD); ++k) {
+                if (k < D) { const float t = v[k] - sq[q * D + k]; d2 = fmaf(t, t, d2); }
+            }
+            if (norm_diffs && in) norm_diffs[(int64_t)(q0 + q) * hw + pix] = sqrtf(d2);
+            unsigned long long key = cand ? (((unsigned long long)__float_as_uint(d2)) << 32) | (unsigned long long)(unsigned)pix
+                                          : ~0ull;
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) {
+                const unsigned long long o = __shfl_down(key, off, 64);
+                key = o < key ? o : key;
+            }
+            if ((threadIdx.x & 63) == 0 && key != ~0ull) atomicMin(best + q0 + q, key);
+        }
+    }
+}
+
+__global__ void __launch_bounds__(256)
+best_match_unpack_kernel(const unsigned long long* __restrict__ best, int nq, int64_t* __restrict__ idx,
+                         float* __restrict__ dist) {
+    const int q = blockIdx.x * 256 + threadIdx.x;
+    if (q >= nq) return;
+    const unsigned long long k = best[q];
+    if (k == ~0ull) { idx[q] = -1; dist[q] = INFINITY; return; }  // empty mask
+    idx[q] = (int64_t)(k & 0xffffffffull);
+    dist[q] = sqrtf(__uint_as_float((unsigned)(k >> 32)));
+}
+
+}  // namespace
+
+extern "C" size_t dcn_find_best_match_workspace(int q) { return (size_t)(q > 0 ? q : 1) * sizeof(unsigned long long); }
+
+extern "C" int dcn_find_best_match(const float* res, int64_t hw, int d, const float* queries, int q,
+                                   const unsigned char* mask, int64_t* best_idx, float* best_dist, float* norm_diffs,
+                                   void* workspace, void* stream) {
+    if (!res || !queries || !best_idx || !best_dist || !workspace || hw < 1 || hw >= ((int64_t)1 << 32) || d < 1 ||
+        d > kMaxD || q < 1)
+        return DCN_E_INVALID;
+    hipStream_t st = (hipStream_t)stream;
+    unsigned long long* best = (unsigned long long*)workspace;
+    if (hipMemsetAsync(best, 0xFF, (size_t)q * sizeof(unsigned long long), st) != hipSuccess) return DCN_E_LAUNCH;
+    const dim3 grid((unsigned)dcn::ceil_div64(hw, kMT)), block(kMT);
+#define DCN_BM(DT) \
+    hipLaunchKernelGGL((best_match_kernel<DT>), grid, block, 0, st, res, hw, d, queries, q, mask, best, norm_diffs)
+    switch (d) {
+        case 3: DCN_BM(3); break;
+        case 4: DCN_BM(4); break;
+        case 8: DCN_BM(8); break;
+        case 16: DCN_BM(16); break;
+        case 32: DCN_BM(32); break;
+        default: DCN_BM(0); break;
+    }
+#undef DCN_BM
+    hipLaunchKernelGGL(best_match_unpack_kernel, dim3(dcn::ceil_div(q, 256)), dim3(256), 0, st,
+                       (const unsigned long long*)best, q, best_idx, best_dist);
+    return dcn::check_launch();
+}

@@ -53,7 +53,7 @@ SYMBOLS = {
                                      ctypes.POINTER(ctypes.c_double)]),
     "dcn_backbone_forward": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_float, c_int, c_int, c_void_p,
                                      c_void_p, c_void_p, c_void_p]),
-    "dcn_backbone_backward": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "dcn_backbone_backward": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
     "dcn_conv_forward": (c_int, [ctypes.POINTER(ConvDesc), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                  c_void_p]),
     "dcn_conv_gemm_workspace": (c_size_t, [ctypes.POINTER(ConvDesc), c_int]),
@@ -62,6 +62,9 @@ SYMBOLS = {
     "dcn_conv_wgrad": (c_int, [ctypes.POINTER(ConvDesc), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "dcn_conv_wgrad_workspace": (c_size_t, [ctypes.POINTER(ConvDesc)]),
     "dcn_transpose_weight": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
+    "dcn_find_best_match": (c_int, [c_void_p, c_int64, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
+                                    c_void_p, c_void_p]),
+    "dcn_find_best_match_workspace": (c_size_t, [c_int]),
     "dcn_upsample_forward": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p,
                                      c_void_p]),
     "dcn_upsample_backward": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p,

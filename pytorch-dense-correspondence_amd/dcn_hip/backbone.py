@@ -104,8 +104,6 @@ class _BackboneFn(torch.autograd.Function):
             raise ValueError("expected a float32 [N,3,H,W] image batch, got %s %s" % (tuple(image.shape), image.dtype))
         if tuple(image.shape) != (plan.n, 3, plan.h, plan.w):
             raise ValueError("plan %s does not match input %s" % (plan.key, tuple(image.shape)))
-        if normalize and training and any(p.requires_grad for p in params):
-            raise NotImplementedError("dcn_hip: backward through normalize=True descriptors is not implemented yet")
         image = image.contiguous()
         dev = image.device
         kparams = [_kernel_layout(p.detach()) for p in params]
@@ -124,6 +122,7 @@ class _BackboneFn(torch.autograd.Function):
         ctx.saved_arena = saved
         ctx.kparams = kparams
         ctx.trained = bool(training)
+        ctx.normalize = bool(normalize)
         # logical [N,D,H,W] over NHWC memory == torch.channels_last
         return desc.permute(0, 3, 1, 2)
 
@@ -141,7 +140,7 @@ class _BackboneFn(torch.autograd.Function):
         gptr = (ctypes.c_void_p * len(plan.param_numel))(*[base + 4 * o for o in plan.grad_offsets[:-1]])
         pptr = (ctypes.c_void_p * len(ctx.kparams))(*[p.data_ptr() for p in ctx.kparams])
         rc = lib.dcn_backbone_backward(plan.handle, _lib.ptr(g), pptr, _lib.ptr(ctx.saved_arena), _lib.ptr(ws), gptr,
-                                       _lib.stream_ptr())
+                                       int(ctx.normalize), _lib.stream_ptr())
         _lib.check(rc, "dcn_backbone_backward")
         ctx.saved_arena = None
         sink = ctx.grad_sink

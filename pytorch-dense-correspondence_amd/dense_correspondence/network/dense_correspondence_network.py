@@ -278,5 +278,19 @@ class DenseCorrespondenceNetwork(nn.Module):
         best_match_uv = (best_match_xy[1], best_match_xy[0])
         return best_match_uv, best_match_diff, norm_diffs
 
+    @staticmethod
+    def find_best_matches(pixels_a, res_a, res_b, mask_b=None, return_norm_diffs=False):
+        """MI355X extension of ``find_best_match`` (:488-525) for MANY query pixels at once, on device tensors:
+        pixels_a [Q,2] (u,v) into res_a [H,W,D]; res_b [H,W,D].  One pass over res_b answers every query
+        (the reference scans the image once per query in numpy).
+        -> (best_match_uv int64 [Q,2], best_match_diff [Q], norm_diffs [Q,H,W] or None)"""
+        from dcn_hip import match as _match
+        pixels_a = torch.as_tensor(pixels_a, device=res_a.device).long().reshape(-1, 2)
+        queries = res_a[pixels_a[:, 1], pixels_a[:, 0]]
+        idx, dist, nd = _match.find_best_matches(res_b, queries, mask_b, return_norm_diffs)
+        width = res_b.shape[1]
+        uv = torch.stack([idx % width, idx // width], dim=1)
+        return uv, dist, nd
+
     def evaluate_descriptor_at_keypoints(self, res, keypoint_list):
         raise NotImplementedError("This function is currently broken")  # :565, same as the reference

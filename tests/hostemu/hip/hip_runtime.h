@@ -228,6 +228,13 @@ static inline unsigned long long atomicAdd(unsigned long long* p, unsigned long 
     return __atomic_fetch_add(p, v, __ATOMIC_RELAXED);
 }
 
+static inline unsigned long long atomicMin(unsigned long long* p, unsigned long long v) {
+    unsigned long long old = __atomic_load_n(p, __ATOMIC_RELAXED);
+    while (v < old && !__atomic_compare_exchange_n(p, &old, v, false, __ATOMIC_RELAXED, __ATOMIC_RELAXED)) {}
+    return old;
+}
+static inline unsigned __float_as_uint(float f) { unsigned u; memcpy(&u, &f, 4); return u; }
+static inline float __uint_as_float(unsigned u) { float f; memcpy(&f, &u, 4); return f; }
 #define unsafeAtomicAdd atomicAdd
 static inline unsigned __umulhi(unsigned a, unsigned b) { return (unsigned)(((unsigned long long)a * b) >> 32); }
 template <class T> static inline T min(T a, T b) { return a < b ? a : b; }

@@ -65,6 +65,25 @@ def test_forward_backward_with_stream_k_forced(monkeypatch):
     assert max(rel_err(p.grad, po.grad) for p, po in zip(m.parameters(), o.parameters())) < 1e-4
 
 
+def test_normalized_descriptors_forward_backward():
+    """DenseCorrespondenceNetwork(normalize=True): res / ||res||_2 over D (network.py:256-259), fused into the upsample
+    kernel; backward through it."""
+    from dense_correspondence.network.dense_correspondence_network import DenseCorrespondenceNetwork
+    m, o = _pair("Resnet18_8s", 4, 8)
+    dcn = DenseCorrespondenceNetwork(m, 4, image_width=40, image_height=32, normalize=True)
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(1, 3, 32, 40, generator=g)
+    gy = torch.randn(1, 4, 32, 40, generator=g)
+    dcn.train(); o.train()
+    y = dcn.forward(x)
+    ro = o(x)
+    yo = ro / torch.norm(ro, 2, 1, keepdim=True)
+    assert rel_err(y, yo) < 2e-5
+    assert float((y.norm(2, 1) - 1).abs().max()) < 1e-5
+    (y * gy).sum().backward(); (yo * gy).sum().backward()
+    assert max(rel_err(p.grad, po.grad) for p, po in zip(m.parameters(), o.parameters())) < 2e-4
+
+
 def test_real_width_resnet34_small_image():
     """The real Resnet34_8s (base width 64, 21.3 M parameters): exercises full 128x128 tiles, multiple N tiles,
     K = 4608 reductions and the split-K wgrad path."""

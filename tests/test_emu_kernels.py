@@ -123,3 +123,35 @@ def test_upsample_forward_backward(L, shape):
     assert lib.dcn_upsample_forward(L.ptr(lowp), n, hl, wl, ld, D, H, W, 1, L.ptr(outn), None) == 0
     r = ref.detach()
     assert rel_err(outn, (r / r.norm(2, 1, keepdim=True)).permute(0, 2, 3, 1)) < 3e-6
+
+
+@pytest.mark.parametrize("D", [3, 16, 5])
+def test_best_match_search_vs_numpy(L, D):
+    """network.py:517-523: norm_diffs = sqrt(sum(square(res_b - d), axis=2)); argmin (first occurrence)."""
+    import numpy as np
+    from dense_correspondence.network.dense_correspondence_network import DenseCorrespondenceNetwork as DCN
+    H, W, Q = 23, 31, 37       # 713 pixels: three workgroups, the last one ragged; two query tiles
+    g = torch.Generator().manual_seed(D)
+    res_a = torch.randn(H, W, D, generator=g)
+    res_b = torch.randn(H, W, D, generator=g)
+    res_b[5, 7] = res_b[20, 3] = res_a[2, 4]          # an exact tie: np.argmin returns the first (row-major) pixel
+    pix = torch.stack([torch.randint(0, W, (Q,), generator=g), torch.randint(0, H, (Q,), generator=g)], 1)
+    pix[0] = torch.tensor([4, 2])
+    uv, dist, nd = DCN.find_best_matches(pix, res_a, res_b, return_norm_diffs=True)
+    for i in range(Q):
+        ref_uv, ref_diff, ref_nd = DCN.find_best_match((int(pix[i, 0]), int(pix[i, 1])), res_a.numpy(), res_b.numpy())
+        assert (int(uv[i, 0]), int(uv[i, 1])) == (int(ref_uv[0]), int(ref_uv[1])), i
+        np.testing.assert_allclose(dist[i].item(), ref_diff, rtol=1e-5, atol=1e-6)
+        np.testing.assert_allclose(nd[i].numpy(), ref_nd, rtol=1e-5, atol=1e-6)
+    assert (int(uv[0, 0]), int(uv[0, 1])) == (7, 5) and dist[0].item() == 0.0
+    # masked search (evaluation.py masks out the background): only candidates with mask != 0
+    mask = torch.zeros(H, W, dtype=torch.uint8)
+    mask[10:, :] = 1
+    uvm, distm, _ = DCN.find_best_matches(pix, res_a, res_b, mask_b=mask)
+    ndm = nd.clone()
+    ndm[:, :10, :] = float("inf")
+    flat = ndm.view(Q, -1).argmin(1)
+    assert torch.equal(uvm[:, 0], flat % W) and torch.equal(uvm[:, 1], flat // W)
+    empty = torch.zeros(H, W, dtype=torch.uint8)
+    uve, diste, _ = DCN.find_best_matches(pix[:2], res_a, res_b, mask_b=empty)
+    assert torch.isinf(diste).all()

@@ -108,3 +108,41 @@ def test_training_step_matches_oracle(B):
             assert float((p - po).abs().max()) < 2.5e-4, (it, k)
         # continue from IDENTICAL parameters, otherwise those sign flips (not the kernels) are what iteration 2 compares
         dcn.fcn.load_state_dict(o.state_dict())
+
+
+def test_checkpoint_round_trip_through_model_folder(tmp_path):
+    """training.py:501-521 saves `dcn.state_dict()` as %06d.pth next to training.yaml; network.py:441-485 loads it back.
+    Keys must be the reference's (`_fcn.<backbone>.…`), including BN buffers; the legacy fallback (state dict of the
+    bare fcn, network.py:429-433) must load too."""
+    import yaml
+    from dense_correspondence.network.dense_correspondence_network import DenseCorrespondenceNetwork
+    dcn, o = _make()
+    x = torch.randn(1, 3, 32, 48)
+    dcn.train()
+    with torch.no_grad():
+        dcn.forward(x)                       # moves the BN running statistics
+    dcn.eval()
+    with torch.no_grad():
+        y_ref = dcn.forward(x).clone()
+    sd = dcn.state_dict()
+    assert all(k.startswith("_fcn.resnet18_8s.") for k in sd) and "_fcn.resnet18_8s.bn1.num_batches_tracked" in sd
+    torch.save(sd, str(tmp_path / "003500.pth"))
+    torch.save({"dummy": 0}, str(tmp_path / "003500.pth.opt"))
+    cfg = {"dense_correspondence_network": {"descriptor_dimension": 3, "image_width": 48, "image_height": 32,
+                                            "backbone": {"model_class": "Resnet", "resnet_name": "NarrowTestNet"}}}
+    (tmp_path / "training.yaml").write_text(yaml.safe_dump(cfg))
+    loaded = DenseCorrespondenceNetwork.from_model_folder(str(tmp_path))
+    assert loaded.constructed_from_model_folder and loaded.config["model_param_filename_tail"] == "003500.pth"
+    loaded.eval()
+    with torch.no_grad():
+        assert torch.equal(loaded.forward(x), y_ref)
+    # conv weights keep the kernels' channels_last storage after load_state_dict
+    w = loaded.fcn.resnet18_8s.get_parameter("layer1.0.conv1.weight")
+    assert w.is_contiguous(memory_format=torch.channels_last)
+    # legacy checkpoints hold the bare backbone's state dict
+    torch.save(dcn.fcn.state_dict(), str(tmp_path / "legacy.pth"))
+    legacy = DenseCorrespondenceNetwork.from_config(dict(cfg["dense_correspondence_network"]), load_stored_params=True,
+                                                    model_param_file=str(tmp_path / "legacy.pth"))
+    legacy.eval()
+    with torch.no_grad():
+        assert torch.equal(legacy.forward(x), y_ref)

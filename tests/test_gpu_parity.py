@@ -314,3 +314,51 @@ def test_config2_full_size_properties(L):
     assert ya.shape == (4, 3, 480, 640) and ya.is_contiguous(memory_format=torch.channels_last)
     assert (hard[:, 1] <= c["Pk"]).all() and (hard[:, 0] == c["Pm"]).all()
     assert abs(float(terms[:, 0].mean()) - loss.item()) <= 1e-6 * abs(loss.item())
+
+
+def test_best_match_search_full_size(L):
+    """100 queries against a 640x480 D=3 descriptor image (evaluation.py:932-950's workload) vs the numpy formula."""
+    from dense_correspondence.network.dense_correspondence_network import DenseCorrespondenceNetwork as DCN
+    H, W, D, Q = 480, 640, 3, 100
+    g = torch.Generator().manual_seed(8)
+    res_a = torch.randn(H, W, D, generator=g)
+    res_b = torch.randn(H, W, D, generator=g)
+    pix = torch.stack([torch.randint(0, W, (Q,), generator=g), torch.randint(0, H, (Q,), generator=g)], 1)
+    res_b[100, 200] = res_b[400, 17] = res_a[int(pix[0, 1]), int(pix[0, 0])]   # exact tie -> first occurrence wins
+    uv, dist, nd = DCN.find_best_matches(pix.cuda(), res_a.cuda(), res_b.cuda(), return_norm_diffs=True)
+    uv, dist = uv.cpu(), dist.cpu()
+    for i in range(0, Q, 7):
+        ref_uv, ref_diff, ref_nd = DCN.find_best_match((int(pix[i, 0]), int(pix[i, 1])), res_a.numpy(), res_b.numpy())
+        assert (int(uv[i, 0]), int(uv[i, 1])) == (int(ref_uv[0]), int(ref_uv[1])), i
+        np.testing.assert_allclose(dist[i].item(), ref_diff, rtol=1e-5, atol=1e-6)
+        if i == 0:
+            np.testing.assert_allclose(nd[0].cpu().numpy(), ref_nd, rtol=1e-5, atol=1e-6)
+    assert (int(uv[0, 0]), int(uv[0, 1])) == (200, 100)
+
+
+def test_normalized_descriptor_training_step(L):
+    """normalize=True (network.py:256-259) forward + backward on the GPU vs the oracle."""
+    from dense_correspondence.network.dense_correspondence_network import DenseCorrespondenceNetwork
+    from oracle import resnet_dilated_oracle
+    H, W, D = 96, 128, 3
+    cfg = {"descriptor_dimension": D, "image_width": W, "image_height": H, "normalize": True}
+    dcn = DenseCorrespondenceNetwork.from_config(cfg, load_stored_params=False)
+    o = resnet_dilated_oracle.build("Resnet34_8s", D, seed=0)
+    dcn.fcn.load_state_dict(o.state_dict())
+    g = torch.Generator().manual_seed(12)
+    x = torch.randn(2, 3, H, W, generator=g)
+    gy = torch.randn(2, D, H, W, generator=g)
+    o.train()
+    y = dcn.forward(x.cuda())
+    ro = o(x)
+    yo = ro / torch.norm(ro, 2, 1, keepdim=True)
+    # unit vectors are ill-conditioned where ||v|| is small: an error e in v moves v/||v|| by ~e/||v||, so the 1e-4 bound
+    # on the raw map (relative to max|v|) becomes 1e-4 * max|v| / ||v|| per pixel
+    nv = torch.norm(ro, 2, 1, keepdim=True).detach()
+    scaled = ((y.detach().cpu() - yo.detach()).abs() * nv).max() / ro.detach().abs().max()
+    assert float(scaled) < 2 * TOL, float(scaled)
+    assert float((y.detach().norm(2, 1) - 1).abs().max()) < 1e-5
+    (y * gy.cuda()).sum().backward(); (yo * gy).sum().backward()
+    for (k, p), (_, po) in zip(dcn.fcn.named_parameters(), o.named_parameters()):
+        l2 = float((p.grad.cpu() - po.grad).norm() / po.grad.norm().clamp_min(1e-30))
+        assert l2 < 5e-2, (k, l2)
