@@ -51,18 +51,54 @@ WORKLOADS = {
                     desc="BASELINE configs[2]: B=32 pairs 640x480 D=16 Resnet34_8s 10000/50000/50000 pairs"),
     "config4": dict(B=8, H=480, W=640, D=3, Pm=5000, Pk=2500, Pg=2500, backbone="Resnet34_8s",
                     desc="BASELINE configs[3] per-GPU share: B=8 pairs 640x480 D=3 Resnet34_8s"),
+    "config5": dict(B=2, H=960, W=1280, D=32, Pm=2500, Pk=5000, Pg=5000, backbone="Resnet50_8s", masked=True,
+                    desc="BASELINE configs[4] per-GPU share: B=2 pairs 1280x960 D=32 Resnet50_8s, masked / background "
+                         "non-match sampling (2500 matches x 2 masked + 2 background non-matches)"),
     "tiny": dict(B=1, H=96, W=128, D=3, Pm=500, Pk=250, Pg=250, backbone="Resnet34_8s", desc="smoke-size workload"),
 }
 FP32_MFMA_PEAK_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 256 CUs @ 2.4 GHz
 
 
-def make_batch(B, H, W, Pm, Pk, Pg, seed):
+
+
+def make_masked_index_lists(B, H, W, Pm, per_match, gen):
+    """BASELINE config 5 "masked-background non-match sampling" (SURVEY.md section 8d): a random elliptic object mask
+    (~15 % of the image) per image; matches lie on the mask in both images; for every match ``per_match`` masked
+    non-matches (b index ON the mask) and ``per_match`` background non-matches (b index OFF the mask), with the a index
+    repeated per match -- the grouped layout of spartan_dataset_masked.py:841-858."""
+    out = []
+    ys = torch.arange(H).view(H, 1).float()
+    xs = torch.arange(W).view(1, W).float()
+    for _ in range(B):
+        masks = []
+        for _side in range(2):
+            cy = (0.3 + 0.4 * torch.rand(1, generator=gen)) * H
+            cx = (0.3 + 0.4 * torch.rand(1, generator=gen)) * W
+            ry, rx = 0.22 * H, 0.22 * W
+            masks.append((((ys - cy) / ry) ** 2 + ((xs - cx) / rx) ** 2 <= 1.0).reshape(-1))
+        on_a, on_b = masks[0].nonzero().reshape(-1), masks[1].nonzero().reshape(-1)
+        off_b = (~masks[1]).nonzero().reshape(-1)
+        pick = lambda pool, n: pool[torch.randint(0, pool.numel(), (n,), generator=gen)]
+        ma, mb = pick(on_a, Pm), pick(on_b, Pm)
+        rep = ma.repeat_interleave(per_match)
+        d = {"matches_a": ma, "matches_b": mb,
+             "masked_non_matches_a": rep.clone(), "masked_non_matches_b": pick(on_b, Pm * per_match),
+             "background_non_matches_a": rep.clone(), "background_non_matches_b": pick(off_b, Pm * per_match),
+             "blind_non_matches_a": torch.tensor([-1], dtype=torch.int64),
+             "blind_non_matches_b": torch.tensor([-1], dtype=torch.int64)}
+        out.append(d)
+    return out
+
+
+def make_batch(B, H, W, Pm, Pk, Pg, seed, masked=False):
     """Seeded synthetic batch: mean/std-normalised uniform images, uniformly drawn int64 pixel pairs."""
     gen = torch.Generator().manual_seed(seed)
     mean = torch.tensor(DEFAULT_IMAGE_MEAN).view(1, 3, 1, 1)
     std = torch.tensor(DEFAULT_IMAGE_STD_DEV).view(1, 3, 1, 1)
     img_a = (torch.rand(B, 3, H, W, generator=gen) - mean) / std
     img_b = (torch.rand(B, 3, H, W, generator=gen) - mean) / std
+    if masked:
+        return img_a, img_b, make_masked_index_lists(B, H, W, Pm, Pk // Pm, gen)
     lists = []
     for _ in range(B):
         d = {}
@@ -104,7 +140,8 @@ def cpu_baseline(wl, steps, warmup):
     torch.set_num_threads(cores)
     model = resnet_dilated_oracle.build(wl["backbone"], wl["D"], seed=0)
     model.train()
-    img_a, img_b, lists = synth.make_batch(1, wl["H"], wl["W"], wl["Pm"], wl["Pk"], wl["Pg"], seed=1)
+    img_a, img_b, lists = synth.make_batch(1, wl["H"], wl["W"], wl["Pm"], wl["Pk"], wl["Pg"], seed=1,
+                                           masked=wl.get("masked", False))
     sec = ostep.time_cpu_step(model, img_a, img_b, lists, synth.LOSS_CONFIG, steps=steps, warmup=warmup)
     return {"value": 2.0 / sec, "unit": "images/s", "cores": cores, "host_logical_cpus": os.cpu_count(), "kind": "port",
             "sample": "oracle (py3 CPU restatement of training.py:325-346, torch %s, fp32) on 1 image pair of the "
@@ -165,7 +202,7 @@ def main():
     pcl = PixelwiseContrastiveLoss(image_shape=dcn.image_shape, config=LOSS_CONFIG)
     grads = FlatGradients(dcn)
     opt = torch.optim.Adam(dcn.parameters(), lr=1.0e-4, weight_decay=1.0e-4)
-    img_a, img_b, lists = make_batch(B, H, W, wl["Pm"], wl["Pk"], wl["Pg"], seed=1 + rank)
+    img_a, img_b, lists = make_batch(B, H, W, wl["Pm"], wl["Pk"], wl["Pg"], seed=1 + rank, masked=wl.get("masked", False))
     img_a, img_b = img_a.to(dev), img_b.to(dev)
     pair_lists = PairLists.from_lists(as_tuples(lists), dev)
     match_type = 0  # SINGLE_OBJECT_WITHIN_SCENE

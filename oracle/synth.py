@@ -37,7 +37,7 @@ CONFIGS = {
     2: dict(B=4, H=480, W=640, D=3, Pm=5000, Pk=2500, Pg=2500, backbone="Resnet34_8s"),
     3: dict(B=32, H=480, W=640, D=16, Pm=10000, Pk=50000, Pg=50000, backbone="Resnet34_8s"),
     4: dict(B=8, H=480, W=640, D=3, Pm=5000, Pk=2500, Pg=2500, backbone="Resnet34_8s"),   # per GPU, x8 GPUs
-    5: dict(B=2, H=960, W=1280, D=32, Pm=5000, Pk=2500, Pg=2500, backbone="Resnet50_8s"),  # per GPU, x8 GPUs
+    5: dict(B=2, H=960, W=1280, D=32, Pm=2500, Pk=5000, Pg=5000, backbone="Resnet50_8s", masked=True),  # per GPU, x8
 }
 
 
@@ -66,10 +66,44 @@ def make_index_lists(B, HW, Pm, Pk, Pg, gen):
     return out
 
 
-def make_batch(B, H, W, Pm, Pk, Pg, seed=1):
+
+
+def make_masked_index_lists(B, H, W, Pm, per_match, gen):
+    """BASELINE config 5 "masked-background non-match sampling" (SURVEY.md section 8d): a random elliptic object mask
+    (~15 % of the image) per image; matches lie on the mask in both images; for every match ``per_match`` masked
+    non-matches (b index ON the mask) and ``per_match`` background non-matches (b index OFF the mask), with the a index
+    repeated per match -- the grouped layout of spartan_dataset_masked.py:841-858."""
+    out = []
+    ys = torch.arange(H).view(H, 1).float()
+    xs = torch.arange(W).view(1, W).float()
+    for _ in range(B):
+        masks = []
+        for _side in range(2):
+            cy = (0.3 + 0.4 * torch.rand(1, generator=gen)) * H
+            cx = (0.3 + 0.4 * torch.rand(1, generator=gen)) * W
+            ry, rx = 0.22 * H, 0.22 * W
+            masks.append((((ys - cy) / ry) ** 2 + ((xs - cx) / rx) ** 2 <= 1.0).reshape(-1))
+        on_a, on_b = masks[0].nonzero().reshape(-1), masks[1].nonzero().reshape(-1)
+        off_b = (~masks[1]).nonzero().reshape(-1)
+        pick = lambda pool, n: pool[torch.randint(0, pool.numel(), (n,), generator=gen)]
+        ma, mb = pick(on_a, Pm), pick(on_b, Pm)
+        rep = ma.repeat_interleave(per_match)
+        d = {"matches_a": ma, "matches_b": mb,
+             "masked_non_matches_a": rep.clone(), "masked_non_matches_b": pick(on_b, Pm * per_match),
+             "background_non_matches_a": rep.clone(), "background_non_matches_b": pick(off_b, Pm * per_match),
+             "blind_non_matches_a": torch.tensor([-1], dtype=torch.int64),
+             "blind_non_matches_b": torch.tensor([-1], dtype=torch.int64)}
+        out.append(d)
+    return out
+
+
+def make_batch(B, H, W, Pm, Pk, Pg, seed=1, masked=False):
     gen = torch.Generator().manual_seed(seed)
     img_a, img_b = make_images(B, H, W, gen)
-    lists = make_index_lists(B, H * W, Pm, Pk, Pg, gen)
+    if masked:
+        lists = make_masked_index_lists(B, H, W, Pm, Pk // Pm, gen)
+    else:
+        lists = make_index_lists(B, H * W, Pm, Pk, Pg, gen)
     return img_a, img_b, lists
 
 

@@ -97,7 +97,11 @@ def test_synth_constants_consistent_with_bench():
     assert torch.equal(a1, a2) and torch.equal(b1, b2)
     for x, y in zip(l1, l2):
         assert all(torch.equal(x[k], y[k]) for k in y)
-    for k in (1, 2, 3):
+    a1, b1, l1 = bench.make_batch(1, 32, 48, 20, 40, 40, seed=5, masked=True)
+    a2, b2, l2 = synth.make_batch(1, 32, 48, 20, 40, 40, seed=5, masked=True)
+    assert torch.equal(a1, a2) and all(torch.equal(l1[0][k], l2[0][k]) for k in l2[0])
+    assert l1[0]["masked_non_matches_a"].numel() == 40 and torch.equal(l1[0]["masked_non_matches_a"][::2], l1[0]["matches_a"])
+    for k in (1, 2, 3, 5):
         c = synth.CONFIGS[k]
         w = bench.WORKLOADS["config%d" % k]
         assert all(w[f] == c[f] for f in ("B", "H", "W", "D", "Pm", "Pk", "Pg", "backbone"))
