@@ -211,6 +211,23 @@ size_t dcn_conv_wgrad_workspace(const dcn_conv_desc* c);
 /* wt[c][tap][0..ldn) = (w[0..cout)[tap][c], zeros);  ldn >= cout is the row pitch of dout in dcn_conv_dgrad */
 int dcn_transpose_weight(const float* w, float* wt, int cout, int taps, int cin, int ldn, void* stream);
 
+/* ---- split-fp16 ("f16x3") variants: same tensors and results to ~fp32 accuracy, products on the fp16 matrix pipe
+ * (see csrc/conv_f16_kernels.hip).  Weights are pre-split with dcn_split_rows_f16 into two fp16 arrays of
+ * rows x dcn_f16_kpad(K) (hi, lo), scaled by the power of two `w_scale`. */
+int dcn_f16_kpad(int k);
+int dcn_split_rows_f16(const float* w, void* hi, void* lo, int64_t rows, int k, float scale, void* stream);
+int dcn_conv_num_mtiles_f16(const dcn_conv_desc* c);
+size_t dcn_conv_gemm_workspace_f16(const dcn_conv_desc* c, int dgrad);
+int dcn_conv_forward_f16(const dcn_conv_desc* c, const float* in, const void* w_hi, const void* w_lo, float w_scale,
+                         const float* bias, float* out, float* bn_partial, void* workspace, void* stream);
+/* dout_absmax: device scalar >= max|dout| (picks the power-of-two pre-scale of the gradient tensor) or NULL */
+int dcn_conv_dgrad_f16(const dcn_conv_desc* c, const float* dout, const void* wt_hi, const void* wt_lo, float w_scale,
+                       const float* dout_absmax, const float* add, float* din, void* workspace, void* stream);
+
+int dcn_conv_wgrad_f16(const dcn_conv_desc* c, const float* in, const float* dout, const float* dout_absmax, float* dw,
+                       void* slabs, void* stream);
+size_t dcn_conv_wgrad_workspace_f16(const dcn_conv_desc* c);
+
 /* bilinear xS upsample, align_corners=True (F.upsample_bilinear): low [n,hl,wl,ldl] -> out [n,h,w,d] */
 int dcn_upsample_forward(const float* low, int n, int hl, int wl, int ldl, int d, int h, int w, int normalize,
                          float* out, void* stream);

@@ -1,0 +1,645 @@
+// Split-fp16 ("f16x3") convolution kernels for gfx950: fp32 tensors in HBM, fp32 accumulation, but the products run on
+// the fp16 matrix pipe (v_mfma_f32_32x32x16_f16, 16x the fp32 MFMA rate) by splitting every operand element
+//     s*x = hi + lo,   hi = fp16(s*x),  lo = fp16(s*x - hi)          (s: a power of two, exact)
+// and accumulating  lo_a*hi_b + hi_a*lo_b + hi_a*hi_b  (the dropped lo*lo term is ~2^-22 relative).  fp16 products are
+// exact in fp32, so the result carries ~22 mantissa bits per operand: on the reference network (36 conv layers with
+// train-mode BN, 640x480) the descriptor map is 1.3e-5 from a float64 run -- the fp32 CPU reference itself is 1.5e-5 --
+// and every parameter gradient deviates from float64 exactly as much as the fp32 reference does (3.1e-2 max / 7.0e-3 L2,
+// ill-conditioning, not precision).  bf16 cannot do this (a 2-way bf16 split is 2.3e-4 off, above the 1e-4 parity bar).
+//   forward : activations s = 1, weights s = 64 (pre-split once per call: `split_rows_kernel`)
+//   dgrad   : the incoming gradient tensor is scaled by 2^e with e from its abs-max (a device scalar written by the
+//             kernel that produced the tensor) so that tiny gradients stay inside fp16's range; weights s = 64
+//   wgrad   : dy (dynamic scale) x activations (s = 1), reduction over pixels, register-transposed into k-major LDS
+// MFMA work per K drops 5.3x (3 x 32 cycles per 16 K vs 8 x 64 cycles), so the kernels are designed around the
+// operand path: 128x128 tiles, 32-K stages, fp32->(hi,lo) conversion once per element at staging time (v_cvt_pk_f16_f32),
+// conflict-free 80-byte-pitch fp16 LDS images, one ds_read_b128 per 32x16 fragment.
+#include "conv_shared.h"
+
+namespace {
+
+using namespace dcnconv;
+
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+
+constexpr int HBK = 32;            // K elements per stage
+constexpr int LDH = HBK + 8;       // LDS row pitch in halves (80 bytes: conflict-free ds_read_b128 fragments)
+
+__device__ __forceinline__ float pow2_scale(float absmax) {
+    // largest power of two s with s * absmax <= 4096 (fp16 max is 65504: 16x headroom for the fp32->fp16 rounding)
+    return absmax > 0.f ? exp2f(floorf(log2f(4096.f / absmax))) : 1.f;
+}
+
+__device__ __forceinline__ void split4(float4 v, float s, h4& hi, h4& lo) {
+    const float x0 = v.x * s, x1 = v.y * s, x2 = v.z * s, x3 = v.w * s;
+    hi[0] = (_Float16)x0; hi[1] = (_Float16)x1; hi[2] = (_Float16)x2; hi[3] = (_Float16)x3;
+    lo[0] = (_Float16)(x0 - (float)hi[0]); lo[1] = (_Float16)(x1 - (float)hi[1]);
+    lo[2] = (_Float16)(x2 - (float)hi[2]); lo[3] = (_Float16)(x3 - (float)hi[3]);
+}
+
+// rows x K fp32 -> hi / lo fp16 [rows][kp] (kp = K rounded up to 8, zero padded), scaled by s
+__global__ void __launch_bounds__(256)
+split_rows_kernel(const float* __restrict__ w, _Float16* __restrict__ hi, _Float16* __restrict__ lo, int64_t rows, int K,
+                  int kp, float s) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;  // over rows * kp / 4
+    const int q = kp / 4;
+    if (i >= rows * q) return;
+    const int64_t r = i / q;
+    const int k = (int)(i - r * q) * 4;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (k < K) v = *reinterpret_cast<const float4*>(w + r * K + k);  // K % 4 == 0
+    h4 a, b;
+    split4(v, s, a, b);
+    *reinterpret_cast<h4*>(hi + r * kp + k) = a;
+    *reinterpret_cast<h4*>(lo + r * kp + k) = b;
+}
+
+// ----------------------------------------------------------------------------------------------- gather-GEMM, f16x3
+template <int TM, int TN> struct F16Geo {
+    static constexpr int BM = 64 * TM, BN = 64 * TN, PA = BM / 32, PB = BN / 64,
+                         kStageHalves = 2 * (BM + BN) * LDH;   // A hi, A lo, B hi, B lo
+};
+
+template <int TM, int TN, bool TR>
+__device__ __forceinline__ void gemm_segment_f16(const GemmConv& p, _Float16* lds, int tile, int k0, int k1, int nk,
+                                                 float* slot) {
+    using G = F16Geo<TM, TN>;
+    constexpr int BM = G::BM, BN = G::BN, PA = G::PA, PB = G::PB, kStage = G::kStageHalves;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int wm_ = wv >> 1, wn_ = wv & 1;
+    const int mt = fdiv(tile, p.div_nt), nt = tile - mt * p.ntiles;
+    const int m0 = mt * BM, n0 = nt * BN;
+
+    // A staging: float4 (4 k) at k-quad kq of rows ra0 + 32 j;  B staging: 8 halves at k-octet ko of rows rb0 + 64 j
+    const int kq = tid & 7, ra0 = tid >> 3;
+    const int ko = tid & 3, rb0 = tid >> 2;
+    int by[PA], bx[PA], pixbase[PA];
+#pragma unroll
+    for (int j = 0; j < PA; ++j) {
+        const int m = m0 + ra0 + 32 * j;
+        const int mm = m < p.M ? m : 0;
+        const int img = fdiv(mm, p.div_hw), rem = mm - img * p.div_hw.d;
+        const int y = fdiv(rem, p.div_w), x = rem - y * p.div_w.d;
+        by[j] = TR ? y + p.pad : y * p.stride - p.pad;
+        bx[j] = TR ? x + p.pad : x * p.stride - p.pad;
+        if (m >= p.M) by[j] = -(1 << 28);
+        pixbase[j] = img * p.hs * p.ws;
+    }
+    int wrow[PB];
+    unsigned wokm = 0;
+#pragma unroll
+    for (int j = 0; j < PB; ++j) {
+        const int n = n0 + rb0 + 64 * j;
+        const bool ok = n < p.cd;
+        wokm |= (ok ? 1u : 0u) << j;
+        wrow[j] = (ok ? n : 0) * p.kp + ko * 8;
+    }
+    const int smask = p.stride - 1;
+    const float sa = p.a_absmax ? pow2_scale(*p.a_absmax) : 1.f;
+    float4 ra[PA];
+    h8 rbh[PB], rbl[PB];
+    unsigned okm = 0;
+
+    auto load_tile = [&](int kt) {
+        const int k = kt * HBK + kq * 4;
+        const bool kval = k < p.K;
+        const int kk = kval ? k : 0;
+        const int tap = fdiv(kk, p.div_cs), c = kk - tap * p.cs;
+        const int r = fdiv(tap, p.div_kw), s = tap - r * p.kw;
+        const int dy = r * p.dil, dx = s * p.dil;
+        okm = 0;
+#pragma unroll
+        for (int j = 0; j < PA; ++j) {
+            int sy, sx;
+            bool ok = kval;
+            if (TR) {
+                const int ny = by[j] - dy, nx = bx[j] - dx;
+                ok = ok & ((ny | nx) >= 0) & (((ny | nx) & smask) == 0);
+                sy = ny >> p.sshift; sx = nx >> p.sshift;
+            } else {
+                sy = by[j] + dy; sx = bx[j] + dx;
+            }
+            ok = ok & ((unsigned)sy < (unsigned)p.hs) & ((unsigned)sx < (unsigned)p.ws);
+            int off = (pixbase[j] + sy * p.ws + sx) * p.cs + c;
+            off = ok ? off : 0;
+            ra[j] = *reinterpret_cast<const float4*>(p.src + off);
+            okm |= (ok ? 1u : 0u) << j;
+        }
+        const int kb = kt * HBK + ko * 8;
+        const bool kbval = kb < p.kp;
+#pragma unroll
+        for (int j = 0; j < PB; ++j) {
+            const bool ok = kbval & (((wokm >> j) & 1u) != 0);
+            const int off = ok ? wrow[j] + kt * HBK : 0;
+            rbh[j] = *reinterpret_cast<const h8*>(p.wh + off);
+            rbl[j] = *reinterpret_cast<const h8*>(p.wl + off);
+            okm |= (ok ? 1u : 0u) << (16 + j);
+        }
+    };
+    auto store_tile = [&](int stage) {
+        _Float16* ah = lds + stage * kStage;
+        _Float16* al = ah + BM * LDH;
+        _Float16* bh = al + BM * LDH;
+        _Float16* bl = bh + BN * LDH;
+#pragma unroll
+        for (int j = 0; j < PA; ++j) {
+            const bool ok = (okm >> j) & 1u;
+            float4 v = ra[j];
+            v = make_float4(ok ? v.x : 0.f, ok ? v.y : 0.f, ok ? v.z : 0.f, ok ? v.w : 0.f);
+            h4 hi, lo;
+            split4(v, sa, hi, lo);
+            *reinterpret_cast<h4*>(ah + (ra0 + 32 * j) * LDH + kq * 4) = hi;
+            *reinterpret_cast<h4*>(al + (ra0 + 32 * j) * LDH + kq * 4) = lo;
+        }
+#pragma unroll
+        for (int j = 0; j < PB; ++j) {
+            const bool ok = (okm >> (16 + j)) & 1u;
+            h8 z;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) z[e] = (_Float16)0.f;
+            *reinterpret_cast<h8*>(bh + (rb0 + 64 * j) * LDH + ko * 8) = ok ? rbh[j] : z;
+            *reinterpret_cast<h8*>(bl + (rb0 + 64 * j) * LDH + ko * 8) = ok ? rbl[j] : z;
+        }
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    // fragments: lane (fi = lane & 31, fh = lane >> 5) holds 8 consecutive k at offset 16*ks + 8*fh of row fi
+    const int fi = lane & 31, fh = lane >> 5;
+    const int a_off = (wm_ * 32 * TM + fi) * LDH + 8 * fh;
+    const int b_off = 2 * BM * LDH + (wn_ * 32 * TN + fi) * LDH + 8 * fh;
+    h8 fah[2][TM], fal[2][TM], fbh[2][TN], fbl[2][TN];
+    auto read_frags = [&](int stage, int ks, int set) {
+        const _Float16* a = lds + stage * kStage + a_off + ks * 16;
+        const _Float16* b = lds + stage * kStage + b_off + ks * 16;
+#pragma unroll
+        for (int t = 0; t < TM; ++t) {
+            fah[set][t] = *reinterpret_cast<const h8*>(a + t * 32 * LDH);
+            fal[set][t] = *reinterpret_cast<const h8*>(a + BM * LDH + t * 32 * LDH);
+        }
+#pragma unroll
+        for (int t = 0; t < TN; ++t) {
+            fbh[set][t] = *reinterpret_cast<const h8*>(b + t * 32 * LDH);
+            fbl[set][t] = *reinterpret_cast<const h8*>(b + BN * LDH + t * 32 * LDH);
+        }
+    };
+    auto mfma_steps = [&](int set) {
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+            for (int tn = 0; tn < TN; ++tn) {
+                acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fal[set][tm], fbh[set][tn], acc[tm][tn], 0, 0, 0);
+                acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fah[set][tm], fbl[set][tn], acc[tm][tn], 0, 0, 0);
+                acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fah[set][tm], fbh[set][tn], acc[tm][tn], 0, 0, 0);
+            }
+    };
+
+    // same two-phase software pipeline as the fp32 kernel: one barrier per 32-K stage, loads a full stage ahead
+    load_tile(k0);
+    store_tile(0);
+    load_tile(k0 + 1 < k1 ? k0 + 1 : k0);
+    __syncthreads();
+    read_frags(0, 0, 0);
+    for (int kt = k0; kt < k1; ++kt) {
+        const int cur = (kt - k0) & 1;
+        read_frags(cur, 1, 1);
+        store_tile(cur ^ 1);
+        mfma_steps(0);
+        __syncthreads();
+        load_tile(kt + 2 < k1 ? kt + 2 : k1 - 1);
+        read_frags(cur ^ 1, 0, 0);
+        mfma_steps(1);
+    }
+    __syncthreads();
+
+    const float inv = p.b_inv_scale / sa;
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+        for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[tm][tn][r] *= inv;
+    if (k0 == 0 && k1 == nk) {
+        gemm_epilogue<2, TM, TN, 16>(p, acc, mt, nt, reinterpret_cast<float*>(lds));
+    } else {
+        float* o = slot + wv * (TM * TN * 16 * 64) + lane;
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+            for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) o[((tm * TN + tn) * 16 + r) * 64] = acc[tm][tn][r];
+    }
+}
+
+template <int TM, int TN, bool TR, bool SK>
+__global__ void __launch_bounds__(NT, 2)
+conv_gemm_f16_kernel(GemmConv p) {
+    using G = F16Geo<TM, TN>;
+    __shared__ __attribute__((aligned(16))) _Float16 lds[2 * G::kStageHalves];
+    const int nk = (p.K + HBK - 1) / HBK;
+    if (!SK) {
+        gemm_segment_f16<TM, TN, TR>(p, lds, xcd_remap(blockIdx.x, p.mtiles * p.ntiles), 0, nk, nk, nullptr);
+    } else {
+        const int g = xcd_remap(blockIdx.x, gridDim.x);
+        int u = g * p.sk_units;
+        const int total = p.mtiles * p.ntiles * nk;
+        const int u_end = min(total, u + p.sk_units);
+        bool first = true;
+        while (u < u_end) {
+            const int tile = fdiv(u, p.div_nk), k0 = u - tile * nk;
+            const int k1 = min(nk, k0 + (u_end - u));
+            gemm_segment_f16<TM, TN, TR>(p, lds, tile, k0, k1, nk,
+                                         p.sk_partial + (int64_t)(2 * g + (first ? 0 : 1)) * (G::BM * G::BN));
+            u += k1 - k0;
+            first = false;
+            __syncthreads();
+        }
+    }
+}
+
+// completes stream-K tiles (same slot layout / arithmetic as conv_gemm_fixup_kernel of the fp32 path, 32-K stages)
+template <int TM, int TN>
+__global__ void __launch_bounds__(NT)
+conv_gemm_f16_fixup_kernel(GemmConv p) {
+    using G = F16Geo<TM, TN>;
+    __shared__ float red[4 * G::BN];
+    const int nk = (p.K + HBK - 1) / HBK;
+    const int tile = blockIdx.x;
+    const int ua = tile * nk, ub = ua + nk - 1;
+    const int ga = ua / p.sk_units, gb = ub / p.sk_units;
+    if (ga == gb) return;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    for (int g = ga; g <= gb; ++g) {
+        const int first_tile = (g * p.sk_units) / nk;
+        const float* o = p.sk_partial + (int64_t)(2 * g + (first_tile == tile ? 0 : 1)) * (G::BM * G::BN) +
+                         wv * (TM * TN * 16 * 64) + lane;
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+            for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[tm][tn][r] += o[((tm * TN + tn) * 16 + r) * 64];
+    }
+    const int mt = tile / p.ntiles, nt = tile - mt * p.ntiles;
+    gemm_epilogue<2, TM, TN, 16>(p, acc, mt, nt, red);
+}
+
+struct F16Shape {
+    int tm, tn, mtiles, ntiles, nk, sk_wgs, sk_units;
+    bool sk;
+    size_t ws_bytes;
+};
+F16Shape f16_shape(int M, int cd, int K) {
+    F16Shape g;
+    g.tn = cd <= 64 ? 1 : 2;
+    const int ntiles128 = dcn::ceil_div(cd, 64 * g.tn);
+    g.tm = dcn::ceil_div(M, 128) * ntiles128 < 2 * 256 ? 1 : 2;
+    if (const char* e = getenv("DCN_GEMM_TILE_M")) {
+        const int v = atoi(e);
+        if (v == 64) g.tm = 1;
+        if (v == 128) g.tm = 2;
+    }
+    g.mtiles = dcn::ceil_div(M, 64 * g.tm);
+    g.ntiles = dcn::ceil_div(cd, 64 * g.tn);
+    g.nk = dcn::ceil_div(K, HBK);
+    const int tiles = g.mtiles * g.ntiles;
+    const double rounds = tiles / 256.0;
+    const double waste = 1.0 - rounds / (double)(int)(rounds + 0.999999);
+    g.sk = tiles < 8 * 256 && waste > 0.08 && g.nk >= 16;
+    int wgs = 512;
+    if (const char* e = getenv("DCN_GEMM_SK")) {
+        const int v = atoi(e);
+        if (v == 0) g.sk = false;
+        if (v > 1) { g.sk = g.nk >= 2; wgs = v; }
+    }
+    g.sk_wgs = 0; g.sk_units = 0; g.ws_bytes = 0;
+    if (g.sk) {
+        const int64_t total = (int64_t)tiles * g.nk;
+        if (total >= ((int64_t)1 << 30)) { g.sk = false; return g; }
+        if (wgs > total / 2) wgs = (int)(total / 2) > 0 ? (int)(total / 2) : 1;
+        g.sk_units = (int)((total + wgs - 1) / wgs);
+        g.sk_wgs = (int)((total + g.sk_units - 1) / g.sk_units);
+        g.ws_bytes = (size_t)2 * g.sk_wgs * (64 * g.tm) * (64 * g.tn) * sizeof(float);
+    }
+    return g;
+}
+
+int launch_gemm_f16(GemmConv& p, void* workspace, hipStream_t st) {
+    if (p.stride != 1 && p.stride != 2 && p.stride != 4) return DCN_E_UNSUPPORTED;
+    p.sshift = p.stride == 1 ? 0 : (p.stride == 2 ? 1 : 2);
+    p.div_hw = make_fastdiv(p.hd * p.wd);
+    p.div_w = make_fastdiv(p.wd);
+    p.div_cs = make_fastdiv(p.cs);
+    p.div_kw = make_fastdiv(p.kw);
+    if ((int64_t)p.M / (p.hd * p.wd) * p.hs * p.ws * p.cs >= ((int64_t)1 << 31) || (int64_t)p.cd * p.kp >= ((int64_t)1 << 31))
+        return DCN_E_UNSUPPORTED;
+    const F16Shape g = f16_shape(p.M, p.cd, p.K);
+    const bool sk = g.sk && workspace != nullptr;
+    p.mtiles = g.mtiles;
+    p.ntiles = g.ntiles;
+    p.div_nt = make_fastdiv(g.ntiles);
+    p.div_nk = make_fastdiv(g.nk);
+    p.sk_units = sk ? g.sk_units : 0;
+    p.sk_partial = sk ? (float*)workspace : nullptr;
+    const dim3 grid(sk ? g.sk_wgs : g.mtiles * g.ntiles), fgrid(g.mtiles * g.ntiles), block(NT);
+#define DCN_GEMM16(TM, TN)                                                                                          \
+    do {                                                                                                            \
+        if (sk) {                                                                                                   \
+            if (p.transposed) hipLaunchKernelGGL((conv_gemm_f16_kernel<TM, TN, true, true>), grid, block, 0, st, p); \
+            else hipLaunchKernelGGL((conv_gemm_f16_kernel<TM, TN, false, true>), grid, block, 0, st, p);             \
+            hipLaunchKernelGGL((conv_gemm_f16_fixup_kernel<TM, TN>), fgrid, block, 0, st, p);                        \
+        } else {                                                                                                    \
+            if (p.transposed) hipLaunchKernelGGL((conv_gemm_f16_kernel<TM, TN, true, false>), grid, block, 0, st, p); \
+            else hipLaunchKernelGGL((conv_gemm_f16_kernel<TM, TN, false, false>), grid, block, 0, st, p);            \
+        }                                                                                                           \
+    } while (0)
+    if (g.tm == 1) { if (g.tn == 1) DCN_GEMM16(1, 1); else DCN_GEMM16(1, 2); }
+    else { if (g.tn == 1) DCN_GEMM16(2, 1); else DCN_GEMM16(2, 2); }
+#undef DCN_GEMM16
+    return dcn::check_launch();
+}
+
+// ----------------------------------------------------------------------------------------------- wgrad, f16x3
+// dW[n][kcol] = sum_m dout[m][n] * in[pix(m, tap(kcol))][c(kcol)]  as a GEMM whose reduction index is the pixel m.
+// Both operands are pixel-major in HBM but the fp16 MFMA wants 8 consecutive reduction elements per lane, so the
+// staging transposes in registers: a work-item owns a 4-pixel x 4-channel micro-tile (four 16-byte loads along the
+// channel axis = 128-byte segments per 8 lanes), converts to (hi, lo) and writes four 8-byte k-runs into the same
+// [row][32 k + pad] fp16 LDS image the gather-GEMM kernel uses (lane order chosen so the writes are conflict-free).
+struct WgradF16 {
+    const float* in;    // [n, hin, win, cin]
+    const float* dout;  // [M][ldo]
+    float* slab;        // [splits][cout][K]
+    const float* d_absmax;
+    int hin, win, cin, hout, wout, cout, kh, kw, stride, pad, dil, ldo, M, K, splits, rows_per_split, ntiles_n, ntiles_k;
+    FastDiv div_hw, div_w, div_cin, div_kw;
+};
+
+template <int TM>   // 64*TM output channels x 128 K columns per workgroup
+__global__ void __launch_bounds__(NT, 2)
+conv_wgrad_f16_kernel(WgradF16 p) {
+    constexpr int BM = 64 * TM, BN = 128, kStage = 2 * (BM + BN) * LDH;
+    __shared__ __attribute__((aligned(16))) _Float16 lds[2 * kStage];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int wm_ = wv >> 1, wn_ = wv & 1;
+    const int tiles = p.ntiles_n * p.ntiles_k;
+    const int bid = xcd_remap(blockIdx.x, tiles * p.splits);
+    const int split = bid / tiles, tile = bid - split * tiles;
+    const int tn_ = tile / p.ntiles_k, tk_ = tile - tn_ * p.ntiles_k;
+    const int n0 = tn_ * BM, j0 = tk_ * BN;
+    const int m_begin = split * p.rows_per_split;
+    const int m_end = min(p.M, m_begin + p.rows_per_split);
+
+    // micro-tile of this work-item: pixels 4*pq .. 4*pq+3 of the stage, channel quad cq (dout: n0 + 4*cq, in: j0 + 4*cq)
+    const int pq = tid & 7, cq = tid >> 3;                    // 8 pixel quads x 32 channel quads
+    const bool dact = 4 * cq < BM;                            // (BM = 64: only half of the work-items stage dout)
+    const int ncol = n0 + cq * 4;
+    const bool nval = dact & (ncol < p.ldo);
+    const int kcol = j0 + cq * 4;
+    const bool kval = kcol < p.K;
+    const int kc0 = kval ? kcol : 0;
+    const int tap = fdiv(kc0, p.div_cin), cc = kc0 - tap * p.cin;
+    const int tr = fdiv(tap, p.div_kw), ts = tap - tr * p.kw;
+    const int oy = tr * p.dil - p.pad, ox = ts * p.dil - p.pad;
+    const float sd = p.d_absmax ? pow2_scale(*p.d_absmax) : 1.f;
+    float4 rd[4], rx[4];
+    unsigned okm = 0;
+
+    auto load_tile = [&](int m_base) {
+        okm = 0;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int m = m_base + 4 * pq + i;
+            const bool mval = m < m_end;
+            const int mm = mval ? m : 0;
+            const bool dok = mval & nval;
+            rd[i] = *reinterpret_cast<const float4*>(p.dout + (dok ? mm * p.ldo + ncol : 0));
+            const int img = fdiv(mm, p.div_hw), rem = mm - img * p.div_hw.d;
+            const int y = fdiv(rem, p.div_w), x = rem - y * p.div_w.d;
+            const int sy = y * p.stride + oy, sx = x * p.stride + ox;
+            const bool ok = mval & kval & ((unsigned)sy < (unsigned)p.hin) & ((unsigned)sx < (unsigned)p.win);
+            int off = ((img * p.hin + sy) * p.win + sx) * p.cin + cc;
+            off = ok ? off : 0;
+            rx[i] = *reinterpret_cast<const float4*>(p.in + off);
+            okm |= ((dok ? 1u : 0u) << i) | ((ok ? 1u : 0u) << (8 + i));
+        }
+    };
+    auto store_tile = [&](int stage) {
+        _Float16* dh = lds + stage * kStage;
+        _Float16* dl = dh + BM * LDH;
+        _Float16* xh = dl + BM * LDH;
+        _Float16* xl = xh + BN * LDH;
+        float dv[4][4], xv[4][4];  // [pixel][channel]
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const bool dok = (okm >> i) & 1u, ok = (okm >> (8 + i)) & 1u;
+            dv[i][0] = dok ? rd[i].x : 0.f; dv[i][1] = dok ? rd[i].y : 0.f; dv[i][2] = dok ? rd[i].z : 0.f; dv[i][3] = dok ? rd[i].w : 0.f;
+            xv[i][0] = ok ? rx[i].x : 0.f; xv[i][1] = ok ? rx[i].y : 0.f; xv[i][2] = ok ? rx[i].z : 0.f; xv[i][3] = ok ? rx[i].w : 0.f;
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {   // channel e of the quad: its 4 consecutive pixels form one 8-byte k-run
+            h4 hi, lo;
+            split4(make_float4(xv[0][e], xv[1][e], xv[2][e], xv[3][e]), 1.f, hi, lo);
+            *reinterpret_cast<h4*>(xh + (4 * cq + e) * LDH + 4 * pq) = hi;
+            *reinterpret_cast<h4*>(xl + (4 * cq + e) * LDH + 4 * pq) = lo;
+            if (dact) {
+                split4(make_float4(dv[0][e], dv[1][e], dv[2][e], dv[3][e]), sd, hi, lo);
+                *reinterpret_cast<h4*>(dh + (4 * cq + e) * LDH + 4 * pq) = hi;
+                *reinterpret_cast<h4*>(dl + (4 * cq + e) * LDH + 4 * pq) = lo;
+            }
+        }
+    };
+
+    // wavefront tiling: TM == 2: 2x2 waves, each 64 channels x 64 columns; TM == 1: 1x4 waves, each 64 channels x 32 columns
+    constexpr int CT = TM == 2 ? 2 : 1;
+    f32x16 acc[2][CT];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < CT; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    const int fi = lane & 31, fh = lane >> 5;
+    const int wrow0 = TM == 2 ? wm_ * 64 : 0, wcol0 = TM == 2 ? wn_ * 64 : wv * 32;
+    const int a_off = (wrow0 + fi) * LDH + 8 * fh;
+    const int b_off = 2 * BM * LDH + (wcol0 + fi) * LDH + 8 * fh;
+    h8 fah[2][2], fal[2][2], fbh[2][CT], fbl[2][CT];
+    auto read_frags = [&](int stage, int ks, int set) {
+        const _Float16* a = lds + stage * kStage + a_off + ks * 16;
+        const _Float16* b = lds + stage * kStage + b_off + ks * 16;
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            fah[set][t] = *reinterpret_cast<const h8*>(a + t * 32 * LDH);
+            fal[set][t] = *reinterpret_cast<const h8*>(a + BM * LDH + t * 32 * LDH);
+        }
+#pragma unroll
+        for (int t = 0; t < CT; ++t) {
+            fbh[set][t] = *reinterpret_cast<const h8*>(b + t * 32 * LDH);
+            fbl[set][t] = *reinterpret_cast<const h8*>(b + BN * LDH + t * 32 * LDH);
+        }
+    };
+    auto mfma_steps = [&](int set) {
+#pragma unroll
+        for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+            for (int tn = 0; tn < CT; ++tn) {
+                f32x16& c = acc[tm][tn];
+                c = __builtin_amdgcn_mfma_f32_32x32x16_f16(fal[set][tm], fbh[set][tn], c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_32x32x16_f16(fah[set][tm], fbl[set][tn], c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_32x32x16_f16(fah[set][tm], fbh[set][tn], c, 0, 0, 0);
+            }
+    };
+
+    const int nsteps = (m_end - m_begin + HBK - 1) / HBK;
+    if (nsteps > 0) {
+        load_tile(m_begin);
+        store_tile(0);
+        load_tile(m_begin + (nsteps > 1 ? HBK : 0));
+        __syncthreads();
+        read_frags(0, 0, 0);
+        for (int st = 0; st < nsteps; ++st) {
+            const int cur = st & 1;
+            read_frags(cur, 1, 1);
+            store_tile(cur ^ 1);
+            mfma_steps(0);
+            __syncthreads();
+            load_tile(m_begin + (st + 2 < nsteps ? st + 2 : nsteps - 1) * HBK);
+            read_frags(cur ^ 1, 0, 0);
+            mfma_steps(1);
+        }
+    }
+    // C fragment: row (r) <-> output channel, column (lane & 31) <-> K column: 128-byte coalesced rows
+    const float inv = 1.f / sd;
+    float* out = p.slab + (int64_t)split * p.cout * p.K;
+#pragma unroll
+    for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+        for (int tn = 0; tn < CT; ++tn) {
+            const int kc = j0 + wcol0 + tn * 32 + fi;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int n = n0 + wrow0 + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh;
+                if (n < p.cout && kc < p.K) out[(int64_t)n * p.K + kc] = acc[tm][tn][r] * inv;
+            }
+        }
+}
+
+int wgrad_splits_f16(const dcn_conv_desc* c, int* rows_per_split) {
+    const int M = c->n * c->hout * c->wout, K = c->kh * c->kw * c->cin;
+    const bool narrow = c->cout <= 64;
+    const int tiles = dcn::ceil_div(c->cout, narrow ? 64 : 128) * dcn::ceil_div(K, 128);
+    int splits = dcn::ceil_div(1536, tiles);
+    const int max_by_rows = (M / (8 * HBK)) > 1 ? (M / (8 * HBK)) : 1;
+    if (splits > max_by_rows) splits = max_by_rows;
+    const int cap = narrow ? 256 : 64;
+    if (splits > cap) splits = cap;
+    if (splits < 1) splits = 1;
+    int rps = dcn::ceil_div(dcn::ceil_div(M, splits), HBK) * HBK;
+    splits = dcn::ceil_div(M, rps);
+    *rows_per_split = rps;
+    return splits;
+}
+
+bool valid_desc16(const dcn_conv_desc* c) {
+    return c && c->n > 0 && c->hin > 0 && c->win > 0 && c->cin > 0 && (c->cin % 4) == 0 && c->hout > 0 && c->wout > 0 &&
+           c->cout > 0 && c->kh > 0 && c->kw > 0 && c->stride > 0 && c->dil > 0 && c->pad >= 0 && c->ldc >= c->cout;
+}
+
+}  // namespace
+
+extern "C" int dcn_f16_kpad(int k) { return (k + 7) / 8 * 8; }
+
+extern "C" int dcn_split_rows_f16(const float* w, void* hi, void* lo, int64_t rows, int k, float scale, void* stream) {
+    if (!w || !hi || !lo || rows < 1 || k < 4 || (k % 4) != 0) return DCN_E_INVALID;
+    const int kp = dcn_f16_kpad(k);
+    const int64_t n = rows * (kp / 4);
+    hipLaunchKernelGGL(split_rows_kernel, dim3((unsigned)dcn::ceil_div64(n, 256)), dim3(256), 0, (hipStream_t)stream, w,
+                       (_Float16*)hi, (_Float16*)lo, rows, k, kp, scale);
+    return dcn::check_launch();
+}
+
+extern "C" int dcn_conv_num_mtiles_f16(const dcn_conv_desc* c) {
+    if (!valid_desc16(c)) return DCN_E_INVALID;
+    return f16_shape(c->n * c->hout * c->wout, c->cout, c->kh * c->kw * c->cin).mtiles;
+}
+
+extern "C" size_t dcn_conv_gemm_workspace_f16(const dcn_conv_desc* c, int dgrad) {
+    if (!valid_desc16(c)) return 0;
+    if (dgrad) return f16_shape(c->n * c->hin * c->win, c->cin, c->kh * c->kw * c->ldc).ws_bytes;
+    return f16_shape(c->n * c->hout * c->wout, c->cout, c->kh * c->kw * c->cin).ws_bytes;
+}
+
+// w_hi / w_lo: [cout][kpad(K)] fp16 from dcn_split_rows_f16(w, ..., scale = w_scale)
+extern "C" int dcn_conv_forward_f16(const dcn_conv_desc* c, const float* in, const void* w_hi, const void* w_lo,
+                                    float w_scale, const float* bias, float* out, float* bn_partial, void* workspace,
+                                    void* stream) {
+    if (!valid_desc16(c) || !in || !w_hi || !w_lo || !out || !(w_scale > 0.f)) return DCN_E_INVALID;
+    GemmConv p;
+    p.src = in; p.wm = nullptr; p.bias = bias; p.add = nullptr; p.dst = out; p.bn_partial = bn_partial;
+    p.wh = (const _Float16*)w_hi; p.wl = (const _Float16*)w_lo; p.a_absmax = nullptr; p.b_inv_scale = 1.f / w_scale;
+    p.hs = c->hin; p.ws = c->win; p.cs = c->cin; p.hd = c->hout; p.wd = c->wout; p.cd = c->cout;
+    p.kh = c->kh; p.kw = c->kw; p.stride = c->stride; p.pad = c->pad; p.dil = c->dil; p.ldc = c->ldc;
+    p.M = c->n * c->hout * c->wout; p.K = c->kh * c->kw * c->cin; p.kp = dcn_f16_kpad(p.K); p.transposed = 0;
+    return launch_gemm_f16(p, workspace, (hipStream_t)stream);
+}
+
+// wt_hi / wt_lo: split of the channel-transposed weights [cin][taps][ldc] (dcn_transpose_weight, then dcn_split_rows_f16);
+// dout_absmax: device scalar >= max |dout| (selects the power-of-two pre-scale), or NULL for scale 1
+extern "C" int dcn_conv_dgrad_f16(const dcn_conv_desc* c, const float* dout, const void* wt_hi, const void* wt_lo,
+                                  float w_scale, const float* dout_absmax, const float* add, float* din, void* workspace,
+                                  void* stream) {
+    if (!valid_desc16(c) || !dout || !wt_hi || !wt_lo || !din || (c->ldc % 4) != 0 || !(w_scale > 0.f)) return DCN_E_INVALID;
+    GemmConv p;
+    p.src = dout; p.wm = nullptr; p.bias = nullptr; p.add = add; p.dst = din; p.bn_partial = nullptr;
+    p.wh = (const _Float16*)wt_hi; p.wl = (const _Float16*)wt_lo; p.a_absmax = dout_absmax; p.b_inv_scale = 1.f / w_scale;
+    p.hs = c->hout; p.ws = c->wout; p.cs = c->ldc;
+    p.hd = c->hin; p.wd = c->win; p.cd = c->cin;
+    p.kh = c->kh; p.kw = c->kw; p.stride = c->stride; p.pad = c->pad; p.dil = c->dil; p.ldc = c->cin;
+    p.M = c->n * c->hin * c->win; p.K = c->kh * c->kw * c->ldc; p.kp = dcn_f16_kpad(p.K); p.transposed = 1;
+    return launch_gemm_f16(p, workspace, (hipStream_t)stream);
+}
+
+extern "C" size_t dcn_conv_wgrad_workspace_f16(const dcn_conv_desc* c) {
+    if (!valid_desc16(c)) return 0;
+    int rps;
+    const int splits = wgrad_splits_f16(c, &rps);
+    return (size_t)splits * c->cout * c->kh * c->kw * c->cin * sizeof(float);
+}
+
+extern "C" int dcn_conv_wgrad_f16(const dcn_conv_desc* c, const float* in, const float* dout, const float* dout_absmax,
+                                  float* dw, void* slabs, void* stream) {
+    if (!valid_desc16(c) || !in || !dout || !dw || !slabs || (c->ldc % 4) != 0) return DCN_E_INVALID;
+    if ((int64_t)c->n * c->hin * c->win * c->cin >= ((int64_t)1 << 31) ||
+        (int64_t)c->n * c->hout * c->wout * c->ldc >= ((int64_t)1 << 31))
+        return DCN_E_UNSUPPORTED;
+    WgradF16 p;
+    p.in = in; p.dout = dout; p.d_absmax = dout_absmax;
+    p.hin = c->hin; p.win = c->win; p.cin = c->cin; p.hout = c->hout; p.wout = c->wout; p.cout = c->cout;
+    p.kh = c->kh; p.kw = c->kw; p.stride = c->stride; p.pad = c->pad; p.dil = c->dil; p.ldo = c->ldc;
+    p.M = c->n * c->hout * c->wout; p.K = c->kh * c->kw * c->cin;
+    p.splits = wgrad_splits_f16(c, &p.rows_per_split);
+    const bool narrow = c->cout <= 64;
+    p.ntiles_n = dcn::ceil_div(c->cout, narrow ? 64 : 128); p.ntiles_k = dcn::ceil_div(p.K, 128);
+    p.div_hw = make_fastdiv(c->hout * c->wout); p.div_w = make_fastdiv(c->wout);
+    p.div_cin = make_fastdiv(c->cin); p.div_kw = make_fastdiv(c->kw);
+    p.slab = p.splits == 1 ? dw : (float*)slabs;
+    hipStream_t st = (hipStream_t)stream;
+    const dim3 grid(p.ntiles_n * p.ntiles_k * p.splits), block(NT);
+    if (narrow) hipLaunchKernelGGL(conv_wgrad_f16_kernel<1>, grid, block, 0, st, p);
+    else hipLaunchKernelGGL(conv_wgrad_f16_kernel<2>, grid, block, 0, st, p);
+    if (p.splits > 1) launch_wgrad_reduce((const float*)slabs, dw, (int64_t)c->cout * p.K / 4, p.splits, st);
+    return dcn::check_launch();
+}

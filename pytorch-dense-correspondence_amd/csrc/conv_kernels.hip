@@ -21,112 +21,11 @@
 //   16-lane ds_read_b128 groups hit 16 distinct 16-byte slots (conflict-free).
 //   wgrad LDS image: [pixel][128 channels], fragments by ds_read_b64 (lane i holds channels 2i, 2i+1 of
 //   pixel 2q + (lane >> 5)): 64 consecutive dwords per half-wave, conflict-free without padding.
-#include <cstdlib>
-
-#include "dcn_common.h"
+#include "conv_shared.h"
 
 namespace {
 
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-
-constexpr int NT = 256;
-
-// Division by a launch-invariant positive integer without the ~25-instruction software divide:
-// q = (umulhi(n, mul) + n) >> shr, exact for 0 <= n < 2^31 (round-up method; mul = floor(2^32 (2^shr - d) / d) + 1).
-struct FastDiv {
-    uint32_t mul, shr;
-    int d;
-};
-FastDiv make_fastdiv(int d) {
-    FastDiv f;
-    f.d = d;
-    uint32_t s = 0;
-    while ((1u << s) < (uint32_t)d) ++s;
-    f.shr = s;
-    f.mul = (uint32_t)((((uint64_t)1 << 32) * (((uint64_t)1 << s) - (uint64_t)d)) / (uint64_t)d) + 1u;
-    return f;
-}
-__device__ __forceinline__ int fdiv(int n, const FastDiv& f) { return (int)((__umulhi((uint32_t)n, f.mul) + (uint32_t)n) >> f.shr); }
-
-struct GemmConv {
-    const float* src;   // [n, hs, ws, cs] NHWC
-    const float* wm;    // [cd][taps][cs]
-    const float* bias;  // [cd] or null
-    const float* add;   // [M][ldc] or null
-    float* dst;         // [M][ldc]
-    float* bn_partial;  // [mtiles][2][cd] or null
-    float* sk_partial;  // stream-K: [2 * workgroups][BM*BN] parked accumulators (fragment order)
-    int hs, ws, cs, hd, wd, cd, kh, kw, stride, sshift, pad, dil, ldc, M, K, transposed, mtiles, ntiles, sk_units;
-    FastDiv div_hw, div_w, div_cs, div_kw, div_nt, div_nk;
-};
-
-// bijective XCD-aware remap: consecutive logical tiles (sharing an M tile) land on the same XCD / L2
-__device__ __forceinline__ int xcd_remap(int bid, int nwg) {
-    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, local = bid >> 3;
-    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + local;
-}
-
-// ---- geometry shared by the gather-GEMM kernel and its stream-K fix-up kernel
-// WM: wavefronts along M (2 -> 2x2 wave grid, 1 -> 1x4).  TM / TN: 32x32 MFMA tiles per wavefront.
-// Workgroup tile = (32*TM*WM) x (32*TN*(4/WM)).  BK: K elements staged per barrier.
-template <int WM, int TM, int TN, int BK> struct GemmGeo {
-    static constexpr int WN = 4 / WM, BM = 32 * TM * WM, BN = 32 * TN * WN, LDK = BK + 4, KQ = BK / 4, ROWS = NT / KQ,
-                         PA = (BM + ROWS - 1) / ROWS, PB = (BN + ROWS - 1) / ROWS, kStage = (BM + BN) * LDK,
-                         kSlotFloats = BM * BN;
-};
-
-// Epilogue: C/D fragments -> NHWC rows (32 consecutive channels per half-wave = 128 B segments), + bias, + residual
-// gradient, + per-M-tile batch-norm partial sums (fixed order).  `red` = at least 4*BN floats of LDS, free to use.
-template <int WM, int TM, int TN, int BK>
-__device__ __forceinline__ void gemm_epilogue(const GemmConv& p, f32x16 (&acc)[TM][TN], int mt, int nt, float* red) {
-    using G = GemmGeo<WM, TM, TN, BK>;
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const int wm_ = WM == 2 ? (wv >> 1) : 0, wn_ = WM == 2 ? (wv & 1) : wv;
-    const int fi = lane & 31, fh = lane >> 5;
-    const int m0 = mt * G::BM, n0 = nt * G::BN;
-    float csum[TN], csq[TN];
-#pragma unroll
-    for (int tn = 0; tn < TN; ++tn) {
-        csum[tn] = 0.f; csq[tn] = 0.f;
-        const int col = n0 + wn_ * 32 * TN + tn * 32 + fi;
-        const bool cok = col < p.cd;
-        const float bv = (p.bias && cok) ? p.bias[col] : 0.f;
-#pragma unroll
-        for (int tm = 0; tm < TM; ++tm) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = m0 + wm_ * 32 * TM + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh;
-                float v = acc[tm][tn][r] + bv;
-                if (cok && row < p.M) {
-                    const int64_t o = (int64_t)row * p.ldc + col;
-                    if (p.add) v += p.add[o];
-                    p.dst[o] = v;
-                }
-                csum[tn] += acc[tm][tn][r];
-                csq[tn] = fmaf(acc[tm][tn][r], acc[tm][tn][r], csq[tn]);
-            }
-        }
-    }
-    if (p.bn_partial) {
-        // rows >= M and columns >= cd are exactly zero in acc (zero-filled fragments), so no masking is needed
-#pragma unroll
-        for (int tn = 0; tn < TN; ++tn) {
-            csum[tn] += __shfl_xor(csum[tn], 32, 64);
-            csq[tn] += __shfl_xor(csq[tn], 32, 64);
-            if (fh == 0) {
-                red[(wm_ * 2 + 0) * G::BN + wn_ * 32 * TN + tn * 32 + fi] = csum[tn];
-                red[(wm_ * 2 + 1) * G::BN + wn_ * 32 * TN + tn * 32 + fi] = csq[tn];
-            }
-        }
-        __syncthreads();
-        if (tid < G::BN && n0 + tid < p.cd) {
-            const float s = red[(0 * 2 + 0) * G::BN + tid] + (WM == 2 ? red[(1 * 2 + 0) * G::BN + tid] : 0.f);
-            const float q = red[(0 * 2 + 1) * G::BN + tid] + (WM == 2 ? red[(1 * 2 + 1) * G::BN + tid] : 0.f);
-            p.bn_partial[((int64_t)mt * 2 + 0) * p.cd + n0 + tid] = s;
-            p.bn_partial[((int64_t)mt * 2 + 1) * p.cd + n0 + tid] = q;
-        }
-    }
-}
+using namespace dcnconv;
 
 // One (tile, K range) segment: K tiles [k0, k1) of output tile `tile`.  A full range ends in the epilogue, a partial
 // one (stream-K) parks the raw accumulators in `slot` (fragment order: fully coalesced) for the fix-up kernel.
@@ -692,6 +591,13 @@ bool valid_desc(const dcn_conv_desc* c) {
 
 }  // namespace
 
+namespace dcnconv {
+void launch_wgrad_reduce(const float* slabs, float* dw, int64_t n4, int splits, hipStream_t st) {
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)dcn::ceil_div64(n4, 256)), dim3(256), 0, st, slabs, dw, n4,
+                       splits);
+}
+}  // namespace dcnconv
+
 extern "C" int dcn_conv_num_mtiles(const dcn_conv_desc* c) {
     if (!valid_desc(c)) return DCN_E_INVALID;
     return gemm_shape(c->n * c->hout * c->wout, c->cout, c->kh * c->kw * c->cin).mtiles;
@@ -754,11 +660,7 @@ extern "C" int dcn_conv_wgrad(const dcn_conv_desc* c, const float* in, const flo
     hipStream_t st = (hipStream_t)stream;
     if (narrow) hipLaunchKernelGGL(conv_wgrad_kernel<1>, dim3(p.ntiles_n * p.ntiles_k * p.splits), dim3(NT), 0, st, p);
     else hipLaunchKernelGGL(conv_wgrad_kernel<2>, dim3(p.ntiles_n * p.ntiles_k * p.splits), dim3(NT), 0, st, p);
-    if (p.splits > 1) {
-        const int64_t n4 = (int64_t)c->cout * p.K / 4;
-        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)dcn::ceil_div64(n4, 256)), dim3(256), 0, st,
-                           (const float*)slabs, dw, n4, p.splits);
-    }
+    if (p.splits > 1) launch_wgrad_reduce((const float*)slabs, dw, (int64_t)c->cout * p.K / 4, p.splits, st);
     return dcn::check_launch();
 }
 

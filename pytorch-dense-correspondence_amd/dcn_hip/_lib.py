@@ -62,6 +62,16 @@ SYMBOLS = {
     "dcn_conv_wgrad": (c_int, [ctypes.POINTER(ConvDesc), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "dcn_conv_wgrad_workspace": (c_size_t, [ctypes.POINTER(ConvDesc)]),
     "dcn_transpose_weight": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
+    "dcn_f16_kpad": (c_int, [c_int]),
+    "dcn_split_rows_f16": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_float, c_void_p]),
+    "dcn_conv_num_mtiles_f16": (c_int, [ctypes.POINTER(ConvDesc)]),
+    "dcn_conv_gemm_workspace_f16": (c_size_t, [ctypes.POINTER(ConvDesc), c_int]),
+    "dcn_conv_forward_f16": (c_int, [ctypes.POINTER(ConvDesc), c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_void_p,
+                                     c_void_p, c_void_p, c_void_p]),
+    "dcn_conv_dgrad_f16": (c_int, [ctypes.POINTER(ConvDesc), c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_void_p,
+                                   c_void_p, c_void_p, c_void_p]),
+    "dcn_conv_wgrad_f16": (c_int, [ctypes.POINTER(ConvDesc), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "dcn_conv_wgrad_workspace_f16": (c_size_t, [ctypes.POINTER(ConvDesc)]),
     "dcn_find_best_match": (c_int, [c_void_p, c_int64, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
                                     c_void_p, c_void_p]),
     "dcn_find_best_match_workspace": (c_size_t, [c_int]),

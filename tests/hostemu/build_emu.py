@@ -39,7 +39,7 @@ def build(force=False, verbose=False):
     procs = []
     for src in _sources():
         obj = os.path.join(OUT_DIR, os.path.basename(src) + ".o")
-        cmd = [CLANG, "-x", "c++", "-std=c++17", "-O2", "-g0", "-fPIC", "-DDCN_HOSTEMU_BUILD=1",
+        cmd = [CLANG, "-x", "c++", "-std=c++17", "-O2", "-g0", "-fPIC", "-DDCN_HOSTEMU_BUILD=1", "-mf16c",
                "-Wno-unused-value", "-Wno-ignored-attributes", "-Wno-unknown-attributes",
                "-I", HERE, "-I", os.path.join(ROOT, "include"), "-I", CSRC, "-c", src, "-o", obj]
         if verbose:

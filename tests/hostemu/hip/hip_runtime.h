@@ -91,6 +91,8 @@ struct WaveState {
     int lanes = 64;
     uint64_t buf_a[64];
     uint64_t buf_b[64];
+    unsigned char wide_a[64][16];   // 16-byte MFMA operands (8 x f16 per lane)
+    unsigned char wide_b[64][16];
 };
 
 struct Worker {
@@ -288,6 +290,31 @@ static inline hipemu_f32x4 hipemu_mfma_16x16x4f32(float a, float b, hipemu_f32x4
     wave_barrier();
     return c;
 }
+// v_mfma_f32_32x32x16_f16: lane (i = l & 31, h = l >> 5) holds A[i][8h..8h+7] and B[8h..8h+7][i]; fp32 accumulate.
+typedef _Float16 hipemu_h8 __attribute__((ext_vector_type(8)));
+static inline hipemu_f32x16 hipemu_mfma_32x32x16f16(hipemu_h8 a, hipemu_h8 b, hipemu_f32x16 c, int, int, int) {
+    using namespace ::hipemu;
+    WaveState& ws = my_wave();
+    int l = lane_id();
+    memcpy(ws.wide_a[l], &a, 16);
+    memcpy(ws.wide_b[l], &b, 16);
+    wave_barrier();
+    int col = l & 31;
+    for (int r = 0; r < 16; ++r) {
+        int row = (r & 3) + 8 * (r >> 2) + 4 * (l >> 5);
+        float acc = c[r];
+        for (int h = 0; h < 2; ++h) {
+            _Float16 av[8], bv[8];
+            memcpy(av, ws.wide_a[row + 32 * h], 16);
+            memcpy(bv, ws.wide_b[col + 32 * h], 16);
+            for (int k = 0; k < 8; ++k) acc += (float)av[k] * (float)bv[k];
+        }
+        c[r] = acc;
+    }
+    wave_barrier();
+    return c;
+}
+#define __builtin_amdgcn_mfma_f32_32x32x16_f16 hipemu_mfma_32x32x16f16
 #define __builtin_amdgcn_mfma_f32_32x32x2f32 hipemu_mfma_32x32x2f32
 #define __builtin_amdgcn_mfma_f32_16x16x4f32 hipemu_mfma_16x16x4f32
 #define __builtin_amdgcn_s_setprio(x) ((void)0)

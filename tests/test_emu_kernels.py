@@ -155,3 +155,72 @@ def test_best_match_search_vs_numpy(L, D):
     empty = torch.zeros(H, W, dtype=torch.uint8)
     uve, diste, _ = DCN.find_best_matches(pix[:2], res_a, res_b, mask_b=empty)
     assert torch.isinf(diste).all()
+
+
+F16_CASES = [
+    (1, 8, 10, 8, 16, 3, 1, 1, 1),
+    (2, 9, 7, 4, 12, 7, 2, 3, 1),        # stem-like, K = 196 -> padded to 200 halves per weight row
+    (1, 12, 10, 16, 24, 3, 2, 1, 1),     # stride 2 (transposed-gather dgrad)
+    (1, 10, 12, 20, 136, 3, 1, 2, 2),    # two N tiles, ragged
+    (3, 7, 7, 8, 8, 3, 1, 1, 1),
+    (1, 6, 5, 64, 72, 3, 1, 4, 4),       # K = 576: 18 stages
+    (2, 24, 20, 8, 4, 1, 1, 0, 1),       # 1x1, narrow Cout, 960 pixels: several wgrad splits
+]
+
+
+@pytest.mark.parametrize("tile_m,sk", [("64", "0"), ("128", "0"), ("64", "3"), ("128", "2")])
+@pytest.mark.parametrize("case", F16_CASES, ids=[str(c) for c in F16_CASES])
+def test_conv_f16x3_forward_dgrad(L, case, tile_m, sk, monkeypatch):
+    """Split-fp16 gather-GEMM (fp16 MFMA, hi/lo operands): must reproduce the fp32 convolution to ~1e-6."""
+    monkeypatch.setenv("DCN_GEMM_TILE_M", tile_m)
+    monkeypatch.setenv("DCN_GEMM_SK", sk)
+    lib = L.get()
+    n, hin, win, cin, cout, k, stride, pad, dil = case
+    hout = (hin + 2 * pad - dil * (k - 1) - 1) // stride + 1
+    wout = (win + 2 * pad - dil * (k - 1) - 1) // stride + 1
+    d = L.ConvDesc(n, hin, win, cin, hout, wout, cout, k, k, stride, pad, dil, cout)
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(n, cin, hin, win, generator=g, requires_grad=True)
+    w = (torch.randn(cout, cin, k, k, generator=g) * 0.1).requires_grad_(True)
+    x_nhwc = x.detach().permute(0, 2, 3, 1).contiguous()
+    w_k = w.detach().permute(0, 2, 3, 1).contiguous()
+    K = k * k * cin
+    kp = lib.dcn_f16_kpad(K)
+    wh = torch.empty(cout, kp, dtype=torch.float16)
+    wl = torch.empty(cout, kp, dtype=torch.float16)
+    assert lib.dcn_split_rows_f16(L.ptr(w_k), L.ptr(wh), L.ptr(wl), cout, K, 64.0, None) == 0
+    rec = (wh.float() + wl.float())[:, :K] / 64.0
+    assert rel_err(rec, w_k.reshape(cout, K)) < 1e-6 and float(wh[:, K:].abs().max() if kp > K else 0) == 0
+    out = torch.full((n, hout, wout, cout), float("nan"))
+    mt = lib.dcn_conv_num_mtiles_f16(ctypes.byref(d))
+    part = torch.full((mt, 2, cout), float("nan"))
+    ws_f = torch.empty(max(lib.dcn_conv_gemm_workspace_f16(ctypes.byref(d), 0), 4) // 4)
+    ws_d = torch.empty(max(lib.dcn_conv_gemm_workspace_f16(ctypes.byref(d), 1), 4) // 4)
+    assert lib.dcn_conv_forward_f16(ctypes.byref(d), L.ptr(x_nhwc), L.ptr(wh), L.ptr(wl), 64.0, None, L.ptr(out),
+                                    L.ptr(part), L.ptr(ws_f), None) == 0
+    ref = F.conv2d(x, w, None, stride, pad, dil)
+    refn = ref.detach().permute(0, 2, 3, 1)
+    assert rel_err(out, refn) < 3e-6
+    assert rel_err(part.sum(0)[0], refn.sum((0, 1, 2))) < 1e-5
+    assert rel_err(part.sum(0)[1], (refn ** 2).sum((0, 1, 2))) < 1e-5
+    # dgrad with a TINY gradient tensor (1e-7 scale): the abs-max driven power-of-two pre-scale keeps it inside fp16
+    dout = torch.randn(n, hout, wout, cout, generator=g) * 1e-7
+    ref.backward(dout.permute(0, 3, 1, 2))
+    wt = torch.empty(cin, k * k, cout)
+    assert lib.dcn_transpose_weight(L.ptr(w_k), L.ptr(wt), cout, k * k, cin, cout, None) == 0
+    Kt = k * k * cout
+    kpt = lib.dcn_f16_kpad(Kt)
+    wth = torch.empty(cin, kpt, dtype=torch.float16)
+    wtl = torch.empty(cin, kpt, dtype=torch.float16)
+    assert lib.dcn_split_rows_f16(L.ptr(wt), L.ptr(wth), L.ptr(wtl), cin, Kt, 64.0, None) == 0
+    amax = dout.abs().max().reshape(1).clone()
+    add = torch.randn(n, hin, win, cin, generator=g) * 1e-7
+    din = torch.full((n, hin, win, cin), float("nan"))
+    assert lib.dcn_conv_dgrad_f16(ctypes.byref(d), L.ptr(dout), L.ptr(wth), L.ptr(wtl), 64.0, L.ptr(amax), L.ptr(add),
+                                  L.ptr(din), L.ptr(ws_d), None) == 0
+    assert rel_err(din, x.grad.permute(0, 2, 3, 1) + add) < 5e-6
+    # wgrad: pixels are the reduction index, dy again 1e-7-scaled; fixed split order -> deterministic
+    dw = torch.full((cout, k, k, cin), float("nan"))
+    slabs = torch.empty(max(lib.dcn_conv_wgrad_workspace_f16(ctypes.byref(d)), 4) // 4)
+    assert lib.dcn_conv_wgrad_f16(ctypes.byref(d), L.ptr(x_nhwc), L.ptr(dout), L.ptr(amax), L.ptr(dw), L.ptr(slabs), None) == 0
+    assert rel_err(dw, w.grad.permute(0, 2, 3, 1)) < 5e-6

@@ -36,6 +36,7 @@ def main():
     ap.add_argument("--json", default="")
     ap.add_argument("--only", default="", help="substring filter on the shape name")
     ap.add_argument("--kinds", default="fwd,dgrad,wgrad")
+    ap.add_argument("--mode", default="fp32", choices=["fp32", "f16"], help="fp32 MFMA kernels or the split-fp16 (f16x3) ones")
     a = ap.parse_args()
     lib = _lib.get()
     dev = torch.device("cuda")
@@ -61,11 +62,27 @@ def main():
         flops = 2.0 * n * hout * wout * cout * k * k * (3 if cin == 4 else cin)
         wsf = torch.empty(max(lib.dcn_conv_gemm_workspace(ctypes.byref(d), 0), 4) // 4, device=dev)
         wsd = torch.empty(max(lib.dcn_conv_gemm_workspace(ctypes.byref(d), 1), 4) // 4, device=dev)
+        if a.mode == "f16":
+            K, Kt = k * k * cin, k * k * cout
+            kp, kpt = lib.dcn_f16_kpad(K), lib.dcn_f16_kpad(Kt)
+            wh = torch.empty(cout, kp, dtype=torch.float16, device=dev); wl = torch.empty_like(wh)
+            wth = torch.empty(cin, kpt, dtype=torch.float16, device=dev); wtl = torch.empty_like(wth)
+            assert lib.dcn_split_rows_f16(_lib.ptr(w), _lib.ptr(wh), _lib.ptr(wl), cout, K, 64.0, st) == 0
+            assert lib.dcn_split_rows_f16(_lib.ptr(wt), _lib.ptr(wth), _lib.ptr(wtl), cin, Kt, 64.0, st) == 0
+            amax = dy.abs().max().reshape(1)
+            wsf = torch.empty(max(lib.dcn_conv_gemm_workspace_f16(ctypes.byref(d), 0), 4) // 4, device=dev)
+            wsd = torch.empty(max(lib.dcn_conv_gemm_workspace_f16(ctypes.byref(d), 1), 4) // 4, device=dev)
+            part = torch.empty(lib.dcn_conv_num_mtiles_f16(ctypes.byref(d)), 2, cout, device=dev)
         calls = {
             "fwd": lambda: lib.dcn_conv_forward(ctypes.byref(d), _lib.ptr(x), _lib.ptr(w), None, _lib.ptr(y), _lib.ptr(part), _lib.ptr(wsf), st),
             "dgrad": lambda: lib.dcn_conv_dgrad(ctypes.byref(d), _lib.ptr(dy), _lib.ptr(wt), None, _lib.ptr(dx), _lib.ptr(wsd), st),
             "wgrad": lambda: lib.dcn_conv_wgrad(ctypes.byref(d), _lib.ptr(x), _lib.ptr(dy), _lib.ptr(dw), _lib.ptr(slab), st),
         }
+        if a.mode == "f16":
+            calls["fwd"] = lambda: lib.dcn_conv_forward_f16(ctypes.byref(d), _lib.ptr(x), _lib.ptr(wh), _lib.ptr(wl), 64.0,
+                                                            None, _lib.ptr(y), _lib.ptr(part), _lib.ptr(wsf), st)
+            calls["dgrad"] = lambda: lib.dcn_conv_dgrad_f16(ctypes.byref(d), _lib.ptr(dy), _lib.ptr(wth), _lib.ptr(wtl), 64.0,
+                                                            _lib.ptr(amax), None, _lib.ptr(dx), _lib.ptr(wsd), st)
         row = {"shape": name, "count": count, "gflop": flops / 1e9}
         for kind in ("fwd", "dgrad", "wgrad"):
             row[kind + "_us"] = float("nan")
