@@ -56,6 +56,8 @@ WORKLOADS = {
                          "non-match sampling (2500 matches x 2 masked + 2 background non-matches)"),
     "tiny": dict(B=1, H=96, W=128, D=3, Pm=500, Pk=250, Pg=250, backbone="Resnet34_8s", desc="smoke-size workload"),
 }
+F16_MFMA_PEAK_TFLOPS = 2516.6   # v_mfma_f32_32x32x16_f16: 1024 FLOP/clk/SIMD x 1024 SIMDs x 2.4 GHz ("~2.5 PF dense")
+F16X3_PEAK_TFLOPS = F16_MFMA_PEAK_TFLOPS / 3.0
 FP32_MFMA_PEAK_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 256 CUs @ 2.4 GHz
 
 
@@ -159,6 +161,9 @@ def main():
     ap.add_argument("--batch", type=int, default=0, help="override image pairs per GPU per step")
     ap.add_argument("--cpu-baseline-steps", type=int, default=3, help="0 disables the CPU baseline leg")
     ap.add_argument("--profile-steps", type=int, default=3, help="extra steps with per-launch HIP events (roofline)")
+    ap.add_argument("--conv-mode", default="f16x3", choices=["f16x3", "fp32"],
+                    help="convolution arithmetic (include/dcn_hip.h): split-fp16 on the fp16 MFMA pipe with fp32-level "
+                         "accuracy (default), or fp32 MFMA")
     ap.add_argument("--force-dist", action="store_true", help="initialise RCCL even with one rank (smoke-tests the collective path)")
     args = ap.parse_args()
 
@@ -181,6 +186,7 @@ def main():
         ctypes.CDLL(None).fflush(None)  # RCCL's version banner sits in the C stdio buffer: emit it now, not after the JSON line
 
     from dcn_hip import _lib, backbone as bb
+    bb.set_conv_mode(args.conv_mode)
     from dcn_hip.distributed import FlatGradients, broadcast_module
     from dcn_hip.loss import PairLists
     from dense_correspondence.loss_functions import loss_composer
@@ -254,14 +260,23 @@ def main():
         wms, wn, wfl = prof["conv_wgrad"]
         if n > 0 and ms > 0:
             achieved = fl / (ms * 1e-3) / 1e12
-            roofline = {"bound": "mfma", "kernel": "conv_gemm_kernel (fp32 v_mfma_f32_32x32x2_f32; forward + dgrad)",
-                        "achieved": achieved, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                        "frac": achieved / FP32_MFMA_PEAK_TFLOPS, "traffic": None,
+            if args.conv_mode == "fp32":
+                peak, kern = FP32_MFMA_PEAK_TFLOPS, "conv_gemm_kernel (fp32 v_mfma_f32_32x32x2_f32; forward + dgrad)"
+                peak_note = "fp32 MFMA dense peak"
+            else:
+                # one fp32-accurate multiply-add = 3 fp16 MFMA products (hi*hi + hi*lo + lo*hi): the ceiling for
+                # ALGORITHMIC flops is a third of the fp16 pipe's dense peak
+                peak, kern = F16X3_PEAK_TFLOPS, "conv_gemm_f16_kernel (3x v_mfma_f32_32x32x16_f16 per product; forward + dgrad)"
+                peak_note = "fp16 MFMA dense peak %.1f / 3 products per fp32-accurate MAC (fp32 MFMA peak: %.1f)" % (
+                    F16_MFMA_PEAK_TFLOPS, FP32_MFMA_PEAK_TFLOPS)
+            roofline = {"bound": "mfma", "kernel": kern,
+                        "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "peak_note": peak_note,
+                        "frac": achieved / peak, "traffic": None,
                         "launches_per_step": n / args.profile_steps, "avg_launch_us": 1e3 * ms / n,
                         "algorithmic_gflop_per_launch": fl / n / 1e9,
                         "kernel_ms_per_step": ms / args.profile_steps,
                         "conv_wgrad": {"achieved": (wfl / (wms * 1e-3) / 1e12) if wms > 0 else None,
-                                       "frac": (wfl / (wms * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS) if wms > 0 else None,
+                                       "frac": (wfl / (wms * 1e-3) / 1e12 / peak) if wms > 0 else None,
                                        "launches_per_step": wn / args.profile_steps,
                                        "avg_launch_us": (1e3 * wms / wn) if wn else None,
                                        "kernel_ms_per_step": wms / args.profile_steps}}
@@ -304,10 +319,13 @@ def main():
                "value": images_per_step * args.steps / elapsed, "unit": "images/s", "n_gpus": world,
                "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
                "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+               "arithmetic": ("fp32 tensors and accumulation; convolution products as 3 fp16 MFMAs on exact hi/lo operand "
+                              "splits (~22 mantissa bits per operand; parity with the fp32 reference at 1e-4, tests/test_gpu_parity.py)"
+                              if args.conv_mode == "f16x3" else "fp32 MFMA"),
                "config": {"workload": wl["desc"], "pairs_per_gpu": B, "images_per_step": images_per_step,
                           "image": "%dx%d" % (W, H), "descriptor_dim": D, "backbone": wl["backbone"],
                           "pixel_pairs_per_image_pair": [wl["Pm"], wl["Pk"], wl["Pg"]],
-                          "optimizer": "Adam lr 1e-4 wd 1e-4", "parallelism": "dp%d" % world,
+                          "conv_mode": args.conv_mode, "optimizer": "Adam lr 1e-4 wd 1e-4", "parallelism": "dp%d" % world,
                           "library": info["version"], "final_loss": final_loss,
                           "train_gflop_per_image": 3 * bb.get_plan(wl["backbone"], 64, B, H, W, D).forward_flops / B / 1e9},
                "roofline": roofline, "roofline_loss_gather": loss_roof}

@@ -144,6 +144,21 @@ typedef struct dcn_plan dcn_plan;
 int dcn_plan_create(const char* arch, int base_width, int n, int h, int w, int d, dcn_plan** out);
 void dcn_plan_destroy(dcn_plan* plan);
 
+/* How the plan's convolutions multiply.  Both modes take and return fp32 tensors and accumulate in fp32.
+ *   DCN_CONV_FP32  : fp32 MFMA (v_mfma_f32_32x32x2_f32), 157 TFLOP/s peak.
+ *   DCN_CONV_F16X3 : split-fp16 -- every operand element x is split on the fly into fp16 hi + lo with
+ *                    s*x = hi + lo (s a power of two: 64 for weights, chosen from the tensor's abs-max for
+ *                    gradients, 1 for activations) and hi*hi + hi*lo + lo*hi runs on the fp16 MFMA pipe.
+ *                    ~22 mantissa bits per operand: indistinguishable from fp32 on this network,
+ *                    ~2x faster.  Operand range: |activation| < 65504, |weight| < 1023.
+ * Default: DCN_CONV_F16X3, or the environment variable DCN_CONV_MODE = "fp32" | "f16x3" at plan creation.
+ * The saved / workspace arenas are sized for either mode, so the mode may be switched between steps (not between a
+ * forward and its backward). */
+#define DCN_CONV_FP32 0
+#define DCN_CONV_F16X3 1
+int dcn_plan_set_conv_mode(dcn_plan* plan, int mode);
+int dcn_plan_conv_mode(const dcn_plan* plan);
+
 int dcn_plan_num_params(const dcn_plan* plan);
 int dcn_plan_num_bn(const dcn_plan* plan);
 /* name (without the "resnet34_8s." prefix) and logical OIHW / [C] shape of parameter i; ndim is 4 or 1. */

@@ -14,7 +14,10 @@
 //   workspace arena : 6 activation-gradient buffers, transposed-weight scratch, wgrad split slabs, BN
 //                     partial sums, stem padding buffers, low-resolution descriptor map and its gradient
 // All launches go to the caller's stream; there is no host synchronisation anywhere.
+#include <algorithm>
 #include <cstdio>
+#include <cstdlib>
+#include <cstring>
 #include <string>
 #include <vector>
 
@@ -31,7 +34,8 @@ struct ConvL {
     int bn = -1;
     size_t x = 0;      // conv output offset (floats) in the saved arena
     int cin_true = 0;
-    int mtiles = 0;
+    int mtiles[2] = {0, 0};   // BN partial-sum rows of the forward kernel, per conv mode
+    int idx = 0;
     std::string name;
 };
 struct BnL {
@@ -71,7 +75,8 @@ struct dcn_plan {
     size_t s_in4 = 0, s_stem_y = 0, s_pool = 0, s_argmax = 0, s_low = 0, saved_floats = 0;
     // workspace offsets (floats)
     size_t w_buf[6] = {0, 0, 0, 0, 0, 0}, w_wt = 0, w_slab = 0, w_part = 0, w_k123 = 0, w_wstem = 0, w_dwstem = 0,
-           w_glow = 0, w_ups = 0, w_sk = 0, w_gnorm = 0, ws_floats = 0;
+           w_glow = 0, w_ups = 0, w_sk = 0, w_gnorm = 0, w_wh = 0, w_wl = 0, w_amax = 0, ws_floats = 0;
+    int conv_mode = DCN_CONV_F16X3;
     size_t max_act = 0;
     double flops = 0;
     // optional launch-level timing (dcn_plan_profile_begin/end)
@@ -121,7 +126,9 @@ struct Builder {
         c.w = add_param(name + ".weight", {cout, cin, k, k});
         if (bias) c.b = add_param(name + ".bias", {cout});
         const int64_t M = (int64_t)n * c.d.hout * c.d.wout;
-        c.mtiles = dcn_conv_num_mtiles(&c.d);  // M tiles of the forward kernel == rows of its BN partial sums
+        c.mtiles[DCN_CONV_FP32] = dcn_conv_num_mtiles(&c.d);  // M tiles of the forward kernel == rows of its BN partial sums
+        c.mtiles[DCN_CONV_F16X3] = dcn_conv_num_mtiles_f16(&c.d);
+        c.idx = (int)p.convs.size();
         c.flops = 2.0 * (double)M * cout * (double)(k * k * cin);
         p.flops += c.flops;
         p.convs.push_back(c);
@@ -252,18 +259,21 @@ int build_plan(dcn_plan& p) {
     size_t ws = 0;
     auto alloc = [&](size_t fl) { const size_t o = ws; ws = align64(ws + fl); return o; };
     for (int i = 0; i < 6; ++i) p.w_buf[i] = alloc(p.max_act);
-    size_t max_w = 0, max_slab = 0, max_part = 0, max_sk = 0;
+    size_t max_w = 0, max_slab = 0, max_part = 0, max_sk = 0, max_wh = 0;   // sized for either conv mode
     int max_c = 4;
     for (const ConvL& c : p.convs) {
         const size_t welems = (size_t)c.d.ldc * c.d.kh * c.d.kw * c.d.cin;
         if (welems > max_w) max_w = welems;
-        const size_t sl = dcn_conv_wgrad_workspace(&c.d) / sizeof(float);
+        const size_t sl = std::max(dcn_conv_wgrad_workspace(&c.d), dcn_conv_wgrad_workspace_f16(&c.d)) / sizeof(float);
         if (sl > max_slab) max_slab = sl;
         for (int dg = 0; dg < 2; ++dg) {
-            const size_t sk = dcn_conv_gemm_workspace(&c.d, dg) / sizeof(float);
+            const size_t sk = std::max(dcn_conv_gemm_workspace(&c.d, dg), dcn_conv_gemm_workspace_f16(&c.d, dg)) / sizeof(float);
             if (sk > max_sk) max_sk = sk;
         }
-        const size_t pf = (size_t)c.mtiles * 2 * c.d.cout;
+        const int taps = c.d.kh * c.d.kw;
+        const size_t wh = std::max((size_t)c.d.cout * dcn_f16_kpad(taps * c.d.cin), (size_t)c.d.cin * dcn_f16_kpad(taps * c.d.ldc));
+        if (wh > max_wh) max_wh = wh;
+        const size_t pf = (size_t)std::max(c.mtiles[0], c.mtiles[1]) * 2 * c.d.cout;
         if (pf > max_part) max_part = pf;
         if (c.d.cout > max_c) max_c = c.d.cout;
     }
@@ -281,6 +291,9 @@ int build_plan(dcn_plan& p) {
     p.w_glow = alloc((size_t)N * p.hl * p.wl * p.Dp);
     p.w_gnorm = alloc((size_t)N * p.H * p.W * p.D);
     p.w_ups = alloc(dcn::upsample_bwd_tmp_bytes(N, p.hl, p.W, p.D) / sizeof(float));
+    p.w_wh = alloc((max_wh + 1) / 2);   // fp16 hi / lo images of one weight tensor (split per use)
+    p.w_wl = alloc((max_wh + 1) / 2);
+    p.w_amax = alloc(p.convs.size());   // abs-max of the gradient w.r.t. each convolution's output
     p.ws_floats = ws;
     return DCN_OK;
 }
@@ -300,6 +313,8 @@ colsum_kernel(const float* __restrict__ m, int64_t rows, int ld, float* __restri
         const int rc__ = (expr);         \
         if (rc__ != DCN_OK) return rc__; \
     } while (0)
+
+constexpr float kWeightScale = 64.f;   // power-of-two pre-scale of the fp16 weight images
 
 struct Run {
     dcn_plan& p;
@@ -331,17 +346,27 @@ struct Run {
     float* Wk(size_t off) const { return ws + off; }
     const float* P(int i) const { return params[i]; }
 
+    // forward convolution in the plan's conv mode (w: [cout][taps][d.cin] fp32)
+    int conv_fwd(const ConvL& c, const float* in, const float* w, const float* bias, float* out, float* part) {
+        if (p.conv_mode == DCN_CONV_FP32)
+            return timed(0, c.flops, [&] { return dcn_conv_forward(&c.d, in, w, bias, out, part, Wk(p.w_sk), st); });
+        DCN_TRY(dcn_split_rows_f16(w, Wk(p.w_wh), Wk(p.w_wl), c.d.cout, c.d.kh * c.d.kw * c.d.cin, kWeightScale, st));
+        return timed(0, c.flops, [&] {
+            return dcn_conv_forward_f16(&c.d, in, Wk(p.w_wh), Wk(p.w_wl), kWeightScale, bias, out, part, Wk(p.w_sk), st);
+        });
+    }
+
     // conv + BN statistics -> scale/shift in the saved arena
     int conv_bn(const ConvL& c, const float* in, const float* w, float* const* bn_running, float momentum, float eps,
                 int training) {
         float* part = training ? Wk(p.w_part) : nullptr;
-        DCN_TRY(timed(0, c.flops, [&] { return dcn_conv_forward(&c.d, in, w, nullptr, S(c.x), part, Wk(p.w_sk), st); }));
+        DCN_TRY(conv_fwd(c, in, w, nullptr, S(c.x), part));
         const BnL& b = p.bns[c.bn];
         float* stats = S(b.stats);
         float* rm = bn_running ? bn_running[2 * b.idx] : nullptr;
         float* rv = bn_running ? bn_running[2 * b.idx + 1] : nullptr;
         if (!training && (!rm || !rv)) return DCN_E_INVALID;
-        dcn::launch_bn_finalize(part, c.mtiles, b.C, (double)b.rows, P(b.g), P(b.b), rm, rv, momentum, eps, training,
+        dcn::launch_bn_finalize(part, c.mtiles[p.conv_mode], b.C, (double)b.rows, P(b.g), P(b.b), rm, rv, momentum, eps, training,
                                 stats, stats + b.C, stats + 2 * b.C, stats + 3 * b.C, st);
         return DCN_OK;
     }
@@ -354,6 +379,11 @@ extern "C" int dcn_plan_create(const char* arch, int base_width, int n, int h, i
         return DCN_E_INVALID;
     dcn_plan* p = new dcn_plan();
     p->arch = arch; p->N = n; p->H = h; p->W = w; p->D = d; p->base = base_width;
+    if (const char* m = getenv("DCN_CONV_MODE")) {
+        if (!strcmp(m, "fp32")) p->conv_mode = DCN_CONV_FP32;
+        else if (!strcmp(m, "f16x3")) p->conv_mode = DCN_CONV_F16X3;
+        else { delete p; return DCN_E_INVALID; }
+    }
     const int rc = build_plan(*p);
     if (rc != DCN_OK) { delete p; return rc; }
     *out = p;
@@ -364,6 +394,12 @@ extern "C" void dcn_plan_destroy(dcn_plan* plan) {
     for (hipEvent_t e : plan->prof_ev) hipEventDestroy(e);
     delete plan;
 }
+extern "C" int dcn_plan_set_conv_mode(dcn_plan* plan, int mode) {
+    if (!plan || (mode != DCN_CONV_FP32 && mode != DCN_CONV_F16X3)) return DCN_E_INVALID;
+    plan->conv_mode = mode;   // arenas are sized for either mode
+    return DCN_OK;
+}
+extern "C" int dcn_plan_conv_mode(const dcn_plan* plan) { return plan ? plan->conv_mode : DCN_E_INVALID; }
 extern "C" int dcn_plan_profile_begin(dcn_plan* plan) {
     if (!plan) return DCN_E_INVALID;
     plan->prof_on = true;
@@ -462,10 +498,7 @@ extern "C" int dcn_backbone_forward(dcn_plan* plan, const float* image, const fl
     const ConvL& fc = p.convs[p.fc];
     const size_t low_bytes = (size_t)N * p.hl * p.wl * p.Dp * sizeof(float);
     if (hipMemsetAsync(R.S(p.s_low), 0, low_bytes, st) != hipSuccess) return DCN_E_LAUNCH;
-    DCN_TRY(R.timed(0, fc.flops, [&] {
-        return dcn_conv_forward(&fc.d, R.S(p.blocks.back().out), R.P(fc.w), R.P(fc.b), R.S(p.s_low), nullptr,
-                                R.Wk(p.w_sk), st);
-    }));
+    DCN_TRY(R.conv_fwd(fc, R.S(p.blocks.back().out), R.P(fc.w), R.P(fc.b), R.S(p.s_low), nullptr));
     dcn::launch_upsample_fwd(R.S(p.s_low), N, p.hl, p.wl, p.Dp, p.D, p.H, p.W, normalize, descriptors, st);
     return dcn::check_launch();
 }
@@ -482,21 +515,32 @@ extern "C" int dcn_backbone_backward(dcn_plan* plan, const float* grad_descripto
     float* k123 = R.Wk(p.w_k123);
     float* wt = R.Wk(p.w_wt);
     float* slab = R.Wk(p.w_slab);
+    float* amax = R.Wk(p.w_amax);
+    const bool f16 = p.conv_mode == DCN_CONV_F16X3;
 
     // BN backward of conv c's batch norm: dy (+ optional relu mask from relu_out) -> dx; g_out optional
     auto bn_bwd = [&](const ConvL& c, const float* dy, const float* relu_out, float* dx, float* g_out) {
         const BnL& b = p.bns[c.bn];
         const float* s = R.S(b.stats);
         dcn::launch_bn_bwd(dy, relu_out, R.S(c.x), s + 2 * b.C, s + 3 * b.C, R.P(b.g), b.C, b.rows, part, grads[b.g],
-                           grads[b.b], k123, dx, g_out, st);
+                           grads[b.b], k123, dx, g_out, f16 ? amax + c.idx : nullptr, st);
     };
     auto wgrad = [&](const ConvL& c, const float* in, const float* dx, float* dw) -> int {
+        if (f16) return R.timed(1, c.flops, [&] { return dcn_conv_wgrad_f16(&c.d, in, dx, amax + c.idx, dw, slab, st); });
         return R.timed(1, c.flops, [&] { return dcn_conv_wgrad(&c.d, in, dx, dw, slab, st); });
     };
     auto dgrad = [&](const ConvL& c, const float* dx, const float* add, float* din) -> int {
-        DCN_TRY(dcn_transpose_weight(R.P(c.w), wt, c.d.cout, c.d.kh * c.d.kw, c.d.cin, c.d.ldc, st));
-        return R.timed(0, c.flops, [&] { return dcn_conv_dgrad(&c.d, dx, wt, add, din, R.Wk(p.w_sk), st); });
+        const int taps = c.d.kh * c.d.kw;
+        DCN_TRY(dcn_transpose_weight(R.P(c.w), wt, c.d.cout, taps, c.d.cin, c.d.ldc, st));
+        if (!f16) return R.timed(0, c.flops, [&] { return dcn_conv_dgrad(&c.d, dx, wt, add, din, R.Wk(p.w_sk), st); });
+        DCN_TRY(dcn_split_rows_f16(wt, R.Wk(p.w_wh), R.Wk(p.w_wl), c.d.cin, taps * c.d.ldc, kWeightScale, st));
+        return R.timed(0, c.flops, [&] {
+            return dcn_conv_dgrad_f16(&c.d, dx, R.Wk(p.w_wh), R.Wk(p.w_wl), kWeightScale, amax + c.idx, add, din,
+                                      R.Wk(p.w_sk), st);
+        });
     };
+    // split-fp16 mode: every gradient tensor that feeds a convolution records its abs-max (pre-scale selection)
+    if (f16 && hipMemsetAsync(amax, 0, p.convs.size() * sizeof(float), st) != hipSuccess) return DCN_E_LAUNCH;
 
     // ---- upsample + scoring layer
     float* glow = R.Wk(p.w_glow);
@@ -504,7 +548,8 @@ extern "C" int dcn_backbone_backward(dcn_plan* plan, const float* grad_descripto
         dcn::launch_normalize_bwd(R.S(p.s_low), N, p.hl, p.wl, p.Dp, p.D, p.H, p.W, grad_descriptors, R.Wk(p.w_gnorm), st);
         grad_descriptors = R.Wk(p.w_gnorm);
     }
-    dcn::launch_upsample_bwd(grad_descriptors, N, p.hl, p.wl, p.Dp, p.D, p.H, p.W, R.Wk(p.w_ups), glow, st);
+    dcn::launch_upsample_bwd(grad_descriptors, N, p.hl, p.wl, p.Dp, p.D, p.H, p.W, R.Wk(p.w_ups), glow,
+                             f16 ? amax + p.convs[p.fc].idx : nullptr, st);
     const ConvL& fc = p.convs[p.fc];
     const float* feat = R.S(p.blocks.back().out);
     DCN_TRY(wgrad(fc, feat, glow, grads[fc.w]));

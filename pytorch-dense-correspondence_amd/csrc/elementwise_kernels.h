@@ -20,7 +20,7 @@ int bn_bwd_chunks(int64_t rows);
 // partial: bn_bwd_chunks(rows)*2*C floats, k123: 3*C floats.  g_out (nullable) receives the relu-masked dy.
 void launch_bn_bwd(const float* dy, const float* relu_out, const float* x, const float* mean, const float* invstd,
                    const float* gamma, int C, int64_t rows, float* partial, float* dgamma, float* dbeta, float* k123,
-                   float* dx, float* g_out, hipStream_t st);
+                   float* dx, float* g_out, float* absmax, hipStream_t st);   // absmax (optional): max |dx| accumulated
 void launch_add(const float* a, const float* b, float* out, int64_t n, hipStream_t st);
 
 void launch_maxpool_fwd(const float* in, float* out, unsigned char* argmax, int n, int hin, int win, int hout,
@@ -35,6 +35,6 @@ size_t upsample_bwd_tmp_bytes(int n, int hl, int w, int d);
 void launch_normalize_bwd(const float* low, int n, int hl, int wl, int ldl, int d, int h, int w, const float* gout,
                           float* gv, hipStream_t st);
 void launch_upsample_bwd(const float* gout, int n, int hl, int wl, int ldl, int d, int h, int w, float* tmp,
-                         float* glow, hipStream_t st);
+                         float* glow, float* absmax, hipStream_t st);
 
 }  // namespace dcn

@@ -195,13 +195,23 @@ bn_bwd_finalize_kernel(const float* __restrict__ partial, int chunks, int C, dou
     k3[c] = (float)(b / count);
 }
 
+// max |.| over a wavefront, then one atomic per wavefront (non-negative floats order like their bit patterns).
+// The abs-max of every gradient tensor feeds the power-of-two pre-scale of the split-fp16 convolutions; a NaN
+// anywhere propagates through the scaled products exactly as it would through the fp32 ones.
+__device__ __forceinline__ void wave_atomic_absmax(float amax, float* absmax) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) amax = fmaxf(amax, __shfl_xor(amax, o));
+    if ((threadIdx.x & 63) == 0 && amax > 0.f) atomicMax(reinterpret_cast<unsigned*>(absmax), __float_as_uint(amax));
+}
+
 // dx = k1*(g - k2 - (x-mean)*invstd*k3); optionally also writes g (the relu-masked upstream gradient) for the
 // residual branch.
 __global__ void __launch_bounds__(256)
 bn_bwd_apply_kernel(const float* __restrict__ dy, const float* __restrict__ relu_out, const float* __restrict__ x,
                     const float* __restrict__ mean, const float* __restrict__ invstd, const float* __restrict__ k1,
                     const float* __restrict__ k2, const float* __restrict__ k3, float* __restrict__ dx,
-                    float* __restrict__ g_out, int c4n, int64_t total4) {
+                    float* __restrict__ g_out, float* __restrict__ absmax, int c4n, int64_t total4) {
+    float amax = 0.f;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total4; i += (int64_t)gridDim.x * 256) {
         const int c = (int)(i % c4n) * 4;
         float4 g = reinterpret_cast<const float4*>(dy)[i];
@@ -223,7 +233,18 @@ bn_bwd_apply_kernel(const float* __restrict__ dy, const float* __restrict__ relu
         o.w = a.w * (g.w - b.w - (v.w - mu.w) * is.w * d.w);
         reinterpret_cast<float4*>(dx)[i] = o;
         if (g_out) reinterpret_cast<float4*>(g_out)[i] = g;
+        amax = fmaxf(fmaxf(amax, fmaxf(fabsf(o.x), fabsf(o.y))), fmaxf(fabsf(o.z), fabsf(o.w)));
     }
+    if (absmax) wave_atomic_absmax(amax, absmax);
+}
+
+// absmax[0] = max(absmax[0], max |v[i]|)
+__global__ void __launch_bounds__(256)
+absmax_kernel(const float* __restrict__ v, int64_t total, float* __restrict__ absmax) {
+    float amax = 0.f;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256)
+        amax = fmaxf(amax, fabsf(v[i]));
+    wave_atomic_absmax(amax, absmax);
 }
 
 // out = a + b
@@ -477,7 +498,7 @@ int bn_bwd_chunks(int64_t rows) {
 }
 void launch_bn_bwd(const float* dy, const float* relu_out, const float* x, const float* mean, const float* invstd,
                    const float* gamma, int C, int64_t rows, float* partial, float* dgamma, float* dbeta, float* k123,
-                   float* dx, float* g_out, hipStream_t st) {
+                   float* dx, float* g_out, float* absmax, hipStream_t st) {
     const int chunks = bn_bwd_chunks(rows);
     const int rpc = (int)ceil_div64(rows, chunks);
     hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(ceil_div(C, 64), chunks), dim3(256), 0, st, dy, relu_out, x, mean,
@@ -487,7 +508,7 @@ void launch_bn_bwd(const float* dy, const float* relu_out, const float* x, const
     const int64_t total4 = rows * (C / 4);
     hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(blocks_for(total4, kGridCap)), dim3(256), 0, st, dy, relu_out, x, mean,
                        invstd, (const float*)k123, (const float*)(k123 + C), (const float*)(k123 + 2 * C), dx, g_out,
-                       C / 4, total4);
+                       absmax, C / 4, total4);
 }
 void launch_add(const float* a, const float* b, float* out, int64_t n, hipStream_t st) {
     hipLaunchKernelGGL(add_kernel, dim3(blocks_for(n / 4, kGridCap)), dim3(256), 0, st, a, b, out, n / 4);
@@ -519,13 +540,14 @@ void launch_normalize_bwd(const float* low, int n, int hl, int wl, int ldl, int 
                        ac_scale(hl, h), ac_scale(wl, w), gout, gv, total);
 }
 void launch_upsample_bwd(const float* gout, int n, int hl, int wl, int ldl, int d, int h, int w, float* tmp,
-                         float* glow, hipStream_t st) {
+                         float* glow, float* absmax, hipStream_t st) {
     const int64_t t1 = (int64_t)n * hl * w * d;
     hipLaunchKernelGGL(upsample_bwd_rows_kernel, dim3(blocks_for(t1)), dim3(256), 0, st, gout, hl, d, h, w,
                        ac_scale(hl, h), tmp, t1);
     const int64_t t2 = (int64_t)n * hl * wl * ldl;
     hipLaunchKernelGGL(upsample_bwd_cols_kernel, dim3(blocks_for(t2)), dim3(256), 0, st, (const float*)tmp, hl, wl, ldl,
                        d, w, ac_scale(wl, w), glow, t2);
+    if (absmax) hipLaunchKernelGGL(absmax_kernel, dim3(blocks_for(t2, 256)), dim3(256), 0, st, (const float*)glow, t2, absmax);
 }
 
 }  // namespace dcn
@@ -544,6 +566,6 @@ extern "C" size_t dcn_upsample_backward_tmp_bytes(int n, int hl, int w, int d) {
 extern "C" int dcn_upsample_backward(const float* gout, int n, int hl, int wl, int ldl, int d, int h, int w, float* glow,
                                      float* tmp, void* stream) {
     if (!gout || !glow || !tmp || n < 1 || hl < 1 || wl < 1 || d < 1 || ldl < d || h < 1 || w < 1) return DCN_E_INVALID;
-    dcn::launch_upsample_bwd(gout, n, hl, wl, ldl, d, h, w, tmp, glow, (hipStream_t)stream);
+    dcn::launch_upsample_bwd(gout, n, hl, wl, ldl, d, h, w, tmp, glow, nullptr, (hipStream_t)stream);
     return dcn::check_launch();
 }

@@ -70,6 +70,8 @@ SYMBOLS = {
                                      c_void_p, c_void_p, c_void_p]),
     "dcn_conv_dgrad_f16": (c_int, [ctypes.POINTER(ConvDesc), c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_void_p,
                                    c_void_p, c_void_p, c_void_p]),
+    "dcn_plan_set_conv_mode": (c_int, [c_void_p, c_int]),
+    "dcn_plan_conv_mode": (c_int, [c_void_p]),
     "dcn_conv_wgrad_f16": (c_int, [ctypes.POINTER(ConvDesc), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "dcn_conv_wgrad_workspace_f16": (c_size_t, [ctypes.POINTER(ConvDesc)]),
     "dcn_find_best_match": (c_int, [c_void_p, c_int64, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p,

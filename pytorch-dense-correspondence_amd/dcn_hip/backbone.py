@@ -47,6 +47,14 @@ class Plan(object):
         for nmel in self.param_numel:
             self.grad_offsets.append((self.grad_offsets[-1] + nmel + 3) // 4 * 4)  # keep every gradient 16-B aligned
 
+    @property
+    def conv_mode(self):
+        """"fp32" (fp32 MFMA) or "f16x3" (split-fp16 on the fp16 MFMA pipe, fp32-level accuracy) -- include/dcn_hip.h."""
+        return CONV_MODES[_lib.get().dcn_plan_conv_mode(self.handle)]
+
+    def set_conv_mode(self, mode):
+        _lib.check(_lib.get().dcn_plan_set_conv_mode(self.handle, CONV_MODES.index(mode)), "dcn_plan_set_conv_mode")
+
     def profile_begin(self):
         _lib.check(_lib.get().dcn_plan_profile_begin(self.handle), "dcn_plan_profile_begin")
 
@@ -67,6 +75,18 @@ class Plan(object):
 
 _PLANS = {}
 _lib._reset_hooks.append(_PLANS.clear)
+CONV_MODES = ("fp32", "f16x3")
+_conv_mode = [None]   # None: the library default (f16x3, or the DCN_CONV_MODE environment variable)
+
+
+def set_conv_mode(mode):
+    """Process-wide convolution arithmetic for all plans, existing and future: "fp32", "f16x3" or None (library default)."""
+    if mode is not None and mode not in CONV_MODES:
+        raise ValueError("conv mode must be one of %s" % (CONV_MODES,))
+    _conv_mode[0] = mode
+    if mode is not None:
+        for p in _PLANS.values():
+            p.set_conv_mode(mode)
 
 
 def get_plan(arch, base_width, n, h, w, d):
@@ -74,6 +94,8 @@ def get_plan(arch, base_width, n, h, w, d):
     p = _PLANS.get(key)
     if p is None:
         p = _PLANS[key] = Plan(*key)
+        if _conv_mode[0] is not None:
+            p.set_conv_mode(_conv_mode[0])
     return p
 
 

@@ -14,6 +14,15 @@ def _lib():
     return use_emulation_library()
 
 
+@pytest.fixture(autouse=True, params=["fp32", "f16x3"])
+def conv_mode(request):
+    """Every test of this file runs in both convolution arithmetics; the tolerances are the same (include/dcn_hip.h)."""
+    from dcn_hip import backbone
+    backbone.set_conv_mode(request.param)
+    yield request.param
+    backbone.set_conv_mode(None)
+
+
 def _pair(arch, D, bw, seed=0):
     from oracle import resnet_dilated_oracle as orc
     from pytorch_segmentation_detection.models import resnet_dilated as prod
@@ -49,6 +58,20 @@ def test_forward_backward_vs_oracle(arch, bw, shape, D):
     # BN running statistics / counters follow nn.BatchNorm2d
     for (k, b), (_, bo) in zip(m.named_buffers(), o.named_buffers()):
         assert rel_err(b.float(), bo.float()) < 1e-4 or float((b.float() - bo.float()).abs().max()) < 1e-5, k
+
+
+@pytest.mark.parametrize("gscale", [1e-9, 1e6])
+def test_gradient_scale_invariance(gscale, conv_mode):
+    """Tiny / huge incoming gradients (loss scaling, very small learning signals): the split-fp16 convolutions pre-scale
+    every gradient tensor by a power of two chosen from its abs-max, so the result is that of the fp32 kernels."""
+    m, o = _pair("Resnet18_8s", 3, 8)
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(2, 3, 32, 40, generator=g)
+    gy = torch.randn(2, 3, 32, 40, generator=g) * gscale
+    m.train(); o.train()
+    (m(x) * gy).sum().backward(); (o(x) * gy).sum().backward()
+    for (k, p), po in zip(m.named_parameters(), o.parameters()):
+        assert rel_err(p.grad, po.grad) < 2e-4, (k, conv_mode)
 
 
 def test_forward_backward_with_stream_k_forced(monkeypatch):

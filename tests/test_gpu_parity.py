@@ -163,6 +163,68 @@ def test_conv_kernels_vs_torch_cpu(L, case):
     assert torch.equal(dw, dw2)
 
 
+@pytest.mark.parametrize("case", GPU_CONV_CASES, ids=[str(c) for c in GPU_CONV_CASES])
+def test_conv_f16x3_kernels_vs_torch_cpu(L, case):
+    """The split-fp16 kernels (fp16 MFMA pipe, hi/lo operands) against the same torch CPU fp32 convolution and the same
+    1e-5 bound as the fp32 MFMA kernels; gradients of magnitude 1e-6 exercise the abs-max driven pre-scale."""
+    lib = L.get()
+    n, hin, win, cin, cout, k, stride, pad, dil = case
+    hout = (hin + 2 * pad - dil * (k - 1) - 1) // stride + 1
+    wout = (win + 2 * pad - dil * (k - 1) - 1) // stride + 1
+    d = L.ConvDesc(n, hin, win, cin, hout, wout, cout, k, k, stride, pad, dil, cout)
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(n, cin, hin, win, generator=g, requires_grad=True)
+    w = (torch.randn(cout, cin, k, k, generator=g) * (1.0 / (cin * k * k) ** 0.5)).requires_grad_(True)
+    dout = torch.randn(n, hout, wout, cout, generator=g) * 1e-6
+    ref = F.conv2d(x, w, None, stride, pad, dil)
+    ref.backward(dout.permute(0, 3, 1, 2))
+    refn = ref.detach().permute(0, 2, 3, 1)
+    xg = x.detach().permute(0, 2, 3, 1).contiguous().cuda()
+    wg = w.detach().permute(0, 2, 3, 1).contiguous().cuda()
+    st = L.stream_ptr()
+    K, Kt = k * k * cin, k * k * cout
+    wh = torch.empty(cout, lib.dcn_f16_kpad(K), dtype=torch.float16, device="cuda"); wl = torch.empty_like(wh)
+    assert lib.dcn_split_rows_f16(L.ptr(wg), L.ptr(wh), L.ptr(wl), cout, K, 64.0, st) == 0
+    out = torch.full((n, hout, wout, cout), float("nan"), device="cuda")
+    part = torch.full((lib.dcn_conv_num_mtiles_f16(ctypes.byref(d)), 2, cout), float("nan"), device="cuda")
+    ws_f = torch.empty(max(lib.dcn_conv_gemm_workspace_f16(ctypes.byref(d), 0), 4) // 4, device="cuda")
+    ws_d = torch.empty(max(lib.dcn_conv_gemm_workspace_f16(ctypes.byref(d), 1), 4) // 4, device="cuda")
+    assert lib.dcn_conv_forward_f16(ctypes.byref(d), L.ptr(xg), L.ptr(wh), L.ptr(wl), 64.0, None, L.ptr(out), L.ptr(part),
+                                    L.ptr(ws_f), st) == 0
+    assert rel_err(out.cpu(), refn) < 1e-5
+    assert rel_err(part.sum(0)[0].cpu(), refn.sum((0, 1, 2))) < 2e-5
+    assert rel_err(part.sum(0)[1].cpu(), (refn ** 2).sum((0, 1, 2))) < 2e-5
+    wt = torch.empty(cin, k * k, cout, device="cuda")
+    assert lib.dcn_transpose_weight(L.ptr(wg), L.ptr(wt), cout, k * k, cin, cout, st) == 0
+    wth = torch.empty(cin, lib.dcn_f16_kpad(Kt), dtype=torch.float16, device="cuda"); wtl = torch.empty_like(wth)
+    assert lib.dcn_split_rows_f16(L.ptr(wt), L.ptr(wth), L.ptr(wtl), cin, Kt, 64.0, st) == 0
+    dg = dout.cuda()
+    amax = dg.abs().max().reshape(1)
+    add = torch.randn(n, hin, win, cin, generator=g) * 1e-6
+    addg = add.cuda()
+    din = torch.full((n, hin, win, cin), float("nan"), device="cuda")
+    assert lib.dcn_conv_dgrad_f16(ctypes.byref(d), L.ptr(dg), L.ptr(wth), L.ptr(wtl), 64.0, L.ptr(amax), L.ptr(addg),
+                                  L.ptr(din), L.ptr(ws_d), st) == 0
+    assert rel_err(din.cpu(), x.grad.permute(0, 2, 3, 1) + add) < 1e-5
+    dw = torch.full((cout, k, k, cin), float("nan"), device="cuda")
+    slab = torch.empty(max(lib.dcn_conv_wgrad_workspace_f16(ctypes.byref(d)), 4) // 4, device="cuda")
+    assert lib.dcn_conv_wgrad_f16(ctypes.byref(d), L.ptr(xg), L.ptr(dg), L.ptr(amax), L.ptr(dw), L.ptr(slab), st) == 0
+    assert rel_err(dw.cpu(), w.grad.permute(0, 2, 3, 1)) < 1e-5
+    dw2 = torch.empty_like(dw)
+    assert lib.dcn_conv_wgrad_f16(ctypes.byref(d), L.ptr(xg), L.ptr(dg), L.ptr(amax), L.ptr(dw2), L.ptr(slab), st) == 0
+    assert torch.equal(dw, dw2)
+
+
+@pytest.fixture(params=["f16x3", "fp32"])
+def conv_mode(request):
+    """Backbone tests run in both convolution arithmetics against the SAME tolerances (include/dcn_hip.h)."""
+    from dcn_hip import backbone
+    backbone.set_conv_mode(request.param)
+    yield request.param
+    backbone.set_conv_mode(None)
+
+
+
 # ------------------------------------------------------------------------------------------------ backbone + step
 def _dcn_and_oracle(arch, D, H, W):
     from dense_correspondence.network.dense_correspondence_network import DenseCorrespondenceNetwork
@@ -189,7 +251,7 @@ def _gpu_step(dcn, img_a, img_b, lists, B):
     return loss, terms, hard, ya, yb
 
 
-def test_config1_full_size_vs_committed_oracle_fixture(L):
+def test_config1_full_size_vs_committed_oracle_fixture(L, conv_mode):
     """BASELINE config 1 at full size (1 pair, 640x480, D=3, Resnet34_8s): descriptor maps, loss terms and every
     parameter gradient against the committed oracle fixture -- no oracle run needed on the GPU box."""
     from oracle import synth
@@ -223,7 +285,7 @@ def test_config1_full_size_vs_committed_oracle_fixture(L):
     assert rel_err(dcn.fcn.resnet34_8s.bn1.running_mean.cpu(), z["running_mean_bn1"]) < 1e-5
 
 
-def test_config1_full_size_vs_live_oracle(L):
+def test_config1_full_size_vs_live_oracle(L, conv_mode):
     """Same configuration against the oracle run live on the host cores (takes a few seconds)."""
     from oracle import step as ostep, synth
     c = synth.CONFIGS[1]
@@ -246,7 +308,7 @@ def test_config1_full_size_vs_live_oracle(L):
         assert rel_err(p.grad.cpu(), po.grad) < 1e-1, (k, rel_err(p.grad.cpu(), po.grad))
 
 
-def test_batched_step_small_images_vs_oracle(L):
+def test_batched_step_small_images_vs_oracle(L, conv_mode):
     """B = 3 pairs (BN statistics over 3 images per call), D = 16, 96x128 images, with Adam."""
     from oracle import step as ostep, synth
     H, W, D, B = 96, 128, 16, 3
@@ -274,7 +336,7 @@ def test_batched_step_small_images_vs_oracle(L):
     assert abs(loss2.item() - loss_o2.item()) <= TOL * abs(loss_o2.item())
 
 
-def test_resnet50_8s_forward_backward_vs_oracle(L):
+def test_resnet50_8s_forward_backward_vs_oracle(L, conv_mode):
     """Bottleneck family (BASELINE config 5's backbone) at a small size, D = 32."""
     import copy
     H, W, D = 128, 160, 32    # 2 x 16 x 20 = 640 samples per batch-norm channel in layer3/4
@@ -293,7 +355,7 @@ def test_resnet50_8s_forward_backward_vs_oracle(L):
         assert l2(p.grad) < 5 * l2(po.grad) + 2e-3, (k, l2(p.grad), l2(po.grad))
 
 
-def test_config2_full_size_properties(L):
+def test_config2_full_size_properties(L, conv_mode):
     """BASELINE config 2 (B = 4 pairs, 640x480): too slow for the CPU oracle in a unit test, so properties:
     bitwise run-to-run determinism of the forward, finite outputs, eval-mode idempotence, gradient flat buffer."""
     from dcn_hip.distributed import FlatGradients
@@ -336,7 +398,7 @@ def test_best_match_search_full_size(L):
     assert (int(uv[0, 0]), int(uv[0, 1])) == (200, 100)
 
 
-def test_normalized_descriptor_training_step(L):
+def test_normalized_descriptor_training_step(L, conv_mode):
     """normalize=True (network.py:256-259) forward + backward on the GPU vs the oracle."""
     from dense_correspondence.network.dense_correspondence_network import DenseCorrespondenceNetwork
     from oracle import resnet_dilated_oracle

@@ -36,6 +36,7 @@ def main():
     ap.add_argument("--json", default="")
     ap.add_argument("--only", default="", help="substring filter on the shape name")
     ap.add_argument("--kinds", default="fwd,dgrad,wgrad")
+    ap.add_argument("--check", action="store_true", help="with --mode f16: compare against the fp32 kernels")
     ap.add_argument("--mode", default="fp32", choices=["fp32", "f16"], help="fp32 MFMA kernels or the split-fp16 (f16x3) ones")
     a = ap.parse_args()
     lib = _lib.get()
@@ -83,6 +84,22 @@ def main():
                                                             None, _lib.ptr(y), _lib.ptr(part), _lib.ptr(wsf), st)
             calls["dgrad"] = lambda: lib.dcn_conv_dgrad_f16(ctypes.byref(d), _lib.ptr(dy), _lib.ptr(wth), _lib.ptr(wtl), 64.0,
                                                             _lib.ptr(amax), None, _lib.ptr(dx), _lib.ptr(wsd), st)
+            slab = torch.empty(max(lib.dcn_conv_wgrad_workspace_f16(ctypes.byref(d)), 4) // 4, device=dev)
+            calls["wgrad"] = lambda: lib.dcn_conv_wgrad_f16(ctypes.byref(d), _lib.ptr(x), _lib.ptr(dy), _lib.ptr(amax),
+                                                            _lib.ptr(dw), _lib.ptr(slab), st)
+            if a.check:   # f16x3 vs the fp32 MFMA kernels on the same operands
+                y2, dx2, dw2 = torch.empty_like(y), torch.empty_like(dx), torch.empty_like(dw)
+                part2 = torch.empty(lib.dcn_conv_num_mtiles(ctypes.byref(d)), 2, cout, device=dev)
+                w2 = torch.empty(max(lib.dcn_conv_gemm_workspace(ctypes.byref(d), 0), lib.dcn_conv_gemm_workspace(ctypes.byref(d), 1),
+                                     lib.dcn_conv_wgrad_workspace(ctypes.byref(d)), 4) // 4, device=dev)
+                assert lib.dcn_conv_forward(ctypes.byref(d), _lib.ptr(x), _lib.ptr(w), None, _lib.ptr(y2), _lib.ptr(part2), _lib.ptr(w2), st) == 0
+                assert lib.dcn_conv_dgrad(ctypes.byref(d), _lib.ptr(dy), _lib.ptr(wt), None, _lib.ptr(dx2), _lib.ptr(w2), st) == 0
+                assert lib.dcn_conv_wgrad(ctypes.byref(d), _lib.ptr(x), _lib.ptr(dy), _lib.ptr(dw2), _lib.ptr(w2), st) == 0
+                for fn in calls.values():
+                    assert fn() == 0
+                torch.cuda.synchronize()
+                rel = lambda p_, q_: float((p_ - q_).abs().max() / q_.abs().max())
+                print("  check %-24s y %.2e  dx %.2e  dw %.2e" % (name, rel(y, y2), rel(dx, dx2), rel(dw, dw2)), flush=True)
         row = {"shape": name, "count": count, "gflop": flops / 1e9}
         for kind in ("fwd", "dgrad", "wgrad"):
             row[kind + "_us"] = float("nan")
