@@ -278,7 +278,7 @@ int build_plan(dcn_plan& p) {
         if (c.d.cout > max_c) max_c = c.d.cout;
     }
     for (const BnL& b : p.bns) {
-        const size_t pb = (size_t)dcn::bn_bwd_chunks(b.rows) * 2 * b.C;
+        const size_t pb = (size_t)dcn::bn_bwd_chunks(b.rows) * 4 * b.C;
         if (pb > max_part) max_part = pb;
     }
     p.w_wt = alloc(max_w);

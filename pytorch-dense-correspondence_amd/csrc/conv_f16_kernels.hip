@@ -319,7 +319,7 @@ F16Shape f16_shape(int M, int cd, int K) {
     const int tiles = g.mtiles * g.ntiles;
     const double rounds = tiles / 256.0;
     const double waste = 1.0 - rounds / (double)(int)(rounds + 0.999999);
-    g.sk = tiles < 8 * 256 && waste > 0.08 && g.nk >= 16;
+    g.sk = tiles < 8 * 256 && waste > 0.08 && g.nk >= 32;   // measured: below ~32 K stages the fix-up pass costs more than the tail it removes
     int wgs = 512;
     if (const char* e = getenv("DCN_GEMM_SK")) {
         const int v = atoi(e);

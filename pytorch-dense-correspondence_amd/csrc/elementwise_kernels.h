@@ -17,10 +17,10 @@ void launch_bn_finalize(const float* partial, int tiles, int C, double count, co
 void launch_bn_apply(const float* x, const float* s1, const float* b1, const float* res, const float* s2,
                      const float* b2, int relu, float* y, int C, int64_t rows, hipStream_t st);
 int bn_bwd_chunks(int64_t rows);
-// partial: bn_bwd_chunks(rows)*2*C floats, k123: 3*C floats.  g_out (nullable) receives the relu-masked dy.
+// partial: bn_bwd_chunks(rows)*4*C floats, k123: 3*C floats.  g_out (nullable) receives the relu-masked dy.
 void launch_bn_bwd(const float* dy, const float* relu_out, const float* x, const float* mean, const float* invstd,
                    const float* gamma, int C, int64_t rows, float* partial, float* dgamma, float* dbeta, float* k123,
-                   float* dx, float* g_out, float* absmax, hipStream_t st);   // absmax (optional): max |dx| accumulated
+                   float* dx, float* g_out, float* absmax, hipStream_t st);   // absmax (optional): raised to an upper bound of max |dx|
 void launch_add(const float* a, const float* b, float* out, int64_t n, hipStream_t st);
 
 void launch_maxpool_fwd(const float* in, float* out, unsigned char* argmax, int n, int hin, int win, int hout,

@@ -118,7 +118,8 @@ bn_apply_kernel(const float* __restrict__ x, const float* __restrict__ s1, const
 }
 
 // Backward reduction.  g = relu_out ? (relu_out > 0 ? dy : 0) : dy.
-// partial[chunk][2][C] = ( sum g , sum g * (x - mean) * invstd ) over the chunk's rows.
+// partial[chunk][4][C] = ( sum g , sum g * xhat , max |g| , max |xhat| ) over the chunk's rows, xhat = (x - mean) * invstd.
+// (The two maxima bound |dx| per channel without another pass or any atomics in the big kernels: bn_bwd_finalize.)
 // work-item (c4 = tid & 15, rl = tid >> 4): 16 channel quads x 16 row lanes; grid = (C/64 groups, chunks).
 __global__ void __launch_bounds__(256)
 bn_bwd_reduce_kernel(const float* __restrict__ dy, const float* __restrict__ relu_out, const float* __restrict__ x,
@@ -126,9 +127,11 @@ bn_bwd_reduce_kernel(const float* __restrict__ dy, const float* __restrict__ rel
                      int rows_per_chunk, float* __restrict__ partial) {
     __shared__ float4 s_g[16][16];
     __shared__ float4 s_gx[16][16];
+    __shared__ float4 s_mg[16][16];
+    __shared__ float4 s_mx[16][16];
     const int c4 = threadIdx.x & 15, rl = threadIdx.x >> 4;
     const int c = blockIdx.x * 64 + c4 * 4;
-    float4 ag = make_float4(0.f, 0.f, 0.f, 0.f), agx = ag;
+    float4 ag = make_float4(0.f, 0.f, 0.f, 0.f), agx = ag, mg = ag, mx = ag;
     if (c < C) {
         const float4 mu = *reinterpret_cast<const float4*>(mean + c);
         const float4 is = *reinterpret_cast<const float4*>(invstd + c);
@@ -144,55 +147,99 @@ bn_bwd_reduce_kernel(const float* __restrict__ dy, const float* __restrict__ rel
                 g.z = y.z > 0.f ? g.z : 0.f; g.w = y.w > 0.f ? g.w : 0.f;
             }
             const float4 v = *reinterpret_cast<const float4*>(x + o);
+            const float4 xh = make_float4((v.x - mu.x) * is.x, (v.y - mu.y) * is.y, (v.z - mu.z) * is.z, (v.w - mu.w) * is.w);
             ag.x += g.x; ag.y += g.y; ag.z += g.z; ag.w += g.w;
-            agx.x = fmaf(g.x, (v.x - mu.x) * is.x, agx.x); agx.y = fmaf(g.y, (v.y - mu.y) * is.y, agx.y);
-            agx.z = fmaf(g.z, (v.z - mu.z) * is.z, agx.z); agx.w = fmaf(g.w, (v.w - mu.w) * is.w, agx.w);
+            agx.x = fmaf(g.x, xh.x, agx.x); agx.y = fmaf(g.y, xh.y, agx.y);
+            agx.z = fmaf(g.z, xh.z, agx.z); agx.w = fmaf(g.w, xh.w, agx.w);
+            mg.x = fmaxf(mg.x, fabsf(g.x)); mg.y = fmaxf(mg.y, fabsf(g.y));
+            mg.z = fmaxf(mg.z, fabsf(g.z)); mg.w = fmaxf(mg.w, fabsf(g.w));
+            mx.x = fmaxf(mx.x, fabsf(xh.x)); mx.y = fmaxf(mx.y, fabsf(xh.y));
+            mx.z = fmaxf(mx.z, fabsf(xh.z)); mx.w = fmaxf(mx.w, fabsf(xh.w));
         }
     }
     s_g[rl][c4] = ag;
     s_gx[rl][c4] = agx;
+    s_mg[rl][c4] = mg;
+    s_mx[rl][c4] = mx;
     __syncthreads();
     if (rl == 0 && c < C) {
         for (int i = 1; i < 16; ++i) {
-            const float4 a = s_g[i][c4], b = s_gx[i][c4];
+            const float4 a = s_g[i][c4], b = s_gx[i][c4], m1 = s_mg[i][c4], m2 = s_mx[i][c4];
             ag.x += a.x; ag.y += a.y; ag.z += a.z; ag.w += a.w;
             agx.x += b.x; agx.y += b.y; agx.z += b.z; agx.w += b.w;
+            mg.x = fmaxf(mg.x, m1.x); mg.y = fmaxf(mg.y, m1.y); mg.z = fmaxf(mg.z, m1.z); mg.w = fmaxf(mg.w, m1.w);
+            mx.x = fmaxf(mx.x, m2.x); mx.y = fmaxf(mx.y, m2.y); mx.z = fmaxf(mx.z, m2.z); mx.w = fmaxf(mx.w, m2.w);
         }
-        float* p = partial + ((int64_t)blockIdx.y * 2) * C + c;
+        float* p = partial + ((int64_t)blockIdx.y * 4) * C + c;
         *reinterpret_cast<float4*>(p) = ag;
         *reinterpret_cast<float4*>(p + C) = agx;
+        *reinterpret_cast<float4*>(p + 2 * C) = mg;
+        *reinterpret_cast<float4*>(p + 3 * C) = mx;
     }
 }
 
-// partial[chunk][2][C] -> dgamma, dbeta and the coefficients of the apply pass:
+// partial[chunk][4][C] -> dgamma, dbeta and the coefficients of the apply pass:
 //   dx = k1 * (g - k2 - xhat * k3),  k1 = gamma*invstd, k2 = sum_g / M, k3 = sum_gx / M
+// and, when absmax is given, raises absmax[0] to  max_c |k1| (max|g| + |k2| + max|xhat| |k3|)  >=  max |dx|  (the
+// pre-scale of the split-fp16 convolutions only needs an upper bound within a small factor of the true abs-max).
 __global__ void __launch_bounds__(256)
 bn_bwd_finalize_kernel(const float* __restrict__ partial, int chunks, int C, double count,
                        const float* __restrict__ gamma, const float* __restrict__ invstd, float* __restrict__ dgamma,
                        float* __restrict__ dbeta, float* __restrict__ k1, float* __restrict__ k2,
-                       float* __restrict__ k3) {
-    __shared__ double s_a[4][64];
-    __shared__ double s_b[4][64];
-    const int cl = threadIdx.x & 63, part = threadIdx.x >> 6;
-    const int c = blockIdx.x * 64 + cl;
+                       float* __restrict__ k3, float* __restrict__ absmax) {
+    // 16 channels x 16 chunk-parts per workgroup (C / 16 workgroups: a 64-channel layer still gets 4 CUs and every
+    // work-item only walks chunks / 16 partial rows); fixed summation order
+    __shared__ double s_a[16][16];
+    __shared__ double s_b[16][16];
+    const int cl = threadIdx.x & 15, part = threadIdx.x >> 4;
+    const int c = blockIdx.x * 16 + cl;
+    __shared__ float s_mg[16][16];
+    __shared__ float s_mx[16][16];
     double a = 0.0, b = 0.0;
+    float mg = 0.f, mx = 0.f;
     if (c < C) {
-        for (int t = part; t < chunks; t += 4) {
-            a += (double)partial[((int64_t)t * 2 + 0) * C + c];
-            b += (double)partial[((int64_t)t * 2 + 1) * C + c];
+#pragma unroll 4
+        for (int t = part; t < chunks; t += 16) {
+            const float* row = partial + (int64_t)t * 4 * C + c;
+            a += (double)row[0];
+            b += (double)row[C];
+            mg = fmaxf(mg, row[2 * C]);
+            mx = fmaxf(mx, row[3 * C]);
         }
     }
     s_a[part][cl] = a;
     s_b[part][cl] = b;
+    s_mg[part][cl] = mg;
+    s_mx[part][cl] = mx;
     __syncthreads();
-    if (part != 0 || c >= C) return;
-    a = s_a[0][cl] + s_a[1][cl] + s_a[2][cl] + s_a[3][cl];
-    b = s_b[0][cl] + s_b[1][cl] + s_b[2][cl] + s_b[3][cl];
-    dbeta[c] = (float)a;
-    dgamma[c] = (float)b;
-    k1[c] = gamma[c] * invstd[c];
-    k2[c] = (float)(a / count);
-    k3[c] = (float)(b / count);
+    float bound = 0.f;
+    if (part == 0 && c < C) {
+        a = 0.0; b = 0.0;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            a += s_a[q][cl]; b += s_b[q][cl];
+            mg = fmaxf(mg, s_mg[q][cl]); mx = fmaxf(mx, s_mx[q][cl]);
+        }
+        const float c1 = gamma[c] * invstd[c], c2 = (float)(a / count), c3 = (float)(b / count);
+        dbeta[c] = (float)a;
+        dgamma[c] = (float)b;
+        k1[c] = c1;
+        k2[c] = c2;
+        k3[c] = c3;
+        bound = fabsf(c1) * (mg + fabsf(c2) + mx * fabsf(c3));
+    }
+    if (absmax) {
+        __syncthreads();
+        if (part == 0) s_mg[0][cl] = bound;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+#pragma unroll
+            for (int q = 1; q < 16; ++q) bound = fmaxf(bound, s_mg[0][q]);
+            const unsigned bits = __float_as_uint(bound);
+            if (bound > 0.f && bits > __atomic_load_n(reinterpret_cast<unsigned*>(absmax), __ATOMIC_RELAXED))
+                atomicMax(reinterpret_cast<unsigned*>(absmax), bits);
+        }
+    }
 }
 
 // max |.| over a wavefront, then one atomic per wavefront (non-negative floats order like their bit patterns).
@@ -201,7 +248,13 @@ bn_bwd_finalize_kernel(const float* __restrict__ partial, int chunks, int C, dou
 __device__ __forceinline__ void wave_atomic_absmax(float amax, float* absmax) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) amax = fmaxf(amax, __shfl_xor(amax, o));
-    if ((threadIdx.x & 63) == 0 && amax > 0.f) atomicMax(reinterpret_cast<unsigned*>(absmax), __float_as_uint(amax));
+    // thousands of wavefronts target one address: look first (plain load, served by L2) and only the few wavefronts that
+    // would actually raise the value issue the atomic -- the value only ever grows, so a stale look is merely conservative
+    if ((threadIdx.x & 63) == 0 && amax > 0.f) {
+        const unsigned bits = __float_as_uint(amax);
+        if (bits > __atomic_load_n(reinterpret_cast<unsigned*>(absmax), __ATOMIC_RELAXED))
+            atomicMax(reinterpret_cast<unsigned*>(absmax), bits);
+    }
 }
 
 // dx = k1*(g - k2 - (x-mean)*invstd*k3); optionally also writes g (the relu-masked upstream gradient) for the
@@ -210,8 +263,7 @@ __global__ void __launch_bounds__(256)
 bn_bwd_apply_kernel(const float* __restrict__ dy, const float* __restrict__ relu_out, const float* __restrict__ x,
                     const float* __restrict__ mean, const float* __restrict__ invstd, const float* __restrict__ k1,
                     const float* __restrict__ k2, const float* __restrict__ k3, float* __restrict__ dx,
-                    float* __restrict__ g_out, float* __restrict__ absmax, int c4n, int64_t total4) {
-    float amax = 0.f;
+                    float* __restrict__ g_out, int c4n, int64_t total4) {
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total4; i += (int64_t)gridDim.x * 256) {
         const int c = (int)(i % c4n) * 4;
         float4 g = reinterpret_cast<const float4*>(dy)[i];
@@ -233,9 +285,7 @@ bn_bwd_apply_kernel(const float* __restrict__ dy, const float* __restrict__ relu
         o.w = a.w * (g.w - b.w - (v.w - mu.w) * is.w * d.w);
         reinterpret_cast<float4*>(dx)[i] = o;
         if (g_out) reinterpret_cast<float4*>(g_out)[i] = g;
-        amax = fmaxf(fmaxf(amax, fmaxf(fabsf(o.x), fabsf(o.y))), fmaxf(fabsf(o.z), fabsf(o.w)));
     }
-    if (absmax) wave_atomic_absmax(amax, absmax);
 }
 
 // absmax[0] = max(absmax[0], max |v[i]|)
@@ -503,12 +553,12 @@ void launch_bn_bwd(const float* dy, const float* relu_out, const float* x, const
     const int rpc = (int)ceil_div64(rows, chunks);
     hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(ceil_div(C, 64), chunks), dim3(256), 0, st, dy, relu_out, x, mean,
                        invstd, C, rows, rpc, partial);
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(ceil_div(C, 64)), dim3(256), 0, st, (const float*)partial, chunks, C,
-                       (double)rows, gamma, invstd, dgamma, dbeta, k123, k123 + C, k123 + 2 * C);
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(ceil_div(C, 16)), dim3(256), 0, st, (const float*)partial, chunks, C,
+                       (double)rows, gamma, invstd, dgamma, dbeta, k123, k123 + C, k123 + 2 * C, absmax);
     const int64_t total4 = rows * (C / 4);
     hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(blocks_for(total4, kGridCap)), dim3(256), 0, st, dy, relu_out, x, mean,
                        invstd, (const float*)k123, (const float*)(k123 + C), (const float*)(k123 + 2 * C), dx, g_out,
-                       absmax, C / 4, total4);
+                       C / 4, total4);
 }
 void launch_add(const float* a, const float* b, float* out, int64_t n, hipStream_t st) {
     hipLaunchKernelGGL(add_kernel, dim3(blocks_for(n / 4, kGridCap)), dim3(256), 0, st, a, b, out, n / 4);
