@@ -30,11 +30,28 @@ __device__ __forceinline__ float pow2_scale(float absmax) {
     return absmax > 0.f ? exp2f(floorf(log2f(4096.f / absmax))) : 1.f;
 }
 
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+
+// (x0, x1) -> packed hi = rn16(x), lo = rn16(x - hi): one v_cvt_pk_f16_f32 per pair for hi, two v_cvt_f32_f16 back,
+// two subtractions, one v_cvt_pk_f16_f32 for lo (vector conversions keep hipcc from converting every element twice)
+__device__ __forceinline__ void split2(float x0, float x1, h2& hi, h2& lo) {
+    f32x2 v = {x0, x1};
+    hi = __builtin_convertvector(v, h2);
+    const f32x2 back = __builtin_convertvector(hi, f32x2);
+    lo = __builtin_convertvector(v - back, h2);
+}
+
+__device__ __forceinline__ void split4_unscaled(float4 v, h4& hi, h4& lo) {
+    h2 a, b, c, d;
+    split2(v.x, v.y, a, b);
+    split2(v.z, v.w, c, d);
+    hi = h4{a[0], a[1], c[0], c[1]};
+    lo = h4{b[0], b[1], d[0], d[1]};
+}
+
 __device__ __forceinline__ void split4(float4 v, float s, h4& hi, h4& lo) {
-    const float x0 = v.x * s, x1 = v.y * s, x2 = v.z * s, x3 = v.w * s;
-    hi[0] = (_Float16)x0; hi[1] = (_Float16)x1; hi[2] = (_Float16)x2; hi[3] = (_Float16)x3;
-    lo[0] = (_Float16)(x0 - (float)hi[0]); lo[1] = (_Float16)(x1 - (float)hi[1]);
-    lo[2] = (_Float16)(x2 - (float)hi[2]); lo[3] = (_Float16)(x3 - (float)hi[3]);
+    split4_unscaled(make_float4(v.x * s, v.y * s, v.z * s, v.w * s), hi, lo);
 }
 
 // rows x K fp32 -> hi / lo fp16 [rows][kp] (kp = K rounded up to 8, zero padded), scaled by s
@@ -60,7 +77,14 @@ template <int TM, int TN> struct F16Geo {
                          kStageHalves = 2 * (BM + BN) * LDH;   // A hi, A lo, B hi, B lo
 };
 
-template <int TM, int TN, bool TR>
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+constexpr int kOob = (int)0x80000000;   // voffset that fails the bounds check of any buffer <= 2 GiB: the load returns 0
+
+// UNI: cs % 32 == 0, so a 32-K stage lies inside ONE filter tap and everything about the tap is wave-uniform: the
+// gather is `buffer_load_dwordx4 voffset[row] + soffset(channel chunk)` with per-row byte offsets that only change when
+// the tap does; out-of-image taps, rows past M and weight rows past cd get an out-of-range voffset and come back as
+// zeros from the bounds check (no address clamps, no zero-fill selects in the K loop).
+template <int TM, int TN, bool TR, bool UNI>
 __device__ __forceinline__ void gemm_segment_f16(const GemmConv& p, _Float16* lds, int tile, int k0, int k1, int nk,
                                                  float* slot) {
     using G = F16Geo<TM, TN>;
@@ -71,8 +95,11 @@ __device__ __forceinline__ void gemm_segment_f16(const GemmConv& p, _Float16* ld
     const int m0 = mt * BM, n0 = nt * BN;
 
     // A staging: float4 (4 k) at k-quad kq of rows ra0 + 32 j;  B staging: 8 halves at k-octet ko of rows rb0 + 64 j
-    const int kq = tid & 7, ra0 = tid >> 3;
-    const int ko = tid & 3, rb0 = tid >> 2;
+    // Row order within a store lane-group: the 16 lanes of a ds_write_b64 group (8 of a ds_write_b128 group) cover two
+    // rows; rows r and r + 4 are 320 bytes = 16 banks apart, so the two 64-byte runs tile all 32 banks exactly (rows r and
+    // r + 1 would overlap on 4 banks: measured as SQ_LDS_BANK_CONFLICT = 50 % extra LDS cycles).
+    const int kq = tid & 7, ra0 = ((tid >> 4) & 3) + 4 * ((tid >> 3) & 1) + 8 * (tid >> 6);
+    const int ko = tid & 3, rb0 = ((tid >> 3) & 3) + 4 * ((tid >> 2) & 1) + 8 * (tid >> 5);
     int by[PA], bx[PA], pixbase[PA];
 #pragma unroll
     for (int j = 0; j < PA; ++j) {
@@ -95,19 +122,94 @@ __device__ __forceinline__ void gemm_segment_f16(const GemmConv& p, _Float16* ld
         wrow[j] = (ok ? n : 0) * p.kp + ko * 8;
     }
     const int smask = p.stride - 1;
-    const float sa = p.a_absmax ? pow2_scale(*p.a_absmax) : 1.f;
-    float4 ra[PA];
-    h8 rbh[PB], rbl[PB];
-    unsigned okm = 0;
+    const float sa = (TR && p.a_absmax) ? pow2_scale(*p.a_absmax) : 1.f;   // only gradient tensors are pre-scaled
+    // two register sets: global loads run TWO 32-K stages ahead of the MFMAs (a stage of fp16 MFMA work is ~0.3 us,
+    // shorter than a trip to L2 / HBM under load)
+    float4 ra[2][PA];
+    h8 rbh[2][PB], rbl[2][PB];
+    unsigned okm[2] = {0u, 0u};
 
-    auto load_tile = [&](int kt) {
+    // ---- UNI state
+    const __amdgpu_buffer_rsrc_t rs_a = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.src), 0, (int)p.src_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_h = __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16*>(p.wh), 0, (int)p.w_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_l = __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16*>(p.wl), 0, (int)p.w_bytes, 0x00020000);
+    const int cpt = p.cs / HBK;                                     // 32-K chunks per tap
+    const int cbs = (4 * p.cs) >> (TR ? p.sshift : 0);             // bytes per unit of (by, bx)
+    // K traversal of the UNI path: channel-chunk groups outermost (kcg chunks = up to 128 channels), then the filter
+    // taps, then the chunks of the group -- a tap change (new voff[]) only every kcg stages, and the SAME input pixels
+    // come back for the next tap after kcg stages, while they are still in this XCD's L2 (tap-major order re-reads them
+    // cs / 32 stages later: measured 48 % L2 hit rate on the 512-channel layers).
+    const int kcg = (cpt & 3) == 0 ? 4 : ((cpt & 1) == 0 ? 2 : 1);
+    const int taps = p.kh * p.kw;
+    int rowoff[PA], voff[PA], voffb[PB];
+    int u_tap = 0, u_grp = 0, u_c = 0, u_kt = k0;
+    auto set_tap = [&](int tap) {
+        const int r = fdiv(tap, p.div_kw), s = tap - r * p.kw;
+        const int dy = r * p.dil, dx = s * p.dil;
+        const int delta = (dy * p.ws + dx) * cbs;
+#pragma unroll
+        for (int j = 0; j < PA; ++j) {
+            bool ok;
+            if (TR) {
+                const int ny = by[j] - dy, nx = bx[j] - dx;
+                ok = ((ny | nx) >= 0) & (((ny | nx) & smask) == 0) & ((ny >> p.sshift) < p.hs) & ((nx >> p.sshift) < p.ws);
+            } else {
+                ok = ((unsigned)(by[j] + dy) < (unsigned)p.hs) & ((unsigned)(bx[j] + dx) < (unsigned)p.ws);
+            }
+            voff[j] = ok ? (TR ? rowoff[j] - delta : rowoff[j] + delta) : kOob;
+        }
+    };
+    if (UNI) {
+#pragma unroll
+        for (int j = 0; j < PA; ++j)   // (rows past M carry by = -2^28: never inside the image)
+            rowoff[j] = 4 * (pixbase[j] * p.cs + kq * 4) + (by[j] > -(1 << 27) ? (by[j] * p.ws + bx[j]) * cbs : 0);
+#pragma unroll
+        for (int j = 0; j < PB; ++j) voffb[j] = ((wokm >> j) & 1u) ? 2 * wrow[j] : kOob;
+        const int per_grp = taps * kcg;       // stage index -> (group, tap, chunk in group)
+        u_grp = k0 / per_grp;
+        const int rem = k0 - u_grp * per_grp;
+        u_tap = rem / kcg;
+        u_c = rem - u_tap * kcg;
+        set_tap(u_tap);
+    }
+    // issues the loads of stage u_kt, then steps to the next stage of the segment (staying on the last one)
+    auto load_next = [&](int set) {
+        const int chunk = u_grp * kcg + u_c;
+        const int soff = chunk * (HBK * 4);
+#pragma unroll
+        for (int j = 0; j < PA; ++j)
+            ra[set][j] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rs_a, voff[j], soff, 0));
+        const int soffb = (u_tap * p.cs + chunk * HBK) * 2;
+#pragma unroll
+        for (int j = 0; j < PB; ++j) {
+            rbh[set][j] = __builtin_bit_cast(h8, __builtin_amdgcn_raw_buffer_load_b128(rs_h, voffb[j], soffb, 0));
+            rbl[set][j] = __builtin_bit_cast(h8, __builtin_amdgcn_raw_buffer_load_b128(rs_l, voffb[j], soffb, 0));
+        }
+    };
+    // (kept apart from the loads: the tap change is a uniform branch, and placed after the MFMAs of the phase it leaves
+    // "loads + fragment reads + MFMAs" as ONE scheduling region for the interleave below)
+    auto advance = [&]() {
+        if (!UNI) return;
+        if (u_kt + 1 < k1) {
+            ++u_kt;
+            if (++u_c == kcg) {
+                u_c = 0;
+                if (++u_tap == taps) { u_tap = 0; ++u_grp; }
+                set_tap(u_tap);
+            }
+        }
+    };
+
+    auto load_tile = [&](int kt, int set) {
+        if (UNI) { load_next(set); return; }
+        kt = kt < k1 ? kt : k1 - 1;
         const int k = kt * HBK + kq * 4;
         const bool kval = k < p.K;
         const int kk = kval ? k : 0;
         const int tap = fdiv(kk, p.div_cs), c = kk - tap * p.cs;
         const int r = fdiv(tap, p.div_kw), s = tap - r * p.kw;
         const int dy = r * p.dil, dx = s * p.dil;
-        okm = 0;
+        unsigned om = 0;
 #pragma unroll
         for (int j = 0; j < PA; ++j) {
             int sy, sx;
@@ -122,8 +224,8 @@ __device__ __forceinline__ void gemm_segment_f16(const GemmConv& p, _Float16* ld
             ok = ok & ((unsigned)sy < (unsigned)p.hs) & ((unsigned)sx < (unsigned)p.ws);
             int off = (pixbase[j] + sy * p.ws + sx) * p.cs + c;
             off = ok ? off : 0;
-            ra[j] = *reinterpret_cast<const float4*>(p.src + off);
-            okm |= (ok ? 1u : 0u) << j;
+            ra[set][j] = *reinterpret_cast<const float4*>(p.src + off);
+            om |= (ok ? 1u : 0u) << j;
         }
         const int kb = kt * HBK + ko * 8;
         const bool kbval = kb < p.kp;
@@ -131,34 +233,36 @@ __device__ __forceinline__ void gemm_segment_f16(const GemmConv& p, _Float16* ld
         for (int j = 0; j < PB; ++j) {
             const bool ok = kbval & (((wokm >> j) & 1u) != 0);
             const int off = ok ? wrow[j] + kt * HBK : 0;
-            rbh[j] = *reinterpret_cast<const h8*>(p.wh + off);
-            rbl[j] = *reinterpret_cast<const h8*>(p.wl + off);
-            okm |= (ok ? 1u : 0u) << (16 + j);
+            rbh[set][j] = *reinterpret_cast<const h8*>(p.wh + off);
+            rbl[set][j] = *reinterpret_cast<const h8*>(p.wl + off);
+            om |= (ok ? 1u : 0u) << (16 + j);
         }
+        okm[set] = om;
     };
-    auto store_tile = [&](int stage) {
+    auto store_tile = [&](int stage, int set) {
         _Float16* ah = lds + stage * kStage;
         _Float16* al = ah + BM * LDH;
         _Float16* bh = al + BM * LDH;
         _Float16* bl = bh + BN * LDH;
 #pragma unroll
         for (int j = 0; j < PA; ++j) {
-            const bool ok = (okm >> j) & 1u;
-            float4 v = ra[j];
+            const bool ok = UNI | (((okm[set] >> j) & 1u) != 0);
+            float4 v = ra[set][j];
             v = make_float4(ok ? v.x : 0.f, ok ? v.y : 0.f, ok ? v.z : 0.f, ok ? v.w : 0.f);
             h4 hi, lo;
-            split4(v, sa, hi, lo);
+            if (TR) split4(v, sa, hi, lo);
+            else split4_unscaled(v, hi, lo);   // forward: activations are taken as they are
             *reinterpret_cast<h4*>(ah + (ra0 + 32 * j) * LDH + kq * 4) = hi;
             *reinterpret_cast<h4*>(al + (ra0 + 32 * j) * LDH + kq * 4) = lo;
         }
 #pragma unroll
         for (int j = 0; j < PB; ++j) {
-            const bool ok = (okm >> (16 + j)) & 1u;
+            const bool ok = UNI | (((okm[set] >> (16 + j)) & 1u) != 0);
             h8 z;
 #pragma unroll
             for (int e = 0; e < 8; ++e) z[e] = (_Float16)0.f;
-            *reinterpret_cast<h8*>(bh + (rb0 + 64 * j) * LDH + ko * 8) = ok ? rbh[j] : z;
-            *reinterpret_cast<h8*>(bl + (rb0 + 64 * j) * LDH + ko * 8) = ok ? rbl[j] : z;
+            *reinterpret_cast<h8*>(bh + (rb0 + 64 * j) * LDH + ko * 8) = ok ? rbh[set][j] : z;
+            *reinterpret_cast<h8*>(bl + (rb0 + 64 * j) * LDH + ko * 8) = ok ? rbl[set][j] : z;
         }
     };
 
@@ -189,32 +293,68 @@ __device__ __forceinline__ void gemm_segment_f16(const GemmConv& p, _Float16* ld
             fbl[set][t] = *reinterpret_cast<const h8*>(b + BN * LDH + t * 32 * LDH);
         }
     };
+    // product-type outermost: consecutive MFMAs go to different accumulators (no back-to-back read-after-write); the
+    // small cross terms are accumulated before the large hi*hi term
     auto mfma_steps = [&](int set) {
 #pragma unroll
-        for (int tm = 0; tm < TM; ++tm)
+        for (int pt = 0; pt < 3; ++pt)
 #pragma unroll
-            for (int tn = 0; tn < TN; ++tn) {
-                acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fal[set][tm], fbh[set][tn], acc[tm][tn], 0, 0, 0);
-                acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fah[set][tm], fbl[set][tn], acc[tm][tn], 0, 0, 0);
-                acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fah[set][tm], fbh[set][tn], acc[tm][tn], 0, 0, 0);
-            }
+            for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+                for (int tn = 0; tn < TN; ++tn)
+                    acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(pt == 0 ? fal[set][tm] : fah[set][tm],
+                                                                         pt == 1 ? fbl[set][tn] : fbh[set][tn],
+                                                                         acc[tm][tn], 0, 0, 0);
     };
 
-    // same two-phase software pipeline as the fp32 kernel: one barrier per 32-K stage, loads a full stage ahead
-    load_tile(k0);
-    store_tile(0);
-    load_tile(k0 + 1 < k1 ? k0 + 1 : k0);
+    // two-phase software pipeline, one barrier per 32-K stage; LDS stage (kt - k0) & 1 holds stage kt, register set
+    // (kt - k0) & 1 carries stage kt on its way to LDS, and the loads of stage kt + 3 are issued as soon as set
+    // (kt + 1) & 1 has been stored.  The loop is unrolled by two so that the set / stage indices are literals.
+    // sched_group_barrier pins "1 MFMA, then a few of the other instructions" inside each phase, so that the conversion
+    // VALU, the LDS traffic and the global loads issue in the shadow of the 32-cycle MFMAs instead of in front of them.
+    constexpr int kMfma = 3 * TM * TN;   // per phase
+    auto interleave_a = [&]() {
+#pragma unroll
+        for (int i = 0; i < kMfma; ++i) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                   // 1 MFMA
+            __builtin_amdgcn_sched_group_barrier(0x306, 84 / kMfma + 1, 0);      // VALU | SALU | DS
+        }
+    };
+    auto interleave_b = [&]() {
+#pragma unroll
+        for (int i = 0; i < kMfma; ++i) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                   // 1 MFMA
+            __builtin_amdgcn_sched_group_barrier(0x126, 24 / kMfma + 1, 0);      // VALU | SALU | VMEM read | DS read
+        }
+    };
+    load_tile(k0, 0); advance();
+    load_tile(k0 + 1, 1); advance();
+    store_tile(0, 0);
+    load_tile(k0 + 2, 0); advance();
     __syncthreads();
     read_frags(0, 0, 0);
-    for (int kt = k0; kt < k1; ++kt) {
-        const int cur = (kt - k0) & 1;
-        read_frags(cur, 1, 1);
-        store_tile(cur ^ 1);
+    for (int kt = k0; kt < k1; kt += 2) {
+        read_frags(0, 1, 1);
+        store_tile(1, 1);          // stage kt + 1
         mfma_steps(0);
+        interleave_a();
         __syncthreads();
-        load_tile(kt + 2 < k1 ? kt + 2 : k1 - 1);
-        read_frags(cur ^ 1, 0, 0);
+        load_tile(kt + 3, 1);
+        read_frags(1, 0, 0);
         mfma_steps(1);
+        interleave_b();
+        advance();
+        if (kt + 1 >= k1) break;
+        read_frags(1, 1, 1);
+        store_tile(0, 0);          // stage kt + 2
+        mfma_steps(0);
+        interleave_a();
+        __syncthreads();
+        load_tile(kt + 4, 0);
+        read_frags(0, 0, 0);
+        mfma_steps(1);
+        interleave_b();
+        advance();
     }
     __syncthreads();
 
@@ -238,24 +378,30 @@ __device__ __forceinline__ void gemm_segment_f16(const GemmConv& p, _Float16* ld
     }
 }
 
-template <int TM, int TN, bool TR, bool SK>
+template <int TM, int TN, bool TR, bool SK, bool UNI>
 __global__ void __launch_bounds__(NT, 2)
 conv_gemm_f16_kernel(GemmConv p) {
     using G = F16Geo<TM, TN>;
     __shared__ __attribute__((aligned(16))) _Float16 lds[2 * G::kStageHalves];
     const int nk = (p.K + HBK - 1) / HBK;
     if (!SK) {
-        gemm_segment_f16<TM, TN, TR>(p, lds, xcd_remap(blockIdx.x, p.mtiles * p.ntiles), 0, nk, nk, nullptr);
+        gemm_segment_f16<TM, TN, TR, UNI>(p, lds, xcd_remap(blockIdx.x, p.mtiles * p.ntiles), 0, nk, nk, nullptr);
     } else {
+        // hybrid schedule: whole rounds of tiles data-parallel (all workgroups of an XCD walk K in step and share their
+        // operands through L2), then ONE stream-K pass that splits the K stages of the leftover tiles evenly
         const int g = xcd_remap(blockIdx.x, gridDim.x);
-        int u = g * p.sk_units;
+        for (int tile = g; tile < p.sk_dp; tile += gridDim.x) {
+            gemm_segment_f16<TM, TN, TR, UNI>(p, lds, tile, 0, nk, nk, nullptr);
+            __syncthreads();
+        }
+        int u = p.sk_dp * nk + g * p.sk_units;
         const int total = p.mtiles * p.ntiles * nk;
         const int u_end = min(total, u + p.sk_units);
         bool first = true;
         while (u < u_end) {
             const int tile = fdiv(u, p.div_nk), k0 = u - tile * nk;
             const int k1 = min(nk, k0 + (u_end - u));
-            gemm_segment_f16<TM, TN, TR>(p, lds, tile, k0, k1, nk,
+            gemm_segment_f16<TM, TN, TR, UNI>(p, lds, tile, k0, k1, nk,
                                          p.sk_partial + (int64_t)(2 * g + (first ? 0 : 1)) * (G::BM * G::BN));
             u += k1 - k0;
             first = false;
@@ -271,8 +417,8 @@ conv_gemm_f16_fixup_kernel(GemmConv p) {
     using G = F16Geo<TM, TN>;
     __shared__ float red[4 * G::BN];
     const int nk = (p.K + HBK - 1) / HBK;
-    const int tile = blockIdx.x;
-    const int ua = tile * nk, ub = ua + nk - 1;
+    const int tile = p.sk_dp + blockIdx.x;               // only the leftover tiles were stream-K'd
+    const int ua = blockIdx.x * nk, ub = ua + nk - 1;    // unit range relative to the start of the stream-K pass
     const int ga = ua / p.sk_units, gb = ub / p.sk_units;
     if (ga == gb) return;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -285,7 +431,7 @@ conv_gemm_f16_fixup_kernel(GemmConv p) {
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
     for (int g = ga; g <= gb; ++g) {
         const int first_tile = (g * p.sk_units) / nk;
-        const float* o = p.sk_partial + (int64_t)(2 * g + (first_tile == tile ? 0 : 1)) * (G::BM * G::BN) +
+        const float* o = p.sk_partial + (int64_t)(2 * g + (first_tile == (int)blockIdx.x ? 0 : 1)) * (G::BM * G::BN) +
                          wv * (TM * TN * 16 * 64) + lane;
 #pragma unroll
         for (int tm = 0; tm < TM; ++tm)
@@ -299,7 +445,7 @@ conv_gemm_f16_fixup_kernel(GemmConv p) {
 }
 
 struct F16Shape {
-    int tm, tn, mtiles, ntiles, nk, sk_wgs, sk_units;
+    int tm, tn, mtiles, ntiles, nk, sk_wgs, sk_units, sk_dp;
     bool sk;
     size_t ws_bytes;
 };
@@ -319,20 +465,24 @@ F16Shape f16_shape(int M, int cd, int K) {
     const int tiles = g.mtiles * g.ntiles;
     const double rounds = tiles / 256.0;
     const double waste = 1.0 - rounds / (double)(int)(rounds + 0.999999);
-    g.sk = tiles < 8 * 256 && waste > 0.08 && g.nk >= 32;   // measured: below ~32 K stages the fix-up pass costs more than the tail it removes
+    int sk_min_nk = 32;   // measured: below ~32 K stages the fix-up pass costs more than the tail it removes
+    if (const char* e = getenv("DCN_GEMM_SK_MIN_NK")) sk_min_nk = atoi(e);
+    g.sk = tiles < 8 * 256 && waste > 0.08 && g.nk >= sk_min_nk;
     int wgs = 512;
     if (const char* e = getenv("DCN_GEMM_SK")) {
         const int v = atoi(e);
         if (v == 0) g.sk = false;
         if (v > 1) { g.sk = g.nk >= 2; wgs = v; }
     }
-    g.sk_wgs = 0; g.sk_units = 0; g.ws_bytes = 0;
+    g.sk_wgs = 0; g.sk_units = 0; g.sk_dp = 0; g.ws_bytes = 0;
     if (g.sk) {
-        const int64_t total = (int64_t)tiles * g.nk;
-        if (total >= ((int64_t)1 << 30)) { g.sk = false; return g; }
-        if (wgs > total / 2) wgs = (int)(total / 2) > 0 ? (int)(total / 2) : 1;
+        if ((int64_t)tiles * g.nk >= ((int64_t)1 << 30)) { g.sk = false; return g; }
+        g.sk_dp = tiles / wgs * wgs;                       // whole rounds stay data-parallel
+        const int64_t total = (int64_t)(tiles - g.sk_dp) * g.nk;
+        if (total == 0) { g.sk = false; g.sk_dp = 0; return g; }
+        if (g.sk_dp == 0 && wgs > total / 2) wgs = (int)(total / 2) > 0 ? (int)(total / 2) : 1;
         g.sk_units = (int)((total + wgs - 1) / wgs);
-        g.sk_wgs = (int)((total + g.sk_units - 1) / g.sk_units);
+        g.sk_wgs = g.sk_dp > 0 ? wgs : (int)((total + g.sk_units - 1) / g.sk_units);
         g.ws_bytes = (size_t)2 * g.sk_wgs * (64 * g.tm) * (64 * g.tn) * sizeof(float);
     }
     return g;
@@ -354,21 +504,34 @@ int launch_gemm_f16(GemmConv& p, void* workspace, hipStream_t st) {
     p.div_nt = make_fastdiv(g.ntiles);
     p.div_nk = make_fastdiv(g.nk);
     p.sk_units = sk ? g.sk_units : 0;
+    p.sk_dp = sk ? g.sk_dp : 0;
     p.sk_partial = sk ? (float*)workspace : nullptr;
-    const dim3 grid(sk ? g.sk_wgs : g.mtiles * g.ntiles), fgrid(g.mtiles * g.ntiles), block(NT);
-#define DCN_GEMM16(TM, TN)                                                                                          \
-    do {                                                                                                            \
-        if (sk) {                                                                                                   \
-            if (p.transposed) hipLaunchKernelGGL((conv_gemm_f16_kernel<TM, TN, true, true>), grid, block, 0, st, p); \
-            else hipLaunchKernelGGL((conv_gemm_f16_kernel<TM, TN, false, true>), grid, block, 0, st, p);             \
-            hipLaunchKernelGGL((conv_gemm_f16_fixup_kernel<TM, TN>), fgrid, block, 0, st, p);                        \
-        } else {                                                                                                    \
-            if (p.transposed) hipLaunchKernelGGL((conv_gemm_f16_kernel<TM, TN, true, false>), grid, block, 0, st, p); \
-            else hipLaunchKernelGGL((conv_gemm_f16_kernel<TM, TN, false, false>), grid, block, 0, st, p);            \
-        }                                                                                                           \
+    // uniform-tap fast path: whole 32-K stages inside one filter tap, tensors addressable through 2 GiB buffer resources
+    const int64_t src_bytes = (int64_t)p.M / (p.hd * p.wd) * p.hs * p.ws * p.cs * 4, w_bytes = (int64_t)p.cd * p.kp * 2;
+    bool uni = (p.cs % HBK) == 0 && src_bytes <= ((int64_t)1 << 31) && w_bytes <= ((int64_t)1 << 31);
+    if (const char* e = getenv("DCN_GEMM_UNI")) uni = uni && atoi(e) != 0;
+    p.src_bytes = uni ? (unsigned)src_bytes : 0u;
+    p.w_bytes = uni ? (unsigned)w_bytes : 0u;
+    const dim3 grid(sk ? g.sk_wgs : g.mtiles * g.ntiles), fgrid(g.mtiles * g.ntiles - g.sk_dp), block(NT);
+#define DCN_GEMM16_K(TM, TN, TR, SK)                                                                        \
+    do {                                                                                                    \
+        if (uni) hipLaunchKernelGGL((conv_gemm_f16_kernel<TM, TN, TR, SK, true>), grid, block, 0, st, p);   \
+        else hipLaunchKernelGGL((conv_gemm_f16_kernel<TM, TN, TR, SK, false>), grid, block, 0, st, p);      \
+    } while (0)
+#define DCN_GEMM16(TM, TN)                                                                     \
+    do {                                                                                       \
+        if (sk) {                                                                              \
+            if (p.transposed) DCN_GEMM16_K(TM, TN, true, true);                                \
+            else DCN_GEMM16_K(TM, TN, false, true);                                            \
+            hipLaunchKernelGGL((conv_gemm_f16_fixup_kernel<TM, TN>), fgrid, block, 0, st, p);  \
+        } else {                                                                               \
+            if (p.transposed) DCN_GEMM16_K(TM, TN, true, false);                               \
+            else DCN_GEMM16_K(TM, TN, false, false);                                           \
+        }                                                                                      \
     } while (0)
     if (g.tm == 1) { if (g.tn == 1) DCN_GEMM16(1, 1); else DCN_GEMM16(1, 2); }
     else { if (g.tn == 1) DCN_GEMM16(2, 1); else DCN_GEMM16(2, 2); }
+#undef DCN_GEMM16_K
 #undef DCN_GEMM16
     return dcn::check_launch();
 }

@@ -43,7 +43,8 @@ struct GemmConv {
     const float* a_absmax;
     float b_inv_scale;
     int kp;
-    int hs, ws, cs, hd, wd, cd, kh, kw, stride, sshift, pad, dil, ldc, M, K, transposed, mtiles, ntiles, sk_units;
+    unsigned src_bytes, w_bytes;   // extents of src and of each weight image (buffer-resource bounds; 0: tensor too large)
+    int hs, ws, cs, hd, wd, cd, kh, kw, stride, sshift, pad, dil, ldc, M, K, transposed, mtiles, ntiles, sk_units, sk_dp;
     FastDiv div_hw, div_w, div_cs, div_kw, div_nt, div_nk;
 };
 

@@ -319,6 +319,32 @@ static inline hipemu_f32x16 hipemu_mfma_32x32x16f16(hipemu_h8 a, hipemu_h8 b, hi
     wave_barrier();
     return c;
 }
+// raw buffer resources (stride 0): loads whose byte offset (voffset; the scalar offset is NOT range-checked, as on the
+// hardware) reaches past num_records return zeros
+struct hipemu_buffer_rsrc { const char* base; unsigned num_records; };
+typedef unsigned hipemu_u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned hipemu_u32x2 __attribute__((ext_vector_type(2)));
+static inline hipemu_buffer_rsrc hipemu_make_buffer_rsrc(const void* p, short, int num_records, int) {
+    return hipemu_buffer_rsrc{(const char*)p, (unsigned)num_records};
+}
+static inline hipemu_u32x4 hipemu_raw_buffer_load_b128(hipemu_buffer_rsrc r, int voffset, int soffset, int) {
+    hipemu_u32x4 v = {0u, 0u, 0u, 0u};
+    for (int i = 0; i < 4; ++i)
+        if ((unsigned long long)(unsigned)voffset + 4ull * i + 4ull <= r.num_records)
+            { unsigned w; memcpy(&w, r.base + (long long)(unsigned)voffset + (unsigned)soffset + 4 * i, 4); v[i] = w; }
+    return v;
+}
+static inline hipemu_u32x2 hipemu_raw_buffer_load_b64(hipemu_buffer_rsrc r, int voffset, int soffset, int) {
+    hipemu_u32x2 v = {0u, 0u};
+    for (int i = 0; i < 2; ++i)
+        if ((unsigned long long)(unsigned)voffset + 4ull * i + 4ull <= r.num_records)
+            { unsigned w; memcpy(&w, r.base + (long long)(unsigned)voffset + (unsigned)soffset + 4 * i, 4); v[i] = w; }
+    return v;
+}
+#define __amdgpu_buffer_rsrc_t hipemu_buffer_rsrc
+#define __builtin_amdgcn_make_buffer_rsrc(p, stride, n, flags) hipemu_make_buffer_rsrc((const void*)(p), stride, n, flags)
+#define __builtin_amdgcn_raw_buffer_load_b128 hipemu_raw_buffer_load_b128
+#define __builtin_amdgcn_raw_buffer_load_b64 hipemu_raw_buffer_load_b64
 #define __builtin_amdgcn_mfma_f32_32x32x16_f16 hipemu_mfma_32x32x16f16
 #define __builtin_amdgcn_mfma_f32_32x32x2f32 hipemu_mfma_32x32x2f32
 #define __builtin_amdgcn_mfma_f32_16x16x4f32 hipemu_mfma_16x16x4f32

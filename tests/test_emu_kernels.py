@@ -165,6 +165,11 @@ F16_CASES = [
     (3, 7, 7, 8, 8, 3, 1, 1, 1),
     (1, 6, 5, 64, 72, 3, 1, 4, 4),       # K = 576: 18 stages
     (2, 24, 20, 8, 4, 1, 1, 0, 1),       # 1x1, narrow Cout, 960 pixels: several wgrad splits
+    # channel counts that are multiples of 32: the uniform-tap buffer-load path (forward: cin, dgrad: cout)
+    (1, 9, 11, 32, 64, 3, 1, 2, 2),      # dilated, ragged M (99 pixels)
+    (2, 10, 9, 64, 96, 3, 2, 1, 1),      # stride 2 (transposed gather with the divisibility test), Cout not a tile multiple
+    (1, 12, 10, 64, 128, 1, 2, 0, 1),    # 1x1 stride-2 downsample
+    (1, 5, 6, 96, 32, 3, 1, 4, 4),       # dilation 4 on a 5x6 map: most taps fall outside the image
 ]
 
 
