@@ -15,7 +15,7 @@ def main():
     tot = sum(float(r["TotalDurationNs"]) for r in rows)
     for h in sys.argv[2:]:
         print("# " + h)
-    print("# kernel | calls | total ms | avg us | % of GPU kernel time   (total %.1f ms)" % (tot / 1e6))
+    print("# kernel | calls | total ms | avg us | %% of GPU kernel time   (total %.1f ms)" % (tot / 1e6))
     for r in rows:
         name = r["Name"].replace("(anonymous namespace)::", "")
         name = re.sub(r"\(.*$", "", name)[:84]
