@@ -239,7 +239,15 @@ int dcn_conv_forward_f16(const dcn_conv_desc* c, const float* in, const void* w_
 int dcn_conv_dgrad_f16(const dcn_conv_desc* c, const float* dout, const void* wt_hi, const void* wt_lo, float w_scale,
                        const float* dout_absmax, const float* add, float* din, void* workspace, void* stream);
 
-int dcn_conv_wgrad_f16(const dcn_conv_desc* c, const float* in, const float* dout, const float* dout_absmax, float* dw,
+/* wgrad consumes PRE-SPLIT operands (every element takes part in many tiles, so the fp32 -> fp16 hi/lo split is done
+ * once per tensor).  Both split tensors have the byte size of their fp32 source:
+ *   activations  xs[pixel][c/4][hi x4 | lo x4]                       dcn_split_act_f16 (n elements, n % 4 == 0)
+ *   out-gradient dq[m/4][4 sub-planes][ldc/4][2 channels x 4 pixels], scaled by the power of two chosen from *absmax
+ *                (dcn_split_grad_blocked_f16; dcn_grad_blocked_bytes(M, ldc) bytes).  dout_absmax = the same scalar. */
+int dcn_split_act_f16(const float* src, void* xs, int64_t n, void* stream);
+size_t dcn_grad_blocked_bytes(int m, int ld);
+int dcn_split_grad_blocked_f16(const float* dy, int m, int ld, const float* absmax, void* dq, void* stream);
+int dcn_conv_wgrad_f16(const dcn_conv_desc* c, const void* xs, const void* dq, const float* dout_absmax, float* dw,
                        void* slabs, void* stream);
 size_t dcn_conv_wgrad_workspace_f16(const dcn_conv_desc* c);
 

@@ -78,6 +78,7 @@ template <int TM, int TN> struct F16Geo {
 };
 
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 constexpr int kOob = (int)0x80000000;   // voffset that fails the bounds check of any buffer <= 2 GiB: the load returns 0
 
 // UNI: cs % 32 == 0, so a 32-K stage lies inside ONE filter tap and everything about the tap is wave-uniform: the
@@ -538,20 +539,73 @@ int launch_gemm_f16(GemmConv& p, void* workspace, hipStream_t st) {
 
 // ----------------------------------------------------------------------------------------------- wgrad, f16x3
 // dW[n][kcol] = sum_m dout[m][n] * in[pix(m, tap(kcol))][c(kcol)]  as a GEMM whose reduction index is the pixel m.
-// Both operands are pixel-major in HBM but the fp16 MFMA wants 8 consecutive reduction elements per lane, so the
-// staging transposes in registers: a work-item owns a 4-pixel x 4-channel micro-tile (four 16-byte loads along the
-// channel axis = 128-byte segments per 8 lanes), converts to (hi, lo) and writes four 8-byte k-runs into the same
-// [row][32 k + pad] fp16 LDS image the gather-GEMM kernel uses (lane order chosen so the writes are conflict-free).
+// Every operand element takes part in many tiles here (an input element in up to taps x Cout/128 of them, a gradient
+// element in K/128), so the fp32 -> (hi, lo) split is done ONCE per tensor by the two kernels below and the GEMM
+// kernel's operand path is pure data movement:
+//   * gradient tensor, "pixel-blocked": dq[m >> 2][sub][n >> 2][8 halves], sub = 0: hi of channels (4q, 4q+1) x pixels
+//     4(m>>2)..+3, 1: hi of (4q+2, 4q+3), 2 / 3: the lo parts.  A work-item's 4-pixel x 4-channel micro-tile is four 16-byte
+//     loads (8 lanes = 128 contiguous bytes each), and every channel's 4 consecutive pixels (= 4 consecutive reduction
+//     indices) are one 8-byte run that goes to LDS as it is;
+//   * activation tensor, channel-contiguous like the fp32 tensor (the gather shifts pixels by the filter tap, so
+//     pixel-blocking is impossible): xs[pixel][c >> 2][hi x4 | lo x4] -- one 16-byte load per (pixel, channel quad),
+//     transposed 4x4 in registers with byte-permutes.
+// Both have the byte size of the fp32 tensor.  LDS image, fragment reads and MFMA loop are those of the gather-GEMM kernel.
+__global__ void __launch_bounds__(256)
+split_act_kernel(const float* __restrict__ src, u32x4* __restrict__ dst, int64_t n4) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+        h4 a, b;
+        split4_unscaled(reinterpret_cast<const float4*>(src)[i], a, b);
+        const u32x2 ua = __builtin_bit_cast(u32x2, a), ub = __builtin_bit_cast(u32x2, b);
+        dst[i] = u32x4{ua[0], ua[1], ub[0], ub[1]};
+    }
+}
+
+// dy [M][ld] fp32 -> dq (layout above); one work-item per (pixel quad, channel quad)
+__global__ void __launch_bounds__(256)
+split_grad_blocked_kernel(const float* __restrict__ dy, int M, int ld, const float* __restrict__ absmax,
+                          u32x4* __restrict__ dq) {
+    const float s = absmax ? pow2_scale(*absmax) : 1.f;
+    const int c4n = ld >> 2;
+    const int64_t total = (int64_t)((M + 3) >> 2) * c4n;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int64_t q = i / c4n;
+        const int cq = (int)(i - q * c4n);
+        float v[4][4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int64_t m = q * 4 + r;
+            const float4 x = m < M ? *reinterpret_cast<const float4*>(dy + m * ld + cq * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+            v[r][0] = x.x; v[r][1] = x.y; v[r][2] = x.z; v[r][3] = x.w;
+        }
+        u32x2 hi[4], lo[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            h4 a, b;
+            split4(make_float4(v[0][e], v[1][e], v[2][e], v[3][e]), s, a, b);
+            hi[e] = __builtin_bit_cast(u32x2, a);
+            lo[e] = __builtin_bit_cast(u32x2, b);
+        }
+        u32x4* o = dq + q * 4 * c4n + cq;
+        o[0] = u32x4{hi[0][0], hi[0][1], hi[1][0], hi[1][1]};
+        o[c4n] = u32x4{hi[2][0], hi[2][1], hi[3][0], hi[3][1]};
+        o[2 * c4n] = u32x4{lo[0][0], lo[0][1], lo[1][0], lo[1][1]};
+        o[3 * c4n] = u32x4{lo[2][0], lo[2][1], lo[3][0], lo[3][1]};
+    }
+}
+
 struct WgradF16 {
-    const float* in;    // [n, hin, win, cin]
-    const float* dout;  // [M][ldo]
-    float* slab;        // [splits][cout][K]
+    const void* xs;       // split activations [n, hin, win, cin/4][hi x4 | lo x4]
+    const void* dq;       // split gradient, pixel-blocked (layout above), pre-scaled by pow2_scale(*d_absmax)
+    float* slab;          // [splits][cout][K]
     const float* d_absmax;
+    unsigned x_bytes, d_bytes;
     int hin, win, cin, hout, wout, cout, kh, kw, stride, pad, dil, ldo, M, K, splits, rows_per_split, ntiles_n, ntiles_k;
     FastDiv div_hw, div_w, div_cin, div_kw;
 };
 
-template <int TM>   // 64*TM output channels x 128 K columns per workgroup
+// FAST: wout % 4 == 0 and wout >= 32 (every real layer): a work-item's pixel quad lies in one image row and its
+// (image, y, x) position is carried from stage to stage with a few selects instead of being re-derived by division.
+template <int TM, bool FAST>   // 64*TM output channels x 128 K columns per workgroup
 __global__ void __launch_bounds__(NT, 2)
 conv_wgrad_f16_kernel(WgradF16 p) {
     constexpr int BM = 64 * TM, BN = 128, kStage = 2 * (BM + BN) * LDH;
@@ -566,6 +620,9 @@ conv_wgrad_f16_kernel(WgradF16 p) {
     const int m_begin = split * p.rows_per_split;
     const int m_end = min(p.M, m_begin + p.rows_per_split);
 
+    const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.xs), 0, (int)p.x_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_d = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.dq), 0, (int)p.d_bytes, 0x00020000);
+
     // micro-tile of this work-item: pixels 4*pq .. 4*pq+3 of the stage, channel quad cq (dout: n0 + 4*cq, in: j0 + 4*cq)
     const int pq = tid & 7, cq = tid >> 3;                    // 8 pixel quads x 32 channel quads
     const bool dact = 4 * cq < BM;                            // (BM = 64: only half of the work-items stage dout)
@@ -577,51 +634,98 @@ conv_wgrad_f16_kernel(WgradF16 p) {
     const int tap = fdiv(kc0, p.div_cin), cc = kc0 - tap * p.cin;
     const int tr = fdiv(tap, p.div_kw), ts = tap - tr * p.kw;
     const int oy = tr * p.dil - p.pad, ox = ts * p.dil - p.pad;
-    const float sd = p.d_absmax ? pow2_scale(*p.d_absmax) : 1.f;
-    float4 rd[4], rx[4];
-    unsigned okm = 0;
+    u32x4 rd[4];       // sub-planes: hi (ch 0,1), hi (ch 2,3), lo (ch 0,1), lo (ch 2,3), each x 4 pixels
+    u32x4 rx[4];       // per pixel: hi x4 | lo x4
+    const int d_sub = (p.ldo >> 2) * 16;   // bytes between sub-planes of one pixel quad
 
-    auto load_tile = [&](int m_base) {
-        okm = 0;
+    // Addresses of a stage are prepared ahead (prep: VALU only, placed before the barrier) so that the loads of the next
+    // stage issue back to back right behind the barrier; everything is 32-bit unsigned arithmetic and branch-free,
+    // invalid pieces get the out-of-range offset and load zeros.
+    int doff, xoff[4];
+    int px = 0, py = 0, pimg = 0;   // FAST: position of pixel 4*pq of the stage being prepared
+    if (FAST) {
+        const int m = m_begin + 4 * pq;
+        const int mm = m < p.M ? m : 0;
+        pimg = fdiv(mm, p.div_hw);
+        const int rem = mm - pimg * p.div_hw.d;
+        py = fdiv(rem, p.div_w);
+        px = rem - py * p.div_w.d;
+    }
+    const unsigned cin4 = (unsigned)p.cin * 4u;
+    auto prep = [&](int m_base) {
+        const int mq = (m_base >> 2) + pq;                    // (m_base is a multiple of 32)
+        const bool dok = nval & (4 * mq < m_end);
+        doff = dok ? (int)((unsigned)mq * 4u * (unsigned)d_sub + (unsigned)(ncol >> 2) * 16u) : kOob;
+        if (FAST) {
+            const bool qval = kval & (m_base + 4 * pq < m_end);
+            const int sy = py * p.stride + oy;
+            const bool oky = qval & ((unsigned)sy < (unsigned)p.hin);
+            const unsigned rowb = ((unsigned)(pimg * p.hin + sy) * (unsigned)p.win) * cin4 + (unsigned)cc * 4u;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int m = m_base + 4 * pq + i;
-            const bool mval = m < m_end;
-            const int mm = mval ? m : 0;
-            const bool dok = mval & nval;
-            rd[i] = *reinterpret_cast<const float4*>(p.dout + (dok ? mm * p.ldo + ncol : 0));
-            const int img = fdiv(mm, p.div_hw), rem = mm - img * p.div_hw.d;
-            const int y = fdiv(rem, p.div_w), x = rem - y * p.div_w.d;
-            const int sy = y * p.stride + oy, sx = x * p.stride + ox;
-            const bool ok = mval & kval & ((unsigned)sy < (unsigned)p.hin) & ((unsigned)sx < (unsigned)p.win);
-            int off = ((img * p.hin + sy) * p.win + sx) * p.cin + cc;
-            off = ok ? off : 0;
-            rx[i] = *reinterpret_cast<const float4*>(p.in + off);
-            okm |= ((dok ? 1u : 0u) << i) | ((ok ? 1u : 0u) << (8 + i));
+            for (int i = 0; i < 4; ++i) {
+                const int sx = (px + i) * p.stride + ox;
+                const bool ok = oky & ((unsigned)sx < (unsigned)p.win);
+                xoff[i] = ok ? (int)(rowb + (unsigned)sx * cin4) : kOob;
+            }
+            px += HBK;                                        // wout >= 32: at most one row wrap per stage
+            const bool wx = px >= p.wout;
+            px -= wx ? p.wout : 0;
+            py += wx ? 1 : 0;
+            const bool wy = py >= p.hout;
+            py = wy ? 0 : py;
+            pimg += wy ? 1 : 0;
+        } else {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int m = m_base + 4 * pq + i;
+                const bool mval = m < m_end;
+                const int mm = mval ? m : 0;
+                const int img = fdiv(mm, p.div_hw), rem = mm - img * p.div_hw.d;
+                const int y = fdiv(rem, p.div_w), x = rem - y * p.div_w.d;
+                const int sy = y * p.stride + oy, sx = x * p.stride + ox;
+                const bool ok = mval & kval & ((unsigned)sy < (unsigned)p.hin) & ((unsigned)sx < (unsigned)p.win);
+                const unsigned off = ((unsigned)((img * p.hin + sy) * p.win + sx)) * cin4 + (unsigned)cc * 4u;
+                xoff[i] = ok ? (int)off : kOob;
+            }
         }
+    };
+    auto issue_loads = [&]() {
+#pragma unroll
+        for (int h = 0; h < 4; ++h) rd[h] = __builtin_amdgcn_raw_buffer_load_b128(rs_d, doff, h * d_sub, 0);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) rx[i] = __builtin_amdgcn_raw_buffer_load_b128(rs_x, xoff[i], 0, 0);
     };
     auto store_tile = [&](int stage) {
         _Float16* dh = lds + stage * kStage;
         _Float16* dl = dh + BM * LDH;
         _Float16* xh = dl + BM * LDH;
         _Float16* xl = xh + BN * LDH;
-        float dv[4][4], xv[4][4];  // [pixel][channel]
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const bool dok = (okm >> i) & 1u, ok = (okm >> (8 + i)) & 1u;
-            dv[i][0] = dok ? rd[i].x : 0.f; dv[i][1] = dok ? rd[i].y : 0.f; dv[i][2] = dok ? rd[i].z : 0.f; dv[i][3] = dok ? rd[i].w : 0.f;
-            xv[i][0] = ok ? rx[i].x : 0.f; xv[i][1] = ok ? rx[i].y : 0.f; xv[i][2] = ok ? rx[i].z : 0.f; xv[i][3] = ok ? rx[i].w : 0.f;
-        }
+        for (int pl = 0; pl < 2; ++pl) {
+            _Float16* xd = pl ? xl : xh;
+            // 4x4 transpose of halves: channel e of pixels 0..3 = {lo/hi half of dword e>>1 of each pixel}
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {   // channel e of the quad: its 4 consecutive pixels form one 8-byte k-run
-            h4 hi, lo;
-            split4(make_float4(xv[0][e], xv[1][e], xv[2][e], xv[3][e]), 1.f, hi, lo);
-            *reinterpret_cast<h4*>(xh + (4 * cq + e) * LDH + 4 * pq) = hi;
-            *reinterpret_cast<h4*>(xl + (4 * cq + e) * LDH + 4 * pq) = lo;
+            for (int e = 0; e < 4; ++e) {
+                const int w = 2 * pl + (e >> 1);
+                u32x2 o;
+                if ((e & 1) == 0) {
+                    o[0] = (rx[0][w] & 0xffffu) | (rx[1][w] << 16);
+                    o[1] = (rx[2][w] & 0xffffu) | (rx[3][w] << 16);
+                } else {
+                    o[0] = (rx[0][w] >> 16) | (rx[1][w] & 0xffff0000u);
+                    o[1] = (rx[2][w] >> 16) | (rx[3][w] & 0xffff0000u);
+                }
+                *reinterpret_cast<u32x2*>(xd + (4 * cq + e) * LDH + 4 * pq) = o;
+            }
             if (dact) {
-                split4(make_float4(dv[0][e], dv[1][e], dv[2][e], dv[3][e]), sd, hi, lo);
-                *reinterpret_cast<h4*>(dh + (4 * cq + e) * LDH + 4 * pq) = hi;
-                *reinterpret_cast<h4*>(dl + (4 * cq + e) * LDH + 4 * pq) = lo;
+                _Float16* dd = pl ? dl : dh;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    u32x2 o;
+                    o[0] = rd[2 * pl + (e >> 1)][2 * (e & 1)];
+                    o[1] = rd[2 * pl + (e >> 1)][2 * (e & 1) + 1];
+                    *reinterpret_cast<u32x2*>(dd + (4 * cq + e) * LDH + 4 * pq) = o;
+                }
             }
         }
     };
@@ -656,21 +760,25 @@ conv_wgrad_f16_kernel(WgradF16 p) {
     };
     auto mfma_steps = [&](int set) {
 #pragma unroll
-        for (int tm = 0; tm < 2; ++tm)
+        for (int pt = 0; pt < 3; ++pt)
 #pragma unroll
-            for (int tn = 0; tn < CT; ++tn) {
-                f32x16& c = acc[tm][tn];
-                c = __builtin_amdgcn_mfma_f32_32x32x16_f16(fal[set][tm], fbh[set][tn], c, 0, 0, 0);
-                c = __builtin_amdgcn_mfma_f32_32x32x16_f16(fah[set][tm], fbl[set][tn], c, 0, 0, 0);
-                c = __builtin_amdgcn_mfma_f32_32x32x16_f16(fah[set][tm], fbh[set][tn], c, 0, 0, 0);
-            }
+            for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+                for (int tn = 0; tn < CT; ++tn)
+                    acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(pt == 0 ? fal[set][tm] : fah[set][tm],
+                                                                         pt == 1 ? fbl[set][tn] : fbh[set][tn],
+                                                                         acc[tm][tn], 0, 0, 0);
     };
 
     const int nsteps = (m_end - m_begin + HBK - 1) / HBK;
     if (nsteps > 0) {
-        load_tile(m_begin);
+        // (stages past the end of the split prepare out-of-range addresses: their loads return zeros and are never used)
+        prep(m_begin);
+        issue_loads();
+        prep(m_begin + HBK);
         store_tile(0);
-        load_tile(m_begin + (nsteps > 1 ? HBK : 0));
+        issue_loads();
+        prep(m_begin + 2 * HBK);
         __syncthreads();
         read_frags(0, 0, 0);
         for (int st = 0; st < nsteps; ++st) {
@@ -679,13 +787,14 @@ conv_wgrad_f16_kernel(WgradF16 p) {
             store_tile(cur ^ 1);
             mfma_steps(0);
             __syncthreads();
-            load_tile(m_begin + (st + 2 < nsteps ? st + 2 : nsteps - 1) * HBK);
+            issue_loads();                                   // stage st + 2
             read_frags(cur ^ 1, 0, 0);
             mfma_steps(1);
+            prep(m_begin + (st + 3) * HBK);
         }
     }
     // C fragment: row (r) <-> output channel, column (lane & 31) <-> K column: 128-byte coalesced rows
-    const float inv = 1.f / sd;
+    const float inv = 1.f / (p.d_absmax ? pow2_scale(*p.d_absmax) : 1.f);
     float* out = p.slab + (int64_t)split * p.cout * p.K;
 #pragma unroll
     for (int tm = 0; tm < 2; ++tm)
@@ -700,20 +809,34 @@ conv_wgrad_f16_kernel(WgradF16 p) {
         }
 }
 
+// Pixel-range splits: enough workgroups to fill the chip (2 resident per CU), chosen so that the LAST round of
+// workgroups is nearly full -- e.g. 144 tiles x 11 splits = 1584 workgroups = 3.09 rounds of 512 wastes a quarter of the
+// machine, 144 x 10 = 2.81 rounds does not.  Fewer splits win ties (less slab traffic for the reduce pass).
 int wgrad_splits_f16(const dcn_conv_desc* c, int* rows_per_split) {
     const int M = c->n * c->hout * c->wout, K = c->kh * c->kw * c->cin;
     const bool narrow = c->cout <= 64;
     const int tiles = dcn::ceil_div(c->cout, narrow ? 64 : 128) * dcn::ceil_div(K, 128);
-    int splits = dcn::ceil_div(1536, tiles);
+    const int slots = 512;
     const int max_by_rows = (M / (8 * HBK)) > 1 ? (M / (8 * HBK)) : 1;
-    if (splits > max_by_rows) splits = max_by_rows;
-    const int cap = narrow ? 256 : 64;
-    if (splits > cap) splits = cap;
-    if (splits < 1) splits = 1;
-    int rps = dcn::ceil_div(dcn::ceil_div(M, splits), HBK) * HBK;
-    splits = dcn::ceil_div(M, rps);
+    int cap = narrow ? 256 : 64;
+    if (cap > max_by_rows) cap = max_by_rows;
+    const int target = dcn::ceil_div(3 * slots, tiles);
+    int lo = target / 2 > 1 ? target / 2 : 1, hi = target + target / 2;
+    if (hi > cap) hi = cap;
+    if (lo > hi) lo = hi;
+    int best = hi;
+    double best_score = -1.0;
+    for (int s = lo; s <= hi; ++s) {
+        const int rps = dcn::ceil_div(dcn::ceil_div(M, s), HBK) * HBK;
+        const int real = dcn::ceil_div(M, rps);                       // splits actually launched with 32-row granularity
+        const int wgs = real * tiles;
+        const double eff = (double)wgs / (double)(dcn::ceil_div(wgs, slots) * slots);
+        const double score = eff - 0.004 * real - (wgs < slots ? 0.5 * (1.0 - (double)wgs / slots) : 0.0);
+        if (score > best_score) { best_score = score; best = s; }
+    }
+    int rps = dcn::ceil_div(dcn::ceil_div(M, best), HBK) * HBK;
     *rows_per_split = rps;
-    return splits;
+    return dcn::ceil_div(M, rps);
 }
 
 bool valid_desc16(const dcn_conv_desc* c) {
@@ -775,6 +898,26 @@ extern "C" int dcn_conv_dgrad_f16(const dcn_conv_desc* c, const float* dout, con
     return launch_gemm_f16(p, workspace, (hipStream_t)stream);
 }
 
+extern "C" int dcn_split_act_f16(const float* src, void* dst, int64_t n, void* stream) {
+    if (!src || !dst || n < 4 || (n % 4) != 0) return DCN_E_INVALID;
+    const int64_t n4 = n / 4;
+    const unsigned blocks = (unsigned)(dcn::ceil_div64(n4, 256) > 8192 ? 8192 : dcn::ceil_div64(n4, 256));
+    hipLaunchKernelGGL(split_act_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, src, (u32x4*)dst, n4);
+    return dcn::check_launch();
+}
+
+extern "C" size_t dcn_grad_blocked_bytes(int m, int ld) { return (size_t)((m + 3) / 4) * 4 * (size_t)ld * 4; }
+
+extern "C" int dcn_split_grad_blocked_f16(const float* dy, int m, int ld, const float* absmax, void* dq, void* stream) {
+    if (!dy || !dq || m < 1 || ld < 4 || (ld % 4) != 0) return DCN_E_INVALID;
+    const int64_t total = (int64_t)((m + 3) / 4) * (ld / 4);
+    const unsigned blocks = (unsigned)(dcn::ceil_div64(total, 256) > 8192 ? 8192 : dcn::ceil_div64(total, 256));
+    hipLaunchKernelGGL(split_grad_blocked_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, dy, m, ld, absmax,
+                       (u32x4*)dq);
+    return dcn::check_launch();
+}
+
+// slab bytes only; the split operands are the caller's (dcn_split_act_f16 / dcn_split_grad_blocked_f16)
 extern "C" size_t dcn_conv_wgrad_workspace_f16(const dcn_conv_desc* c) {
     if (!valid_desc16(c)) return 0;
     int rps;
@@ -782,14 +925,15 @@ extern "C" size_t dcn_conv_wgrad_workspace_f16(const dcn_conv_desc* c) {
     return (size_t)splits * c->cout * c->kh * c->kw * c->cin * sizeof(float);
 }
 
-extern "C" int dcn_conv_wgrad_f16(const dcn_conv_desc* c, const float* in, const float* dout, const float* dout_absmax,
+extern "C" int dcn_conv_wgrad_f16(const dcn_conv_desc* c, const void* xs, const void* dq, const float* dout_absmax,
                                   float* dw, void* slabs, void* stream) {
-    if (!valid_desc16(c) || !in || !dout || !dw || !slabs || (c->ldc % 4) != 0) return DCN_E_INVALID;
-    if ((int64_t)c->n * c->hin * c->win * c->cin >= ((int64_t)1 << 31) ||
-        (int64_t)c->n * c->hout * c->wout * c->ldc >= ((int64_t)1 << 31))
-        return DCN_E_UNSUPPORTED;
+    if (!valid_desc16(c) || !xs || !dq || !dw || !slabs || (c->ldc % 4) != 0) return DCN_E_INVALID;
+    const int64_t x_bytes = (int64_t)c->n * c->hin * c->win * c->cin * 4;
+    const int64_t d_bytes = (int64_t)dcn_grad_blocked_bytes(c->n * c->hout * c->wout, c->ldc);
+    if (x_bytes > ((int64_t)1 << 31) || d_bytes > ((int64_t)1 << 31)) return DCN_E_UNSUPPORTED;
     WgradF16 p;
-    p.in = in; p.dout = dout; p.d_absmax = dout_absmax;
+    p.xs = xs; p.dq = dq;
+    p.d_absmax = dout_absmax; p.x_bytes = (unsigned)x_bytes; p.d_bytes = (unsigned)d_bytes;
     p.hin = c->hin; p.win = c->win; p.cin = c->cin; p.hout = c->hout; p.wout = c->wout; p.cout = c->cout;
     p.kh = c->kh; p.kw = c->kw; p.stride = c->stride; p.pad = c->pad; p.dil = c->dil; p.ldo = c->ldc;
     p.M = c->n * c->hout * c->wout; p.K = c->kh * c->kw * c->cin;
@@ -801,8 +945,14 @@ extern "C" int dcn_conv_wgrad_f16(const dcn_conv_desc* c, const float* in, const
     p.slab = p.splits == 1 ? dw : (float*)slabs;
     hipStream_t st = (hipStream_t)stream;
     const dim3 grid(p.ntiles_n * p.ntiles_k * p.splits), block(NT);
-    if (narrow) hipLaunchKernelGGL(conv_wgrad_f16_kernel<1>, grid, block, 0, st, p);
-    else hipLaunchKernelGGL(conv_wgrad_f16_kernel<2>, grid, block, 0, st, p);
+    const bool fast = (c->wout % 4) == 0 && c->wout >= HBK;
+    if (narrow) {
+        if (fast) hipLaunchKernelGGL((conv_wgrad_f16_kernel<1, true>), grid, block, 0, st, p);
+        else hipLaunchKernelGGL((conv_wgrad_f16_kernel<1, false>), grid, block, 0, st, p);
+    } else {
+        if (fast) hipLaunchKernelGGL((conv_wgrad_f16_kernel<2, true>), grid, block, 0, st, p);
+        else hipLaunchKernelGGL((conv_wgrad_f16_kernel<2, false>), grid, block, 0, st, p);
+    }
     if (p.splits > 1) launch_wgrad_reduce((const float*)slabs, dw, (int64_t)c->cout * p.K / 4, p.splits, st);
     return dcn::check_launch();
 }

@@ -3,6 +3,7 @@ PyTorch fp32 on CPU: fp32-MFMA implicit-GEMM convolution (forward / dgrad / wgra
 sums), bilinear upsample and its backward.  The MFMA fragment maps, LDS images and index arithmetic executed
 here are the ones that run on the GPU."""
 import ctypes
+import math
 
 import pytest
 import torch
@@ -170,6 +171,10 @@ F16_CASES = [
     (2, 10, 9, 64, 96, 3, 2, 1, 1),      # stride 2 (transposed gather with the divisibility test), Cout not a tile multiple
     (1, 12, 10, 64, 128, 1, 2, 0, 1),    # 1x1 stride-2 downsample
     (1, 5, 6, 96, 32, 3, 1, 4, 4),       # dilation 4 on a 5x6 map: most taps fall outside the image
+    # output rows of >= 32 pixels, width % 4 == 0: wgrad's carried (image, y, x) position instead of divisions
+    (1, 3, 36, 8, 8, 3, 1, 1, 1),
+    (1, 6, 72, 4, 12, 3, 2, 1, 1),       # stride 2
+    (2, 2, 40, 8, 16, 1, 1, 0, 1),       # row and image wrap inside a split
 ]
 
 
@@ -227,5 +232,19 @@ def test_conv_f16x3_forward_dgrad(L, case, tile_m, sk, monkeypatch):
     # wgrad: pixels are the reduction index, dy again 1e-7-scaled; fixed split order -> deterministic
     dw = torch.full((cout, k, k, cin), float("nan"))
     slabs = torch.empty(max(lib.dcn_conv_wgrad_workspace_f16(ctypes.byref(d)), 4) // 4)
-    assert lib.dcn_conv_wgrad_f16(ctypes.byref(d), L.ptr(x_nhwc), L.ptr(dout), L.ptr(amax), L.ptr(dw), L.ptr(slabs), None) == 0
+    M = n * hout * wout
+    xs = torch.full((x_nhwc.numel() // 4, 8), float("nan"), dtype=torch.float16)     # [pixel*c/4][hi x4 | lo x4]
+    assert lib.dcn_split_act_f16(L.ptr(x_nhwc), L.ptr(xs), x_nhwc.numel(), None) == 0
+    assert rel_err((xs[:, :4].float() + xs[:, 4:].float()).reshape(x_nhwc.shape), x_nhwc) < 1e-6
+    qb = lib.dcn_grad_blocked_bytes(M, cout)
+    mq = (M + 3) // 4
+    assert qb == mq * 4 * cout * 4
+    dq = torch.full((mq, 4, cout // 4, 2, 4), float("nan"), dtype=torch.float16)     # [m/4][sub][c/4][2 ch][4 px]
+    assert lib.dcn_split_grad_blocked_f16(L.ptr(dout), M, cout, L.ptr(amax), L.ptr(dq), None) == 0
+    rec = dq[:, :2].float() + dq[:, 2:].float()                                       # [mq][2 pairs][c/4][2][4 px]
+    rec = rec.permute(0, 4, 2, 1, 3).reshape(mq * 4, cout)                            # -> [pixel][channel]
+    scale = float(rec[:M].abs().max() / dout.abs().max())
+    assert abs(math.log2(scale) - round(math.log2(scale))) < 1e-3 and 1024 < scale * float(amax) <= 4096
+    assert rel_err(rec[:M] / scale, dout.reshape(M, cout)) < 1e-6 and float(rec[M:].abs().sum()) == 0
+    assert lib.dcn_conv_wgrad_f16(ctypes.byref(d), L.ptr(xs), L.ptr(dq), L.ptr(amax), L.ptr(dw), L.ptr(slabs), None) == 0
     assert rel_err(dw, w.grad.permute(0, 2, 3, 1)) < 5e-6

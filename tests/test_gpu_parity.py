@@ -208,10 +208,16 @@ def test_conv_f16x3_kernels_vs_torch_cpu(L, case):
     assert rel_err(din.cpu(), x.grad.permute(0, 2, 3, 1) + add) < 1e-5
     dw = torch.full((cout, k, k, cin), float("nan"), device="cuda")
     slab = torch.empty(max(lib.dcn_conv_wgrad_workspace_f16(ctypes.byref(d)), 4) // 4, device="cuda")
-    assert lib.dcn_conv_wgrad_f16(ctypes.byref(d), L.ptr(xg), L.ptr(dg), L.ptr(amax), L.ptr(dw), L.ptr(slab), st) == 0
+    M = n * hout * wout
+    xs = torch.empty(xg.numel(), dtype=torch.float32, device="cuda")                  # split tensors: fp32-sized byte buffers
+    assert lib.dcn_split_act_f16(L.ptr(xg), L.ptr(xs), xg.numel(), st) == 0
+    dq = torch.empty(lib.dcn_grad_blocked_bytes(M, cout) // 4, dtype=torch.float32, device="cuda")
+    assert lib.dcn_split_grad_blocked_f16(L.ptr(dg), M, cout, L.ptr(amax), L.ptr(dq), st) == 0
+    wg_args = (ctypes.byref(d), L.ptr(xs), L.ptr(dq), L.ptr(amax))
+    assert lib.dcn_conv_wgrad_f16(*wg_args, L.ptr(dw), L.ptr(slab), st) == 0
     assert rel_err(dw.cpu(), w.grad.permute(0, 2, 3, 1)) < 1e-5
     dw2 = torch.empty_like(dw)
-    assert lib.dcn_conv_wgrad_f16(ctypes.byref(d), L.ptr(xg), L.ptr(dg), L.ptr(amax), L.ptr(dw2), L.ptr(slab), st) == 0
+    assert lib.dcn_conv_wgrad_f16(*wg_args, L.ptr(dw2), L.ptr(slab), st) == 0
     assert torch.equal(dw, dw2)
 
 

@@ -36,6 +36,7 @@ def main():
     ap.add_argument("--json", default="")
     ap.add_argument("--only", default="", help="substring filter on the shape name")
     ap.add_argument("--kinds", default="fwd,dgrad,wgrad")
+    ap.add_argument("--no-split", action="store_true", help="f16 wgrad: time the GEMM kernel alone (planes prepared once)")
     ap.add_argument("--check", action="store_true", help="with --mode f16: compare against the fp32 kernels")
     ap.add_argument("--mode", default="fp32", choices=["fp32", "f16"], help="fp32 MFMA kernels or the split-fp16 (f16x3) ones")
     a = ap.parse_args()
@@ -85,8 +86,19 @@ def main():
             calls["dgrad"] = lambda: lib.dcn_conv_dgrad_f16(ctypes.byref(d), _lib.ptr(dy), _lib.ptr(wth), _lib.ptr(wtl), 64.0,
                                                             _lib.ptr(amax), None, _lib.ptr(dx), _lib.ptr(wsd), st)
             slab = torch.empty(max(lib.dcn_conv_wgrad_workspace_f16(ctypes.byref(d)), 4) // 4, device=dev)
-            calls["wgrad"] = lambda: lib.dcn_conv_wgrad_f16(ctypes.byref(d), _lib.ptr(x), _lib.ptr(dy), _lib.ptr(amax),
-                                                            _lib.ptr(dw), _lib.ptr(slab), st)
+            M = n * hout * wout
+            xs = torch.empty(x.numel(), device=dev)
+            dq = torch.empty(lib.dcn_grad_blocked_bytes(M, cout) // 4, device=dev)
+
+            def wgrad_f16(split=not a.no_split):   # the two split passes are part of the cost unless --no-split
+                rc = 0
+                if split:
+                    rc |= lib.dcn_split_act_f16(_lib.ptr(x), _lib.ptr(xs), x.numel(), st)
+                    rc |= lib.dcn_split_grad_blocked_f16(_lib.ptr(dy), M, cout, _lib.ptr(amax), _lib.ptr(dq), st)
+                return rc | lib.dcn_conv_wgrad_f16(ctypes.byref(d), _lib.ptr(xs), _lib.ptr(dq), _lib.ptr(amax), _lib.ptr(dw),
+                                                   _lib.ptr(slab), st)
+            assert wgrad_f16(True) == 0
+            calls["wgrad"] = wgrad_f16
             if a.check:   # f16x3 vs the fp32 MFMA kernels on the same operands
                 y2, dx2, dw2 = torch.empty_like(y), torch.empty_like(dx), torch.empty_like(dw)
                 part2 = torch.empty(lib.dcn_conv_num_mtiles(ctypes.byref(d)), 2, cout, device=dev)
