@@ -164,6 +164,8 @@ def main():
     ap.add_argument("--conv-mode", default="f16x3", choices=["f16x3", "fp32"],
                     help="convolution arithmetic (include/dcn_hip.h): split-fp16 on the fp16 MFMA pipe with fp32-level "
                          "accuracy (default), or fp32 MFMA")
+    ap.add_argument("--separate-forwards", action="store_true",
+                    help="forward(img_a) and forward(img_b) as two engine calls (default: one grouped call with identical results)")
     ap.add_argument("--force-dist", action="store_true", help="initialise RCCL even with one rank (smoke-tests the collective path)")
     args = ap.parse_args()
 
@@ -218,8 +220,12 @@ def main():
         if it % 250 == 0 and it > 0:  # training.yaml:4-5 step decay
             for g in opt.param_groups:
                 g["lr"] *= 0.9
-        pa = dcn.process_network_output(dcn.forward(img_a), B)
-        pb = dcn.process_network_output(dcn.forward(img_b), B)
+        if args.separate_forwards:   # literally training.py:329-333
+            ya, yb = dcn.forward(img_a), dcn.forward(img_b)
+        else:                        # the same two network calls as ONE grouped launch sequence (BN statistics per image batch)
+            ya, yb = dcn.forward_pair(img_a, img_b)
+        pa = dcn.process_network_output(ya, B)
+        pb = dcn.process_network_output(yb, B)
         loss, terms, hard = loss_composer.get_loss_batched(pcl, match_type, pa, pb, pair_lists)
         loss.backward()
         grads.all_reduce_mean()
@@ -251,7 +257,8 @@ def main():
     # ---- roofline of the dominant kernel: extra steps, every conv_gemm / conv_wgrad launch bracketed by HIP events
     roofline = None
     if args.profile_steps > 0:
-        plan = bb.get_plan(wl["backbone"], 64, B, H, W, D)
+        plan = bb.get_plan(wl["backbone"], 64, B, H, W, D) if args.separate_forwards else \
+            bb.get_plan(wl["backbone"], 64, 2 * B, H, W, D, 2)
         plan.profile_begin()
         for it in range(args.profile_steps):
             step(args.warmup + args.steps + it)
@@ -325,7 +332,10 @@ def main():
                "config": {"workload": wl["desc"], "pairs_per_gpu": B, "images_per_step": images_per_step,
                           "image": "%dx%d" % (W, H), "descriptor_dim": D, "backbone": wl["backbone"],
                           "pixel_pairs_per_image_pair": [wl["Pm"], wl["Pk"], wl["Pg"]],
-                          "conv_mode": args.conv_mode, "optimizer": "Adam lr 1e-4 wd 1e-4", "parallelism": "dp%d" % world,
+                          "conv_mode": args.conv_mode,
+                          "forward_calls": "forward(img_a), forward(img_b)" if args.separate_forwards else
+                          "forward_pair(img_a, img_b): both network calls of the step as one grouped launch sequence, batch-norm "
+                          "statistics / running statistics / gradients per image batch (identical results)", "optimizer": "Adam lr 1e-4 wd 1e-4", "parallelism": "dp%d" % world,
                           "library": info["version"], "final_loss": final_loss,
                           "train_gflop_per_image": 3 * bb.get_plan(wl["backbone"], 64, B, H, W, D).forward_flops / B / 1e9},
                "roofline": roofline, "roofline_loss_gather": loss_roof}

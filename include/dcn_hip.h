@@ -142,6 +142,11 @@ typedef struct dcn_plan dcn_plan;
 /* arch: "Resnet18_8s" | "Resnet34_8s" | "Resnet50_8s" | "Resnet101_8s".  base_width = 64 for the real
  * networks (smaller widths, multiples of 4, exist for tests). */
 int dcn_plan_create(const char* arch, int base_width, int n, int h, int w, int d, dcn_plan** out);
+/* `groups` (1 or 2) independent batches of n / groups images stacked along N: ONE launch sequence computes what
+ * `groups` consecutive forward calls of the reference compute (training.py:329-333 forwards img_a and img_b through the
+ * same weights) -- batch-norm statistics, their backward and the running-statistics updates are per group, in order.
+ * Larger launches fill the 256 CUs better at small batch.  DCN_E_UNSUPPORTED if a group's rows are not tile-aligned. */
+int dcn_plan_create_grouped(const char* arch, int base_width, int n, int groups, int h, int w, int d, dcn_plan** out);
 void dcn_plan_destroy(dcn_plan* plan);
 
 /* How the plan's convolutions multiply.  Both modes take and return fp32 tensors and accumulate in fp32.
@@ -206,6 +211,8 @@ typedef struct dcn_conv_desc {
     int32_t hout, wout, cout;   /* output [n, hout, wout, cout], leading dimension ldc >= cout */
     int32_t kh, kw, stride, pad, dil;
     int32_t ldc;
+    int32_t group_rows;         /* 0, or: output rows (pixels) per batch-norm group -- the forward kernel then picks an M
+                                   tile that divides it, so that no row of bn_partial mixes two groups (% 64 == 0 required) */
 } dcn_conv_desc;
 
 /* out = conv(in, w) [+ bias];  w: [cout][kh][kw][cin].  If bn_partial != NULL also writes per-M-tile

@@ -64,6 +64,7 @@ struct ParamInfo {
 struct dcn_plan {
     std::string arch, prefix;
     int N = 0, H = 0, W = 0, D = 0, Dp = 0, base = 64;
+    int groups = 1;   // independent batches stacked along N (batch-norm statistics per group); N % groups == 0
     bool bottleneck = false;
     std::vector<ConvL> convs;
     std::vector<BnL> bns;
@@ -123,6 +124,8 @@ struct Builder {
         c.d.wout = (win + 2 * pad - dil * (k - 1) - 1) / stride + 1;
         c.d.cout = cout;
         c.d.ldc = ldc ? ldc : cout;
+        // M tiles (= rows of the BN partial sums) must not straddle a group boundary
+        c.d.group_rows = p.groups > 1 ? n / p.groups * c.d.hout * c.d.wout : 0;
         c.w = add_param(name + ".weight", {cout, cin, k, k});
         if (bias) c.b = add_param(name + ".bias", {cout});
         const int64_t M = (int64_t)n * c.d.hout * c.d.wout;
@@ -142,7 +145,7 @@ struct Builder {
         b.g = add_param(name + ".weight", {C});
         b.b = add_param(name + ".bias", {C});
         b.idx = (int)p.bns.size();
-        b.stats = alloc_saved((size_t)4 * C);
+        b.stats = alloc_saved((size_t)4 * C * p.groups);
         p.bns.push_back(b);
         return b.idx;
     }
@@ -255,6 +258,10 @@ int build_plan(dcn_plan& p) {
         if (in4 > p.max_act) p.max_act = in4;
     }
 
+    if (p.groups > 1)
+        for (const ConvL& c : p.convs)   // every tile size the kernels may pick must divide the rows of a group
+            if (c.bn >= 0 && (c.d.group_rows % 64) != 0) return DCN_E_UNSUPPORTED;
+
     // ---- workspace
     size_t ws = 0;
     auto alloc = [&](size_t fl) { const size_t o = ws; ws = align64(ws + fl); return o; };
@@ -278,14 +285,14 @@ int build_plan(dcn_plan& p) {
         if (c.d.cout > max_c) max_c = c.d.cout;
     }
     for (const BnL& b : p.bns) {
-        const size_t pb = (size_t)dcn::bn_bwd_chunks(b.rows) * 4 * b.C;
+        const size_t pb = (size_t)p.groups * dcn::bn_bwd_chunks(b.rows / p.groups) * 4 * b.C;
         if (pb > max_part) max_part = pb;
     }
     p.w_wt = alloc(max_w);
     p.w_slab = alloc(max_slab);
     p.w_sk = alloc(max_sk);
     p.w_part = alloc(max_part);
-    p.w_k123 = alloc((size_t)3 * max_c);
+    p.w_k123 = alloc((size_t)3 * max_c * p.groups);
     p.w_wstem = alloc((size_t)p.base * 49 * 4);
     p.w_dwstem = alloc((size_t)p.base * 49 * 4);
     p.w_glow = alloc((size_t)N * p.hl * p.wl * p.Dp);
@@ -375,8 +382,8 @@ struct Run {
         float* rm = bn_running ? bn_running[2 * b.idx] : nullptr;
         float* rv = bn_running ? bn_running[2 * b.idx + 1] : nullptr;
         if (!training && (!rm || !rv)) return DCN_E_INVALID;
-        dcn::launch_bn_finalize(part, c.mtiles[p.conv_mode], b.C, (double)b.rows, P(b.g), P(b.b), rm, rv, momentum, eps, training,
-                                stats, stats + b.C, stats + 2 * b.C, stats + 3 * b.C, st);
+        dcn::launch_bn_finalize(part, c.mtiles[p.conv_mode] / p.groups, p.groups, b.C, (double)(b.rows / p.groups), P(b.g),
+                                P(b.b), rm, rv, momentum, eps, training, stats, st);
         return DCN_OK;
     }
 };
@@ -384,10 +391,15 @@ struct Run {
 }  // namespace
 
 extern "C" int dcn_plan_create(const char* arch, int base_width, int n, int h, int w, int d, dcn_plan** out) {
-    if (!arch || !out || n < 1 || h < 8 || w < 8 || d < 1 || base_width < 4 || (base_width % 4))
+    return dcn_plan_create_grouped(arch, base_width, n, 1, h, w, d, out);
+}
+extern "C" int dcn_plan_create_grouped(const char* arch, int base_width, int n, int groups, int h, int w, int d,
+                                       dcn_plan** out) {
+    if (!arch || !out || n < 1 || h < 8 || w < 8 || d < 1 || base_width < 4 || (base_width % 4) || groups < 1 ||
+        groups > 2 || (n % groups))
         return DCN_E_INVALID;
     dcn_plan* p = new dcn_plan();
-    p->arch = arch; p->N = n; p->H = h; p->W = w; p->D = d; p->base = base_width;
+    p->arch = arch; p->N = n; p->H = h; p->W = w; p->D = d; p->base = base_width; p->groups = groups;
     if (const char* m = getenv("DCN_CONV_MODE")) {
         if (!strcmp(m, "fp32")) p->conv_mode = DCN_CONV_FP32;
         else if (!strcmp(m, "f16x3")) p->conv_mode = DCN_CONV_F16X3;
@@ -473,7 +485,7 @@ extern "C" int dcn_backbone_forward(dcn_plan* plan, const float* image, const fl
     {
         const BnL& b = p.bns[stem.bn];
         const float* s = R.S(b.stats);
-        dcn::launch_bn_apply(R.S(stem.x), s, s + b.C, nullptr, nullptr, nullptr, 1, R.S(p.s_stem_y), b.C, b.rows, st);
+        dcn::launch_bn_apply(R.S(stem.x), s, nullptr, nullptr, 1, R.S(p.s_stem_y), b.C, b.rows, p.groups, st);
         const int hp = (stem.d.hout + 2 - 3) / 2 + 1, wp = (stem.d.wout + 2 - 3) / 2 + 1;
         dcn::launch_maxpool_fwd(R.S(p.s_stem_y), R.S(p.s_pool), (unsigned char*)R.S(p.s_argmax), N, stem.d.hout,
                                 stem.d.wout, hp, wp, b.C, st);
@@ -487,7 +499,7 @@ extern "C" int dcn_backbone_forward(dcn_plan* plan, const float* image, const fl
             if (i + 1 < blk.nconv) {
                 const BnL& b = p.bns[c.bn];
                 const float* s = R.S(b.stats);
-                dcn::launch_bn_apply(R.S(c.x), s, s + b.C, nullptr, nullptr, nullptr, 1, R.S(blk.mid[i]), b.C, b.rows, st);
+                dcn::launch_bn_apply(R.S(c.x), s, nullptr, nullptr, 1, R.S(blk.mid[i]), b.C, b.rows, p.groups, st);
                 cur = R.S(blk.mid[i]);
             }
         }
@@ -498,9 +510,9 @@ extern "C" int dcn_backbone_forward(dcn_plan* plan, const float* image, const fl
             const ConvL& dc = p.convs[blk.down];
             DCN_TRY(R.conv_bn(dc, in, R.P(dc.w), bn_running, momentum, eps, training));
             const float* sd = R.S(p.bns[dc.bn].stats);
-            dcn::launch_bn_apply(R.S(last.x), sl, sl + bl.C, R.S(dc.x), sd, sd + bl.C, 1, R.S(blk.out), bl.C, bl.rows, st);
+            dcn::launch_bn_apply(R.S(last.x), sl, R.S(dc.x), sd, 1, R.S(blk.out), bl.C, bl.rows, p.groups, st);
         } else {
-            dcn::launch_bn_apply(R.S(last.x), sl, sl + bl.C, in, nullptr, nullptr, 1, R.S(blk.out), bl.C, bl.rows, st);
+            dcn::launch_bn_apply(R.S(last.x), sl, in, nullptr, 1, R.S(blk.out), bl.C, bl.rows, p.groups, st);
         }
     }
     // scoring layer (1x1 conv + bias) into the padded low-resolution map, then bilinear upsample
@@ -531,7 +543,7 @@ extern "C" int dcn_backbone_backward(dcn_plan* plan, const float* grad_descripto
     auto bn_bwd = [&](const ConvL& c, const float* dy, const float* relu_out, float* dx, float* g_out) {
         const BnL& b = p.bns[c.bn];
         const float* s = R.S(b.stats);
-        dcn::launch_bn_bwd(dy, relu_out, R.S(c.x), s + 2 * b.C, s + 3 * b.C, R.P(b.g), b.C, b.rows, part, grads[b.g],
+        dcn::launch_bn_bwd(dy, relu_out, R.S(c.x), s, R.P(b.g), b.C, b.rows, p.groups, part, grads[b.g],
                            grads[b.b], k123, dx, g_out, f16 ? amax + c.idx : nullptr, st);
     };
     const float* planes_of = nullptr;   // activation tensor whose planes are in w_xh / w_xl (block input: two consumers)

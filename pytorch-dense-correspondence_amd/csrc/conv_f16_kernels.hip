@@ -450,7 +450,8 @@ struct F16Shape {
     bool sk;
     size_t ws_bytes;
 };
-F16Shape f16_shape(int M, int cd, int K) {
+// align: 0, or the M tile must divide it (rows per batch-norm group)
+F16Shape f16_shape(int M, int cd, int K, int align = 0) {
     F16Shape g;
     g.tn = cd <= 64 ? 1 : 2;
     const int ntiles128 = dcn::ceil_div(cd, 64 * g.tn);
@@ -460,6 +461,7 @@ F16Shape f16_shape(int M, int cd, int K) {
         if (v == 64) g.tm = 1;
         if (v == 128) g.tm = 2;
     }
+    if (align > 0 && (align % (64 * g.tm)) != 0) g.tm = 1;
     g.mtiles = dcn::ceil_div(M, 64 * g.tm);
     g.ntiles = dcn::ceil_div(cd, 64 * g.tn);
     g.nk = dcn::ceil_div(K, HBK);
@@ -489,7 +491,8 @@ F16Shape f16_shape(int M, int cd, int K) {
     return g;
 }
 
-int launch_gemm_f16(GemmConv& p, void* workspace, hipStream_t st) {
+int launch_gemm_f16(GemmConv& p, void* workspace, hipStream_t st, int align = 0) {
+    if (align > 0 && (align % 64) != 0) return DCN_E_UNSUPPORTED;
     if (p.stride != 1 && p.stride != 2 && p.stride != 4) return DCN_E_UNSUPPORTED;
     p.sshift = p.stride == 1 ? 0 : (p.stride == 2 ? 1 : 2);
     p.div_hw = make_fastdiv(p.hd * p.wd);
@@ -498,7 +501,7 @@ int launch_gemm_f16(GemmConv& p, void* workspace, hipStream_t st) {
     p.div_kw = make_fastdiv(p.kw);
     if ((int64_t)p.M / (p.hd * p.wd) * p.hs * p.ws * p.cs >= ((int64_t)1 << 31) || (int64_t)p.cd * p.kp >= ((int64_t)1 << 31))
         return DCN_E_UNSUPPORTED;
-    const F16Shape g = f16_shape(p.M, p.cd, p.K);
+    const F16Shape g = f16_shape(p.M, p.cd, p.K, align);
     const bool sk = g.sk && workspace != nullptr;
     p.mtiles = g.mtiles;
     p.ntiles = g.ntiles;
@@ -859,13 +862,13 @@ extern "C" int dcn_split_rows_f16(const float* w, void* hi, void* lo, int64_t ro
 
 extern "C" int dcn_conv_num_mtiles_f16(const dcn_conv_desc* c) {
     if (!valid_desc16(c)) return DCN_E_INVALID;
-    return f16_shape(c->n * c->hout * c->wout, c->cout, c->kh * c->kw * c->cin).mtiles;
+    return f16_shape(c->n * c->hout * c->wout, c->cout, c->kh * c->kw * c->cin, c->group_rows).mtiles;
 }
 
 extern "C" size_t dcn_conv_gemm_workspace_f16(const dcn_conv_desc* c, int dgrad) {
     if (!valid_desc16(c)) return 0;
     if (dgrad) return f16_shape(c->n * c->hin * c->win, c->cin, c->kh * c->kw * c->ldc).ws_bytes;
-    return f16_shape(c->n * c->hout * c->wout, c->cout, c->kh * c->kw * c->cin).ws_bytes;
+    return f16_shape(c->n * c->hout * c->wout, c->cout, c->kh * c->kw * c->cin, c->group_rows).ws_bytes;
 }
 
 // w_hi / w_lo: [cout][kpad(K)] fp16 from dcn_split_rows_f16(w, ..., scale = w_scale)
@@ -879,7 +882,7 @@ extern "C" int dcn_conv_forward_f16(const dcn_conv_desc* c, const float* in, con
     p.hs = c->hin; p.ws = c->win; p.cs = c->cin; p.hd = c->hout; p.wd = c->wout; p.cd = c->cout;
     p.kh = c->kh; p.kw = c->kw; p.stride = c->stride; p.pad = c->pad; p.dil = c->dil; p.ldc = c->ldc;
     p.M = c->n * c->hout * c->wout; p.K = c->kh * c->kw * c->cin; p.kp = dcn_f16_kpad(p.K); p.transposed = 0;
-    return launch_gemm_f16(p, workspace, (hipStream_t)stream);
+    return launch_gemm_f16(p, workspace, (hipStream_t)stream, c->group_rows);
 }
 
 // wt_hi / wt_lo: split of the channel-transposed weights [cin][taps][ldc] (dcn_transpose_weight, then dcn_split_rows_f16);

@@ -277,13 +277,16 @@ conv_gemm_fixup_kernel(GemmConv p) {
 // Tile-shape choice (fp32 MFMA is slow enough that load balance across the 256 CUs matters more than tile reuse):
 //   N tile  64 when the layer has at most 64 output channels (no MFMA work on padding), else 128
 //   M tile  128, or 64 when 128-row tiles would give the chip fewer than ~3 workgroups per CU (tail effect)
-int gemm_tile_m(int M, int cd) {
+int gemm_tile_m(int M, int cd, int align) {
+    int bm;
+    const int ntiles = dcn::ceil_div(cd, cd <= 64 ? 64 : 128);
+    bm = dcn::ceil_div(M, 128) * ntiles < 3 * 256 ? 64 : 128;
     if (const char* e = getenv("DCN_GEMM_TILE_M")) {  // tuning / test override
         const int v = atoi(e);
-        if (v == 32 || v == 64 || v == 128) return (v == 32 && cd <= 64) ? 64 : v;
+        if (v == 32 || v == 64 || v == 128) bm = (v == 32 && cd <= 64) ? 64 : v;
     }
-    const int ntiles = dcn::ceil_div(cd, cd <= 64 ? 64 : 128);
-    return dcn::ceil_div(M, 128) * ntiles < 3 * 256 ? 64 : 128;
+    if (align > 0 && (align % bm) != 0) bm = 64;   // rows per batch-norm group: a multiple of 64 (checked by the launcher)
+    return bm;
 }
 
 // Stream-K decision.  With one workgroup per tile the chip processes ceil(tiles / 256) "rounds"; when the last round
@@ -293,10 +296,10 @@ struct GemmShape {
     bool narrow, sk;
     size_t ws_bytes;
 };
-GemmShape gemm_shape(int M, int cd, int K) {
+GemmShape gemm_shape(int M, int cd, int K, int align = 0) {
     GemmShape g;
     g.narrow = cd <= 64;
-    g.bm = gemm_tile_m(M, cd);
+    g.bm = gemm_tile_m(M, cd, align);
     g.bn = g.bm == 32 ? 128 : (g.narrow ? 64 : 128);
     g.mtiles = dcn::ceil_div(M, g.bm);
     g.ntiles = dcn::ceil_div(cd, g.bn);
@@ -323,7 +326,8 @@ GemmShape gemm_shape(int M, int cd, int K) {
     return g;
 }
 
-int launch_gemm(GemmConv& p, void* workspace, hipStream_t st) {
+int launch_gemm(GemmConv& p, void* workspace, hipStream_t st, int align = 0) {
+    if (align > 0 && (align % 64) != 0) return DCN_E_UNSUPPORTED;
     if (p.stride != 1 && p.stride != 2 && p.stride != 4) return DCN_E_UNSUPPORTED;
     p.sshift = p.stride == 1 ? 0 : (p.stride == 2 ? 1 : 2);
     p.div_hw = make_fastdiv(p.hd * p.wd);
@@ -333,7 +337,7 @@ int launch_gemm(GemmConv& p, void* workspace, hipStream_t st) {
     // 32-bit element offsets inside the kernel
     if ((int64_t)p.M / (p.hd * p.wd) * p.hs * p.ws * p.cs >= ((int64_t)1 << 31) || (int64_t)p.cd * p.K >= ((int64_t)1 << 31))
         return DCN_E_UNSUPPORTED;
-    const GemmShape g = gemm_shape(p.M, p.cd, p.K);
+    const GemmShape g = gemm_shape(p.M, p.cd, p.K, align);
     const bool sk = g.sk && workspace != nullptr;
     p.mtiles = g.mtiles;
     p.ntiles = g.ntiles;
@@ -600,13 +604,13 @@ void launch_wgrad_reduce(const float* slabs, float* dw, int64_t n4, int splits, 
 
 extern "C" int dcn_conv_num_mtiles(const dcn_conv_desc* c) {
     if (!valid_desc(c)) return DCN_E_INVALID;
-    return gemm_shape(c->n * c->hout * c->wout, c->cout, c->kh * c->kw * c->cin).mtiles;
+    return gemm_shape(c->n * c->hout * c->wout, c->cout, c->kh * c->kw * c->cin, c->group_rows).mtiles;
 }
 
 extern "C" size_t dcn_conv_gemm_workspace(const dcn_conv_desc* c, int dgrad) {
     if (!valid_desc(c)) return 0;
     if (dgrad) return gemm_shape(c->n * c->hin * c->win, c->cin, c->kh * c->kw * c->ldc).ws_bytes;
-    return gemm_shape(c->n * c->hout * c->wout, c->cout, c->kh * c->kw * c->cin).ws_bytes;
+    return gemm_shape(c->n * c->hout * c->wout, c->cout, c->kh * c->kw * c->cin, c->group_rows).ws_bytes;
 }
 
 extern "C" int dcn_conv_forward(const dcn_conv_desc* c, const float* in, const float* w, const float* bias, float* out,
@@ -617,7 +621,7 @@ extern "C" int dcn_conv_forward(const dcn_conv_desc* c, const float* in, const f
     p.hs = c->hin; p.ws = c->win; p.cs = c->cin; p.hd = c->hout; p.wd = c->wout; p.cd = c->cout;
     p.kh = c->kh; p.kw = c->kw; p.stride = c->stride; p.pad = c->pad; p.dil = c->dil; p.ldc = c->ldc;
     p.M = c->n * c->hout * c->wout; p.K = c->kh * c->kw * c->cin; p.transposed = 0;
-    return launch_gemm(p, workspace, (hipStream_t)stream);
+    return launch_gemm(p, workspace, (hipStream_t)stream, c->group_rows);
 }
 
 // The description is the FORWARD convolution's; dout is [n,hout,wout,ld = c->ldc], din is [n,hin,win,cin].

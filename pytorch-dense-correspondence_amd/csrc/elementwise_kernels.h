@@ -9,18 +9,22 @@ void launch_pad_c3_to_c4(const float* w, float* wp, int64_t rows, hipStream_t st
 void launch_unpad_c4_to_c3(const float* wp, float* w, int64_t rows, hipStream_t st);
 void launch_pad_rows(const float* src, float* dst, int64_t rows, int d, int ld, hipStream_t st);
 
-// batch norm: partial[tiles][2][C] (sum, sum of squares) -> scale/shift (+ saved mean/invstd, running update)
-void launch_bn_finalize(const float* partial, int tiles, int C, double count, const float* gamma, const float* beta,
-                        float* rmean, float* rvar, float momentum, float eps, int training, float* scale, float* shift,
-                        float* save_mean, float* save_invstd, hipStream_t st);
-// y = [relu](x*s1 + b1 + (res ? (s2 ? res*s2 + b2 : res) : 0))
-void launch_bn_apply(const float* x, const float* s1, const float* b1, const float* res, const float* s2,
-                     const float* b2, int relu, float* y, int C, int64_t rows, hipStream_t st);
-int bn_bwd_chunks(int64_t rows);
-// partial: bn_bwd_chunks(rows)*4*C floats, k123: 3*C floats.  g_out (nullable) receives the relu-masked dy.
-void launch_bn_bwd(const float* dy, const float* relu_out, const float* x, const float* mean, const float* invstd,
-                   const float* gamma, int C, int64_t rows, float* partial, float* dgamma, float* dbeta, float* k123,
-                   float* dx, float* g_out, float* absmax, hipStream_t st);   // absmax (optional): raised to an upper bound of max |dx|
+// Batch norm.  `groups` (1 or 2) = independent batches stacked along the rows of one launch (forward(img_a) and
+// forward(img_b) of a training step as one launch sequence): statistics per group; rows % groups == 0 and conv M tiles /
+// backward chunks never straddle a group boundary.  stats = [groups][4][C]: scale, shift, mean, invstd.
+// partial[groups * tiles_per_group][2][C] (sum, sum of squares) -> stats (+ running update, once per group, in order)
+void launch_bn_finalize(const float* partial, int tiles_per_group, int groups, int C, double count_per_group,
+                        const float* gamma, const float* beta, float* rmean, float* rvar, float momentum, float eps,
+                        int training, float* stats, hipStream_t st);
+// y = [relu](x*scale1 + shift1 + (res ? (stats2 ? res*scale2 + shift2 : res) : 0))
+void launch_bn_apply(const float* x, const float* stats1, const float* res, const float* stats2, int relu, float* y, int C,
+                     int64_t rows, int groups, hipStream_t st);
+int bn_bwd_chunks(int64_t rows_per_group);
+// partial: groups*bn_bwd_chunks(rows/groups)*4*C floats, k123: groups*3*C floats.  g_out (nullable) receives the
+// relu-masked dy.  absmax (optional): raised to an upper bound of max |dx|
+void launch_bn_bwd(const float* dy, const float* relu_out, const float* x, const float* stats, const float* gamma, int C,
+                   int64_t rows, int groups, float* partial, float* dgamma, float* dbeta, float* k123, float* dx,
+                   float* g_out, float* absmax, hipStream_t st);
 void launch_add(const float* a, const float* b, float* out, int64_t n, hipStream_t st);
 
 void launch_maxpool_fwd(const float* in, float* out, unsigned char* argmax, int n, int hin, int win, int hout,

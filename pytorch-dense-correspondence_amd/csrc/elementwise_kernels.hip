@@ -49,56 +49,63 @@ pad_rows_kernel(const float* __restrict__ src, float* __restrict__ dst, int64_t 
 
 // ---------------------------------------------------------------------------------------------- batch norm
 // partial[tile][2][C] -> per-channel sums (fp64), then scale/shift + saved statistics + running update.
+// GROUPS: the rows of one launch may hold several independent batches ("groups": forward(img_a) and forward(img_b) of a
+// training step run as ONE launch sequence over 2B images); batch statistics are per group -- group g owns tiles
+// [g*tiles, (g+1)*tiles) and the statistics block at offset g*gstride -- and the running statistics are updated once per
+// group, in order, exactly as two consecutive nn.BatchNorm2d calls would.
 __global__ void __launch_bounds__(256)
-bn_finalize_kernel(const float* __restrict__ partial, int tiles, int C, double count, const float* __restrict__ gamma,
-                   const float* __restrict__ beta, float* __restrict__ running_mean, float* __restrict__ running_var,
-                   float momentum, float eps, int training, float* __restrict__ scale, float* __restrict__ shift,
-                   float* __restrict__ save_mean, float* __restrict__ save_invstd) {
+bn_finalize_kernel(const float* __restrict__ partial, int tiles, int groups, int C, double count,
+                   const float* __restrict__ gamma, const float* __restrict__ beta, float* __restrict__ running_mean,
+                   float* __restrict__ running_var, float momentum, float eps, int training, float* __restrict__ scale,
+                   float* __restrict__ shift, float* __restrict__ save_mean, float* __restrict__ save_invstd, int gstride) {
     __shared__ double s_sum[16][16];
     __shared__ double s_sq[16][16];
     const int cl = threadIdx.x & 15, part = threadIdx.x >> 4;
     const int c = blockIdx.x * 16 + cl;
-    double a = 0.0, b = 0.0;
-    if (training && c < C) {
-        for (int t = part; t < tiles; t += 16) {
-            a += (double)partial[((int64_t)t * 2 + 0) * C + c];
-            b += (double)partial[((int64_t)t * 2 + 1) * C + c];
+    for (int g = 0; g < groups; ++g) {
+        double a = 0.0, b = 0.0;
+        if (training && c < C) {
+            for (int t = g * tiles + part; t < (g + 1) * tiles; t += 16) {
+                a += (double)partial[((int64_t)t * 2 + 0) * C + c];
+                b += (double)partial[((int64_t)t * 2 + 1) * C + c];
+            }
         }
-    }
-    s_sum[part][cl] = a;
-    s_sq[part][cl] = b;
-    __syncthreads();
-    if (part != 0 || c >= C) return;
-    double mean, var;
-    if (training) {
-        a = 0.0; b = 0.0;
-        for (int i = 0; i < 16; ++i) { a += s_sum[i][cl]; b += s_sq[i][cl]; }  // fixed order
-        mean = a / count;
-        var = b / count - mean * mean;
-        if (var < 0.0) var = 0.0;
-        if (running_mean) {
-            const double unbiased = count > 1.0 ? var * count / (count - 1.0) : var;
-            running_mean[c] = (float)((1.0 - momentum) * (double)running_mean[c] + momentum * mean);
-            running_var[c] = (float)((1.0 - momentum) * (double)running_var[c] + momentum * unbiased);
+        __syncthreads();
+        s_sum[part][cl] = a;
+        s_sq[part][cl] = b;
+        __syncthreads();
+        if (part != 0 || c >= C) continue;
+        double mean, var;
+        if (training) {
+            a = 0.0; b = 0.0;
+            for (int i = 0; i < 16; ++i) { a += s_sum[i][cl]; b += s_sq[i][cl]; }  // fixed order
+            mean = a / count;
+            var = b / count - mean * mean;
+            if (var < 0.0) var = 0.0;
+            if (running_mean) {
+                const double unbiased = count > 1.0 ? var * count / (count - 1.0) : var;
+                running_mean[c] = (float)((1.0 - momentum) * (double)running_mean[c] + momentum * mean);
+                running_var[c] = (float)((1.0 - momentum) * (double)running_var[c] + momentum * unbiased);
+            }
+        } else {
+            mean = (double)running_mean[c];
+            var = (double)running_var[c];
         }
-    } else {
-        mean = (double)running_mean[c];
-        var = (double)running_var[c];
+        const float invstd = (float)(1.0 / sqrt(var + (double)eps));
+        const float sc = gamma[c] * invstd;
+        scale[g * gstride + c] = sc;
+        shift[g * gstride + c] = beta[c] - (float)mean * sc;
+        if (save_mean) { save_mean[g * gstride + c] = (float)mean; save_invstd[g * gstride + c] = invstd; }
     }
-    const float invstd = (float)(1.0 / sqrt(var + (double)eps));
-    const float sc = gamma[c] * invstd;
-    scale[c] = sc;
-    shift[c] = beta[c] - (float)mean * sc;
-    if (save_mean) { save_mean[c] = (float)mean; save_invstd[c] = invstd; }
 }
 
 // y = [relu]( x*s1 + b1 + (res ? (s2 ? res*s2 + b2 : res) : 0) )
 __global__ void __launch_bounds__(256)
 bn_apply_kernel(const float* __restrict__ x, const float* __restrict__ s1, const float* __restrict__ b1,
                 const float* __restrict__ res, const float* __restrict__ s2, const float* __restrict__ b2, int relu,
-                float* __restrict__ y, int c4n, int64_t total4) {
+                float* __restrict__ y, int c4n, int64_t total4, int64_t group4, int gstride) {
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total4; i += (int64_t)gridDim.x * 256) {
-        const int c = (int)(i % c4n) * 4;
+        const int c = (int)(i % c4n) * 4 + (i >= group4 ? gstride : 0);   // (at most two groups: second group's statistics)
         const float4 v = reinterpret_cast<const float4*>(x)[i];
         const float4 s = *reinterpret_cast<const float4*>(s1 + c);
         const float4 b = *reinterpret_cast<const float4*>(b1 + c);
@@ -123,8 +130,8 @@ bn_apply_kernel(const float* __restrict__ x, const float* __restrict__ s1, const
 // work-item (c4 = tid & 15, rl = tid >> 4): 16 channel quads x 16 row lanes; grid = (C/64 groups, chunks).
 __global__ void __launch_bounds__(256)
 bn_bwd_reduce_kernel(const float* __restrict__ dy, const float* __restrict__ relu_out, const float* __restrict__ x,
-                     const float* __restrict__ mean, const float* __restrict__ invstd, int C, int64_t rows,
-                     int rows_per_chunk, float* __restrict__ partial) {
+                     const float* __restrict__ mean, const float* __restrict__ invstd, int C, int64_t rows_per_group,
+                     int chunks_per_group, int gstride, int rows_per_chunk, float* __restrict__ partial) {
     __shared__ float4 s_g[16][16];
     __shared__ float4 s_gx[16][16];
     __shared__ float4 s_mg[16][16];
@@ -133,11 +140,12 @@ bn_bwd_reduce_kernel(const float* __restrict__ dy, const float* __restrict__ rel
     const int c = blockIdx.x * 64 + c4 * 4;
     float4 ag = make_float4(0.f, 0.f, 0.f, 0.f), agx = ag, mg = ag, mx = ag;
     if (c < C) {
-        const float4 mu = *reinterpret_cast<const float4*>(mean + c);
-        const float4 is = *reinterpret_cast<const float4*>(invstd + c);
-        const int64_t r0 = (int64_t)blockIdx.y * rows_per_chunk;
+        const int g = (int)blockIdx.y / chunks_per_group;            // chunks never straddle a group boundary
+        const float4 mu = *reinterpret_cast<const float4*>(mean + g * gstride + c);
+        const float4 is = *reinterpret_cast<const float4*>(invstd + g * gstride + c);
+        const int64_t r0 = g * rows_per_group + (int64_t)((int)blockIdx.y - g * chunks_per_group) * rows_per_chunk;
         int64_t r1 = r0 + rows_per_chunk;
-        if (r1 > rows) r1 = rows;
+        if (r1 > (g + 1) * rows_per_group) r1 = (g + 1) * rows_per_group;
         for (int64_t r = r0 + rl; r < r1; r += 16) {
             const int64_t o = r * C + c;
             float4 g = *reinterpret_cast<const float4*>(dy + o);
@@ -183,50 +191,60 @@ bn_bwd_reduce_kernel(const float* __restrict__ dy, const float* __restrict__ rel
 // and, when absmax is given, raises absmax[0] to  max_c |k1| (max|g| + |k2| + max|xhat| |k3|)  >=  max |dx|  (the
 // pre-scale of the split-fp16 convolutions only needs an upper bound within a small factor of the true abs-max).
 __global__ void __launch_bounds__(256)
-bn_bwd_finalize_kernel(const float* __restrict__ partial, int chunks, int C, double count,
-                       const float* __restrict__ gamma, const float* __restrict__ invstd, float* __restrict__ dgamma,
-                       float* __restrict__ dbeta, float* __restrict__ k1, float* __restrict__ k2,
-                       float* __restrict__ k3, float* __restrict__ absmax) {
+bn_bwd_finalize_kernel(const float* __restrict__ partial, int chunks, int groups, int C, double count,
+                       const float* __restrict__ gamma, const float* __restrict__ invstd, int gstride,
+                       float* __restrict__ dgamma, float* __restrict__ dbeta, float* __restrict__ k123,
+                       float* __restrict__ absmax) {
     // 16 channels x 16 chunk-parts per workgroup (C / 16 workgroups: a 64-channel layer still gets 4 CUs and every
-    // work-item only walks chunks / 16 partial rows); fixed summation order
+    // work-item only walks chunks / 16 partial rows); fixed summation order.  Per group g (chunks [g*chunks, (g+1)*chunks)):
+    // k123[g][0..2][C]; dgamma / dbeta are the sums over the groups (the parameters are shared).
     __shared__ double s_a[16][16];
     __shared__ double s_b[16][16];
-    const int cl = threadIdx.x & 15, part = threadIdx.x >> 4;
-    const int c = blockIdx.x * 16 + cl;
     __shared__ float s_mg[16][16];
     __shared__ float s_mx[16][16];
-    double a = 0.0, b = 0.0;
-    float mg = 0.f, mx = 0.f;
-    if (c < C) {
+    const int cl = threadIdx.x & 15, part = threadIdx.x >> 4;
+    const int c = blockIdx.x * 16 + cl;
+    double tot_a = 0.0, tot_b = 0.0;
+    float bound = 0.f;
+    for (int g = 0; g < groups; ++g) {
+        double a = 0.0, b = 0.0;
+        float mg = 0.f, mx = 0.f;
+        if (c < C) {
 #pragma unroll 4
-        for (int t = part; t < chunks; t += 16) {
-            const float* row = partial + (int64_t)t * 4 * C + c;
-            a += (double)row[0];
-            b += (double)row[C];
-            mg = fmaxf(mg, row[2 * C]);
-            mx = fmaxf(mx, row[3 * C]);
+            for (int t = g * chunks + part; t < (g + 1) * chunks; t += 16) {
+                const float* row = partial + (int64_t)t * 4 * C + c;
+                a += (double)row[0];
+                b += (double)row[C];
+                mg = fmaxf(mg, row[2 * C]);
+                mx = fmaxf(mx, row[3 * C]);
+            }
+        }
+        __syncthreads();
+        s_a[part][cl] = a;
+        s_b[part][cl] = b;
+        s_mg[part][cl] = mg;
+        s_mx[part][cl] = mx;
+        __syncthreads();
+        if (part == 0 && c < C) {
+            a = 0.0; b = 0.0;
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                a += s_a[q][cl]; b += s_b[q][cl];
+                mg = fmaxf(mg, s_mg[q][cl]); mx = fmaxf(mx, s_mx[q][cl]);
+            }
+            const float c1 = gamma[c] * invstd[g * gstride + c], c2 = (float)(a / count), c3 = (float)(b / count);
+            float* k = k123 + (int64_t)g * 3 * C;
+            k[c] = c1;
+            k[C + c] = c2;
+            k[2 * C + c] = c3;
+            tot_a += a;
+            tot_b += b;
+            bound = fmaxf(bound, fabsf(c1) * (mg + fabsf(c2) + mx * fabsf(c3)));
         }
     }
-    s_a[part][cl] = a;
-    s_b[part][cl] = b;
-    s_mg[part][cl] = mg;
-    s_mx[part][cl] = mx;
-    __syncthreads();
-    float bound = 0.f;
     if (part == 0 && c < C) {
-        a = 0.0; b = 0.0;
-#pragma unroll
-        for (int q = 0; q < 16; ++q) {
-            a += s_a[q][cl]; b += s_b[q][cl];
-            mg = fmaxf(mg, s_mg[q][cl]); mx = fmaxf(mx, s_mx[q][cl]);
-        }
-        const float c1 = gamma[c] * invstd[c], c2 = (float)(a / count), c3 = (float)(b / count);
-        dbeta[c] = (float)a;
-        dgamma[c] = (float)b;
-        k1[c] = c1;
-        k2[c] = c2;
-        k3[c] = c3;
-        bound = fabsf(c1) * (mg + fabsf(c2) + mx * fabsf(c3));
+        dbeta[c] = (float)tot_a;
+        dgamma[c] = (float)tot_b;
     }
     if (absmax) {
         __syncthreads();
@@ -263,9 +281,11 @@ __global__ void __launch_bounds__(256)
 bn_bwd_apply_kernel(const float* __restrict__ dy, const float* __restrict__ relu_out, const float* __restrict__ x,
                     const float* __restrict__ mean, const float* __restrict__ invstd, const float* __restrict__ k1,
                     const float* __restrict__ k2, const float* __restrict__ k3, float* __restrict__ dx,
-                    float* __restrict__ g_out, int c4n, int64_t total4) {
+                    float* __restrict__ g_out, int c4n, int64_t total4, int64_t group4, int gstride, int kstride) {
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total4; i += (int64_t)gridDim.x * 256) {
-        const int c = (int)(i % c4n) * 4;
+        const int c0 = (int)(i % c4n) * 4;
+        const bool second = i >= group4;                          // (at most two groups)
+        const int c = c0 + (second ? gstride : 0), ck = c0 + (second ? kstride : 0);
         float4 g = reinterpret_cast<const float4*>(dy)[i];
         if (relu_out) {
             const float4 y = reinterpret_cast<const float4*>(relu_out)[i];
@@ -275,9 +295,9 @@ bn_bwd_apply_kernel(const float* __restrict__ dy, const float* __restrict__ relu
         const float4 v = reinterpret_cast<const float4*>(x)[i];
         const float4 mu = *reinterpret_cast<const float4*>(mean + c);
         const float4 is = *reinterpret_cast<const float4*>(invstd + c);
-        const float4 a = *reinterpret_cast<const float4*>(k1 + c);
-        const float4 b = *reinterpret_cast<const float4*>(k2 + c);
-        const float4 d = *reinterpret_cast<const float4*>(k3 + c);
+        const float4 a = *reinterpret_cast<const float4*>(k1 + ck);
+        const float4 b = *reinterpret_cast<const float4*>(k2 + ck);
+        const float4 d = *reinterpret_cast<const float4*>(k3 + ck);
         float4 o;
         o.x = a.x * (g.x - b.x - (v.x - mu.x) * is.x * d.x);
         o.y = a.y * (g.y - b.y - (v.y - mu.y) * is.y * d.y);
@@ -527,38 +547,42 @@ void launch_unpad_c4_to_c3(const float* wp, float* w, int64_t rows, hipStream_t 
 void launch_pad_rows(const float* src, float* dst, int64_t rows, int d, int ld, hipStream_t st) {
     hipLaunchKernelGGL(pad_rows_kernel, dim3(blocks_for(rows * ld)), dim3(256), 0, st, src, dst, rows, d, ld);
 }
-void launch_bn_finalize(const float* partial, int tiles, int C, double count, const float* gamma, const float* beta,
-                        float* rmean, float* rvar, float momentum, float eps, int training, float* scale, float* shift,
-                        float* save_mean, float* save_invstd, hipStream_t st) {
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3(ceil_div(C, 16)), dim3(256), 0, st, partial, tiles, C, count, gamma,
-                       beta, rmean, rvar, momentum, eps, training, scale, shift, save_mean, save_invstd);
+void launch_bn_finalize(const float* partial, int tiles_per_group, int groups, int C, double count_per_group,
+                        const float* gamma, const float* beta, float* rmean, float* rvar, float momentum, float eps,
+                        int training, float* stats, hipStream_t st) {
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3(ceil_div(C, 16)), dim3(256), 0, st, partial, tiles_per_group, groups, C,
+                       count_per_group, gamma, beta, rmean, rvar, momentum, eps, training, stats, stats + C, stats + 2 * C,
+                       stats + 3 * C, 4 * C);
 }
-void launch_bn_apply(const float* x, const float* s1, const float* b1, const float* res, const float* s2,
-                     const float* b2, int relu, float* y, int C, int64_t rows, hipStream_t st) {
+void launch_bn_apply(const float* x, const float* stats1, const float* res, const float* stats2, int relu, float* y, int C,
+                     int64_t rows, int groups, hipStream_t st) {
     const int64_t total4 = rows * (C / 4);
-    hipLaunchKernelGGL(bn_apply_kernel, dim3(blocks_for(total4, kGridCap)), dim3(256), 0, st, x, s1, b1, res, s2, b2,
-                       relu, y, C / 4, total4);
+    hipLaunchKernelGGL(bn_apply_kernel, dim3(blocks_for(total4, kGridCap)), dim3(256), 0, st, x, stats1, stats1 + C, res,
+                       stats2, stats2 ? stats2 + C : nullptr, relu, y, C / 4, total4, total4 / groups, 4 * C);
 }
-int bn_bwd_chunks(int64_t rows) {
+int bn_bwd_chunks(int64_t rows_per_group) {
     // enough row chunks that even a 64-channel layer launches >= ~1000 workgroups (HBM-bound pass: fill all 256 CUs)
-    int64_t chunks = ceil_div64(rows, 64);
+    int64_t chunks = ceil_div64(rows_per_group, 64);
     if (chunks > 1024) chunks = 1024;
     if (chunks < 1) chunks = 1;
     return (int)chunks;
 }
-void launch_bn_bwd(const float* dy, const float* relu_out, const float* x, const float* mean, const float* invstd,
-                   const float* gamma, int C, int64_t rows, float* partial, float* dgamma, float* dbeta, float* k123,
-                   float* dx, float* g_out, float* absmax, hipStream_t st) {
-    const int chunks = bn_bwd_chunks(rows);
-    const int rpc = (int)ceil_div64(rows, chunks);
-    hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(ceil_div(C, 64), chunks), dim3(256), 0, st, dy, relu_out, x, mean,
-                       invstd, C, rows, rpc, partial);
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(ceil_div(C, 16)), dim3(256), 0, st, (const float*)partial, chunks, C,
-                       (double)rows, gamma, invstd, dgamma, dbeta, k123, k123 + C, k123 + 2 * C, absmax);
+void launch_bn_bwd(const float* dy, const float* relu_out, const float* x, const float* stats, const float* gamma, int C,
+                   int64_t rows, int groups, float* partial, float* dgamma, float* dbeta, float* k123, float* dx,
+                   float* g_out, float* absmax, hipStream_t st) {
+    const int64_t rpg = rows / groups;
+    const int chunks = bn_bwd_chunks(rpg);   // per group
+    const int rpc = (int)ceil_div64(rpg, chunks);
+    const float* mean = stats + 2 * C;
+    const float* invstd = stats + 3 * C;
+    hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(ceil_div(C, 64), chunks * groups), dim3(256), 0, st, dy, relu_out, x,
+                       mean, invstd, C, rpg, chunks, 4 * C, rpc, partial);
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(ceil_div(C, 16)), dim3(256), 0, st, (const float*)partial, chunks,
+                       groups, C, (double)rpg, gamma, invstd, 4 * C, dgamma, dbeta, k123, absmax);
     const int64_t total4 = rows * (C / 4);
     hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(blocks_for(total4, kGridCap)), dim3(256), 0, st, dy, relu_out, x, mean,
                        invstd, (const float*)k123, (const float*)(k123 + C), (const float*)(k123 + 2 * C), dx, g_out,
-                       C / 4, total4);
+                       C / 4, total4, total4 / groups, 4 * C, 3 * C);
 }
 void launch_add(const float* a, const float* b, float* out, int64_t n, hipStream_t st) {
     hipLaunchKernelGGL(add_kernel, dim3(blocks_for(n / 4, kGridCap)), dim3(256), 0, st, a, b, out, n / 4);

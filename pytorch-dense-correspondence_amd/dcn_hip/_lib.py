@@ -26,7 +26,7 @@ class LossConfig(ctypes.Structure):
 class ConvDesc(ctypes.Structure):
     """struct dcn_conv_desc"""
     _fields_ = [(k, ctypes.c_int32) for k in ("n", "hin", "win", "cin", "hout", "wout", "cout", "kh", "kw", "stride",
-                                              "pad", "dil", "ldc")]
+                                              "pad", "dil", "ldc", "group_rows")]
 
 
 SYMBOLS = {
@@ -70,6 +70,7 @@ SYMBOLS = {
                                      c_void_p, c_void_p, c_void_p]),
     "dcn_conv_dgrad_f16": (c_int, [ctypes.POINTER(ConvDesc), c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_void_p,
                                    c_void_p, c_void_p, c_void_p]),
+    "dcn_plan_create_grouped": (c_int, [c_char_p, c_int, c_int, c_int, c_int, c_int, c_int, ctypes.POINTER(c_void_p)]),
     "dcn_plan_set_conv_mode": (c_int, [c_void_p, c_int]),
     "dcn_plan_conv_mode": (c_int, [c_void_p]),
     "dcn_conv_wgrad_f16": (c_int, [ctypes.POINTER(ConvDesc), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),

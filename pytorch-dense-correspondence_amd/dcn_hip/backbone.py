@@ -14,16 +14,16 @@ from . import _lib
 class Plan(object):
     """dcn_plan for (arch, base_width, N, H, W, D); owns the parameter / batch-norm name tables."""
 
-    def __init__(self, arch, base_width, n, h, w, d):
+    def __init__(self, arch, base_width, n, h, w, d, groups=1):
         lib = _lib.get()
         handle = ctypes.c_void_p()
-        rc = lib.dcn_plan_create(arch.encode(), base_width, n, h, w, d, ctypes.byref(handle))
+        rc = lib.dcn_plan_create_grouped(arch.encode(), base_width, n, groups, h, w, d, ctypes.byref(handle))
         if rc != 0:
-            raise ValueError("dcn_hip: cannot plan %s (base %d) for input [%d,3,%d,%d], D=%d: %s" %
-                             (arch, base_width, n, h, w, d, _lib.ERRORS.get(rc, rc)))
+            raise ValueError("dcn_hip: cannot plan %s (base %d) for input [%d,3,%d,%d] in %d group(s), D=%d: %s" %
+                             (arch, base_width, n, h, w, groups, d, _lib.ERRORS.get(rc, rc)))
         self.handle = handle
-        self.key = (arch, base_width, n, h, w, d)
-        self.n, self.h, self.w, self.d = n, h, w, d
+        self.key = (arch, base_width, n, h, w, d, groups)
+        self.n, self.h, self.w, self.d, self.groups = n, h, w, d, groups
         self.param_names, self.param_shapes = [], []
         buf = ctypes.create_string_buffer(256)
         shape = (ctypes.c_int64 * 4)()
@@ -89,8 +89,9 @@ def set_conv_mode(mode):
             p.set_conv_mode(mode)
 
 
-def get_plan(arch, base_width, n, h, w, d):
-    key = (arch, base_width, n, h, w, d)
+def get_plan(arch, base_width, n, h, w, d, groups=1):
+    """``groups`` > 1: n images = ``groups`` independent batches stacked along N (batch-norm statistics per batch)."""
+    key = (arch, base_width, n, h, w, d, groups)
     p = _PLANS.get(key)
     if p is None:
         p = _PLANS[key] = Plan(*key)

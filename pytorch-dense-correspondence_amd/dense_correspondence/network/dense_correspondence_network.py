@@ -174,6 +174,13 @@ class DenseCorrespondenceNetwork(nn.Module):
             return self.fcn(img_tensor, normalize=True)
         return self.fcn(img_tensor)
 
+    def forward_pair(self, img_a, img_b):
+        """``(forward(img_a), forward(img_b))`` -- the two network calls of a training step (training.py:329-333) -- as ONE
+        grouped engine call: identical values (batch-norm statistics, running statistics and gradients are per image
+        batch, in call order), but every kernel runs over 2N images, which fills the MI355X better at small batch.
+        Not part of the reference API; ``forward`` twice remains valid."""
+        return self.fcn.forward_pair(img_a, img_b, normalize=self._normalize)
+
     def forward_single_image_tensor(self, img_tensor):
         # :265-299
         assert len(img_tensor.shape) == 3

@@ -92,15 +92,31 @@ class _DilatedResnet8s(nn.Module):
             tracked.append(node.num_batches_tracked)
         return params, running, tracked
 
-    def forward(self, x, normalize=False):
+    def forward(self, x, normalize=False, groups=1):
+        """``groups`` = 2: ``x`` stacks two independent batches (``cat([img_a, img_b])``); the result equals two consecutive
+        forward calls -- batch-norm statistics, their gradients and the running-statistics updates are per batch -- but
+        runs as ONE launch sequence (fills the 256 CUs better at small batch).  See ``forward_pair``."""
         n, _, h, w = x.shape
-        plan = _bb.get_plan(self.arch, self.base_width, int(n), int(h), int(w), self.num_classes)
+        plan = _bb.get_plan(self.arch, self.base_width, int(n), int(h), int(w), self.num_classes, int(groups))
         params, running, tracked = self._tables()
         if self.training:
-            torch._foreach_add_(tracked, 1)
+            torch._foreach_add_(tracked, int(groups))
         sink = getattr(self, "_flat_grad_sink", None)
         return _bb.backbone_forward(x, plan, params, running, self.training, normalize, self.bn_momentum, self.bn_eps,
                                     grad_sink=sink)
+
+    def forward_pair(self, x_a, x_b, normalize=False):
+        """forward(x_a), forward(x_b) of the reference's training step (training.py:329-333) as one grouped engine call.
+        Falls back to two calls when the shapes differ or a batch's rows are not tile-aligned."""
+        if x_a.shape == x_b.shape:
+            try:
+                y = self.forward(torch.cat([x_a, x_b], 0), normalize, groups=2)
+            except ValueError:
+                y = None
+            if y is not None:
+                n = x_a.shape[0]
+                return y[:n], y[n:]
+        return self.forward(x_a, normalize), self.forward(x_b, normalize)
 
     def forward_flops(self, n, h, w):
         return _bb.get_plan(self.arch, self.base_width, int(n), int(h), int(w), self.num_classes).forward_flops

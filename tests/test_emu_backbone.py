@@ -146,3 +146,37 @@ def test_container_nodes_refuse_to_run_and_cpu_guard():
     with pytest.raises(ValueError):
         m(torch.zeros(1, 4, 32, 32))
     assert _lib.is_hostemu()   # (the shipped library rejects CPU tensors: see test_abi.py)
+
+
+@pytest.mark.parametrize("arch,bw,shape", [("Resnet18_8s", 8, (1, 64, 64)), ("Resnet34_8s", 8, (2, 64, 64))])
+def test_grouped_pair_forward_equals_two_forward_calls(arch, bw, shape):
+    """forward_pair(a, b) == (forward(a), forward(b)): per-batch BN statistics, running statistics updated once per batch
+    in call order, parameter gradients = sum of both calls' gradients.  Forward against the oracle called twice; gradients
+    against the engine's own two-call result (same arithmetic, so no ReLU-kink lottery: a single pre-activation within
+    round-off of zero moves a whole channel's gradient by per cent, whichever fp32-accurate implementation computes it)."""
+    N, H, W = shape
+    D = 3
+    m, o = _pair(arch, D, bw)
+    m2 = copy.deepcopy(m)
+    g = torch.Generator().manual_seed(3)
+    xa = torch.randn(N, 3, H, W, generator=g)
+    xb = torch.randn(N, 3, H, W, generator=g) * 1.7 + 0.3        # different statistics per batch
+    ga = torch.randn(N, D, H, W, generator=g)
+    gb = torch.randn(N, D, H, W, generator=g)
+    m.train(); m2.train(); o.train()
+    ya, yb = m.forward_pair(xa, xb)
+    za, zb = m2(xa), m2(xb)
+    oa, ob = o(xa), o(xb)
+    assert ya.shape == oa.shape and rel_err(ya, oa) < 2e-5 and rel_err(yb, ob) < 2e-5
+    assert rel_err(ya, za) < 1e-6 and rel_err(yb, zb) < 1e-6
+    ((ya * ga).sum() + (yb * gb).sum()).backward()
+    ((za * ga).sum() + (zb * gb).sum()).backward()
+    for (k, p), p2 in zip(m.named_parameters(), m2.parameters()):
+        assert rel_err(p.grad, p2.grad) < 1e-5, (k, rel_err(p.grad, p2.grad))
+    for (k, b), b2, bo in zip(m.named_buffers(), m2.buffers(), o.buffers()):
+        assert rel_err(b.float(), b2.float()) < 1e-6, k
+        assert rel_err(b.float(), bo.float()) < 1e-4 or float((b.float() - bo.float()).abs().max()) < 1e-5, k
+    # a batch whose rows are not tile-aligned silently takes the two-call route
+    xs = torch.randn(1, 3, 40, 24, generator=g)
+    y1, y2 = m.forward_pair(xs, xs * 0.5)
+    assert rel_err(y1, o(xs)) < 2e-5 and rel_err(y2, o(xs * 0.5)) < 2e-5

@@ -430,3 +430,34 @@ def test_normalized_descriptor_training_step(L, conv_mode):
     for (k, p), (_, po) in zip(dcn.fcn.named_parameters(), o.named_parameters()):
         l2 = float((p.grad.cpu() - po.grad).norm() / po.grad.norm().clamp_min(1e-30))
         assert l2 < 5e-2, (k, l2)
+
+
+def test_forward_pair_equals_two_forward_calls_full_size(L, conv_mode):
+    """config 1 at full size: forward_pair(img_a, img_b) (one grouped launch sequence over both image batches) against two
+    forward calls of the same network -- descriptors, loss, every parameter gradient and the BN running statistics."""
+    import copy
+    from oracle import synth
+    c = synth.CONFIGS[1]
+    dcn, _ = _dcn_and_oracle(c["backbone"], c["D"], c["H"], c["W"])
+    dcn2 = copy.deepcopy(dcn)
+    img_a, img_b, lists = synth.make_batch(2, c["H"], c["W"], c["Pm"], c["Pk"], c["Pg"], seed=4)
+    from dense_correspondence.loss_functions import loss_composer
+    from dense_correspondence.loss_functions.pixelwise_contrastive_loss import PixelwiseContrastiveLoss
+    pcl = PixelwiseContrastiveLoss(image_shape=dcn.image_shape, config=synth.LOSS_CONFIG)
+    tup = [_tuple(Ld, "cuda") for Ld in lists]
+    ya, yb = dcn.forward_pair(img_a.cuda(), img_b.cuda())
+    za, zb = dcn2.forward(img_a.cuda()), dcn2.forward(img_b.cuda())
+    # (not bit-identical: 2N images pick other tile shapes / stream-K splits than N, i.e. another fp32 summation order;
+    #  through 36 conv+BN layers that is ~1e-5 on the descriptors -- the same size as either result's distance from float64)
+    assert rel_err(ya.detach().cpu(), za.detach().cpu()) < 5e-5 and rel_err(yb.detach().cpu(), zb.detach().cpu()) < 5e-5
+    l1 = loss_composer.get_loss_batched(pcl, 0, dcn.process_network_output(ya, 2), dcn.process_network_output(yb, 2), tup)[0]
+    l2 = loss_composer.get_loss_batched(pcl, 0, dcn2.process_network_output(za, 2), dcn2.process_network_output(zb, 2), tup)[0]
+    assert abs(l1.item() - l2.item()) <= TOL * abs(l2.item())
+    l1.backward(); l2.backward()
+    for (k, p), p2 in zip(dcn.fcn.named_parameters(), dcn2.fcn.parameters()):
+        if k.endswith("fc.bias"):
+            continue
+        l2n = float((p.grad - p2.grad).norm() / p2.grad.norm())   # ill-conditioned (ReLU kinks): same bound as the live-oracle test
+        assert l2n < 2e-2, (k, l2n)
+    for (k, b), b2 in zip(dcn.fcn.named_buffers(), dcn2.fcn.buffers()):
+        assert rel_err(b.float().cpu(), b2.float().cpu()) < 1e-5, k
