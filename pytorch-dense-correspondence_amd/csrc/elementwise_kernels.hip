@@ -53,32 +53,48 @@ pad_rows_kernel(const float* __restrict__ src, float* __restrict__ dst, int64_t 
 // training step run as ONE launch sequence over 2B images); batch statistics are per group -- group g owns tiles
 // [g*tiles, (g+1)*tiles) and the statistics block at offset g*gstride -- and the running statistics are updated once per
 // group, in order, exactly as two consecutive nn.BatchNorm2d calls would.
+// Work split of both finalize kernels: 4 channels x 64 row-parts per workgroup (C / 4 workgroups; a work-item walks
+// tiles / 64 partial rows), parts reduced by a fixed xor-shuffle tree inside each wavefront, then across the 4 wavefronts
+// through LDS in fixed order -- deterministic, and a 64-channel layer with 2 x 1024 partial rows finishes in microseconds.
+template <class T> __device__ __forceinline__ T part_tree_sum(T v) {
+#pragma unroll
+    for (int o = 4; o < 64; o <<= 1) v += __shfl_xor(v, o);
+    return v;
+}
+__device__ __forceinline__ float part_tree_max(float v) {
+#pragma unroll
+    for (int o = 4; o < 64; o <<= 1) v = fmaxf(v, __shfl_xor(v, o));
+    return v;
+}
+
 __global__ void __launch_bounds__(256)
 bn_finalize_kernel(const float* __restrict__ partial, int tiles, int groups, int C, double count,
                    const float* __restrict__ gamma, const float* __restrict__ beta, float* __restrict__ running_mean,
                    float* __restrict__ running_var, float momentum, float eps, int training, float* __restrict__ scale,
                    float* __restrict__ shift, float* __restrict__ save_mean, float* __restrict__ save_invstd, int gstride) {
-    __shared__ double s_sum[16][16];
-    __shared__ double s_sq[16][16];
-    const int cl = threadIdx.x & 15, part = threadIdx.x >> 4;
-    const int c = blockIdx.x * 16 + cl;
+    __shared__ double s_sum[4][4];
+    __shared__ double s_sq[4][4];
+    const int cl = threadIdx.x & 3, part = threadIdx.x >> 2, wv = threadIdx.x >> 6;
+    const int c = blockIdx.x * 4 + cl;
     for (int g = 0; g < groups; ++g) {
         double a = 0.0, b = 0.0;
         if (training && c < C) {
-            for (int t = g * tiles + part; t < (g + 1) * tiles; t += 16) {
+#pragma unroll 4
+            for (int t = g * tiles + part; t < (g + 1) * tiles; t += 64) {
                 a += (double)partial[((int64_t)t * 2 + 0) * C + c];
                 b += (double)partial[((int64_t)t * 2 + 1) * C + c];
             }
         }
+        a = part_tree_sum(a);
+        b = part_tree_sum(b);
         __syncthreads();
-        s_sum[part][cl] = a;
-        s_sq[part][cl] = b;
+        if ((threadIdx.x & 63) < 4) { s_sum[wv][cl] = a; s_sq[wv][cl] = b; }
         __syncthreads();
-        if (part != 0 || c >= C) continue;
+        if (threadIdx.x >= 4 || c >= C) continue;
         double mean, var;
         if (training) {
-            a = 0.0; b = 0.0;
-            for (int i = 0; i < 16; ++i) { a += s_sum[i][cl]; b += s_sq[i][cl]; }  // fixed order
+            a = (s_sum[0][cl] + s_sum[1][cl]) + (s_sum[2][cl] + s_sum[3][cl]);
+            b = (s_sq[0][cl] + s_sq[1][cl]) + (s_sq[2][cl] + s_sq[3][cl]);
             mean = a / count;
             var = b / count - mean * mean;
             if (var < 0.0) var = 0.0;
@@ -195,15 +211,15 @@ bn_bwd_finalize_kernel(const float* __restrict__ partial, int chunks, int groups
                        const float* __restrict__ gamma, const float* __restrict__ invstd, int gstride,
                        float* __restrict__ dgamma, float* __restrict__ dbeta, float* __restrict__ k123,
                        float* __restrict__ absmax) {
-    // 16 channels x 16 chunk-parts per workgroup (C / 16 workgroups: a 64-channel layer still gets 4 CUs and every
-    // work-item only walks chunks / 16 partial rows); fixed summation order.  Per group g (chunks [g*chunks, (g+1)*chunks)):
+    // 4 channels x 64 chunk-parts per workgroup (see bn_finalize_kernel).  Per group g (chunks [g*chunks, (g+1)*chunks)):
     // k123[g][0..2][C]; dgamma / dbeta are the sums over the groups (the parameters are shared).
-    __shared__ double s_a[16][16];
-    __shared__ double s_b[16][16];
-    __shared__ float s_mg[16][16];
-    __shared__ float s_mx[16][16];
-    const int cl = threadIdx.x & 15, part = threadIdx.x >> 4;
-    const int c = blockIdx.x * 16 + cl;
+    __shared__ double s_a[4][4];
+    __shared__ double s_b[4][4];
+    __shared__ float s_mg[4][4];
+    __shared__ float s_mx[4][4];
+    const int cl = threadIdx.x & 3, part = threadIdx.x >> 2, wv = threadIdx.x >> 6;
+    const int c = blockIdx.x * 4 + cl;
+    const bool lead = threadIdx.x < 4 && c < C;
     double tot_a = 0.0, tot_b = 0.0;
     float bound = 0.f;
     for (int g = 0; g < groups; ++g) {
@@ -211,7 +227,7 @@ bn_bwd_finalize_kernel(const float* __restrict__ partial, int chunks, int groups
         float mg = 0.f, mx = 0.f;
         if (c < C) {
 #pragma unroll 4
-            for (int t = g * chunks + part; t < (g + 1) * chunks; t += 16) {
+            for (int t = g * chunks + part; t < (g + 1) * chunks; t += 64) {
                 const float* row = partial + (int64_t)t * 4 * C + c;
                 a += (double)row[0];
                 b += (double)row[C];
@@ -219,19 +235,18 @@ bn_bwd_finalize_kernel(const float* __restrict__ partial, int chunks, int groups
                 mx = fmaxf(mx, row[3 * C]);
             }
         }
+        a = part_tree_sum(a);
+        b = part_tree_sum(b);
+        mg = part_tree_max(mg);
+        mx = part_tree_max(mx);
         __syncthreads();
-        s_a[part][cl] = a;
-        s_b[part][cl] = b;
-        s_mg[part][cl] = mg;
-        s_mx[part][cl] = mx;
+        if ((threadIdx.x & 63) < 4) { s_a[wv][cl] = a; s_b[wv][cl] = b; s_mg[wv][cl] = mg; s_mx[wv][cl] = mx; }
         __syncthreads();
-        if (part == 0 && c < C) {
-            a = 0.0; b = 0.0;
-#pragma unroll
-            for (int q = 0; q < 16; ++q) {
-                a += s_a[q][cl]; b += s_b[q][cl];
-                mg = fmaxf(mg, s_mg[q][cl]); mx = fmaxf(mx, s_mx[q][cl]);
-            }
+        if (lead) {
+            a = (s_a[0][cl] + s_a[1][cl]) + (s_a[2][cl] + s_a[3][cl]);
+            b = (s_b[0][cl] + s_b[1][cl]) + (s_b[2][cl] + s_b[3][cl]);
+            mg = fmaxf(fmaxf(s_mg[0][cl], s_mg[1][cl]), fmaxf(s_mg[2][cl], s_mg[3][cl]));
+            mx = fmaxf(fmaxf(s_mx[0][cl], s_mx[1][cl]), fmaxf(s_mx[2][cl], s_mx[3][cl]));
             const float c1 = gamma[c] * invstd[g * gstride + c], c2 = (float)(a / count), c3 = (float)(b / count);
             float* k = k123 + (int64_t)g * 3 * C;
             k[c] = c1;
@@ -242,17 +257,14 @@ bn_bwd_finalize_kernel(const float* __restrict__ partial, int chunks, int groups
             bound = fmaxf(bound, fabsf(c1) * (mg + fabsf(c2) + mx * fabsf(c3)));
         }
     }
-    if (part == 0 && c < C) {
+    if (lead) {
         dbeta[c] = (float)tot_a;
         dgamma[c] = (float)tot_b;
     }
-    if (absmax) {
-        __syncthreads();
-        if (part == 0) s_mg[0][cl] = bound;
-        __syncthreads();
+    if (absmax && threadIdx.x < 64) {   // the 4 leaders sit in lanes 0..3 of wavefront 0
+        bound = fmaxf(bound, __shfl_xor(bound, 1));
+        bound = fmaxf(bound, __shfl_xor(bound, 2));
         if (threadIdx.x == 0) {
-#pragma unroll
-            for (int q = 1; q < 16; ++q) bound = fmaxf(bound, s_mg[0][q]);
             const unsigned bits = __float_as_uint(bound);
             if (bound > 0.f && bits > __atomic_load_n(reinterpret_cast<unsigned*>(absmax), __ATOMIC_RELAXED))
                 atomicMax(reinterpret_cast<unsigned*>(absmax), bits);
@@ -550,7 +562,7 @@ void launch_pad_rows(const float* src, float* dst, int64_t rows, int d, int ld, 
 void launch_bn_finalize(const float* partial, int tiles_per_group, int groups, int C, double count_per_group,
                         const float* gamma, const float* beta, float* rmean, float* rvar, float momentum, float eps,
                         int training, float* stats, hipStream_t st) {
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3(ceil_div(C, 16)), dim3(256), 0, st, partial, tiles_per_group, groups, C,
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3(ceil_div(C, 4)), dim3(256), 0, st, partial, tiles_per_group, groups, C,
                        count_per_group, gamma, beta, rmean, rvar, momentum, eps, training, stats, stats + C, stats + 2 * C,
                        stats + 3 * C, 4 * C);
 }
@@ -577,7 +589,7 @@ void launch_bn_bwd(const float* dy, const float* relu_out, const float* x, const
     const float* invstd = stats + 3 * C;
     hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(ceil_div(C, 64), chunks * groups), dim3(256), 0, st, dy, relu_out, x,
                        mean, invstd, C, rpg, chunks, 4 * C, rpc, partial);
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(ceil_div(C, 16)), dim3(256), 0, st, (const float*)partial, chunks,
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(ceil_div(C, 4)), dim3(256), 0, st, (const float*)partial, chunks,
                        groups, C, (double)rpg, gamma, invstd, 4 * C, dgamma, dbeta, k123, absmax);
     const int64_t total4 = rows * (C / 4);
     hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(blocks_for(total4, kGridCap)), dim3(256), 0, st, dy, relu_out, x, mean,
