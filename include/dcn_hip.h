@@ -123,6 +123,18 @@ int dcn_contrastive_loss_backward(const float* desc_a, const float* desc_b, int 
                                   const int32_t* hard_neg, const float* grad_loss, const float* pair_grad,
                                   float* grad_a, float* grad_b, void* stream);
 
+/* Triplet variant (pixelwise_contrastive_loss.py:104-129, loss_composer.py:145-166):
+ *   loss = 1/n * sum_i sum_k max(0, (a_k - m_k)^2 - (a_k - q_k)^2 + alpha),   a = A[non_a[i]], m = B[match_b[i / (n / n_match)]],
+ *   q = B[non_b[i]]  -- hinge per descriptor component, exactly as the reference computes it.  n % n_match == 0.
+ * desc_a / desc_b: [hw, d] of ONE image pair.  backward ACCUMULATES into grad_a / grad_b (zero-fill them first). */
+size_t dcn_triplet_loss_workspace_bytes(int64_t n);
+int dcn_triplet_loss_forward(const float* desc_a, const float* desc_b, int64_t hw, int d, const int64_t* non_a,
+                             const int64_t* match_b, const int64_t* non_b, int64_t n, int64_t n_match, float alpha,
+                             float* loss, int32_t* status, void* workspace, void* stream);
+int dcn_triplet_loss_backward(const float* desc_a, const float* desc_b, int64_t hw, int d, const int64_t* non_a,
+                              const int64_t* match_b, const int64_t* non_b, int64_t n, int64_t n_match, float alpha,
+                              const float* grad_loss, float* grad_a, float* grad_b, void* stream);
+
 /* =====================================================================================================
  * 2. Dilated-ResNet FCN backbone  (kernels K1-K8, K10)
  *

@@ -299,6 +299,105 @@ int64_t max_len(const int64_t* offsets_host, int num_pairs) {
     return m;
 }
 
+// ------------------------------------------------------------------------------------------------ triplet loss
+// pixelwise_contrastive_loss.py:104-129 (get_triplet_loss):  with a = A[non_a[i]], m = B[match_b[i / multiplier]],
+// n = B[non_b[i]]:   loss = 1/P * sum_i sum_d max(0, (a_d - m_d)^2 - (a_d - n_d)^2 + alpha)
+// -- the hinge is applied PER DESCRIPTOR COMPONENT (the reference never sums over d before the clamp), and the match list
+// is expanded by `multiplier` = P / P_match non-matches per match ("matches_b_long").  One work-item per triplet.
+constexpr int kTripThreads = 256;
+
+__global__ void __launch_bounds__(kTripThreads)
+triplet_fwd_kernel(const float* __restrict__ A, const float* __restrict__ B, int64_t hw, int d,
+                   const int64_t* __restrict__ non_a, const int64_t* __restrict__ match_b,
+                   const int64_t* __restrict__ non_b, int64_t n, int64_t multiplier, float alpha,
+                   double* __restrict__ part, int* __restrict__ status) {
+    __shared__ double s[kTripThreads / dcn::kWave];
+    double acc = 0.0;
+    for (int64_t i = (int64_t)blockIdx.x * kTripThreads + threadIdx.x; i < n; i += (int64_t)gridDim.x * kTripThreads) {
+        const int64_t ia = non_a[i], im = match_b[i / multiplier], in = non_b[i];
+        if (ia < 0 || ia >= hw || im < 0 || im >= hw || in < 0 || in >= hw) { *status = 1; continue; }
+        const float* a = A + ia * d;
+        const float* m = B + im * d;
+        const float* q = B + in * d;
+        float t = 0.f;
+        for (int k = 0; k < d; ++k) {
+            const float dm = a[k] - m[k], dn = a[k] - q[k];
+            t += fmaxf(dm * dm - dn * dn + alpha, 0.f);
+        }
+        acc += (double)t;
+    }
+    acc = dcn::block_sum<kTripThreads>(acc, s);
+    if (threadIdx.x == 0) part[blockIdx.x] = acc;
+}
+
+__global__ void __launch_bounds__(kTripThreads)
+triplet_finalize_kernel(const double* __restrict__ part, int blocks, int64_t n, float* __restrict__ loss) {
+    __shared__ double s[kTripThreads / dcn::kWave];
+    double acc = 0.0;
+    for (int i = threadIdx.x; i < blocks; i += kTripThreads) acc += part[i];   // fixed order
+    acc = dcn::block_sum<kTripThreads>(acc, s);
+    if (threadIdx.x == 0) *loss = (float)(acc / (double)n);
+}
+
+// gA / gB += d loss / d descriptors (hardware fp32 atomics; the caller zero-fills or accumulates on purpose)
+__global__ void __launch_bounds__(kTripThreads)
+triplet_bwd_kernel(const float* __restrict__ A, const float* __restrict__ B, int64_t hw, int d,
+                   const int64_t* __restrict__ non_a, const int64_t* __restrict__ match_b,
+                   const int64_t* __restrict__ non_b, int64_t n, int64_t multiplier, float alpha,
+                   const float* __restrict__ grad_loss, float* __restrict__ gA, float* __restrict__ gB) {
+    const float g2 = 2.f * (*grad_loss) / (float)n;
+    for (int64_t i = (int64_t)blockIdx.x * kTripThreads + threadIdx.x; i < n; i += (int64_t)gridDim.x * kTripThreads) {
+        const int64_t ia = non_a[i], im = match_b[i / multiplier], in = non_b[i];
+        if (ia < 0 || ia >= hw || im < 0 || im >= hw || in < 0 || in >= hw) continue;
+        for (int k = 0; k < d; ++k) {
+            const float a = A[ia * d + k], m = B[im * d + k], q = B[in * d + k];
+            const float dm = a - m, dn = a - q;
+            if (dm * dm - dn * dn + alpha > 0.f) {
+                unsafeAtomicAdd(gA + ia * d + k, g2 * (dm - dn));
+                unsafeAtomicAdd(gB + im * d + k, -g2 * dm);
+                unsafeAtomicAdd(gB + in * d + k, g2 * dn);
+            }
+        }
+    }
+}
+
+int triplet_blocks(int64_t n) {
+    int64_t b = dcn::ceil_div64(n, kTripThreads);
+    if (b > 2048) b = 2048;
+    return b < 1 ? 1 : (int)b;
+}
+
+}  // namespace
+
+extern "C" size_t dcn_triplet_loss_workspace_bytes(int64_t n) { return (size_t)triplet_blocks(n) * sizeof(double) + 64; }
+
+extern "C" int dcn_triplet_loss_forward(const float* desc_a, const float* desc_b, int64_t hw, int d, const int64_t* non_a,
+                                        const int64_t* match_b, const int64_t* non_b, int64_t n, int64_t n_match, float alpha,
+                                        float* loss, int32_t* status, void* workspace, void* stream) {
+    if (!desc_a || !desc_b || !non_a || !match_b || !non_b || !loss || !status || !workspace || hw < 1 || d < 1 || n < 1 ||
+        n_match < 1 || (n % n_match) != 0)   // the reference's index_select shapes only agree for whole multiples
+        return DCN_E_INVALID;
+    hipStream_t st = (hipStream_t)stream;
+    if (hipMemsetAsync(status, 0, sizeof(int32_t), st) != hipSuccess) return DCN_E_LAUNCH;
+    const int blocks = triplet_blocks(n);
+    hipLaunchKernelGGL(triplet_fwd_kernel, dim3(blocks), dim3(kTripThreads), 0, st, desc_a, desc_b, hw, d, non_a, match_b,
+                       non_b, n, n / n_match, alpha, (double*)workspace, (int*)status);
+    hipLaunchKernelGGL(triplet_finalize_kernel, dim3(1), dim3(kTripThreads), 0, st, (const double*)workspace, blocks, n, loss);
+    return dcn::check_launch();
+}
+
+extern "C" int dcn_triplet_loss_backward(const float* desc_a, const float* desc_b, int64_t hw, int d, const int64_t* non_a,
+                                         const int64_t* match_b, const int64_t* non_b, int64_t n, int64_t n_match,
+                                         float alpha, const float* grad_loss, float* grad_a, float* grad_b, void* stream) {
+    if (!desc_a || !desc_b || !non_a || !match_b || !non_b || !grad_loss || !grad_a || !grad_b || hw < 1 || d < 1 || n < 1 ||
+        n_match < 1 || (n % n_match) != 0)
+        return DCN_E_INVALID;
+    hipLaunchKernelGGL(triplet_bwd_kernel, dim3(triplet_blocks(n)), dim3(kTripThreads), 0, (hipStream_t)stream, desc_a,
+                       desc_b, hw, d, non_a, match_b, non_b, n, n / n_match, alpha, grad_loss, grad_a, grad_b);
+    return dcn::check_launch();
+}
+
+namespace {
 }  // namespace
 
 extern "C" size_t dcn_loss_workspace_bytes(int num_pairs, int64_t max_list_len) {

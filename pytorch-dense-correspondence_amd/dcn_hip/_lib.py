@@ -70,6 +70,11 @@ SYMBOLS = {
                                      c_void_p, c_void_p, c_void_p]),
     "dcn_conv_dgrad_f16": (c_int, [ctypes.POINTER(ConvDesc), c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_void_p,
                                    c_void_p, c_void_p, c_void_p]),
+    "dcn_triplet_loss_workspace_bytes": (c_size_t, [c_int64]),
+    "dcn_triplet_loss_forward": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_void_p, c_void_p, c_void_p, c_int64, c_int64,
+                                         c_float, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "dcn_triplet_loss_backward": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_void_p, c_void_p, c_void_p, c_int64, c_int64,
+                                          c_float, c_void_p, c_void_p, c_void_p, c_void_p]),
     "dcn_plan_create_grouped": (c_int, [c_char_p, c_int, c_int, c_int, c_int, c_int, c_int, ctypes.POINTER(c_void_p)]),
     "dcn_plan_set_conv_mode": (c_int, [c_void_p, c_int]),
     "dcn_plan_conv_mode": (c_int, [c_void_p]),

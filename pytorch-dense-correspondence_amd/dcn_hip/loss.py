@@ -177,3 +177,54 @@ def contrastive_loss(desc_a, desc_b, lists, cfg, want_per_term=False):
 def per_term_losses(desc_a, desc_b, lists, cfg):
     """(per-pair vector [total], hard_neg int32 [P,4]); the vector is differentiable."""
     return _PerTermFn.apply(desc_a, desc_b, lists, cfg)
+
+
+class _TripletLossFn(torch.autograd.Function):
+    """pixelwise_contrastive_loss.py:104-129 as one fused gather kernel (+ scatter-add backward)."""
+
+    @staticmethod
+    def forward(ctx, desc_a, desc_b, non_a, match_b, non_b, alpha):
+        lib = _lib.get()
+        _lib.require_device(desc_a, desc_b, non_a, match_b, non_b)
+        if desc_a.dim() != 3 or desc_a.shape[0] != 1 or desc_a.shape != desc_b.shape:
+            raise ValueError("triplet loss: descriptors must be two [1, HW, D] tensors, got %s / %s" %
+                             (tuple(desc_a.shape), tuple(desc_b.shape)))
+        n, n_match = int(non_a.numel()), int(match_b.numel())
+        if int(non_b.numel()) != n or n_match < 1 or n % n_match:
+            raise ValueError("triplet loss: %d non-matches for %d matches (must be a whole multiple, pcl.py:113-120)" %
+                             (n, n_match))
+        desc_a = desc_a.contiguous().float()
+        desc_b = desc_b.contiguous().float()
+        non_a, match_b, non_b = (t.contiguous().to(torch.int64) for t in (non_a, match_b, non_b))
+        _, hw, d = desc_a.shape
+        dev = desc_a.device
+        loss = torch.empty((), dtype=torch.float32, device=dev)
+        status = torch.empty(1, dtype=torch.int32, device=dev)
+        ws = torch.empty(lib.dcn_triplet_loss_workspace_bytes(n), dtype=torch.uint8, device=dev)
+        rc = lib.dcn_triplet_loss_forward(_lib.ptr(desc_a), _lib.ptr(desc_b), hw, d, _lib.ptr(non_a), _lib.ptr(match_b),
+                                          _lib.ptr(non_b), n, n_match, float(alpha), _lib.ptr(loss), _lib.ptr(status),
+                                          _lib.ptr(ws), _lib.stream_ptr())
+        _lib.check(rc, "dcn_triplet_loss_forward")
+        ctx.save_for_backward(desc_a, desc_b, non_a, match_b, non_b)
+        ctx.alpha = float(alpha)
+        ctx.status = status
+        return loss
+
+    @staticmethod
+    def backward(ctx, grad_loss):
+        lib = _lib.get()
+        desc_a, desc_b, non_a, match_b, non_b = ctx.saved_tensors
+        _, hw, d = desc_a.shape
+        ga = torch.zeros_like(desc_a)
+        gb = torch.zeros_like(desc_b)
+        g = grad_loss.to(torch.float32).contiguous()
+        rc = lib.dcn_triplet_loss_backward(_lib.ptr(desc_a), _lib.ptr(desc_b), hw, d, _lib.ptr(non_a), _lib.ptr(match_b),
+                                           _lib.ptr(non_b), int(non_a.numel()), int(match_b.numel()), ctx.alpha,
+                                           _lib.ptr(g), _lib.ptr(ga), _lib.ptr(gb), _lib.stream_ptr())
+        _lib.check(rc, "dcn_triplet_loss_backward")
+        return ga, gb, None, None, None, None
+
+
+def triplet_loss(desc_a, desc_b, non_matches_a, matches_b, non_matches_b, alpha):
+    """0-dim loss of pcl.py:104-129 for one image pair (descriptors [1, HW, D]); differentiable w.r.t. both maps."""
+    return _TripletLossFn.apply(desc_a, desc_b, non_matches_a, matches_b, non_matches_b, alpha)

@@ -155,17 +155,13 @@ class PixelwiseContrastiveLoss(object):
     # ------------------------------------------------------------------ variants off the default path
     @staticmethod
     def get_triplet_loss(image_a_pred, image_b_pred, matches_a, matches_b, non_matches_a, non_matches_b, alpha):
-        """pcl.py:104-129.  Not reached by any training configuration of the reference (the triplet composer,
-        loss_composer.py:145-166, has no caller); kept callable with plain tensor ops, no HIP kernel yet."""
-        num_matches = matches_a.size()[0]
-        num_non_matches = non_matches_a.size()[0]
-        multiplier = num_non_matches // num_matches
-        matches_b_long = torch.t(matches_b.repeat(multiplier, 1)).contiguous().view(-1)
-        a = torch.index_select(image_a_pred, 1, non_matches_a)
-        bm = torch.index_select(image_b_pred, 1, matches_b_long)
-        bn = torch.index_select(image_b_pred, 1, non_matches_b)
-        triplet_losses = (a - bm).pow(2) - (a - bn).pow(2) + alpha
-        return 1.0 / num_non_matches * torch.clamp(triplet_losses, min=0).sum()
+        """pcl.py:104-129: ``1/P * sum max(0, (a - b_match)^2 - (a - b_nonmatch)^2 + alpha)`` with the hinge per descriptor
+        component and the match list expanded ``P / P_match`` times, as ONE fused gather kernel
+        (``dcn_triplet_loss_forward`` / ``_backward``).  ``matches_a`` only contributes its length, as in the reference
+        (``non_matches_a`` already is the replicated ``matches_a``)."""
+        if matches_a.size()[0] != matches_b.size()[0]:
+            raise ValueError("matches_a / matches_b differ in length")
+        return _k.triplet_loss(image_a_pred, image_b_pred, non_matches_a, matches_b, non_matches_b, alpha)
 
     def get_loss_original(self, image_a_pred, image_b_pred, matches_a, matches_b, non_matches_a, non_matches_b,
                           M_margin=0.5, non_match_loss_weight=1.0):

@@ -61,8 +61,17 @@ def test_building_blocks_match_reference_goldens():
     s, h = pcl.non_match_loss_descriptor_only(A, B, ka, kb, M_descriptor=cfg["M_masked"])
     np.testing.assert_allclose(s.item(), z["f7_vec"].sum(), rtol=2e-6)
     assert h == int(z["f7_hard"])
-    trip = PCL.get_triplet_loss(A, B, ma, mb, torch.tensor(z["triplet_non_matches_a"]), kb, cfg["alpha_triplet"])
+    # triplet loss kernel: value against the REFERENCE's golden, gradients against the oracle's autograd
+    tna = torch.tensor(z["triplet_non_matches_a"])
+    A3 = torch.tensor(z["A"], requires_grad=True); B3 = torch.tensor(z["B"], requires_grad=True)
+    trip = PCL.get_triplet_loss(A3, B3, ma, mb, tna, kb, cfg["alpha_triplet"])
     np.testing.assert_allclose(trip.item(), z["triplet"], rtol=1e-6)
+    (trip * 1.7).backward()
+    A4 = torch.tensor(z["A"], requires_grad=True); B4 = torch.tensor(z["B"], requires_grad=True)
+    (loss_oracle.PixelwiseContrastiveLoss.get_triplet_loss(A4, B4, ma, mb, tna, kb, cfg["alpha_triplet"]) * 1.7).backward()
+    assert rel_err(A3.grad, A4.grad) < 1e-5 and rel_err(B3.grad, B4.grad) < 1e-5
+    with pytest.raises(ValueError):   # the reference's index_select shapes only agree for whole multiples
+        PCL.get_triplet_loss(A3, B3, ma, mb, tna[:-1], kb[:-1], cfg["alpha_triplet"])
     orig = pcl.get_loss_original(A, B, ma, mb, ka, kb)
     np.testing.assert_allclose([o.item() for o in orig], z["original_loss"], rtol=1e-6)
 

@@ -461,3 +461,33 @@ def test_forward_pair_equals_two_forward_calls_full_size(L, conv_mode):
         assert l2n < 2e-2, (k, l2n)
     for (k, b), b2 in zip(dcn.fcn.named_buffers(), dcn2.fcn.buffers()):
         assert rel_err(b.float().cpu(), b2.float().cpu()) < 1e-5, k
+
+
+def test_triplet_loss_kernel_vs_reference_golden_and_oracle(L):
+    """pcl.py:104-129 on the GPU: the reference's own golden value (D = 16 case), then a 640x480-sized random case
+    (100 k triplets, 10 non-matches per match) against the oracle, values and gradients."""
+    from dense_correspondence.loss_functions.pixelwise_contrastive_loss import PixelwiseContrastiveLoss as PCL
+    from oracle import loss_oracle
+    path = [p for p in GOLDENS if "triplet" in np.load(p).files][0]
+    z = np.load(path)
+    t = lambda k: torch.tensor(z[k])
+    A = t("A").cuda().requires_grad_(True)
+    B = t("B").cuda().requires_grad_(True)
+    trip = PCL.get_triplet_loss(A, B, t("matches_a").cuda(), t("matches_b").cuda(), t("triplet_non_matches_a").cuda(),
+                                t("masked_b").cuda(), 0.1)
+    np.testing.assert_allclose(trip.item(), z["triplet"], rtol=1e-6)
+    g = torch.Generator().manual_seed(5)
+    HW, D, Pm, mult = 640 * 480, 3, 10000, 10
+    Ac = (torch.rand(1, HW, D, generator=g) - 0.5)
+    Bc = (torch.rand(1, HW, D, generator=g) - 0.5)
+    ma = torch.randint(0, HW, (Pm,), generator=g)
+    mb = torch.randint(0, HW, (Pm,), generator=g)
+    na = ma.repeat_interleave(mult)
+    nb = torch.randint(0, HW, (Pm * mult,), generator=g)
+    Ag, Bg = Ac.cuda().requires_grad_(True), Bc.cuda().requires_grad_(True)
+    lg = PCL.get_triplet_loss(Ag, Bg, ma.cuda(), mb.cuda(), na.cuda(), nb.cuda(), 0.1)
+    Ao, Bo = Ac.clone().requires_grad_(True), Bc.clone().requires_grad_(True)
+    lo = loss_oracle.PixelwiseContrastiveLoss.get_triplet_loss(Ao, Bo, ma, mb, na, nb, 0.1)
+    assert abs(lg.item() - lo.item()) <= TOL * abs(lo.item())
+    lg.backward(); lo.backward()
+    assert rel_err(Ag.grad.cpu(), Ao.grad) < TOL and rel_err(Bg.grad.cpu(), Bo.grad) < TOL
