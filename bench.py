@@ -276,9 +276,21 @@ def main():
                 peak, kern = F16X3_PEAK_TFLOPS, "conv_gemm_f16_kernel (3x v_mfma_f32_32x32x16_f16 per product; forward + dgrad)"
                 peak_note = "fp16 MFMA dense peak %.1f / 3 products per fp32-accurate MAC (fp32 MFMA peak: %.1f)" % (
                     F16_MFMA_PEAK_TFLOPS, FP32_MFMA_PEAK_TFLOPS)
+            # HBM-side traffic of the dominant kernel cannot be measured from inside the process (PMC counters need
+            # rocprofv3): it is the committed measurement of this very command (profiles/, collected and corrected per
+            # MI355X_MICROARCH.md's HBM section), attached only when workload / arithmetic / call pattern match
+            traffic, traffic_note = None, None
+            try:
+                rec = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r1b_hbm_counters.json")))
+                if (rec["workload"] == args.workload and rec["conv_mode"] == args.conv_mode and not args.batch and
+                        (rec["forward_calls"] == "pair") == (not args.separate_forwards)):
+                    traffic = rec["hbm_bytes_per_launch"]
+                    traffic_note = "profiles/r1b_hbm_counters.json: " + rec["correction"]
+            except (OSError, KeyError, ValueError):
+                pass
             roofline = {"bound": "mfma", "kernel": kern,
                         "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "peak_note": peak_note,
-                        "frac": achieved / peak, "traffic": None,
+                        "frac": achieved / peak, "traffic": traffic, "traffic_note": traffic_note,
                         "launches_per_step": n / args.profile_steps, "avg_launch_us": 1e3 * ms / n,
                         "algorithmic_gflop_per_launch": fl / n / 1e9,
                         "kernel_ms_per_step": ms / args.profile_steps,
