@@ -296,6 +296,28 @@ int dcn_find_best_match(const float* res, int64_t hw, int d, const float* querie
                         int64_t* best_idx, float* best_dist, float* norm_diffs, void* workspace, void* stream);
 size_t dcn_find_best_match_workspace(int q);
 
+/* =====================================================================================================
+ * 5. Pair generation on the device -- replaces, for device-resident depth images,
+ *    dense_correspondence/correspondence_tools/correspondence_finder.py
+ *      batch_find_pixel_correspondences (:409-619, from the point where the candidate pixels are chosen, :486)
+ *      create_non_correspondences       (:276-405, sampling part; its perturbation step is inert in the reference)
+ *    Depth images: [h][w] uint16 millimetres.  K, K_inv: row-major 3x3 fp32; pose_a, pose_b_inv: row-major 4x4 fp32
+ *    camera-to-world of image a and world-to-camera of image b (HOST pointers: they travel as kernel arguments).
+ *    Outputs keep candidate order; *out_count (device scalar) matches were written to the front of the out_* arrays.
+ * ===================================================================================================== */
+size_t dcn_find_correspondences_workspace(int64_t n);
+int dcn_find_correspondences(const uint16_t* depth_a, const uint16_t* depth_b, int h, int w, const float* K,
+                             const float* K_inv, const float* pose_a, const float* pose_b_inv, const int64_t* cand_u,
+                             const int64_t* cand_v, int64_t n, int64_t* out_ua, int64_t* out_va, float* out_ub,
+                             float* out_vb, int64_t* out_count, void* workspace, void* stream);
+/* list[0 .. *count) = flat indices of the non-zero mask pixels, increasing (torch.nonzero order) */
+size_t dcn_mask_nonzero_workspace(int64_t hw);
+int dcn_mask_nonzero(const float* mask, int64_t hw, int64_t* list, int64_t* count, void* workspace, void* stream);
+/* list == NULL: (u, v) = (floor(rand[i] * w), floor(rand[n + i] * h))            (pytorch_rand_select_pixel, :29-34)
+ * otherwise   : p = list[floor(rand[i] * *count)], (u, v) = (p % w, p / w)       (:319-324).  u, v: float [n]. */
+int dcn_sample_pixels(const float* rand, int64_t n, int w, int h, const int64_t* list, const int64_t* count, float* u,
+                      float* v, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

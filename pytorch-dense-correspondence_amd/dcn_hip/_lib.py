@@ -75,6 +75,13 @@ SYMBOLS = {
                                          c_float, c_void_p, c_void_p, c_void_p, c_void_p]),
     "dcn_triplet_loss_backward": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_void_p, c_void_p, c_void_p, c_int64, c_int64,
                                           c_float, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "dcn_find_correspondences_workspace": (c_size_t, [c_int64]),
+    "dcn_find_correspondences": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                         c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                         c_void_p]),
+    "dcn_mask_nonzero_workspace": (c_size_t, [c_int64]),
+    "dcn_mask_nonzero": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "dcn_sample_pixels": (c_int, [c_void_p, c_int64, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "dcn_plan_create_grouped": (c_int, [c_char_p, c_int, c_int, c_int, c_int, c_int, c_int, ctypes.POINTER(c_void_p)]),
     "dcn_plan_set_conv_mode": (c_int, [c_void_p, c_int]),
     "dcn_plan_conv_mode": (c_int, [c_void_p]),

@@ -491,3 +491,59 @@ def test_triplet_loss_kernel_vs_reference_golden_and_oracle(L):
     assert abs(lg.item() - lo.item()) <= TOL * abs(lo.item())
     lg.backward(); lo.backward()
     assert rel_err(Ag.grad.cpu(), Ao.grad) < TOL and rel_err(Bg.grad.cpu(), Bo.grad) < TOL
+
+
+# ------------------------------------------------------------------------------------------------ pair generation (8f-2)
+CORR_GOLDENS = sorted(glob.glob(os.path.join(GOLDEN_DIR, "corr_ref_*.npz")))
+
+
+@pytest.mark.parametrize("path", CORR_GOLDENS, ids=[os.path.basename(p)[:-4] for p in CORR_GOLDENS])
+def test_pair_generation_vs_reference_goldens(L, path):
+    """Device pair generation against the outputs of the reference's own correspondence_finder source: the surviving
+    candidates (order and values) and the non-match samples are exact, sub-pixel projections within 3e-4 px."""
+    from dcn_hip import pairgen
+    from oracle import correspondence_oracle as co
+    z = np.load(path)
+    dep = lambda a: torch.from_numpy(a.astype(np.uint16).view(np.int16)).cuda()
+    ua, va, ub, vb = pairgen.find_correspondences(dep(z["depth_a"]), dep(z["depth_b"]), co.get_default_K_matrix(), z["pose_a"],
+                                                  z["pose_b"], torch.tensor(z["cand_u"]).cuda(), torch.tensor(z["cand_v"]).cuda())
+    assert np.array_equal(ua.cpu().numpy(), z["uv_a_u"]) and np.array_equal(va.cpu().numpy(), z["uv_a_v"])
+    np.testing.assert_allclose(ub.cpu().numpy(), z["uv_b_u"], rtol=0, atol=3e-4)
+    np.testing.assert_allclose(vb.cpu().numpy(), z["uv_b_v"], rtol=0, atol=3e-4)
+    H, W = z["depth_a"].shape
+    n = z["non_u"].size
+    rand = torch.tensor(z["rand"]).cuda()
+    if z["mask"].size:
+        lst, cnt = pairgen.mask_nonzero(torch.tensor(z["mask"]).cuda())
+        u, v = pairgen.sample_pixels(rand, n, W, H, lst, cnt)
+    else:
+        u, v = pairgen.sample_pixels(rand, n, W, H)
+    assert np.array_equal(u.cpu().view(z["non_u"].shape).numpy(), z["non_u"])
+    assert np.array_equal(v.cpu().view(z["non_v"].shape).numpy(), z["non_v"])
+
+
+def test_pair_generation_reference_api_full_size(L):
+    """The mirrored correspondence_finder API with its own random candidates at the training configuration's sizes
+    (10 000 attempts, 150 non-matches per match): every returned match must satisfy the oracle's geometric filter, the
+    masked candidates lie on the mask, non-matches lie on (off) the mask."""
+    from dense_correspondence.correspondence_tools import correspondence_finder as cf
+    from oracle import correspondence_oracle as co
+    z = np.load(CORR_GOLDENS[1])
+    H, W = z["depth_a"].shape
+    mask = z["mask"]
+    torch.manual_seed(0)
+    uv_a, uv_b = cf.batch_find_pixel_correspondences(z["depth_a"], z["pose_a"], z["depth_b"], z["pose_b"], num_attempts=10000,
+                                                     img_a_mask=mask)
+    assert uv_a is not None and 1000 < uv_a[0].numel() <= 10000
+    ua, va = uv_a[0].cpu(), uv_a[1].cpu()
+    assert bool((torch.tensor(mask)[va, ua] != 0).all())
+    oa, ob = co.find_correspondences_for_candidates(z["depth_a"], z["pose_a"], z["depth_b"], z["pose_b"], ua, va)
+    assert oa[0].numel() == ua.numel()          # the oracle keeps every one of them
+    np.testing.assert_allclose(uv_b[0].cpu().numpy(), ob[0].numpy(), rtol=0, atol=3e-4)
+    nm = cf.create_non_correspondences(uv_b, (H, W), num_non_matches_per_match=150, img_b_mask=torch.tensor(mask))
+    assert nm[0].shape == (ua.numel(), 150)
+    assert bool((torch.tensor(mask)[nm[1].cpu().long(), nm[0].cpu().long()] != 0).all())
+    bg = cf.create_non_correspondences(uv_b, (H, W), num_non_matches_per_match=150, img_b_mask=1 - torch.tensor(mask))
+    assert bool((torch.tensor(mask)[bg[1].cpu().long(), bg[0].cpu().long()] == 0).all())
+    un = cf.create_non_correspondences(uv_b, (H, W), num_non_matches_per_match=7)
+    assert float(un[0].max()) <= W - 1 and float(un[1].max()) <= H - 1 and float(un[0].min()) >= 0

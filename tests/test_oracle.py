@@ -107,3 +107,24 @@ def test_synth_shapes_and_sentinels():
     assert lists[0]["matches_a"].dtype == torch.int64 and lists[0]["matches_a"].max() < 16 * 24
     assert loss_oracle.is_empty(lists[0]["background_non_matches_a"])
     assert loss_oracle.is_empty(lists[0]["blind_non_matches_a"])
+
+
+# ---------------------------------------------------------------------------------------------- pair generation (8f-2)
+CORR_GOLDENS = sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "corr_ref_*.npz")))
+
+
+@pytest.mark.parametrize("path", CORR_GOLDENS, ids=[os.path.basename(p)[:-4] for p in CORR_GOLDENS])
+def test_correspondence_oracle_matches_reference_goldens(path):
+    """oracle/correspondence_oracle.py against the outputs of the reference's own correspondence_finder source
+    (tests/golden/make_correspondence_goldens_from_reference.py)."""
+    from oracle import correspondence_oracle as co
+    z = np.load(path)
+    uv_a, uv_b = co.find_correspondences_for_candidates(z["depth_a"], z["pose_a"], z["depth_b"], z["pose_b"],
+                                                        torch.tensor(z["cand_u"]), torch.tensor(z["cand_v"]))
+    assert np.array_equal(uv_a[0].numpy(), z["uv_a_u"]) and np.array_equal(uv_a[1].numpy(), z["uv_a_v"])
+    np.testing.assert_allclose(uv_b[0].numpy(), z["uv_b_u"], rtol=1e-6)
+    np.testing.assert_allclose(uv_b[1].numpy(), z["uv_b_v"], rtol=1e-6)
+    mask = torch.tensor(z["mask"]) if z["mask"].size else None
+    H, W = z["depth_a"].shape
+    nu, nv = co.create_non_correspondences(len(z["uv_a_u"]), (H, W), int(z["per_match"]), mask, torch.tensor(z["rand"]))
+    assert np.array_equal(nu.numpy(), z["non_u"]) and np.array_equal(nv.numpy(), z["non_v"])
