@@ -266,8 +266,10 @@ int dcn_conv_dgrad_f16(const dcn_conv_desc* c, const float* dout, const void* wt
 int dcn_split_act_f16(const float* src, void* xs, int64_t n, void* stream);
 size_t dcn_grad_blocked_bytes(int m, int ld);
 int dcn_split_grad_blocked_f16(const float* dy, int m, int ld, const float* absmax, void* dq, void* stream);
-int dcn_conv_wgrad_f16(const dcn_conv_desc* c, const void* xs, const void* dq, const float* dout_absmax, float* dw,
-                       void* slabs, void* stream);
+/* xs_is_fp32 != 0: `xs` is the fp32 activation tensor itself, split on the fly (cheaper than a split pass when every
+ * element is only used by a few tiles, e.g. 1x1 convolutions) */
+int dcn_conv_wgrad_f16(const dcn_conv_desc* c, const void* xs, int xs_is_fp32, const void* dq, const float* dout_absmax,
+                       float* dw, void* slabs, void* stream);
 size_t dcn_conv_wgrad_workspace_f16(const dcn_conv_desc* c);
 
 /* bilinear xS upsample, align_corners=True (F.upsample_bilinear): low [n,hl,wl,ldl] -> out [n,h,w,d] */

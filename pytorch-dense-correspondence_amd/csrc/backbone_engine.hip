@@ -539,23 +539,29 @@ extern "C" int dcn_backbone_backward(dcn_plan* plan, const float* grad_descripto
     float* amax = R.Wk(p.w_amax);
     const bool f16 = p.conv_mode == DCN_CONV_F16X3;
 
+    const float* dq_of = nullptr;       // gradient tensor whose pixel-blocked split copy is in w_dq
     // BN backward of conv c's batch norm: dy (+ optional relu mask from relu_out) -> dx; g_out optional
     auto bn_bwd = [&](const ConvL& c, const float* dy, const float* relu_out, float* dx, float* g_out) {
         const BnL& b = p.bns[c.bn];
         const float* s = R.S(b.stats);
         dcn::launch_bn_bwd(dy, relu_out, R.S(c.x), s, R.P(b.g), b.C, b.rows, p.groups, part, grads[b.g],
-                           grads[b.b], k123, dx, g_out, f16 ? amax + c.idx : nullptr, st);
+                           grads[b.b], k123, dx, g_out, f16 ? amax + c.idx : nullptr, f16 ? (void*)R.Wk(p.w_dq) : nullptr, st);
+        dq_of = f16 ? dx : nullptr;   // the pixel-blocked split copy of this dx now sits in w_dq
     };
-    const float* planes_of = nullptr;   // activation tensor whose planes are in w_xh / w_xl (block input: two consumers)
+    const float* planes_of = nullptr;   // activation tensor whose split copy is in w_xs (block input: two consumers)
     auto wgrad = [&](const ConvL& c, const float* in, const float* dx, float* dw) -> int {
         if (!f16) return R.timed(1, c.flops, [&] { return dcn_conv_wgrad(&c.d, in, dx, dw, slab, st); });
-        if (planes_of != in) {
+        // an activation element is used by taps x (Cout / tile) wgrad tiles: pre-split it once when that is worth a pass
+        const bool presplit = c.d.kh * c.d.kw * ceil_div(c.d.cout, c.d.cout <= 64 ? 64 : 128) >= 4;
+        if (presplit && planes_of != in) {
             DCN_TRY(dcn_split_act_f16(in, R.Wk(p.w_xs), (int64_t)c.d.n * c.d.hin * c.d.win * c.d.cin, st));
             planes_of = in;
         }
-        DCN_TRY(dcn_split_grad_blocked_f16(dx, c.d.n * c.d.hout * c.d.wout, c.d.ldc, amax + c.idx, R.Wk(p.w_dq), st));
+        if (dq_of != dx)   // (BN backward emits it directly; only the scoring layer's gradient needs the separate pass)
+            DCN_TRY(dcn_split_grad_blocked_f16(dx, c.d.n * c.d.hout * c.d.wout, c.d.ldc, amax + c.idx, R.Wk(p.w_dq), st));
         return R.timed(1, c.flops, [&] {
-            return dcn_conv_wgrad_f16(&c.d, R.Wk(p.w_xs), R.Wk(p.w_dq), amax + c.idx, dw, slab, st);
+            return dcn_conv_wgrad_f16(&c.d, presplit ? (const void*)R.Wk(p.w_xs) : (const void*)in, presplit ? 0 : 1,
+                                      R.Wk(p.w_dq), amax + c.idx, dw, slab, st);
         });
     };
     auto dgrad = [&](const ConvL& c, const float* dx, const float* add, float* din) -> int {

@@ -14,45 +14,15 @@
 // operand path: 128x128 tiles, 32-K stages, fp32->(hi,lo) conversion once per element at staging time (v_cvt_pk_f16_f32),
 // conflict-free 80-byte-pitch fp16 LDS images, one ds_read_b128 per 32x16 fragment.
 #include "conv_shared.h"
+#include "f16_split.h"
 
 namespace {
 
 using namespace dcnconv;
-
-typedef _Float16 h8 __attribute__((ext_vector_type(8)));
-typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+using namespace dcnsplit;
 
 constexpr int HBK = 32;            // K elements per stage
 constexpr int LDH = HBK + 8;       // LDS row pitch in halves (80 bytes: conflict-free ds_read_b128 fragments)
-
-__device__ __forceinline__ float pow2_scale(float absmax) {
-    // largest power of two s with s * absmax <= 4096 (fp16 max is 65504: 16x headroom for the fp32->fp16 rounding)
-    return absmax > 0.f ? exp2f(floorf(log2f(4096.f / absmax))) : 1.f;
-}
-
-typedef float f32x2 __attribute__((ext_vector_type(2)));
-typedef _Float16 h2 __attribute__((ext_vector_type(2)));
-
-// (x0, x1) -> packed hi = rn16(x), lo = rn16(x - hi): one v_cvt_pk_f16_f32 per pair for hi, two v_cvt_f32_f16 back,
-// two subtractions, one v_cvt_pk_f16_f32 for lo (vector conversions keep hipcc from converting every element twice)
-__device__ __forceinline__ void split2(float x0, float x1, h2& hi, h2& lo) {
-    f32x2 v = {x0, x1};
-    hi = __builtin_convertvector(v, h2);
-    const f32x2 back = __builtin_convertvector(hi, f32x2);
-    lo = __builtin_convertvector(v - back, h2);
-}
-
-__device__ __forceinline__ void split4_unscaled(float4 v, h4& hi, h4& lo) {
-    h2 a, b, c, d;
-    split2(v.x, v.y, a, b);
-    split2(v.z, v.w, c, d);
-    hi = h4{a[0], a[1], c[0], c[1]};
-    lo = h4{b[0], b[1], d[0], d[1]};
-}
-
-__device__ __forceinline__ void split4(float4 v, float s, h4& hi, h4& lo) {
-    split4_unscaled(make_float4(v.x * s, v.y * s, v.z * s, v.w * s), hi, lo);
-}
 
 // rows x K fp32 -> hi / lo fp16 [rows][kp] (kp = K rounded up to 8, zero padded), scaled by s
 __global__ void __launch_bounds__(256)
@@ -77,8 +47,6 @@ template <int TM, int TN> struct F16Geo {
                          kStageHalves = 2 * (BM + BN) * LDH;   // A hi, A lo, B hi, B lo
 };
 
-typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 constexpr int kOob = (int)0x80000000;   // voffset that fails the bounds check of any buffer <= 2 GiB: the load returns 0
 
 // UNI: cs % 32 == 0, so a 32-K stage lies inside ONE filter tap and everything about the tap is wave-uniform: the
@@ -580,19 +548,7 @@ split_grad_blocked_kernel(const float* __restrict__ dy, int M, int ld, const flo
             const float4 x = m < M ? *reinterpret_cast<const float4*>(dy + m * ld + cq * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
             v[r][0] = x.x; v[r][1] = x.y; v[r][2] = x.z; v[r][3] = x.w;
         }
-        u32x2 hi[4], lo[4];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            h4 a, b;
-            split4(make_float4(v[0][e], v[1][e], v[2][e], v[3][e]), s, a, b);
-            hi[e] = __builtin_bit_cast(u32x2, a);
-            lo[e] = __builtin_bit_cast(u32x2, b);
-        }
-        u32x4* o = dq + q * 4 * c4n + cq;
-        o[0] = u32x4{hi[0][0], hi[0][1], hi[1][0], hi[1][1]};
-        o[c4n] = u32x4{hi[2][0], hi[2][1], hi[3][0], hi[3][1]};
-        o[2 * c4n] = u32x4{lo[0][0], lo[0][1], lo[1][0], lo[1][1]};
-        o[3 * c4n] = u32x4{lo[2][0], lo[2][1], lo[3][0], lo[3][1]};
+        store_blocked_quad(dq, q, cq, c4n, v, s);
     }
 }
 
@@ -608,7 +564,9 @@ struct WgradF16 {
 
 // FAST: wout % 4 == 0 and wout >= 32 (every real layer): a work-item's pixel quad lies in one image row and its
 // (image, y, x) position is carried from stage to stage with a few selects instead of being re-derived by division.
-template <int TM, bool FAST>   // 64*TM output channels x 128 K columns per workgroup
+// XPRE: the activation operand is the pre-split tensor xs; otherwise it is the fp32 tensor itself and is split on the fly
+// (same addresses, 4 bytes per element either way) -- cheaper when an element is only used by a few tiles (1x1 convs).
+template <int TM, bool FAST, bool XPRE>   // 64*TM output channels x 128 K columns per workgroup
 __global__ void __launch_bounds__(NT, 2)
 conv_wgrad_f16_kernel(WgradF16 p) {
     constexpr int BM = 64 * TM, BN = 128, kStage = 2 * (BM + BN) * LDH;
@@ -703,6 +661,15 @@ conv_wgrad_f16_kernel(WgradF16 p) {
         _Float16* dl = dh + BM * LDH;
         _Float16* xh = dl + BM * LDH;
         _Float16* xl = xh + BN * LDH;
+        if (!XPRE) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                h4 a, b;
+                split4_unscaled(__builtin_bit_cast(float4, rx[i]), a, b);
+                const u32x2 ua = __builtin_bit_cast(u32x2, a), ub = __builtin_bit_cast(u32x2, b);
+                rx[i] = u32x4{ua[0], ua[1], ub[0], ub[1]};
+            }
+        }
 #pragma unroll
         for (int pl = 0; pl < 2; ++pl) {
             _Float16* xd = pl ? xl : xh;
@@ -928,8 +895,8 @@ extern "C" size_t dcn_conv_wgrad_workspace_f16(const dcn_conv_desc* c) {
     return (size_t)splits * c->cout * c->kh * c->kw * c->cin * sizeof(float);
 }
 
-extern "C" int dcn_conv_wgrad_f16(const dcn_conv_desc* c, const void* xs, const void* dq, const float* dout_absmax,
-                                  float* dw, void* slabs, void* stream) {
+extern "C" int dcn_conv_wgrad_f16(const dcn_conv_desc* c, const void* xs, int xs_is_fp32, const void* dq,
+                                  const float* dout_absmax, float* dw, void* slabs, void* stream) {
     if (!valid_desc16(c) || !xs || !dq || !dw || !slabs || (c->ldc % 4) != 0) return DCN_E_INVALID;
     const int64_t x_bytes = (int64_t)c->n * c->hin * c->win * c->cin * 4;
     const int64_t d_bytes = (int64_t)dcn_grad_blocked_bytes(c->n * c->hout * c->wout, c->ldc);
@@ -949,13 +916,19 @@ extern "C" int dcn_conv_wgrad_f16(const dcn_conv_desc* c, const void* xs, const 
     hipStream_t st = (hipStream_t)stream;
     const dim3 grid(p.ntiles_n * p.ntiles_k * p.splits), block(NT);
     const bool fast = (c->wout % 4) == 0 && c->wout >= HBK;
-    if (narrow) {
-        if (fast) hipLaunchKernelGGL((conv_wgrad_f16_kernel<1, true>), grid, block, 0, st, p);
-        else hipLaunchKernelGGL((conv_wgrad_f16_kernel<1, false>), grid, block, 0, st, p);
-    } else {
-        if (fast) hipLaunchKernelGGL((conv_wgrad_f16_kernel<2, true>), grid, block, 0, st, p);
-        else hipLaunchKernelGGL((conv_wgrad_f16_kernel<2, false>), grid, block, 0, st, p);
-    }
+#define DCN_WGRAD16(TM)                                                                                        \
+    do {                                                                                                       \
+        if (fast) {                                                                                            \
+            if (xs_is_fp32) hipLaunchKernelGGL((conv_wgrad_f16_kernel<TM, true, false>), grid, block, 0, st, p); \
+            else hipLaunchKernelGGL((conv_wgrad_f16_kernel<TM, true, true>), grid, block, 0, st, p);            \
+        } else {                                                                                               \
+            if (xs_is_fp32) hipLaunchKernelGGL((conv_wgrad_f16_kernel<TM, false, false>), grid, block, 0, st, p); \
+            else hipLaunchKernelGGL((conv_wgrad_f16_kernel<TM, false, true>), grid, block, 0, st, p);           \
+        }                                                                                                      \
+    } while (0)
+    if (narrow) DCN_WGRAD16(1);
+    else DCN_WGRAD16(2);
+#undef DCN_WGRAD16
     if (p.splits > 1) launch_wgrad_reduce((const float*)slabs, dw, (int64_t)c->cout * p.K / 4, p.splits, st);
     return dcn::check_launch();
 }

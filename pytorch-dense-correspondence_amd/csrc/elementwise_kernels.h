@@ -24,7 +24,8 @@ int bn_bwd_chunks(int64_t rows_per_group);
 // relu-masked dy.  absmax (optional): raised to an upper bound of max |dx|
 void launch_bn_bwd(const float* dy, const float* relu_out, const float* x, const float* stats, const float* gamma, int C,
                    int64_t rows, int groups, float* partial, float* dgamma, float* dbeta, float* k123, float* dx,
-                   float* g_out, float* absmax, hipStream_t st);
+                   float* g_out, float* absmax, void* dq, hipStream_t st);   // dq (optional, with absmax): dx also as the
+                                                                             // pixel-blocked split-fp16 tensor (f16_split.h)
 void launch_add(const float* a, const float* b, float* out, int64_t n, hipStream_t st);
 
 void launch_maxpool_fwd(const float* in, float* out, unsigned char* argmax, int n, int hin, int win, int hout,

@@ -9,6 +9,7 @@
 //   bilinear upsample, align_corners=True  == F.upsample_bilinear (called from Resnet34_8s.forward [NOT IN TREE])
 //   optional per-pixel L2 normalisation of the descriptor (dense_correspondence_network.py:256-259)
 #include "elementwise_kernels.h"
+#include "f16_split.h"
 
 namespace dcn {
 
@@ -320,6 +321,54 @@ bn_bwd_apply_kernel(const float* __restrict__ dy, const float* __restrict__ relu
     }
 }
 
+// The same pass for the split-fp16 convolution mode: one work-item per (pixel quad, channel quad) so that it can ALSO emit
+// dx as the pixel-blocked split tensor wgrad consumes (f16_split.h), scaled by the power of two chosen from the bound the
+// finalize kernel has just stored in *absmax -- no separate split pass over dx.  rows_per_group % 4 == 0 when grouped.
+__global__ void __launch_bounds__(256)
+bn_bwd_apply_blocked_kernel(const float* __restrict__ dy, const float* __restrict__ relu_out, const float* __restrict__ x,
+                            const float* __restrict__ mean, const float* __restrict__ invstd, const float* __restrict__ k1,
+                            const float* __restrict__ k2, const float* __restrict__ k3, float* __restrict__ dx,
+                            float* __restrict__ g_out, dcnsplit::u32x4* __restrict__ dq, const float* __restrict__ absmax,
+                            int c4n, int64_t rows, int64_t rows_per_group, int gstride, int kstride) {
+    const float s = dcnsplit::pow2_scale(*absmax);
+    const int64_t total = ((rows + 3) >> 2) * c4n;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int64_t q = i / c4n;
+        const int cq = (int)(i - q * c4n);
+        const bool second = q * 4 >= rows_per_group;
+        const int c = cq * 4 + (second ? gstride : 0), ck = cq * 4 + (second ? kstride : 0);
+        const float4 mu = *reinterpret_cast<const float4*>(mean + c);
+        const float4 is = *reinterpret_cast<const float4*>(invstd + c);
+        const float4 a = *reinterpret_cast<const float4*>(k1 + ck);
+        const float4 b = *reinterpret_cast<const float4*>(k2 + ck);
+        const float4 d = *reinterpret_cast<const float4*>(k3 + ck);
+        float o[4][4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int64_t m = q * 4 + r;
+            if (m < rows) {
+                const int64_t e = m * c4n + cq;
+                float4 g = reinterpret_cast<const float4*>(dy)[e];
+                if (relu_out) {
+                    const float4 y = reinterpret_cast<const float4*>(relu_out)[e];
+                    g.x = y.x > 0.f ? g.x : 0.f; g.y = y.y > 0.f ? g.y : 0.f;
+                    g.z = y.z > 0.f ? g.z : 0.f; g.w = y.w > 0.f ? g.w : 0.f;
+                }
+                const float4 v = reinterpret_cast<const float4*>(x)[e];
+                o[r][0] = a.x * (g.x - b.x - (v.x - mu.x) * is.x * d.x);
+                o[r][1] = a.y * (g.y - b.y - (v.y - mu.y) * is.y * d.y);
+                o[r][2] = a.z * (g.z - b.z - (v.z - mu.z) * is.z * d.z);
+                o[r][3] = a.w * (g.w - b.w - (v.w - mu.w) * is.w * d.w);
+                reinterpret_cast<float4*>(dx)[e] = make_float4(o[r][0], o[r][1], o[r][2], o[r][3]);
+                if (g_out) reinterpret_cast<float4*>(g_out)[e] = g;
+            } else {
+                o[r][0] = o[r][1] = o[r][2] = o[r][3] = 0.f;
+            }
+        }
+        dcnsplit::store_blocked_quad(dq, q, cq, c4n, o, s);
+    }
+}
+
 // absmax[0] = max(absmax[0], max |v[i]|)
 __global__ void __launch_bounds__(256)
 absmax_kernel(const float* __restrict__ v, int64_t total, float* __restrict__ absmax) {
@@ -581,7 +630,7 @@ int bn_bwd_chunks(int64_t rows_per_group) {
 }
 void launch_bn_bwd(const float* dy, const float* relu_out, const float* x, const float* stats, const float* gamma, int C,
                    int64_t rows, int groups, float* partial, float* dgamma, float* dbeta, float* k123, float* dx,
-                   float* g_out, float* absmax, hipStream_t st) {
+                   float* g_out, float* absmax, void* dq, hipStream_t st) {
     const int64_t rpg = rows / groups;
     const int chunks = bn_bwd_chunks(rpg);   // per group
     const int rpc = (int)ceil_div64(rpg, chunks);
@@ -592,6 +641,13 @@ void launch_bn_bwd(const float* dy, const float* relu_out, const float* x, const
     hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(ceil_div(C, 4)), dim3(256), 0, st, (const float*)partial, chunks,
                        groups, C, (double)rpg, gamma, invstd, 4 * C, dgamma, dbeta, k123, absmax);
     const int64_t total4 = rows * (C / 4);
+    if (dq && absmax) {
+        hipLaunchKernelGGL(bn_bwd_apply_blocked_kernel, dim3(blocks_for(((rows + 3) / 4) * (C / 4), kGridCap)), dim3(256), 0, st,
+                           dy, relu_out, x, mean, invstd, (const float*)k123, (const float*)(k123 + C),
+                           (const float*)(k123 + 2 * C), dx, g_out, (dcnsplit::u32x4*)dq, (const float*)absmax, C / 4, rows,
+                           rpg, 4 * C, 3 * C);
+        return;
+    }
     hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(blocks_for(total4, kGridCap)), dim3(256), 0, st, dy, relu_out, x, mean,
                        invstd, (const float*)k123, (const float*)(k123 + C), (const float*)(k123 + 2 * C), dx, g_out,
                        C / 4, total4, total4 / groups, 4 * C, 3 * C);

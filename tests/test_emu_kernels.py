@@ -246,5 +246,10 @@ def test_conv_f16x3_forward_dgrad(L, case, tile_m, sk, monkeypatch):
     scale = float(rec[:M].abs().max() / dout.abs().max())
     assert abs(math.log2(scale) - round(math.log2(scale))) < 1e-3 and 1024 < scale * float(amax) <= 4096
     assert rel_err(rec[:M] / scale, dout.reshape(M, cout)) < 1e-6 and float(rec[M:].abs().sum()) == 0
-    assert lib.dcn_conv_wgrad_f16(ctypes.byref(d), L.ptr(xs), L.ptr(dq), L.ptr(amax), L.ptr(dw), L.ptr(slabs), None) == 0
+    assert lib.dcn_conv_wgrad_f16(ctypes.byref(d), L.ptr(xs), 0, L.ptr(dq), L.ptr(amax), L.ptr(dw), L.ptr(slabs), None) == 0
+    # same result when the activation operand is the fp32 tensor itself, split on the fly
+    dw_direct = torch.full((cout, k, k, cin), float("nan"))
+    assert lib.dcn_conv_wgrad_f16(ctypes.byref(d), L.ptr(x_nhwc), 1, L.ptr(dq), L.ptr(amax), L.ptr(dw_direct), L.ptr(slabs),
+                                  None) == 0
+    assert torch.equal(dw_direct, dw)
     assert rel_err(dw, w.grad.permute(0, 2, 3, 1)) < 5e-6

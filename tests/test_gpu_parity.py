@@ -213,11 +213,14 @@ def test_conv_f16x3_kernels_vs_torch_cpu(L, case):
     assert lib.dcn_split_act_f16(L.ptr(xg), L.ptr(xs), xg.numel(), st) == 0
     dq = torch.empty(lib.dcn_grad_blocked_bytes(M, cout) // 4, dtype=torch.float32, device="cuda")
     assert lib.dcn_split_grad_blocked_f16(L.ptr(dg), M, cout, L.ptr(amax), L.ptr(dq), st) == 0
-    wg_args = (ctypes.byref(d), L.ptr(xs), L.ptr(dq), L.ptr(amax))
+    wg_args = (ctypes.byref(d), L.ptr(xs), 0, L.ptr(dq), L.ptr(amax))
     assert lib.dcn_conv_wgrad_f16(*wg_args, L.ptr(dw), L.ptr(slab), st) == 0
     assert rel_err(dw.cpu(), w.grad.permute(0, 2, 3, 1)) < 1e-5
     dw2 = torch.empty_like(dw)
     assert lib.dcn_conv_wgrad_f16(*wg_args, L.ptr(dw2), L.ptr(slab), st) == 0
+    dw3 = torch.empty_like(dw)   # activation operand = the fp32 tensor, split on the fly: same bits
+    assert lib.dcn_conv_wgrad_f16(ctypes.byref(d), L.ptr(xg), 1, L.ptr(dq), L.ptr(amax), L.ptr(dw3), L.ptr(slab), st) == 0
+    assert torch.equal(dw, dw3)
     assert torch.equal(dw, dw2)
 
 

@@ -95,7 +95,7 @@ def main():
                 if split:
                     rc |= lib.dcn_split_act_f16(_lib.ptr(x), _lib.ptr(xs), x.numel(), st)
                     rc |= lib.dcn_split_grad_blocked_f16(_lib.ptr(dy), M, cout, _lib.ptr(amax), _lib.ptr(dq), st)
-                return rc | lib.dcn_conv_wgrad_f16(ctypes.byref(d), _lib.ptr(xs), _lib.ptr(dq), _lib.ptr(amax), _lib.ptr(dw),
+                return rc | lib.dcn_conv_wgrad_f16(ctypes.byref(d), _lib.ptr(xs), 0, _lib.ptr(dq), _lib.ptr(amax), _lib.ptr(dw),
                                                    _lib.ptr(slab), st)
             assert wgrad_f16(True) == 0
             calls["wgrad"] = wgrad_f16
