@@ -147,15 +147,31 @@ class _BackboneFn(torch.autograd.Function):
         ctx.trained = bool(training)
         ctx.normalize = bool(normalize)
         # logical [N,D,H,W] over NHWC memory == torch.channels_last
+        if plan.groups == 2:
+            # one output per image batch: their gradients arrive separately and channels_last (slicing ONE output instead
+            # makes autograd assemble the gradient in NCHW: a 2N x D x H x W transpose copy per step)
+            half = plan.n // 2
+            return desc[:half].permute(0, 3, 1, 2), desc[half:].permute(0, 3, 1, 2)
         return desc.permute(0, 3, 1, 2)
 
     @staticmethod
-    def backward(ctx, grad_desc):
+    def backward(ctx, *grad_descs):
         lib = _lib.get()
         plan = ctx.plan
         if not ctx.trained:
             raise RuntimeError("dcn_hip: backward through an eval-mode forward is not supported")
-        g = grad_desc.permute(0, 2, 3, 1).contiguous()  # NHWC; no copy when grad is channels_last
+        if plan.groups == 2:
+            half = plan.n // 2
+            ref = next(g for g in grad_descs if g is not None)
+            g = torch.empty((plan.n, plan.h, plan.w, plan.d), dtype=torch.float32, device=ref.device)
+            for k, gk in enumerate(grad_descs):
+                dst = g[k * half:(k + 1) * half]
+                if gk is None:
+                    dst.zero_()
+                else:
+                    dst.copy_(gk.permute(0, 2, 3, 1))   # NHWC; a plain copy when the gradient is channels_last
+        else:
+            g = grad_descs[0].permute(0, 2, 3, 1).contiguous()  # NHWC; no copy when grad is channels_last
         dev = g.device
         ws = torch.empty(plan.workspace_bytes, dtype=torch.uint8, device=dev)
         flat = torch.empty(plan.grad_offsets[-1], dtype=torch.float32, device=dev)

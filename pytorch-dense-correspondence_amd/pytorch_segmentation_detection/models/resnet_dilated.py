@@ -93,8 +93,8 @@ class _DilatedResnet8s(nn.Module):
         return params, running, tracked
 
     def forward(self, x, normalize=False, groups=1):
-        """``groups`` = 2: ``x`` stacks two independent batches (``cat([img_a, img_b])``); the result equals two consecutive
-        forward calls -- batch-norm statistics, their gradients and the running-statistics updates are per batch -- but
+        """``groups`` = 2: ``x`` stacks two independent batches (``cat([img_a, img_b])``) and a PAIR of outputs is returned;
+        the result equals two consecutive forward calls -- batch-norm statistics, their gradients and the running-statistics updates are per batch -- but
         runs as ONE launch sequence (fills the 256 CUs better at small batch).  See ``forward_pair``."""
         n, _, h, w = x.shape
         plan = _bb.get_plan(self.arch, self.base_width, int(n), int(h), int(w), self.num_classes, int(groups))
@@ -114,8 +114,7 @@ class _DilatedResnet8s(nn.Module):
             except ValueError:
                 y = None
             if y is not None:
-                n = x_a.shape[0]
-                return y[:n], y[n:]
+                return y
         return self.forward(x_a, normalize), self.forward(x_b, normalize)
 
     def forward_flops(self, n, h, w):
