@@ -164,6 +164,9 @@ def main():
     ap.add_argument("--conv-mode", default="f16x3", choices=["f16x3", "fp32"],
                     help="convolution arithmetic (include/dcn_hip.h): split-fp16 on the fp16 MFMA pipe with fp32-level "
                          "accuracy (default), or fp32 MFMA")
+    ap.add_argument("--hip-graph", action="store_true",
+                    help="replay forward + loss + backward (~600 launches) from one captured hipGraph instead of launching "
+                         "them every step; measured: no gain -- the step is kernel-bound, the host stays ahead of the GPU")
     ap.add_argument("--separate-forwards", action="store_true",
                     help="forward(img_a) and forward(img_b) as two engine calls (default: one grouped call with identical results)")
     ap.add_argument("--force-dist", action="store_true", help="initialise RCCL even with one rank (smoke-tests the collective path)")
@@ -215,11 +218,8 @@ def main():
     pair_lists = PairLists.from_lists(as_tuples(lists), dev)
     match_type = 0  # SINGLE_OBJECT_WITHIN_SCENE
 
-    def step(it):
+    def forward_backward():
         grads.zero_()
-        if it % 250 == 0 and it > 0:  # training.yaml:4-5 step decay
-            for g in opt.param_groups:
-                g["lr"] *= 0.9
         if args.separate_forwards:   # literally training.py:329-333
             ya, yb = dcn.forward(img_a), dcn.forward(img_b)
         else:                        # the same two network calls as ONE grouped launch sequence (BN statistics per image batch)
@@ -228,6 +228,38 @@ def main():
         pb = dcn.process_network_output(yb, B)
         loss, terms, hard = loss_composer.get_loss_batched(pcl, match_type, pa, pb, pair_lists)
         loss.backward()
+        return loss
+
+    # The ~600 launches of forward + loss + backward are captured ONCE into a hipGraph (inputs, lists, parameters and
+    # the flat gradient buffer are static tensors; a training loop copies each new batch into them) and replayed per
+    # step; the gradient all-reduce and the optimizer stay eager.  Falls back to eager launches if capture fails.
+    graph, static_loss, graph_note = None, None, "off"
+    if args.hip_graph:
+        try:
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                for _ in range(2):
+                    forward_backward()
+            torch.cuda.current_stream().wait_stream(side)
+            torch.cuda.synchronize()
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                static_loss = forward_backward()
+            graph_note = "forward + loss + backward replayed from one captured hipGraph"
+        except Exception as e:  # noqa: BLE001 -- any capture problem: run eagerly, say so in the JSON
+            graph, graph_note = None, "capture failed (%s): eager launches" % (str(e).splitlines()[0][:120],)
+            torch.cuda.synchronize()
+
+    def step(it, eager=False):
+        if it % 250 == 0 and it > 0:  # training.yaml:4-5 step decay
+            for g in opt.param_groups:
+                g["lr"] *= 0.9
+        if graph is not None and not eager:
+            graph.replay()
+            loss = static_loss
+        else:
+            loss = forward_backward()
         grads.all_reduce_mean()
         opt.step()
         return loss
@@ -261,7 +293,7 @@ def main():
             bb.get_plan(wl["backbone"], 64, 2 * B, H, W, D, 2)
         plan.profile_begin()
         for it in range(args.profile_steps):
-            step(args.warmup + args.steps + it)
+            step(args.warmup + args.steps + it, eager=True)   # the engine's per-launch events do not exist inside a graph
         prof = plan.profile_end()
         ms, n, fl = prof["conv_gemm"]
         wms, wn, wfl = prof["conv_wgrad"]
@@ -344,7 +376,7 @@ def main():
                "config": {"workload": wl["desc"], "pairs_per_gpu": B, "images_per_step": images_per_step,
                           "image": "%dx%d" % (W, H), "descriptor_dim": D, "backbone": wl["backbone"],
                           "pixel_pairs_per_image_pair": [wl["Pm"], wl["Pk"], wl["Pg"]],
-                          "conv_mode": args.conv_mode,
+                          "conv_mode": args.conv_mode, "hip_graph": graph_note,
                           "forward_calls": "forward(img_a), forward(img_b)" if args.separate_forwards else
                           "forward_pair(img_a, img_b): both network calls of the step as one grouped launch sequence, batch-norm "
                           "statistics / running statistics / gradients per image batch (identical results)", "optimizer": "Adam lr 1e-4 wd 1e-4", "parallelism": "dp%d" % world,

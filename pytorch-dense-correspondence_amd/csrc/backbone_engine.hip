@@ -518,7 +518,7 @@ extern "C" int dcn_backbone_forward(dcn_plan* plan, const float* image, const fl
     // scoring layer (1x1 conv + bias) into the padded low-resolution map, then bilinear upsample
     const ConvL& fc = p.convs[p.fc];
     const size_t low_bytes = (size_t)N * p.hl * p.wl * p.Dp * sizeof(float);
-    if (hipMemsetAsync(R.S(p.s_low), 0, low_bytes, st) != hipSuccess) return DCN_E_LAUNCH;
+    if (dcn::fill_bytes_async(R.S(p.s_low), 0, low_bytes, st) != DCN_OK) return DCN_E_LAUNCH;
     DCN_TRY(R.conv_fwd(fc, R.S(p.blocks.back().out), R.P(fc.w), R.P(fc.b), R.S(p.s_low), nullptr));
     dcn::launch_upsample_fwd(R.S(p.s_low), N, p.hl, p.wl, p.Dp, p.D, p.H, p.W, normalize, descriptors, st);
     return dcn::check_launch();
@@ -575,7 +575,7 @@ extern "C" int dcn_backbone_backward(dcn_plan* plan, const float* grad_descripto
         });
     };
     // split-fp16 mode: every gradient tensor that feeds a convolution records its abs-max (pre-scale selection)
-    if (f16 && hipMemsetAsync(amax, 0, p.convs.size() * sizeof(float), st) != hipSuccess) return DCN_E_LAUNCH;
+    if (f16 && dcn::fill_bytes_async(amax, 0, p.convs.size() * sizeof(float), st) != DCN_OK) return DCN_E_LAUNCH;
 
     // ---- upsample + scoring layer
     float* glow = R.Wk(p.w_glow);

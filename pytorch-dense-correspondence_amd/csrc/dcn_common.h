@@ -30,6 +30,22 @@ template <int NT, class T> __device__ __forceinline__ T block_sum(T v, T* scratc
     return r;
 }
 
+// Stream-ordered fill of n bytes (n % 4 == 0) with a byte value, as a KERNEL: unlike hipMemsetAsync it is an ordinary
+// kernel node when the caller's stream is being captured into a hipGraph.
+static __global__ void __launch_bounds__(256) fill_words_kernel(unsigned* __restrict__ p, unsigned v, size_t words) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < words; i += (size_t)gridDim.x * 256) p[i] = v;
+}
+inline int fill_bytes_async(void* p, int byte_value, size_t n, hipStream_t st) {
+    if (n == 0) return DCN_OK;
+    if (n % 4) return DCN_E_INVALID;
+    const unsigned b = (unsigned)byte_value & 0xffu, v = b | (b << 8) | (b << 16) | (b << 24);
+    const size_t words = n / 4;
+    size_t blocks = (words + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(fill_words_kernel, dim3((unsigned)blocks), dim3(256), 0, st, (unsigned*)p, v, words);
+    return hipGetLastError() == hipSuccess ? DCN_OK : DCN_E_LAUNCH;
+}
+
 inline int check_launch() { return hipGetLastError() == hipSuccess ? DCN_OK : DCN_E_LAUNCH; }
 
 __host__ __device__ inline int64_t ceil_div64(int64_t a, int64_t b) { return (a + b - 1) / b; }

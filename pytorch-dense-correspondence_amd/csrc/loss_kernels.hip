@@ -378,7 +378,7 @@ extern "C" int dcn_triplet_loss_forward(const float* desc_a, const float* desc_b
         n_match < 1 || (n % n_match) != 0)   // the reference's index_select shapes only agree for whole multiples
         return DCN_E_INVALID;
     hipStream_t st = (hipStream_t)stream;
-    if (hipMemsetAsync(status, 0, sizeof(int32_t), st) != hipSuccess) return DCN_E_LAUNCH;
+    if (dcn::fill_bytes_async(status, 0, sizeof(int32_t), st) != DCN_OK) return DCN_E_LAUNCH;
     const int blocks = triplet_blocks(n);
     hipLaunchKernelGGL(triplet_fwd_kernel, dim3(blocks), dim3(kTripThreads), 0, st, desc_a, desc_b, hw, d, non_a, match_b,
                        non_b, n, n / n_match, alpha, (double*)workspace, (int*)status);
@@ -421,7 +421,7 @@ extern "C" int dcn_contrastive_loss_forward(const float* desc_a, const float* de
     const size_t n = (size_t)4 * num_pairs * chunks;
     double* part_sum = (double*)workspace;
     int* part_cnt = (int*)(part_sum + n);
-    if (hipMemsetAsync(status, 0, sizeof(int32_t), st) != hipSuccess) return DCN_E_LAUNCH;
+    if (dcn::fill_bytes_async(status, 0, sizeof(int32_t), st) != DCN_OK) return DCN_E_LAUNCH;
     const dim3 grid(chunks, 4 * num_pairs), block(kThreads);
 #define DCN_LAUNCH_FWD(DT)                                                                                        \
     hipLaunchKernelGGL((loss_fwd_kernel<DT>), grid, block, 0, st, desc_a, desc_b, hw, d, idx_a, idx_b, offsets_dev, \
@@ -452,8 +452,8 @@ extern "C" int dcn_contrastive_loss_backward(const float* desc_a, const float* d
     if (!pair_grad && (!hard_neg || !grad_loss)) return DCN_E_INVALID;
     hipStream_t st = (hipStream_t)stream;
     const size_t bytes = (size_t)num_pairs * (size_t)hw * (size_t)d * sizeof(float);
-    if (hipMemsetAsync(grad_a, 0, bytes, st) != hipSuccess) return DCN_E_LAUNCH;
-    if (hipMemsetAsync(grad_b, 0, bytes, st) != hipSuccess) return DCN_E_LAUNCH;
+    if (dcn::fill_bytes_async(grad_a, 0, bytes, st) != DCN_OK) return DCN_E_LAUNCH;
+    if (dcn::fill_bytes_async(grad_b, 0, bytes, st) != DCN_OK) return DCN_E_LAUNCH;
     const int64_t ml = max_len(offsets_host, num_pairs);
     if (ml == 0) return DCN_OK;
     const dim3 grid(chunks_for(ml), 4 * num_pairs), block(kThreads);

@@ -86,7 +86,7 @@ extern "C" int dcn_find_best_match(const float* res, int64_t hw, int d, const fl
         return DCN_E_INVALID;
     hipStream_t st = (hipStream_t)stream;
     unsigned long long* best = (unsigned long long*)workspace;
-    if (hipMemsetAsync(best, 0xFF, (size_t)q * sizeof(unsigned long long), st) != hipSuccess) return DCN_E_LAUNCH;
+    if (dcn::fill_bytes_async(best, 0xFF, (size_t)q * sizeof(unsigned long long), st) != DCN_OK) return DCN_E_LAUNCH;
     const dim3 grid((unsigned)dcn::ceil_div64(hw, kMT)), block(kMT);
 #define DCN_BM(DT) \
     hipLaunchKernelGGL((best_match_kernel<DT>), grid, block, 0, st, res, hw, d, queries, q, mask, best, norm_diffs)
