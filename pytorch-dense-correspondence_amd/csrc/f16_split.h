@@ -14,8 +14,11 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 
 __device__ __forceinline__ float pow2_scale(float absmax) {
-    // largest power of two s with s * absmax <= 4096 (fp16 max is 65504: 16x headroom for the fp32->fp16 rounding)
-    return absmax > 0.f ? exp2f(floorf(log2f(4096.f / absmax))) : 1.f;
+    // largest power of two s with s * absmax <= 4096 (fp16 max is 65504: 16x headroom for the fp32->fp16 rounding), kept
+    // inside 2^+-120 so that s and 1/s stay finite for denormal / overflowing abs-max values
+    if (!(absmax > 0.f)) return 1.f;
+    const float e = fminf(fmaxf(floorf(log2f(4096.f / absmax)), -120.f), 120.f);
+    return exp2f(e);
 }
 
 // (x0, x1) -> packed hi = rn16(x), lo = rn16(x - hi): one v_cvt_pk_f16_f32 per pair for hi, two v_cvt_f32_f16 back,

@@ -60,7 +60,7 @@ def test_forward_backward_vs_oracle(arch, bw, shape, D):
         assert rel_err(b.float(), bo.float()) < 1e-4 or float((b.float() - bo.float()).abs().max()) < 1e-5, k
 
 
-@pytest.mark.parametrize("gscale", [1e-9, 1e6])
+@pytest.mark.parametrize("gscale", [1e-30, 1e-9, 1e6, 1e25])
 def test_gradient_scale_invariance(gscale, conv_mode):
     """Tiny / huge incoming gradients (loss scaling, very small learning signals): the split-fp16 convolutions pre-scale
     every gradient tensor by a power of two chosen from its abs-max, so the result is that of the fp32 kernels."""
