@@ -258,6 +258,12 @@ int dcn_conv_forward_f16(const dcn_conv_desc* c, const float* in, const void* w_
 int dcn_conv_dgrad_f16(const dcn_conv_desc* c, const float* dout, const void* wt_hi, const void* wt_lo, float w_scale,
                        const float* dout_absmax, const float* add, float* din, void* workspace, void* stream);
 
+/* All weight tensors of a network in one launch: w[i] = [cout[i]][taps[i]][cin[i]] (device), hi[i] / lo[i] (device) receive
+ * the forward image [cout][kpad(taps*cin)] or, transposed != 0, the dgrad image [cin][kpad(taps*ldn[i])] of
+ * dcn_transpose_weight + dcn_split_rows_f16.  The seven arrays themselves are HOST arrays of length n. */
+int dcn_split_weights_f16(int n, const float* const* w, void* const* hi, void* const* lo, const int* cout, const int* taps,
+                          const int* cin, const int* ldn, int transposed, float scale, void* stream);
+
 /* wgrad consumes PRE-SPLIT operands (every element takes part in many tiles, so the fp32 -> fp16 hi/lo split is done
  * once per tensor).  Both split tensors have the byte size of their fp32 source:
  *   activations  xs[pixel][c/4][hi x4 | lo x4]                       dcn_split_act_f16 (n elements, n % 4 == 0)

@@ -35,6 +35,7 @@ struct ConvL {
     size_t x = 0;      // conv output offset (floats) in the saved arena
     int cin_true = 0;
     int mtiles[2] = {0, 0};   // BN partial-sum rows of the forward kernel, per conv mode
+    size_t wsplit = 0;        // offset (halves) of this conv's fp16 weight image inside w_wh / w_wl (forward or dgrad image)
     int idx = 0;
     std::string name;
 };
@@ -298,8 +299,19 @@ int build_plan(dcn_plan& p) {
     p.w_glow = alloc((size_t)N * p.hl * p.wl * p.Dp);
     p.w_gnorm = alloc((size_t)N * p.H * p.W * p.D);
     p.w_ups = alloc(dcn::upsample_bwd_tmp_bytes(N, p.hl, p.W, p.D) / sizeof(float));
-    p.w_wh = alloc((max_wh + 1) / 2);   // fp16 hi / lo images of one weight tensor (split per use)
-    p.w_wl = alloc((max_wh + 1) / 2);
+    {   // fp16 hi / lo images of ALL weight tensors (one batched split per forward / backward call); a conv's forward image
+        // [cout][kpad(taps*cin)] and its dgrad image [cin][kpad(taps*ldc)] share the slot (max of the two, 16-byte aligned)
+        size_t halves = 0;
+        for (ConvL& c : p.convs) {
+            const int taps = c.d.kh * c.d.kw;
+            const size_t a = (size_t)c.d.cout * dcn_f16_kpad(taps * c.d.cin), b = (size_t)c.d.cin * dcn_f16_kpad(taps * c.d.ldc);
+            c.wsplit = halves;
+            halves += (std::max(a, b) + 7) / 8 * 8;
+        }
+        (void)max_wh;
+        p.w_wh = alloc((halves + 1) / 2);
+        p.w_wl = alloc((halves + 1) / 2);
+    }
     p.w_amax = alloc(p.convs.size());   // abs-max of the gradient w.r.t. each convolution's output
     {   // split (fp16 hi | lo) copies of one activation tensor and one gradient tensor: wgrad operands, split once per tensor
         size_t max_x = 0, max_dq = 0;
@@ -366,10 +378,31 @@ struct Run {
     int conv_fwd(const ConvL& c, const float* in, const float* w, const float* bias, float* out, float* part) {
         if (p.conv_mode == DCN_CONV_FP32)
             return timed(0, c.flops, [&] { return dcn_conv_forward(&c.d, in, w, bias, out, part, Wk(p.w_sk), st); });
-        DCN_TRY(dcn_split_rows_f16(w, Wk(p.w_wh), Wk(p.w_wl), c.d.cout, c.d.kh * c.d.kw * c.d.cin, kWeightScale, st));
+        (void)w;   // split-fp16 mode: the image was produced by split_all_weights at the start of the call
         return timed(0, c.flops, [&] {
-            return dcn_conv_forward_f16(&c.d, in, Wk(p.w_wh), Wk(p.w_wl), kWeightScale, bias, out, part, Wk(p.w_sk), st);
+            return dcn_conv_forward_f16(&c.d, in, wimg(p.w_wh, c), wimg(p.w_wl, c), kWeightScale, bias, out, part, Wk(p.w_sk), st);
         });
+    }
+
+    void* wimg(size_t plane, const ConvL& c) const { return (void*)((_Float16*)Wk(plane) + c.wsplit); }
+
+    // fp16 hi / lo images of every convolution's weights in one launch: forward images, or the channel-transposed dgrad
+    // images (the stem has no dgrad).  `stem_w`: the stem's weights padded to 4 input channels.
+    int split_all_weights(bool transposed, const float* stem_w) {
+        const int n = (int)p.convs.size();
+        std::vector<const float*> w;
+        std::vector<void*> hi, lo;
+        std::vector<int> cout, taps, cin, ldn;
+        for (int i = 0; i < n; ++i) {
+            const ConvL& c = p.convs[i];
+            if (transposed && i == p.stem) continue;
+            w.push_back(i == p.stem ? stem_w : P(c.w));
+            hi.push_back(wimg(p.w_wh, c));
+            lo.push_back(wimg(p.w_wl, c));
+            cout.push_back(c.d.cout); taps.push_back(c.d.kh * c.d.kw); cin.push_back(c.d.cin); ldn.push_back(c.d.ldc);
+        }
+        return dcn_split_weights_f16((int)w.size(), w.data(), hi.data(), lo.data(), cout.data(), taps.data(), cin.data(),
+                                     ldn.data(), transposed ? 1 : 0, kWeightScale, st);
     }
 
     // conv + BN statistics -> scale/shift in the saved arena
@@ -481,6 +514,7 @@ extern "C" int dcn_backbone_forward(dcn_plan* plan, const float* image, const fl
     dcn::launch_nchw3_to_nhwc4(image, R.S(p.s_in4), N, p.H * p.W, st);
     const ConvL& stem = p.convs[p.stem];
     dcn::launch_pad_c3_to_c4(R.P(stem.w), R.Wk(p.w_wstem), (int64_t)p.base * 49, st);
+    if (p.conv_mode == DCN_CONV_F16X3) DCN_TRY(R.split_all_weights(false, R.Wk(p.w_wstem)));
     DCN_TRY(R.conv_bn(stem, R.S(p.s_in4), R.Wk(p.w_wstem), bn_running, momentum, eps, training));
     {
         const BnL& b = p.bns[stem.bn];
@@ -565,15 +599,16 @@ extern "C" int dcn_backbone_backward(dcn_plan* plan, const float* grad_descripto
         });
     };
     auto dgrad = [&](const ConvL& c, const float* dx, const float* add, float* din) -> int {
-        const int taps = c.d.kh * c.d.kw;
-        DCN_TRY(dcn_transpose_weight(R.P(c.w), wt, c.d.cout, taps, c.d.cin, c.d.ldc, st));
-        if (!f16) return R.timed(0, c.flops, [&] { return dcn_conv_dgrad(&c.d, dx, wt, add, din, R.Wk(p.w_sk), st); });
-        DCN_TRY(dcn_split_rows_f16(wt, R.Wk(p.w_wh), R.Wk(p.w_wl), c.d.cin, taps * c.d.ldc, kWeightScale, st));
-        return R.timed(0, c.flops, [&] {
-            return dcn_conv_dgrad_f16(&c.d, dx, R.Wk(p.w_wh), R.Wk(p.w_wl), kWeightScale, amax + c.idx, add, din,
+        if (!f16) {
+            DCN_TRY(dcn_transpose_weight(R.P(c.w), wt, c.d.cout, c.d.kh * c.d.kw, c.d.cin, c.d.ldc, st));
+            return R.timed(0, c.flops, [&] { return dcn_conv_dgrad(&c.d, dx, wt, add, din, R.Wk(p.w_sk), st); });
+        }
+        return R.timed(0, c.flops, [&] {   // (transposed weight images: split_all_weights(true) below)
+            return dcn_conv_dgrad_f16(&c.d, dx, R.wimg(p.w_wh, c), R.wimg(p.w_wl, c), kWeightScale, amax + c.idx, add, din,
                                       R.Wk(p.w_sk), st);
         });
     };
+    if (f16) DCN_TRY(R.split_all_weights(true, nullptr));
     // split-fp16 mode: every gradient tensor that feeds a convolution records its abs-max (pre-scale selection)
     if (f16 && dcn::fill_bytes_async(amax, 0, p.convs.size() * sizeof(float), st) != DCN_OK) return DCN_E_LAUNCH;
 

@@ -41,6 +41,84 @@ split_rows_kernel(const float* __restrict__ w, _Float16* __restrict__ hi, _Float
     *reinterpret_cast<h4*>(lo + r * kp + k) = b;
 }
 
+// All weight tensors of a network in ONE launch (the per-tensor kernels cost ~5 us each, 110 launches per step):
+// entry e splits w[rows][K] (forward image), or -- transposed -- produces the dgrad image wt[cin][taps][ldn] of
+// w[cout][taps][cin] (zero for n >= cout), both as hi / lo fp16 [rows][kp].  The table travels as a kernel argument.
+struct SplitEntry {
+    const float* w;
+    _Float16* hi;
+    _Float16* lo;
+    int rows, K, kp;          // forward: rows = cout, K = taps * cin.   transposed: rows = cin, K = taps * ldn
+    int cout, taps, cin, ldn;
+    int first_block;          // prefix sum of workgroups
+};
+constexpr int kSplitBatch = 56;   // 56 x 56 bytes + header < 4 KB of kernel arguments
+struct SplitTable {
+    SplitEntry e[kSplitBatch];
+    int n;
+    float scale;
+};
+
+__device__ __forceinline__ int split_entry_of(const SplitTable& t, int block) {
+    int e = 0;
+    while (e + 1 < t.n && block >= t.e[e + 1].first_block) ++e;   // (uniform; at most 55 steps)
+    return e;
+}
+
+__global__ void __launch_bounds__(256)
+split_rows_batched_kernel(SplitTable t) {
+    const int ei = split_entry_of(t, blockIdx.x);
+    const SplitEntry& E = t.e[ei];
+    const int64_t i = (int64_t)(blockIdx.x - E.first_block) * 256 + threadIdx.x;
+    const int q = E.kp / 4;
+    if (i >= (int64_t)E.rows * q) return;
+    const int64_t r = i / q;
+    const int k = (int)(i - r * q) * 4;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (k < E.K) v = *reinterpret_cast<const float4*>(E.w + r * E.K + k);
+    h4 a, b;
+    split4(v, t.scale, a, b);
+    *reinterpret_cast<h4*>(E.hi + r * E.kp + k) = a;
+    *reinterpret_cast<h4*>(E.lo + r * E.kp + k) = b;
+}
+
+// workgroup = one 32 (n) x 32 (c) tile of one tap: coalesced reads along c, LDS transpose, each work-item then owns
+// 4 consecutive n of one c = one 8-byte run of the transposed row
+__global__ void __launch_bounds__(256)
+transpose_split_batched_kernel(SplitTable t) {
+    __shared__ float tile[32][33];
+    const int ei = split_entry_of(t, blockIdx.x);
+    const SplitEntry& E = t.e[ei];
+    const int ct = (E.cin + 31) / 32, nt = (E.ldn + 31) / 32;
+    int b = blockIdx.x - E.first_block;
+    const int tap = b / (ct * nt);
+    b -= tap * ct * nt;
+    const int n0 = (b / ct) * 32, c0 = (b % ct) * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 32 x 8
+    for (int i = ty; i < 32; i += 8) {
+        const int n = n0 + i, cc = c0 + tx;
+        tile[i][tx] = (n < E.cout && cc < E.cin) ? E.w[((int64_t)n * E.taps + tap) * E.cin + cc] : 0.f;
+    }
+    __syncthreads();
+    const int cl = threadIdx.x >> 3, nq = threadIdx.x & 7;   // channel 0..31, n quad 0..7
+    const int cc = c0 + cl, n = n0 + 4 * nq;
+    if (cc >= E.cin || n >= E.ldn) return;                   // (ldn % 4 == 0)
+    h4 a, bb;
+    split4(make_float4(tile[4 * nq][cl], tile[4 * nq + 1][cl], tile[4 * nq + 2][cl], tile[4 * nq + 3][cl]), t.scale, a, bb);
+    const int64_t o = (int64_t)cc * E.kp + (int64_t)tap * E.ldn + n;
+    *reinterpret_cast<h4*>(E.hi + o) = a;
+    *reinterpret_cast<h4*>(E.lo + o) = bb;
+    if (tap == E.taps - 1 && n + 4 >= E.ldn) {               // zero the K padding [taps * ldn, kp) of this row
+        h4 z;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) z[k] = (_Float16)0.f;
+        for (int k = E.K; k < E.kp; k += 4) {
+            *reinterpret_cast<h4*>(E.hi + (int64_t)cc * E.kp + k) = z;
+            *reinterpret_cast<h4*>(E.lo + (int64_t)cc * E.kp + k) = z;
+        }
+    }
+}
+
 // ----------------------------------------------------------------------------------------------- gather-GEMM, f16x3
 template <int TM, int TN> struct F16Geo {
     static constexpr int BM = 64 * TM, BN = 64 * TN, PA = BM / 32, PB = BN / 64,
@@ -824,6 +902,41 @@ extern "C" int dcn_split_rows_f16(const float* w, void* hi, void* lo, int64_t ro
     const int64_t n = rows * (kp / 4);
     hipLaunchKernelGGL(split_rows_kernel, dim3((unsigned)dcn::ceil_div64(n, 256)), dim3(256), 0, (hipStream_t)stream, w,
                        (_Float16*)hi, (_Float16*)lo, rows, k, kp, scale);
+    return dcn::check_launch();
+}
+
+// Batched forms of dcn_split_rows_f16 (transposed == 0) and dcn_transpose_weight + dcn_split_rows_f16 (transposed != 0)
+// over n weight tensors: w[i] is [cout[i]][taps[i]][cin[i]]; hi[i] / lo[i] receive [cout][kpad(taps*cin)] or, transposed,
+// [cin][kpad(taps*ldn[i])] (ldn = the output gradient's leading dimension, >= cout, % 4 == 0).  All arrays are HOST arrays.
+extern "C" int dcn_split_weights_f16(int n, const float* const* w, void* const* hi, void* const* lo, const int* cout,
+                                     const int* taps, const int* cin, const int* ldn, int transposed, float scale,
+                                     void* stream) {
+    if (n < 1 || !w || !hi || !lo || !cout || !taps || !cin || (transposed && !ldn) || !(scale > 0.f)) return DCN_E_INVALID;
+    hipStream_t st = (hipStream_t)stream;
+    for (int base = 0; base < n; base += kSplitBatch) {
+        SplitTable t;
+        t.n = n - base < kSplitBatch ? n - base : kSplitBatch;
+        t.scale = scale;
+        int blocks = 0;
+        for (int j = 0; j < t.n; ++j) {
+            const int i = base + j;
+            SplitEntry& E = t.e[j];
+            if (!w[i] || !hi[i] || !lo[i] || cout[i] < 1 || taps[i] < 1 || cin[i] < 4 || (cin[i] % 4)) return DCN_E_INVALID;
+            E.w = w[i]; E.hi = (_Float16*)hi[i]; E.lo = (_Float16*)lo[i];
+            E.cout = cout[i]; E.taps = taps[i]; E.cin = cin[i]; E.ldn = transposed ? ldn[i] : cout[i];
+            E.first_block = blocks;
+            if (transposed) {
+                if (E.ldn < E.cout || (E.ldn % 4)) return DCN_E_INVALID;
+                E.rows = E.cin; E.K = E.taps * E.ldn; E.kp = dcn_f16_kpad(E.K);
+                blocks += E.taps * ((E.cin + 31) / 32) * ((E.ldn + 31) / 32);
+            } else {
+                E.rows = E.cout; E.K = E.taps * E.cin; E.kp = dcn_f16_kpad(E.K);
+                blocks += (int)dcn::ceil_div64((int64_t)E.rows * (E.kp / 4), 256);
+            }
+        }
+        if (transposed) hipLaunchKernelGGL(transpose_split_batched_kernel, dim3(blocks), dim3(256), 0, st, t);
+        else hipLaunchKernelGGL(split_rows_batched_kernel, dim3(blocks), dim3(256), 0, st, t);
+    }
     return dcn::check_launch();
 }
 

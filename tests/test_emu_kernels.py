@@ -253,3 +253,34 @@ def test_conv_f16x3_forward_dgrad(L, case, tile_m, sk, monkeypatch):
                                   None) == 0
     assert torch.equal(dw_direct, dw)
     assert rel_err(dw, w.grad.permute(0, 2, 3, 1)) < 5e-6
+
+
+def test_batched_weight_split_equals_per_tensor_kernels(L):
+    """dcn_split_weights_f16 (all weight tensors in one launch; more than one table's worth) against the per-tensor
+    dcn_split_rows_f16 / dcn_transpose_weight path, bit for bit, forward and transposed images."""
+    lib = L.get()
+    g = torch.Generator().manual_seed(0)
+    shapes = [(64, 49, 4, 64), (64, 9, 64, 64), (128, 9, 64, 128), (3, 1, 32, 4), (40, 1, 24, 40), (8, 9, 8, 8)] * 11   # 66 > 56
+    ws = [torch.randn(co, tp, ci, generator=g) * 0.1 for co, tp, ci, _ in shapes]
+    n = len(shapes)
+    VP, I = ctypes.c_void_p * n, ctypes.c_int * n
+    for transposed in (0, 1):
+        his, los, refs = [], [], []
+        for (co, tp, ci, ldn), w in zip(shapes, ws):
+            rows, K = (ci, tp * ldn) if transposed else (co, tp * ci)
+            kp = lib.dcn_f16_kpad(K)
+            his.append(torch.full((rows, kp), float("nan"), dtype=torch.float16))
+            los.append(torch.full((rows, kp), float("nan"), dtype=torch.float16))
+            rh, rl = torch.empty(rows, kp, dtype=torch.float16), torch.empty(rows, kp, dtype=torch.float16)
+            src = w
+            if transposed:
+                src = torch.empty(ci, tp, ldn)
+                assert lib.dcn_transpose_weight(L.ptr(w), L.ptr(src), co, tp, ci, ldn, None) == 0
+            assert lib.dcn_split_rows_f16(L.ptr(src), L.ptr(rh), L.ptr(rl), rows, K, 64.0, None) == 0
+            refs.append((rh, rl))
+        rc = lib.dcn_split_weights_f16(n, VP(*[w.data_ptr() for w in ws]), VP(*[t.data_ptr() for t in his]),
+                                       VP(*[t.data_ptr() for t in los]), I(*[s[0] for s in shapes]), I(*[s[1] for s in shapes]),
+                                       I(*[s[2] for s in shapes]), I(*[s[3] for s in shapes]), transposed, 64.0, None)
+        assert rc == 0
+        for (rh, rl), h, l_ in zip(refs, his, los):
+            assert torch.equal(h, rh) and torch.equal(l_, rl)
