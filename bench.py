@@ -152,12 +152,80 @@ def cpu_baseline(wl, steps, warmup):
                          warmup, steps, sec)}
 
 
+def pairgen_bench(args):
+    """`--workload pairgen`: device pair generation at the training configuration's sizes
+    (training.yaml:9,17-21: 10 000 matching attempts, 150 masked + 150 background non-matches per match) on a seeded
+    synthetic scene; cpu_baseline = the oracle (the reference's CPU algorithm, restated) on the host cores."""
+    import numpy as np
+    from dense_correspondence.correspondence_tools import correspondence_finder as cf
+    H, W = 480, 640
+    rng = np.random.RandomState(2)
+    ys, xs = np.mgrid[0:H, 0:W].astype(np.float64)
+
+    def surf():
+        d = 900 + 150 * np.sin(xs / (60 + 40 * rng.rand())) + 120 * np.cos(ys / (50 + 30 * rng.rand())) + 40 * rng.rand()
+        d[rng.rand(H, W) < 0.02] = 0
+        return d.astype(np.uint16)
+
+    def pose(ry, t):
+        T = np.eye(4)
+        T[:3, :3] = np.array([[np.cos(ry), 0, np.sin(ry)], [0, 1, 0], [-np.sin(ry), 0, np.cos(ry)]])
+        T[:3, 3] = t
+        return T
+    depth_a, depth_b = surf(), surf()
+    pose_a, pose_b = pose(0.01, [0.02, 0.0, 0.01]), pose(-0.06, [0.08, -0.03, 0.05])
+    mask_np = np.zeros((H, W), np.float32)
+    mask_np[150:380, 180:470] = 1.0
+    mask = torch.tensor(mask_np).cuda()
+    da = torch.from_numpy(depth_a.view(np.int16)).cuda()
+    db = torch.from_numpy(depth_b.view(np.int16)).cuda()
+
+    def one_pair():
+        uv_a, uv_b = cf.batch_find_pixel_correspondences(da, pose_a, db, pose_b, num_attempts=10000, img_a_mask=mask)
+        cf.create_non_correspondences(uv_b, (H, W), 150, img_b_mask=mask)
+        cf.create_non_correspondences(uv_b, (H, W), 150, img_b_mask=1 - mask)
+        return uv_a[0].numel()
+
+    for _ in range(args.warmup):
+        nmatch = one_pair()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        one_pair()
+    torch.cuda.synchronize()
+    ms = 1e3 * (time.perf_counter() - t0) / args.steps
+    out = {"metric": "image pairs/sec, device pair generation 640x480 (10000 attempts, 2 x 150 non-matches per match)",
+           "value": 1e3 / ms, "unit": "image pairs/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
+           "ms_per_step": ms, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32/int64",
+           "data": "synthetic", "config": {"workload": "pairgen", "matches_per_pair": nmatch,
+                                           "non_match_samples_per_pair": 300 * nmatch, "host_syncs_per_pair": 4},
+           "roofline": None, "cpu_baseline": None}
+    if args.cpu_baseline_steps > 0:
+        from oracle import correspondence_oracle as co
+        cores = usable_cpus()
+        torch.set_num_threads(cores)
+        mk = torch.tensor(mask_np)
+        t0 = time.perf_counter()
+        for _ in range(args.cpu_baseline_steps):
+            lst = torch.nonzero(mk.reshape(-1)).squeeze(1)
+            sel = lst[torch.floor(torch.rand(10000) * lst.numel()).long()]
+            ua, _ = co.find_correspondences_for_candidates(depth_a, pose_a, depth_b, pose_b, sel % W, sel // W)
+            n = ua[0].numel() * 150
+            co.create_non_correspondences(ua[0].numel(), (H, W), 150, mk, torch.rand(n))
+            co.create_non_correspondences(ua[0].numel(), (H, W), 150, 1 - mk, torch.rand(n))
+        sec = (time.perf_counter() - t0) / args.cpu_baseline_steps
+        out["cpu_baseline"] = {"value": 1.0 / sec, "unit": "image pairs/s", "cores": cores, "kind": "port",
+                               "sample": "oracle/correspondence_oracle.py (correspondence_finder.py:276-619 restated, torch CPU "
+                                         "ops), same scene and sizes, mean of %d pairs, %.3f s/pair" % (args.cpu_baseline_steps, sec)}
+    print(json.dumps(out), flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--workload", default="config2", choices=sorted(WORKLOADS))
+    ap.add_argument("--workload", default="config2", choices=sorted(WORKLOADS) + ["pairgen"])
     ap.add_argument("--batch", type=int, default=0, help="override image pairs per GPU per step")
     ap.add_argument("--cpu-baseline-steps", type=int, default=3, help="0 disables the CPU baseline leg")
     ap.add_argument("--profile-steps", type=int, default=3, help="extra steps with per-launch HIP events (roofline)")
@@ -190,6 +258,10 @@ def main():
         import ctypes
         ctypes.CDLL(None).fflush(None)  # RCCL's version banner sits in the C stdio buffer: emit it now, not after the JSON line
 
+    if args.workload == "pairgen":
+        if world > 1:
+            raise SystemExit("--workload pairgen is a single-GPU measurement")
+        return pairgen_bench(args)
     from dcn_hip import _lib, backbone as bb
     bb.set_conv_mode(args.conv_mode)
     from dcn_hip.distributed import FlatGradients, broadcast_module
