@@ -264,6 +264,14 @@ int dcn_conv_dgrad_f16(const dcn_conv_desc* c, const float* dout, const void* wt
 int dcn_split_weights_f16(int n, const float* const* w, void* const* hi, void* const* lo, const int* cout, const int* taps,
                           const int* cin, const int* ldn, int transposed, float scale, void* stream);
 
+/* as above with optional per-output-channel factors (forward images only): row_scale[i] = NULL or device vector [cout[i]] */
+int dcn_split_weights_scaled_f16(int n, const float* const* w, const float* const* row_scale, void* const* hi,
+                                 void* const* lo, const int* cout, const int* taps, const int* cin, const int* ldn,
+                                 int transposed, float scale, void* stream);
+/* inference: out = [relu](conv(in, w) + bias [+ add]) in one pass (eval-mode batch norm folded into w and bias) */
+int dcn_conv_forward_fused_f16(const dcn_conv_desc* c, const float* in, const void* w_hi, const void* w_lo, float w_scale,
+                               const float* bias, const float* add, int relu, float* out, void* workspace, void* stream);
+
 /* wgrad consumes PRE-SPLIT operands (every element takes part in many tiles, so the fp32 -> fp16 hi/lo split is done
  * once per tensor).  Both split tensors have the byte size of their fp32 source:
  *   activations  xs[pixel][c/4][hi x4 | lo x4]                       dcn_split_act_f16 (n elements, n % 4 == 0)

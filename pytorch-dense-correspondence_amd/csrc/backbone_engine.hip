@@ -388,21 +388,32 @@ struct Run {
 
     // fp16 hi / lo images of every convolution's weights in one launch: forward images, or the channel-transposed dgrad
     // images (the stem has no dgrad).  `stem_w`: the stem's weights padded to 4 input channels.
-    int split_all_weights(bool transposed, const float* stem_w) {
+    int split_all_weights(bool transposed, const float* stem_w, bool fold_bn = false) {
         const int n = (int)p.convs.size();
-        std::vector<const float*> w;
+        std::vector<const float*> w, rs;
         std::vector<void*> hi, lo;
         std::vector<int> cout, taps, cin, ldn;
         for (int i = 0; i < n; ++i) {
             const ConvL& c = p.convs[i];
             if (transposed && i == p.stem) continue;
             w.push_back(i == p.stem ? stem_w : P(c.w));
+            rs.push_back(fold_bn && c.bn >= 0 ? S(p.bns[c.bn].stats) : nullptr);   // eval-mode BN scale gamma / sqrt(var + eps)
             hi.push_back(wimg(p.w_wh, c));
             lo.push_back(wimg(p.w_wl, c));
             cout.push_back(c.d.cout); taps.push_back(c.d.kh * c.d.kw); cin.push_back(c.d.cin); ldn.push_back(c.d.ldc);
         }
-        return dcn_split_weights_f16((int)w.size(), w.data(), hi.data(), lo.data(), cout.data(), taps.data(), cin.data(),
-                                     ldn.data(), transposed ? 1 : 0, kWeightScale, st);
+        return dcn_split_weights_scaled_f16((int)w.size(), w.data(), fold_bn ? rs.data() : nullptr, hi.data(), lo.data(),
+                                            cout.data(), taps.data(), cin.data(), ldn.data(), transposed ? 1 : 0, kWeightScale,
+                                            st);
+    }
+
+    // inference: conv + folded batch norm (+ residual) (+ ReLU) in one pass; bias = the BN shift beta - mean * scale
+    int conv_fused(const ConvL& c, const float* in, const float* add, int relu, float* out) {
+        const float* shift = S(p.bns[c.bn].stats) + p.bns[c.bn].C;
+        return timed(0, c.flops, [&] {
+            return dcn_conv_forward_fused_f16(&c.d, in, wimg(p.w_wh, c), wimg(p.w_wl, c), kWeightScale, shift, add, relu, out,
+                                              Wk(p.w_sk), st);
+        });
     }
 
     // conv + BN statistics -> scale/shift in the saved arena
@@ -514,6 +525,41 @@ extern "C" int dcn_backbone_forward(dcn_plan* plan, const float* image, const fl
     dcn::launch_nchw3_to_nhwc4(image, R.S(p.s_in4), N, p.H * p.W, st);
     const ConvL& stem = p.convs[p.stem];
     dcn::launch_pad_c3_to_c4(R.P(stem.w), R.Wk(p.w_wstem), (int64_t)p.base * 49, st);
+    const bool fused_eval = !training && p.conv_mode == DCN_CONV_F16X3;
+    if (fused_eval) {
+        // Inference: the BN scale / shift only depend on the running statistics, so they are computed up front, the scale
+        // is folded into the fp16 weight images and every conv + BN (+ residual) + ReLU is ONE kernel pass.
+        if (!bn_running) return DCN_E_INVALID;
+        for (const BnL& b : p.bns) {
+            if (!bn_running[2 * b.idx] || !bn_running[2 * b.idx + 1]) return DCN_E_INVALID;
+            dcn::launch_bn_finalize(nullptr, 0, p.groups, b.C, (double)(b.rows / p.groups), R.P(b.g), R.P(b.b),
+                                    bn_running[2 * b.idx], bn_running[2 * b.idx + 1], momentum, eps, 0, R.S(b.stats), st);
+        }
+        DCN_TRY(R.split_all_weights(false, R.Wk(p.w_wstem), true));
+        DCN_TRY(R.conv_fused(stem, R.S(p.s_in4), nullptr, 1, R.S(p.s_stem_y)));
+        {
+            const BnL& b = p.bns[stem.bn];
+            const int hp = (stem.d.hout + 2 - 3) / 2 + 1, wp = (stem.d.wout + 2 - 3) / 2 + 1;
+            dcn::launch_maxpool_fwd(R.S(p.s_stem_y), R.S(p.s_pool), (unsigned char*)R.S(p.s_argmax), N, stem.d.hout,
+                                    stem.d.wout, hp, wp, b.C, st);
+        }
+        for (const BlockL& blk : p.blocks) {
+            const float* in = R.S(blk.in);
+            const float* cur = in;
+            for (int i = 0; i + 1 < blk.nconv; ++i) {
+                DCN_TRY(R.conv_fused(p.convs[blk.conv[i]], cur, nullptr, 1, R.S(blk.mid[i])));
+                cur = R.S(blk.mid[i]);
+            }
+            const ConvL& last = p.convs[blk.conv[blk.nconv - 1]];
+            const float* res = in;
+            if (blk.down >= 0) {
+                const ConvL& dc = p.convs[blk.down];
+                DCN_TRY(R.conv_fused(dc, in, nullptr, 0, R.S(dc.x)));
+                res = R.S(dc.x);
+            }
+            DCN_TRY(R.conv_fused(last, cur, res, 1, R.S(blk.out)));
+        }
+    } else {
     if (p.conv_mode == DCN_CONV_F16X3) DCN_TRY(R.split_all_weights(false, R.Wk(p.w_wstem)));
     DCN_TRY(R.conv_bn(stem, R.S(p.s_in4), R.Wk(p.w_wstem), bn_running, momentum, eps, training));
     {
@@ -549,6 +595,7 @@ extern "C" int dcn_backbone_forward(dcn_plan* plan, const float* image, const fl
             dcn::launch_bn_apply(R.S(last.x), sl, in, nullptr, 1, R.S(blk.out), bl.C, bl.rows, p.groups, st);
         }
     }
+    }   // !fused_eval
     // scoring layer (1x1 conv + bias) into the padded low-resolution map, then bilinear upsample
     const ConvL& fc = p.convs[p.fc];
     const size_t low_bytes = (size_t)N * p.hl * p.wl * p.Dp * sizeof(float);

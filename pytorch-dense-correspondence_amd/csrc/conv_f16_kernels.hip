@@ -46,13 +46,14 @@ split_rows_kernel(const float* __restrict__ w, _Float16* __restrict__ hi, _Float
 // w[cout][taps][cin] (zero for n >= cout), both as hi / lo fp16 [rows][kp].  The table travels as a kernel argument.
 struct SplitEntry {
     const float* w;
+    const float* row_scale;   // forward image only, optional: row r is multiplied by row_scale[r] (folded eval-mode BN)
     _Float16* hi;
     _Float16* lo;
     int rows, K, kp;          // forward: rows = cout, K = taps * cin.   transposed: rows = cin, K = taps * ldn
     int cout, taps, cin, ldn;
     int first_block;          // prefix sum of workgroups
 };
-constexpr int kSplitBatch = 56;   // 56 x 56 bytes + header < 4 KB of kernel arguments
+constexpr int kSplitBatch = 48;   // 48 x 64 bytes + header < 4 KB of kernel arguments
 struct SplitTable {
     SplitEntry e[kSplitBatch];
     int n;
@@ -77,7 +78,7 @@ split_rows_batched_kernel(SplitTable t) {
     float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
     if (k < E.K) v = *reinterpret_cast<const float4*>(E.w + r * E.K + k);
     h4 a, b;
-    split4(v, t.scale, a, b);
+    split4(v, E.row_scale ? t.scale * E.row_scale[r] : t.scale, a, b);
     *reinterpret_cast<h4*>(E.hi + r * E.kp + k) = a;
     *reinterpret_cast<h4*>(E.lo + r * E.kp + k) = b;
 }
@@ -911,7 +912,15 @@ extern "C" int dcn_split_rows_f16(const float* w, void* hi, void* lo, int64_t ro
 extern "C" int dcn_split_weights_f16(int n, const float* const* w, void* const* hi, void* const* lo, const int* cout,
                                      const int* taps, const int* cin, const int* ldn, int transposed, float scale,
                                      void* stream) {
-    if (n < 1 || !w || !hi || !lo || !cout || !taps || !cin || (transposed && !ldn) || !(scale > 0.f)) return DCN_E_INVALID;
+    return dcn_split_weights_scaled_f16(n, w, nullptr, hi, lo, cout, taps, cin, ldn, transposed, scale, stream);
+}
+
+// row_scale (optional, forward images only): row_scale[i] is NULL or a device vector of cout[i] per-output-channel factors
+extern "C" int dcn_split_weights_scaled_f16(int n, const float* const* w, const float* const* row_scale, void* const* hi,
+                                            void* const* lo, const int* cout, const int* taps, const int* cin,
+                                            const int* ldn, int transposed, float scale, void* stream) {
+    if (n < 1 || !w || !hi || !lo || !cout || !taps || !cin || (transposed && (!ldn || row_scale)) || !(scale > 0.f))
+        return DCN_E_INVALID;
     hipStream_t st = (hipStream_t)stream;
     for (int base = 0; base < n; base += kSplitBatch) {
         SplitTable t;
@@ -923,6 +932,7 @@ extern "C" int dcn_split_weights_f16(int n, const float* const* w, void* const* 
             SplitEntry& E = t.e[j];
             if (!w[i] || !hi[i] || !lo[i] || cout[i] < 1 || taps[i] < 1 || cin[i] < 4 || (cin[i] % 4)) return DCN_E_INVALID;
             E.w = w[i]; E.hi = (_Float16*)hi[i]; E.lo = (_Float16*)lo[i];
+            E.row_scale = row_scale ? row_scale[i] : nullptr;
             E.cout = cout[i]; E.taps = taps[i]; E.cin = cin[i]; E.ldn = transposed ? ldn[i] : cout[i];
             E.first_block = blocks;
             if (transposed) {
@@ -961,7 +971,23 @@ extern "C" int dcn_conv_forward_f16(const dcn_conv_desc* c, const float* in, con
     p.wh = (const _Float16*)w_hi; p.wl = (const _Float16*)w_lo; p.a_absmax = nullptr; p.b_inv_scale = 1.f / w_scale;
     p.hs = c->hin; p.ws = c->win; p.cs = c->cin; p.hd = c->hout; p.wd = c->wout; p.cd = c->cout;
     p.kh = c->kh; p.kw = c->kw; p.stride = c->stride; p.pad = c->pad; p.dil = c->dil; p.ldc = c->ldc;
+    p.M = c->n * c->hout * c->wout; p.K = c->kh * c->kw * c->cin; p.kp = dcn_f16_kpad(p.K); p.transposed = 0; p.relu = 0;
+    return launch_gemm_f16(p, workspace, (hipStream_t)stream, c->group_rows);
+}
+
+// Inference form: out = [relu](conv(in, w) + bias [+ add]) in one pass (w / bias with the eval-mode batch norm folded in:
+// dcn_split_weights_scaled_f16 with row_scale = gamma / sqrt(var + eps), bias = beta - mean * that).  add: [M][ldc] or NULL.
+extern "C" int dcn_conv_forward_fused_f16(const dcn_conv_desc* c, const float* in, const void* w_hi, const void* w_lo,
+                                          float w_scale, const float* bias, const float* add, int relu, float* out,
+                                          void* workspace, void* stream) {
+    if (!valid_desc16(c) || !in || !w_hi || !w_lo || !out || !(w_scale > 0.f)) return DCN_E_INVALID;
+    GemmConv p;
+    p.src = in; p.wm = nullptr; p.bias = bias; p.add = add; p.dst = out; p.bn_partial = nullptr;
+    p.wh = (const _Float16*)w_hi; p.wl = (const _Float16*)w_lo; p.a_absmax = nullptr; p.b_inv_scale = 1.f / w_scale;
+    p.hs = c->hin; p.ws = c->win; p.cs = c->cin; p.hd = c->hout; p.wd = c->wout; p.cd = c->cout;
+    p.kh = c->kh; p.kw = c->kw; p.stride = c->stride; p.pad = c->pad; p.dil = c->dil; p.ldc = c->ldc;
     p.M = c->n * c->hout * c->wout; p.K = c->kh * c->kw * c->cin; p.kp = dcn_f16_kpad(p.K); p.transposed = 0;
+    p.relu = relu ? 1 : 0;
     return launch_gemm_f16(p, workspace, (hipStream_t)stream, c->group_rows);
 }
 
@@ -977,7 +1003,7 @@ extern "C" int dcn_conv_dgrad_f16(const dcn_conv_desc* c, const float* dout, con
     p.hs = c->hout; p.ws = c->wout; p.cs = c->ldc;
     p.hd = c->hin; p.wd = c->win; p.cd = c->cin;
     p.kh = c->kh; p.kw = c->kw; p.stride = c->stride; p.pad = c->pad; p.dil = c->dil; p.ldc = c->cin;
-    p.M = c->n * c->hin * c->win; p.K = c->kh * c->kw * c->ldc; p.kp = dcn_f16_kpad(p.K); p.transposed = 1;
+    p.M = c->n * c->hin * c->win; p.K = c->kh * c->kw * c->ldc; p.kp = dcn_f16_kpad(p.K); p.transposed = 1; p.relu = 0;
     return launch_gemm_f16(p, workspace, (hipStream_t)stream);
 }
 

@@ -620,7 +620,7 @@ extern "C" int dcn_conv_forward(const dcn_conv_desc* c, const float* in, const f
     p.src = in; p.wm = w; p.bias = bias; p.add = nullptr; p.dst = out; p.bn_partial = bn_partial;
     p.hs = c->hin; p.ws = c->win; p.cs = c->cin; p.hd = c->hout; p.wd = c->wout; p.cd = c->cout;
     p.kh = c->kh; p.kw = c->kw; p.stride = c->stride; p.pad = c->pad; p.dil = c->dil; p.ldc = c->ldc;
-    p.M = c->n * c->hout * c->wout; p.K = c->kh * c->kw * c->cin; p.transposed = 0;
+    p.M = c->n * c->hout * c->wout; p.K = c->kh * c->kw * c->cin; p.transposed = 0; p.relu = 0;
     return launch_gemm(p, workspace, (hipStream_t)stream, c->group_rows);
 }
 
@@ -633,7 +633,7 @@ extern "C" int dcn_conv_dgrad(const dcn_conv_desc* c, const float* dout, const f
     p.hs = c->hout; p.ws = c->wout; p.cs = c->ldc;   // source channels = (padded) forward output channels
     p.hd = c->hin; p.wd = c->win; p.cd = c->cin;
     p.kh = c->kh; p.kw = c->kw; p.stride = c->stride; p.pad = c->pad; p.dil = c->dil; p.ldc = c->cin;
-    p.M = c->n * c->hin * c->win; p.K = c->kh * c->kw * c->ldc; p.transposed = 1;
+    p.M = c->n * c->hin * c->win; p.K = c->kh * c->kw * c->ldc; p.transposed = 1; p.relu = 0;
     return launch_gemm(p, workspace, (hipStream_t)stream);
 }
 

@@ -44,7 +44,7 @@ struct GemmConv {
     float b_inv_scale;
     int kp;
     unsigned src_bytes, w_bytes;   // extents of src and of each weight image (buffer-resource bounds; 0: tensor too large)
-    int hs, ws, cs, hd, wd, cd, kh, kw, stride, sshift, pad, dil, ldc, M, K, transposed, mtiles, ntiles, sk_units, sk_dp;
+    int hs, ws, cs, hd, wd, cd, kh, kw, stride, sshift, pad, dil, ldc, M, K, transposed, mtiles, ntiles, sk_units, sk_dp, relu;
     FastDiv div_hw, div_w, div_cs, div_kw, div_nt, div_nk;
 };
 
@@ -88,6 +88,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmConv& p, f32x16 (&acc)[T
                 if (cok && row < p.M) {
                     const int64_t o = (int64_t)row * p.ldc + col;
                     if (p.add) v += p.add[o];
+                    if (p.relu) v = fmaxf(v, 0.f);   // (inference: conv + folded BN + residual + ReLU in one pass)
                     p.dst[o] = v;
                 }
                 csum[tn] += acc[tm][tn][r];

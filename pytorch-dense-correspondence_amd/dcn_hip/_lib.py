@@ -89,6 +89,10 @@ SYMBOLS = {
                                    c_void_p]),
     "dcn_split_weights_f16": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int,
                                       c_float, c_void_p]),
+    "dcn_split_weights_scaled_f16": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                             c_void_p, c_int, c_float, c_void_p]),
+    "dcn_conv_forward_fused_f16": (c_int, [ctypes.POINTER(ConvDesc), c_void_p, c_void_p, c_void_p, c_float, c_void_p,
+                                           c_void_p, c_int, c_void_p, c_void_p, c_void_p]),
     "dcn_split_act_f16": (c_int, [c_void_p, c_void_p, c_int64, c_void_p]),
     "dcn_grad_blocked_bytes": (c_size_t, [c_int, c_int]),
     "dcn_split_grad_blocked_f16": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p]),

@@ -124,18 +124,30 @@ def test_real_width_resnet34_small_image():
     assert worst < 2e-3, worst   # 16 output pixels per BN: ill-conditioned, the float32 oracle is no better
 
 
-def test_eval_mode_uses_running_statistics():
-    m, o = _pair("Resnet18_8s", 3, 8)
+@pytest.mark.parametrize("arch,bw,D", [("Resnet18_8s", 8, 3), ("Resnet34_8s", 8, 4), ("Resnet50_8s", 8, 5)])
+def test_eval_mode_uses_running_statistics(arch, bw, D):
+    """Inference: running statistics; in the split-fp16 mode every conv + BN (+ residual) + ReLU is one fused pass with the
+    BN scale folded into the weight images (identity and downsample residuals, basic and bottleneck blocks)."""
+    m, o = _pair(arch, D, bw)
     g = torch.Generator().manual_seed(2)
     x = torch.randn(2, 3, 32, 32, generator=g)
     m.train(); o.train()
     with torch.no_grad():
         for _ in range(2):
-            m(x); o(x)
+            m(x * 1.5 + 0.2); o(x * 1.5 + 0.2)       # running statistics away from their initial (0, 1)
     m.eval(); o.eval()
     with torch.no_grad():
-        assert rel_err(m(x), o(x)) < 2e-5
-    assert int(m.resnet18_8s.bn1.num_batches_tracked) == 2
+        y, yo = m(x), o(x)
+        assert rel_err(y, yo) < 2e-5
+        yn = m(x, normalize=True)
+        assert rel_err(yn, yo / yo.norm(2, 1, keepdim=True)) < 1e-4
+        # running statistics and counters untouched by inference
+        assert int(getattr(m, m.attr).bn1.num_batches_tracked) == 2
+        for (k, b), bo in zip(m.named_buffers(), o.buffers()):
+            assert rel_err(b.float(), bo.float()) < 1e-4 or float((b.float() - bo.float()).abs().max()) < 1e-5, k
+        # eval mode through the grouped entry point gives the same maps
+        ya, yb = m.forward_pair(torch.cat([x, x]), torch.cat([x * 0.5, x * 0.5]))
+        assert rel_err(ya[:2], yo) < 2e-5 and rel_err(yb[:2], o(x * 0.5)) < 2e-5
 
 
 def test_container_nodes_refuse_to_run_and_cpu_guard():

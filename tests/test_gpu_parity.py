@@ -588,3 +588,22 @@ def test_step_does_not_depend_on_workspace_contents(L, conv_mode):
     assert all(torch.isfinite(b).all() for b in g1)
     # the loss backward scatters with fp32 atomics (order-dependent in the last bits); everything downstream is deterministic
     assert max(rel_err(a.cpu(), b.cpu()) for a, b in zip(g0, g1)) < 1e-5
+
+
+def test_eval_mode_fused_inference_full_size(L, conv_mode):
+    """Inference at 640x480 (running statistics; fused conv + folded BN + residual + ReLU passes in the split-fp16 mode)
+    against the oracle in eval mode, after two training-mode passes have moved the running statistics."""
+    dcn, o = _dcn_and_oracle("Resnet34_8s", 3, 480, 640)
+    g = torch.Generator().manual_seed(7)
+    x = torch.randn(1, 3, 480, 640, generator=g)
+    o.train()
+    with torch.no_grad():
+        for _ in range(2):
+            dcn.forward(x.cuda()); o(x)
+    dcn.eval(); o.eval()
+    with torch.no_grad():
+        y = dcn.forward(x.cuda()).cpu()
+        yo = o(x)
+    assert rel_err(y, yo) < TOL
+    res = dcn.forward_single_image_tensor(x[0])                    # [H, W, D], network.py:265-299
+    assert rel_err(res.cpu(), yo[0].permute(1, 2, 0)) < TOL
