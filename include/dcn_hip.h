@@ -308,6 +308,17 @@ size_t dcn_upsample_backward_tmp_bytes(int n, int hl, int w, int d);
  *   norm_diffs nullable [Q][HW]: the full distance images
  *   workspace  dcn_find_best_match_workspace(Q) bytes
  * ===================================================================================================== */
+/* Match statistics of evaluation.py:1046-1100 for q query matches in ONE pass over the descriptor image res [hw][d]
+ * (row length w):  queries[i] = res_a[uv_a_i], gt_idx[i] = flat index of the ground-truth match in image b.
+ *   best_idx / best_dist  [2][q]: argmin / min of d over the image, and of d + (1 - mask) * 1e6 (mask NULL: same as the image)
+ *   count                 [2][q]: pixels with d < ||queries[i] - res[gt_idx[i]]|| (image / masked)
+ *   dist_sum              [2][q]: sum of the pixel distances of those pixels to the ground-truth pixel
+ *   gt_dist               [q]:    that ground-truth descriptor distance */
+size_t dcn_match_statistics_workspace(int q);
+int dcn_match_statistics(const float* res, int64_t hw, int w, int d, const float* queries, const int64_t* gt_idx, int q,
+                         const unsigned char* mask, int64_t* best_idx, float* best_dist, int32_t* count, float* dist_sum,
+                         float* gt_dist, void* workspace, void* stream);
+
 int dcn_find_best_match(const float* res, int64_t hw, int d, const float* queries, int q, const unsigned char* mask,
                         int64_t* best_idx, float* best_dist, float* norm_diffs, void* workspace, void* stream);
 size_t dcn_find_best_match_workspace(int q);

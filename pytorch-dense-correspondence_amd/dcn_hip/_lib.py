@@ -97,6 +97,9 @@ SYMBOLS = {
     "dcn_grad_blocked_bytes": (c_size_t, [c_int, c_int]),
     "dcn_split_grad_blocked_f16": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "dcn_conv_wgrad_workspace_f16": (c_size_t, [ctypes.POINTER(ConvDesc)]),
+    "dcn_match_statistics_workspace": (c_size_t, [c_int]),
+    "dcn_match_statistics": (c_int, [c_void_p, c_int64, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p,
+                                     c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "dcn_find_best_match": (c_int, [c_void_p, c_int64, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
                                     c_void_p, c_void_p]),
     "dcn_find_best_match_workspace": (c_size_t, [c_int]),

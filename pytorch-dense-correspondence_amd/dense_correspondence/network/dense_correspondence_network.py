@@ -299,5 +299,34 @@ class DenseCorrespondenceNetwork(nn.Module):
         uv = torch.stack([idx % width, idx // width], dim=1)
         return uv, dist, nd
 
+    @staticmethod
+    def compute_match_statistics(uv_a, uv_b, res_a, res_b, mask_b=None):
+        """MI355X extension: the per-match statistics of the quantitative evaluation (``find_best_match`` + the block at
+        evaluation.py:1046-1100) for MANY ground-truth matches of one image pair in a single pass over ``res_b``.
+        uv_a, uv_b: [Q, 2] (u, v) pixel pairs; res_a, res_b: [H, W, D] device tensors; mask_b: [H, W] (non-zero = object).
+        Returns a dict of length-Q device tensors named like the reference's columns."""
+        from dcn_hip import match as _match
+        dev = res_b.device
+        uv_a = torch.as_tensor(uv_a, device=dev).long().reshape(-1, 2)
+        uv_b = torch.as_tensor(uv_b, device=dev).long().reshape(-1, 2)
+        height, width = int(res_b.shape[0]), int(res_b.shape[1])
+        s = _match.match_statistics(res_b, res_a[uv_a[:, 1], uv_a[:, 0]], uv_b[:, 0] + width * uv_b[:, 1], mask_b)
+        out = {"norm_diff_descriptor_ground_truth": s["gt_dist"]}
+        ub = uv_b.float()
+        n_mask = float((mask_b != 0).sum()) if mask_b is not None else float(height * width)
+        for k, (name, denom) in enumerate((("", float(height * width)), ("_masked", n_mask))):
+            idx = s["best_idx"][k]
+            pred = torch.stack([idx % width, idx // width], dim=1)
+            cnt = s["count"][k].float()
+            out["uv_b_pred" + name] = pred
+            out["norm_diff_pred" + name] = s["best_dist"][k]
+            out["pixel_match_error_l2" + name] = (ub - pred.float()).norm(dim=1)
+            out["num_pixels_closer_than_ground_truth" + name] = s["count"][k]
+            out["fraction_pixels_closer_than_ground_truth" + name] = cnt / denom
+            out["average_l2_distance_for_false_positives" + name] = torch.where(cnt > 0, s["dist_sum"][k] / cnt.clamp(min=1),
+                                                                                torch.zeros_like(cnt))
+        out["pixel_match_error_l1"] = (ub - out["uv_b_pred"].float()).abs().sum(dim=1)
+        return out
+
     def evaluate_descriptor_at_keypoints(self, res, keypoint_list):
         raise NotImplementedError("This function is currently broken")  # :565, same as the reference

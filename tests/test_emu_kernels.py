@@ -4,7 +4,9 @@ sums), bilinear upsample and its backward.  The MFMA fragment maps, LDS images a
 here are the ones that run on the GPU."""
 import ctypes
 import math
+import os
 
+import numpy as np
 import pytest
 import torch
 import torch.nn.functional as F
@@ -284,3 +286,32 @@ def test_batched_weight_split_equals_per_tensor_kernels(L):
         assert rc == 0
         for (rh, rl), h, l_ in zip(refs, his, los):
             assert torch.equal(h, rh) and torch.equal(l_, rl)
+
+
+def test_match_statistics_vs_reference_golden(L):
+    """evaluation.py:1046-1100 for 12 matches in one pass, against the outputs of the reference's own source lines.  Counts:
+    the reference compares two float32 norms computed by different summation orders, so a pixel whose distance ties with the
+    ground truth (the ground-truth pixel itself, here) may or may not be counted there: +-1."""
+    from dense_correspondence.network.dense_correspondence_network import DenseCorrespondenceNetwork as DCN
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", "eval_ref.npz"))
+    res_a, res_b, mask = torch.tensor(z["res_a"]), torch.tensor(z["res_b"]), torch.tensor(z["mask_b"])
+    uv = torch.tensor(z["uv"])
+    s = DCN.compute_match_statistics(uv, uv, res_a, res_b, mask)
+    assert np.array_equal(s["uv_b_pred"].numpy(), z["uv_b_pred"].astype(np.int64))
+    assert np.array_equal(s["uv_b_pred_masked"].numpy(), z["uv_b_pred_masked"].astype(np.int64))
+    np.testing.assert_allclose(s["norm_diff_pred"].numpy(), z["best_match_diff"], rtol=1e-5)
+    np.testing.assert_allclose(s["norm_diff_pred_masked"].numpy(), z["best_match_diff_masked"], rtol=1e-5)
+    np.testing.assert_allclose(s["norm_diff_descriptor_ground_truth"].numpy(), z["norm_diff_descriptor_ground_truth"], rtol=1e-5)
+    np.testing.assert_allclose(s["pixel_match_error_l2"].numpy(), z["pixel_match_error_l2"], rtol=1e-6, atol=1e-6)
+    np.testing.assert_allclose(s["pixel_match_error_l2_masked"].numpy(), z["pixel_match_error_l2_masked"], rtol=1e-6, atol=1e-6)
+    np.testing.assert_allclose(s["pixel_match_error_l1"].numpy(), z["pixel_match_error_l1"], rtol=1e-6, atol=1e-6)
+    for name in ("", "_masked"):
+        c = s["num_pixels_closer_than_ground_truth" + name].numpy().astype(np.int64)
+        assert np.abs(c - z["num_pixels_closer_than_ground_truth" + name]).max() <= 1
+        big = z["num_pixels_closer_than_ground_truth" + name] > 20      # the averages: where one tied pixel cannot matter
+        np.testing.assert_allclose(s["average_l2_distance_for_false_positives" + name].numpy()[big],
+                                   z["average_l2_distance_for_false_positives" + name][big], rtol=0.1)
+    # no mask: the "masked" half equals the image half
+    s2 = DCN.compute_match_statistics(uv, uv, res_a, res_b)
+    assert torch.equal(s2["uv_b_pred"], s2["uv_b_pred_masked"])
+    assert torch.equal(s2["num_pixels_closer_than_ground_truth"], s2["num_pixels_closer_than_ground_truth_masked"])

@@ -607,3 +607,34 @@ def test_eval_mode_fused_inference_full_size(L, conv_mode):
     assert rel_err(y, yo) < TOL
     res = dcn.forward_single_image_tensor(x[0])                    # [H, W, D], network.py:265-299
     assert rel_err(res.cpu(), yo[0].permute(1, 2, 0)) < TOL
+
+
+def test_match_statistics_vs_reference_golden_and_full_size(L):
+    """evaluation.py:1046-1100 on the GPU: the reference's golden (12 matches), then 100 matches at 640x480 against the
+    oracle for a few of them."""
+    from dense_correspondence.network.dense_correspondence_network import DenseCorrespondenceNetwork as DCN
+    from oracle import evaluation_oracle as eo
+    z = np.load(os.path.join(GOLDEN_DIR, "eval_ref.npz"))
+    uv = torch.tensor(z["uv"]).cuda()
+    s = DCN.compute_match_statistics(uv, uv, torch.tensor(z["res_a"]).cuda(), torch.tensor(z["res_b"]).cuda(),
+                                     torch.tensor(z["mask_b"]).cuda())
+    assert np.array_equal(s["uv_b_pred"].cpu().numpy(), z["uv_b_pred"].astype(np.int64))
+    assert np.array_equal(s["uv_b_pred_masked"].cpu().numpy(), z["uv_b_pred_masked"].astype(np.int64))
+    for name in ("", "_masked"):
+        c = s["num_pixels_closer_than_ground_truth" + name].cpu().numpy().astype(np.int64)
+        assert np.abs(c - z["num_pixels_closer_than_ground_truth" + name]).max() <= 1
+    g = torch.Generator().manual_seed(3)
+    H, W, D, Q = 480, 640, 3, 100
+    res_a = torch.randn(H, W, D, generator=g)
+    res_b = res_a + 0.5 * torch.randn(H, W, D, generator=g)
+    mask = torch.zeros(H, W)
+    mask[100:400, 150:500] = 1
+    uv = torch.stack([torch.randint(150, 500, (Q,), generator=g), torch.randint(100, 400, (Q,), generator=g)], 1)
+    s = DCN.compute_match_statistics(uv.cuda(), uv.cuda(), res_a.cuda(), res_b.cuda(), mask.cuda())
+    for q in (0, 17, 99):
+        o = eo.match_statistics((int(uv[q, 0]), int(uv[q, 1])), (int(uv[q, 0]), int(uv[q, 1])), res_a.numpy(), res_b.numpy(), mask.numpy())
+        assert tuple(s["uv_b_pred"][q].tolist()) == tuple(int(x) for x in o["uv_b_pred"])
+        assert tuple(s["uv_b_pred_masked"][q].tolist()) == tuple(int(x) for x in o["uv_b_pred_masked"])
+        assert abs(int(s["num_pixels_closer_than_ground_truth"][q]) - o["num_pixels_closer_than_ground_truth"]) <= 1
+        assert abs(int(s["num_pixels_closer_than_ground_truth_masked"][q]) - o["num_pixels_closer_than_ground_truth_masked"]) <= 1
+        assert abs(float(s["norm_diff_descriptor_ground_truth"][q]) - float(o["norm_diff_descriptor_ground_truth"])) < 1e-5

@@ -128,3 +128,25 @@ def test_correspondence_oracle_matches_reference_goldens(path):
     H, W = z["depth_a"].shape
     nu, nv = co.create_non_correspondences(len(z["uv_a_u"]), (H, W), int(z["per_match"]), mask, torch.tensor(z["rand"]))
     assert np.array_equal(nu.numpy(), z["non_u"]) and np.array_equal(nv.numpy(), z["non_v"])
+
+
+def test_evaluation_oracle_matches_reference_golden():
+    """oracle/evaluation_oracle.py against the outputs of the reference's own find_best_match + statistics block
+    (tests/golden/make_eval_goldens_from_reference.py)."""
+    from oracle import evaluation_oracle as eo
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", "eval_ref.npz"))
+    for q, (u, v) in enumerate(z["uv"]):
+        s = eo.match_statistics((int(u), int(v)), (int(u), int(v)), z["res_a"], z["res_b"], z["mask_b"])
+        assert tuple(s["uv_b_pred"]) == tuple(int(x) for x in z["uv_b_pred"][q])
+        assert tuple(s["uv_b_pred_masked"]) == tuple(int(x) for x in z["uv_b_pred_masked"][q])
+        for k_o, k_g in (("norm_diff_pred", "best_match_diff"), ("norm_diff_pred_masked", "best_match_diff_masked"),
+                         ("pixel_match_error_l2", "pixel_match_error_l2"), ("pixel_match_error_l1", "pixel_match_error_l1"),
+                         ("pixel_match_error_l2_masked", "pixel_match_error_l2_masked"),
+                         ("norm_diff_descriptor_ground_truth", "norm_diff_descriptor_ground_truth"),
+                         ("num_pixels_closer_than_ground_truth", "num_pixels_closer_than_ground_truth"),
+                         ("num_pixels_closer_than_ground_truth_masked", "num_pixels_closer_than_ground_truth_masked"),
+                         ("fraction_pixels_closer_than_ground_truth", "fraction_pixels_closer_than_ground_truth"),
+                         ("fraction_pixels_closer_than_ground_truth_masked", "fraction_pixels_closer_than_ground_truth_masked"),
+                         ("average_l2_distance_for_false_positives", "average_l2_distance_for_false_positives"),
+                         ("average_l2_distance_for_false_positives_masked", "average_l2_distance_for_false_positives_masked")):
+            np.testing.assert_allclose(float(s[k_o]), float(z[k_g][q]), rtol=1e-12, err_msg=k_o)
