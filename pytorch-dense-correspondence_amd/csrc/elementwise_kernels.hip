@@ -142,7 +142,8 @@ bn_apply_kernel(const float* __restrict__ x, const float* __restrict__ s1, const
 }
 
 // Backward reduction.  g = relu_out ? (relu_out > 0 ? dy : 0) : dy.
-// partial[chunk][4][C] = ( sum g , sum g * xhat , max |g| , max |xhat| ) over the chunk's rows, xhat = (x - mean) * invstd.
+// partial[chunk][C][4] = ( sum g , sum g * xhat , max |g| , max |xhat| ) over the chunk's rows, xhat = (x - mean) * invstd
+// (the four statistics of a channel are one float4: the finalize kernel reads them with a single load).
 // (The two maxima bound |dx| per channel without another pass or any atomics in the big kernels: bn_bwd_finalize.)
 // work-item (c4 = tid & 15, rl = tid >> 4): 16 channel quads x 16 row lanes; grid = (C/64 groups, chunks).
 __global__ void __launch_bounds__(256)
@@ -195,15 +196,15 @@ bn_bwd_reduce_kernel(const float* __restrict__ dy, const float* __restrict__ rel
             mg.x = fmaxf(mg.x, m1.x); mg.y = fmaxf(mg.y, m1.y); mg.z = fmaxf(mg.z, m1.z); mg.w = fmaxf(mg.w, m1.w);
             mx.x = fmaxf(mx.x, m2.x); mx.y = fmaxf(mx.y, m2.y); mx.z = fmaxf(mx.z, m2.z); mx.w = fmaxf(mx.w, m2.w);
         }
-        float* p = partial + ((int64_t)blockIdx.y * 4) * C + c;
-        *reinterpret_cast<float4*>(p) = ag;
-        *reinterpret_cast<float4*>(p + C) = agx;
-        *reinterpret_cast<float4*>(p + 2 * C) = mg;
-        *reinterpret_cast<float4*>(p + 3 * C) = mx;
+        float4* p = reinterpret_cast<float4*>(partial) + (int64_t)blockIdx.y * C + c;
+        p[0] = make_float4(ag.x, agx.x, mg.x, mx.x);
+        p[1] = make_float4(ag.y, agx.y, mg.y, mx.y);
+        p[2] = make_float4(ag.z, agx.z, mg.z, mx.z);
+        p[3] = make_float4(ag.w, agx.w, mg.w, mx.w);
     }
 }
 
-// partial[chunk][4][C] -> dgamma, dbeta and the coefficients of the apply pass:
+// partial[chunk][C][4] -> dgamma, dbeta and the coefficients of the apply pass:
 //   dx = k1 * (g - k2 - xhat * k3),  k1 = gamma*invstd, k2 = sum_g / M, k3 = sum_gx / M
 // and, when absmax is given, raises absmax[0] to  max_c |k1| (max|g| + |k2| + max|xhat| |k3|)  >=  max |dx|  (the
 // pre-scale of the split-fp16 convolutions only needs an upper bound within a small factor of the true abs-max).
@@ -229,11 +230,11 @@ bn_bwd_finalize_kernel(const float* __restrict__ partial, int chunks, int groups
         if (c < C) {
 #pragma unroll 4
             for (int t = g * chunks + part; t < (g + 1) * chunks; t += 64) {
-                const float* row = partial + (int64_t)t * 4 * C + c;
-                a += (double)row[0];
-                b += (double)row[C];
-                mg = fmaxf(mg, row[2 * C]);
-                mx = fmaxf(mx, row[3 * C]);
+                const float4 s4 = reinterpret_cast<const float4*>(partial)[(int64_t)t * C + c];
+                a += (double)s4.x;
+                b += (double)s4.y;
+                mg = fmaxf(mg, s4.z);
+                mx = fmaxf(mx, s4.w);
             }
         }
         a = part_tree_sum(a);
