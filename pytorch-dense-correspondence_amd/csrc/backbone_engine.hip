@@ -71,6 +71,7 @@ struct dcn_plan {
     std::vector<BnL> bns;
     std::vector<BlockL> blocks;
     std::vector<ParamInfo> params;
+    std::vector<std::pair<size_t, size_t>> relu_masks;   // (post-ReLU activation offset, offset of its one-byte-per-float4 mask)
     int stem = -1, fc = -1;
     int hl = 0, wl = 0, feat_c = 0;
     // saved arena offsets (floats)
@@ -101,6 +102,12 @@ struct Builder {
     size_t alloc_saved(size_t floats) {
         const size_t o = saved;
         saved = align64(saved + floats);
+        return o;
+    }
+    // a post-ReLU activation of `floats` elements plus its ReLU mask (one byte per float4, read by the BN backward passes)
+    size_t alloc_relu_out(size_t floats) {
+        const size_t o = alloc_saved(floats);
+        p.relu_masks.emplace_back(o, alloc_saved((floats / 4 + 3) / 4));
         return o;
     }
     int add_param(const std::string& name, std::initializer_list<int64_t> shape) {
@@ -181,7 +188,7 @@ int build_plan(dcn_plan& p) {
     {
         ConvL& c = p.convs[p.stem];
         c.bn = B.add_bn("bn1", w, B.rows_of(c));
-        p.s_stem_y = B.alloc_saved((size_t)B.rows_of(c) * w);
+        p.s_stem_y = B.alloc_relu_out((size_t)B.rows_of(c) * w);
     }
     int h = p.convs[p.stem].d.hout, wd = p.convs[p.stem].d.wout;
     const int hp = (h + 2 - 3) / 2 + 1, wp = (wd + 2 - 3) / 2 + 1;
@@ -214,7 +221,7 @@ int build_plan(dcn_plan& p) {
                 B.conv_out(blk.conv[0]);
                 const ConvL c0 = p.convs[blk.conv[0]];
                 p.convs[blk.conv[0]].bn = B.add_bn(bname + ".bn1", planes, B.rows_of(c0));
-                blk.mid[0] = B.alloc_saved((size_t)B.rows_of(c0) * planes);
+                blk.mid[0] = B.alloc_relu_out((size_t)B.rows_of(c0) * planes);
                 blk.conv[1] = B.add_conv(bname + ".conv2", N, c0.d.hout, c0.d.wout, planes, planes, 3, 1, dil, dil, false);
                 B.conv_out(blk.conv[1]);
                 p.convs[blk.conv[1]].bn = B.add_bn(bname + ".bn2", planes, B.rows_of(p.convs[blk.conv[1]]));
@@ -224,12 +231,12 @@ int build_plan(dcn_plan& p) {
                 B.conv_out(blk.conv[0]);
                 const ConvL c0 = p.convs[blk.conv[0]];
                 p.convs[blk.conv[0]].bn = B.add_bn(bname + ".bn1", planes, B.rows_of(c0));
-                blk.mid[0] = B.alloc_saved((size_t)B.rows_of(c0) * planes);
+                blk.mid[0] = B.alloc_relu_out((size_t)B.rows_of(c0) * planes);
                 blk.conv[1] = B.add_conv(bname + ".conv2", N, h, wd, planes, planes, 3, bstride, dil, dil, false);
                 B.conv_out(blk.conv[1]);
                 const ConvL c1 = p.convs[blk.conv[1]];
                 p.convs[blk.conv[1]].bn = B.add_bn(bname + ".bn2", planes, B.rows_of(c1));
-                blk.mid[1] = B.alloc_saved((size_t)B.rows_of(c1) * planes);
+                blk.mid[1] = B.alloc_relu_out((size_t)B.rows_of(c1) * planes);
                 blk.conv[2] = B.add_conv(bname + ".conv3", N, c1.d.hout, c1.d.wout, planes, planes * 4, 1, 1, 0, 1, false);
                 B.conv_out(blk.conv[2]);
                 p.convs[blk.conv[2]].bn = B.add_bn(bname + ".bn3", planes * 4, B.rows_of(p.convs[blk.conv[2]]));
@@ -242,7 +249,7 @@ int build_plan(dcn_plan& p) {
             }
             blk.out_rows = B.rows_of(last);
             blk.out_c = planes * exp;
-            blk.out = B.alloc_saved((size_t)blk.out_rows * blk.out_c);
+            blk.out = B.alloc_relu_out((size_t)blk.out_rows * blk.out_c);
             if ((size_t)blk.out_rows * blk.out_c > p.max_act) p.max_act = (size_t)blk.out_rows * blk.out_c;
             p.blocks.push_back(blk);
             cur = blk.out;
@@ -371,6 +378,12 @@ struct Run {
     }
 
     float* S(size_t off) const { return saved + off; }
+    // ReLU mask bytes of the post-ReLU activation at saved-arena offset `off`
+    unsigned char* M(size_t off) const {
+        for (const auto& m : p.relu_masks)
+            if (m.first == off) return (unsigned char*)(saved + m.second);
+        return nullptr;
+    }
     float* Wk(size_t off) const { return ws + off; }
     const float* P(int i) const { return params[i]; }
 
@@ -565,7 +578,7 @@ extern "C" int dcn_backbone_forward(dcn_plan* plan, const float* image, const fl
     {
         const BnL& b = p.bns[stem.bn];
         const float* s = R.S(b.stats);
-        dcn::launch_bn_apply(R.S(stem.x), s, nullptr, nullptr, 1, R.S(p.s_stem_y), b.C, b.rows, p.groups, st);
+        dcn::launch_bn_apply(R.S(stem.x), s, nullptr, nullptr, 1, R.S(p.s_stem_y), R.M(p.s_stem_y), b.C, b.rows, p.groups, st);
         const int hp = (stem.d.hout + 2 - 3) / 2 + 1, wp = (stem.d.wout + 2 - 3) / 2 + 1;
         dcn::launch_maxpool_fwd(R.S(p.s_stem_y), R.S(p.s_pool), (unsigned char*)R.S(p.s_argmax), N, stem.d.hout,
                                 stem.d.wout, hp, wp, b.C, st);
@@ -579,7 +592,7 @@ extern "C" int dcn_backbone_forward(dcn_plan* plan, const float* image, const fl
             if (i + 1 < blk.nconv) {
                 const BnL& b = p.bns[c.bn];
                 const float* s = R.S(b.stats);
-                dcn::launch_bn_apply(R.S(c.x), s, nullptr, nullptr, 1, R.S(blk.mid[i]), b.C, b.rows, p.groups, st);
+                dcn::launch_bn_apply(R.S(c.x), s, nullptr, nullptr, 1, R.S(blk.mid[i]), R.M(blk.mid[i]), b.C, b.rows, p.groups, st);
                 cur = R.S(blk.mid[i]);
             }
         }
@@ -590,9 +603,9 @@ extern "C" int dcn_backbone_forward(dcn_plan* plan, const float* image, const fl
             const ConvL& dc = p.convs[blk.down];
             DCN_TRY(R.conv_bn(dc, in, R.P(dc.w), bn_running, momentum, eps, training));
             const float* sd = R.S(p.bns[dc.bn].stats);
-            dcn::launch_bn_apply(R.S(last.x), sl, R.S(dc.x), sd, 1, R.S(blk.out), bl.C, bl.rows, p.groups, st);
+            dcn::launch_bn_apply(R.S(last.x), sl, R.S(dc.x), sd, 1, R.S(blk.out), R.M(blk.out), bl.C, bl.rows, p.groups, st);
         } else {
-            dcn::launch_bn_apply(R.S(last.x), sl, in, nullptr, 1, R.S(blk.out), bl.C, bl.rows, p.groups, st);
+            dcn::launch_bn_apply(R.S(last.x), sl, in, nullptr, 1, R.S(blk.out), R.M(blk.out), bl.C, bl.rows, p.groups, st);
         }
     }
     }   // !fused_eval
@@ -625,7 +638,9 @@ extern "C" int dcn_backbone_backward(dcn_plan* plan, const float* grad_descripto
     auto bn_bwd = [&](const ConvL& c, const float* dy, const float* relu_out, float* dx, float* g_out) {
         const BnL& b = p.bns[c.bn];
         const float* s = R.S(b.stats);
-        dcn::launch_bn_bwd(dy, relu_out, R.S(c.x), s, R.P(b.g), b.C, b.rows, p.groups, part, grads[b.g],
+        // (the mask bytes the forward wrote next to that activation; relu_out itself is then not read)
+        const unsigned char* mask = relu_out ? R.M((size_t)(relu_out - R.saved)) : nullptr;
+        dcn::launch_bn_bwd(dy, relu_out, mask, R.S(c.x), s, R.P(b.g), b.C, b.rows, p.groups, part, grads[b.g],
                            grads[b.b], k123, dx, g_out, f16 ? amax + c.idx : nullptr, f16 ? (void*)R.Wk(p.w_dq) : nullptr, st);
         dq_of = f16 ? dx : nullptr;   // the pixel-blocked split copy of this dx now sits in w_dq
     };

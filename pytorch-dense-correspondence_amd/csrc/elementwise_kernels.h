@@ -17,12 +17,15 @@ void launch_bn_finalize(const float* partial, int tiles_per_group, int groups, i
                         const float* gamma, const float* beta, float* rmean, float* rvar, float momentum, float eps,
                         int training, float* stats, hipStream_t st);
 // y = [relu](x*scale1 + shift1 + (res ? (stats2 ? res*scale2 + shift2 : res) : 0))
-void launch_bn_apply(const float* x, const float* stats1, const float* res, const float* stats2, int relu, float* y, int C,
-                     int64_t rows, int groups, hipStream_t st);
+// relu_mask (optional, with relu): one byte per float4 of y, bit j = y[4i + j] > 0 (read back by launch_bn_bwd)
+void launch_bn_apply(const float* x, const float* stats1, const float* res, const float* stats2, int relu, float* y,
+                     unsigned char* relu_mask, int C, int64_t rows, int groups, hipStream_t st);
 int bn_bwd_chunks(int64_t rows_per_group);
 // partial: groups*bn_bwd_chunks(rows/groups)*4*C floats, k123: groups*3*C floats.  g_out (nullable) receives the
 // relu-masked dy.  absmax (optional): raised to an upper bound of max |dx|
-void launch_bn_bwd(const float* dy, const float* relu_out, const float* x, const float* stats, const float* gamma, int C,
+// the ReLU mask of dy comes from relu_mask (bytes written by launch_bn_apply) if given, else from relu_out, else none
+void launch_bn_bwd(const float* dy, const float* relu_out, const unsigned char* relu_mask, const float* x, const float* stats,
+                   const float* gamma, int C,
                    int64_t rows, int groups, float* partial, float* dgamma, float* dbeta, float* k123, float* dx,
                    float* g_out, float* absmax, void* dq, hipStream_t st);   // dq (optional, with absmax): dx also as the
                                                                              // pixel-blocked split-fp16 tensor (f16_split.h)

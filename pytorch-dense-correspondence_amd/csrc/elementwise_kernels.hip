@@ -120,7 +120,8 @@ bn_finalize_kernel(const float* __restrict__ partial, int tiles, int groups, int
 __global__ void __launch_bounds__(256)
 bn_apply_kernel(const float* __restrict__ x, const float* __restrict__ s1, const float* __restrict__ b1,
                 const float* __restrict__ res, const float* __restrict__ s2, const float* __restrict__ b2, int relu,
-                float* __restrict__ y, int c4n, int64_t total4, int64_t group4, int gstride) {
+                float* __restrict__ y, unsigned char* __restrict__ relu_mask, int c4n, int64_t total4, int64_t group4,
+                int gstride) {
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total4; i += (int64_t)gridDim.x * 256) {
         const int c = (int)(i % c4n) * 4 + (i >= group4 ? gstride : 0);   // (at most two groups: second group's statistics)
         const float4 v = reinterpret_cast<const float4*>(x)[i];
@@ -138,7 +139,24 @@ bn_apply_kernel(const float* __restrict__ x, const float* __restrict__ s1, const
         }
         if (relu) { o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f); }
         reinterpret_cast<float4*>(y)[i] = o;
+        // which of the four outputs are positive: ONE byte per float4, so that the backward passes read 1 byte instead
+        // of 16 to rebuild the ReLU mask
+        if (relu_mask)
+            relu_mask[i] = (unsigned char)((o.x > 0.f ? 1 : 0) | (o.y > 0.f ? 2 : 0) | (o.z > 0.f ? 4 : 0) | (o.w > 0.f ? 8 : 0));
     }
+}
+
+// relu-masked upstream gradient: from the one-byte-per-float4 mask written by the forward apply pass when there is one,
+// otherwise from the activation itself
+__device__ __forceinline__ float4 relu_masked(float4 g, const float* relu_out, const unsigned char* relu_mask, int64_t i4) {
+    if (relu_mask) {
+        const unsigned m = relu_mask[i4];
+        g.x = (m & 1u) ? g.x : 0.f; g.y = (m & 2u) ? g.y : 0.f; g.z = (m & 4u) ? g.z : 0.f; g.w = (m & 8u) ? g.w : 0.f;
+    } else if (relu_out) {
+        const float4 y = reinterpret_cast<const float4*>(relu_out)[i4];
+        g.x = y.x > 0.f ? g.x : 0.f; g.y = y.y > 0.f ? g.y : 0.f; g.z = y.z > 0.f ? g.z : 0.f; g.w = y.w > 0.f ? g.w : 0.f;
+    }
+    return g;
 }
 
 // Backward reduction.  g = relu_out ? (relu_out > 0 ? dy : 0) : dy.
@@ -147,7 +165,8 @@ bn_apply_kernel(const float* __restrict__ x, const float* __restrict__ s1, const
 // (The two maxima bound |dx| per channel without another pass or any atomics in the big kernels: bn_bwd_finalize.)
 // work-item (c4 = tid & 15, rl = tid >> 4): 16 channel quads x 16 row lanes; grid = (C/64 groups, chunks).
 __global__ void __launch_bounds__(256)
-bn_bwd_reduce_kernel(const float* __restrict__ dy, const float* __restrict__ relu_out, const float* __restrict__ x,
+bn_bwd_reduce_kernel(const float* __restrict__ dy, const float* __restrict__ relu_out,
+                     const unsigned char* __restrict__ relu_mask, const float* __restrict__ x,
                      const float* __restrict__ mean, const float* __restrict__ invstd, int C, int64_t rows_per_group,
                      int chunks_per_group, int gstride, int rows_per_chunk, float* __restrict__ partial) {
     __shared__ float4 s_g[16][16];
@@ -166,12 +185,7 @@ bn_bwd_reduce_kernel(const float* __restrict__ dy, const float* __restrict__ rel
         if (r1 > (g + 1) * rows_per_group) r1 = (g + 1) * rows_per_group;
         for (int64_t r = r0 + rl; r < r1; r += 16) {
             const int64_t o = r * C + c;
-            float4 g = *reinterpret_cast<const float4*>(dy + o);
-            if (relu_out) {
-                const float4 y = *reinterpret_cast<const float4*>(relu_out + o);
-                g.x = y.x > 0.f ? g.x : 0.f; g.y = y.y > 0.f ? g.y : 0.f;
-                g.z = y.z > 0.f ? g.z : 0.f; g.w = y.w > 0.f ? g.w : 0.f;
-            }
+            const float4 g = relu_masked(*reinterpret_cast<const float4*>(dy + o), relu_out, relu_mask, o >> 2);
             const float4 v = *reinterpret_cast<const float4*>(x + o);
             const float4 xh = make_float4((v.x - mu.x) * is.x, (v.y - mu.y) * is.y, (v.z - mu.z) * is.z, (v.w - mu.w) * is.w);
             ag.x += g.x; ag.y += g.y; ag.z += g.z; ag.w += g.w;
@@ -292,7 +306,8 @@ __device__ __forceinline__ void wave_atomic_absmax(float amax, float* absmax) {
 // dx = k1*(g - k2 - (x-mean)*invstd*k3); optionally also writes g (the relu-masked upstream gradient) for the
 // residual branch.
 __global__ void __launch_bounds__(256)
-bn_bwd_apply_kernel(const float* __restrict__ dy, const float* __restrict__ relu_out, const float* __restrict__ x,
+bn_bwd_apply_kernel(const float* __restrict__ dy, const float* __restrict__ relu_out,
+                    const unsigned char* __restrict__ relu_mask, const float* __restrict__ x,
                     const float* __restrict__ mean, const float* __restrict__ invstd, const float* __restrict__ k1,
                     const float* __restrict__ k2, const float* __restrict__ k3, float* __restrict__ dx,
                     float* __restrict__ g_out, int c4n, int64_t total4, int64_t group4, int gstride, int kstride) {
@@ -300,12 +315,7 @@ bn_bwd_apply_kernel(const float* __restrict__ dy, const float* __restrict__ relu
         const int c0 = (int)(i % c4n) * 4;
         const bool second = i >= group4;                          // (at most two groups)
         const int c = c0 + (second ? gstride : 0), ck = c0 + (second ? kstride : 0);
-        float4 g = reinterpret_cast<const float4*>(dy)[i];
-        if (relu_out) {
-            const float4 y = reinterpret_cast<const float4*>(relu_out)[i];
-            g.x = y.x > 0.f ? g.x : 0.f; g.y = y.y > 0.f ? g.y : 0.f;
-            g.z = y.z > 0.f ? g.z : 0.f; g.w = y.w > 0.f ? g.w : 0.f;
-        }
+        const float4 g = relu_masked(reinterpret_cast<const float4*>(dy)[i], relu_out, relu_mask, i);
         const float4 v = reinterpret_cast<const float4*>(x)[i];
         const float4 mu = *reinterpret_cast<const float4*>(mean + c);
         const float4 is = *reinterpret_cast<const float4*>(invstd + c);
@@ -326,7 +336,8 @@ bn_bwd_apply_kernel(const float* __restrict__ dy, const float* __restrict__ relu
 // dx as the pixel-blocked split tensor wgrad consumes (f16_split.h), scaled by the power of two chosen from the bound the
 // finalize kernel has just stored in *absmax -- no separate split pass over dx.  rows_per_group % 4 == 0 when grouped.
 __global__ void __launch_bounds__(256)
-bn_bwd_apply_blocked_kernel(const float* __restrict__ dy, const float* __restrict__ relu_out, const float* __restrict__ x,
+bn_bwd_apply_blocked_kernel(const float* __restrict__ dy, const float* __restrict__ relu_out,
+                            const unsigned char* __restrict__ relu_mask, const float* __restrict__ x,
                             const float* __restrict__ mean, const float* __restrict__ invstd, const float* __restrict__ k1,
                             const float* __restrict__ k2, const float* __restrict__ k3, float* __restrict__ dx,
                             float* __restrict__ g_out, dcnsplit::u32x4* __restrict__ dq, const float* __restrict__ absmax,
@@ -349,12 +360,7 @@ bn_bwd_apply_blocked_kernel(const float* __restrict__ dy, const float* __restric
             const int64_t m = q * 4 + r;
             if (m < rows) {
                 const int64_t e = m * c4n + cq;
-                float4 g = reinterpret_cast<const float4*>(dy)[e];
-                if (relu_out) {
-                    const float4 y = reinterpret_cast<const float4*>(relu_out)[e];
-                    g.x = y.x > 0.f ? g.x : 0.f; g.y = y.y > 0.f ? g.y : 0.f;
-                    g.z = y.z > 0.f ? g.z : 0.f; g.w = y.w > 0.f ? g.w : 0.f;
-                }
+                const float4 g = relu_masked(reinterpret_cast<const float4*>(dy)[e], relu_out, relu_mask, e);
                 const float4 v = reinterpret_cast<const float4*>(x)[e];
                 o[r][0] = a.x * (g.x - b.x - (v.x - mu.x) * is.x * d.x);
                 o[r][1] = a.y * (g.y - b.y - (v.y - mu.y) * is.y * d.y);
@@ -616,11 +622,11 @@ void launch_bn_finalize(const float* partial, int tiles_per_group, int groups, i
                        count_per_group, gamma, beta, rmean, rvar, momentum, eps, training, stats, stats + C, stats + 2 * C,
                        stats + 3 * C, 4 * C);
 }
-void launch_bn_apply(const float* x, const float* stats1, const float* res, const float* stats2, int relu, float* y, int C,
-                     int64_t rows, int groups, hipStream_t st) {
+void launch_bn_apply(const float* x, const float* stats1, const float* res, const float* stats2, int relu, float* y,
+                     unsigned char* relu_mask, int C, int64_t rows, int groups, hipStream_t st) {
     const int64_t total4 = rows * (C / 4);
     hipLaunchKernelGGL(bn_apply_kernel, dim3(blocks_for(total4, kGridCap)), dim3(256), 0, st, x, stats1, stats1 + C, res,
-                       stats2, stats2 ? stats2 + C : nullptr, relu, y, C / 4, total4, total4 / groups, 4 * C);
+                       stats2, stats2 ? stats2 + C : nullptr, relu, y, relu_mask, C / 4, total4, total4 / groups, 4 * C);
 }
 int bn_bwd_chunks(int64_t rows_per_group) {
     // enough row chunks that even a 64-channel layer launches >= ~1000 workgroups (HBM-bound pass: fill all 256 CUs)
@@ -629,7 +635,8 @@ int bn_bwd_chunks(int64_t rows_per_group) {
     if (chunks < 1) chunks = 1;
     return (int)chunks;
 }
-void launch_bn_bwd(const float* dy, const float* relu_out, const float* x, const float* stats, const float* gamma, int C,
+void launch_bn_bwd(const float* dy, const float* relu_out, const unsigned char* relu_mask, const float* x, const float* stats,
+                   const float* gamma, int C,
                    int64_t rows, int groups, float* partial, float* dgamma, float* dbeta, float* k123, float* dx,
                    float* g_out, float* absmax, void* dq, hipStream_t st) {
     const int64_t rpg = rows / groups;
@@ -637,20 +644,20 @@ void launch_bn_bwd(const float* dy, const float* relu_out, const float* x, const
     const int rpc = (int)ceil_div64(rpg, chunks);
     const float* mean = stats + 2 * C;
     const float* invstd = stats + 3 * C;
-    hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(ceil_div(C, 64), chunks * groups), dim3(256), 0, st, dy, relu_out, x,
-                       mean, invstd, C, rpg, chunks, 4 * C, rpc, partial);
+    hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(ceil_div(C, 64), chunks * groups), dim3(256), 0, st, dy, relu_out,
+                       relu_mask, x, mean, invstd, C, rpg, chunks, 4 * C, rpc, partial);
     hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(ceil_div(C, 4)), dim3(256), 0, st, (const float*)partial, chunks,
                        groups, C, (double)rpg, gamma, invstd, 4 * C, dgamma, dbeta, k123, absmax);
     const int64_t total4 = rows * (C / 4);
     if (dq && absmax) {
         hipLaunchKernelGGL(bn_bwd_apply_blocked_kernel, dim3(blocks_for(((rows + 3) / 4) * (C / 4), kGridCap)), dim3(256), 0, st,
-                           dy, relu_out, x, mean, invstd, (const float*)k123, (const float*)(k123 + C),
+                           dy, relu_out, relu_mask, x, mean, invstd, (const float*)k123, (const float*)(k123 + C),
                            (const float*)(k123 + 2 * C), dx, g_out, (dcnsplit::u32x4*)dq, (const float*)absmax, C / 4, rows,
                            rpg, 4 * C, 3 * C);
         return;
     }
-    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(blocks_for(total4, kGridCap)), dim3(256), 0, st, dy, relu_out, x, mean,
-                       invstd, (const float*)k123, (const float*)(k123 + C), (const float*)(k123 + 2 * C), dx, g_out,
+    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(blocks_for(total4, kGridCap)), dim3(256), 0, st, dy, relu_out, relu_mask,
+                       x, mean, invstd, (const float*)k123, (const float*)(k123 + C), (const float*)(k123 + 2 * C), dx, g_out,
                        C / 4, total4, total4 / groups, 4 * C, 3 * C);
 }
 void launch_add(const float* a, const float* b, float* out, int64_t n, hipStream_t st) {
