@@ -7,7 +7,8 @@
 
 One step = one pass of the reference's training iteration (dense_correspondence/training/training.py:325-346)
 over one synthetic batch already resident in HBM:
-    zero grads -> dcn.forward(img_a) -> dcn.forward(img_b) -> process_network_output x2 ->
+    zero grads -> dcn.forward(img_a), dcn.forward(img_b) (by default as ONE grouped engine call, forward_pair: identical
+    values, batch-norm statistics per image batch; --separate-forwards for two calls) -> process_network_output x2 ->
     loss_composer (match + masked + background non-match lists, hard-negative scaling) -> backward ->
     gradient all-reduce (RCCL, N > 1) -> Adam step (lr 1e-4, weight decay 1e-4, training.yaml:3,6).
 Workload at N = 1: BASELINE.json configs[1] -- B = 4 image pairs (8 images / step), 640x480, D = 3,
@@ -15,9 +16,11 @@ Resnet34_8s, 5000 match + 2500 masked + 2500 background non-match pixel pairs pe
 rank runs that same per-GPU workload on its own pairs (weak scaling, BN statistics per rank: the reference has no
 SyncBN); `value` is the whole-job images / second.
 
-Prints ONE JSON line on rank 0 (contract in the task description) with `roofline` (dominant kernel =
-conv_gemm_kernel, fp32 MFMA; algorithmic FLOPs and per-launch durations from HIP events recorded by the engine
-on the launch stream) and `cpu_baseline` (the oracle's step on this box's host cores, bounded sample).
+Prints ONE JSON line on rank 0 (contract in the task description) with `roofline` (dominant kernel = the gather-GEMM
+convolution, conv_gemm_f16_kernel in the default split-fp16 arithmetic / conv_gemm_kernel with --conv-mode fp32;
+algorithmic FLOPs and per-launch durations from HIP events recorded by the engine on the launch stream) and
+`cpu_baseline` (the oracle's step on this box's host cores, bounded sample).  `--workload pairgen` measures the device
+pair generator instead.
 """
 import argparse
 import json

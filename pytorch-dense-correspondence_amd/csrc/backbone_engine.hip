@@ -274,7 +274,7 @@ int build_plan(dcn_plan& p) {
     size_t ws = 0;
     auto alloc = [&](size_t fl) { const size_t o = ws; ws = align64(ws + fl); return o; };
     for (int i = 0; i < 6; ++i) p.w_buf[i] = alloc(p.max_act);
-    size_t max_w = 0, max_slab = 0, max_part = 0, max_sk = 0, max_wh = 0;   // sized for either conv mode
+    size_t max_w = 0, max_slab = 0, max_part = 0, max_sk = 0;   // sized for either conv mode
     int max_c = 4;
     for (const ConvL& c : p.convs) {
         const size_t welems = (size_t)c.d.ldc * c.d.kh * c.d.kw * c.d.cin;
@@ -285,9 +285,6 @@ int build_plan(dcn_plan& p) {
             const size_t sk = std::max(dcn_conv_gemm_workspace(&c.d, dg), dcn_conv_gemm_workspace_f16(&c.d, dg)) / sizeof(float);
             if (sk > max_sk) max_sk = sk;
         }
-        const int taps = c.d.kh * c.d.kw;
-        const size_t wh = std::max((size_t)c.d.cout * dcn_f16_kpad(taps * c.d.cin), (size_t)c.d.cin * dcn_f16_kpad(taps * c.d.ldc));
-        if (wh > max_wh) max_wh = wh;
         const size_t pf = (size_t)std::max(c.mtiles[0], c.mtiles[1]) * 2 * c.d.cout;
         if (pf > max_part) max_part = pf;
         if (c.d.cout > max_c) max_c = c.d.cout;
@@ -315,7 +312,6 @@ int build_plan(dcn_plan& p) {
             c.wsplit = halves;
             halves += (std::max(a, b) + 7) / 8 * 8;
         }
-        (void)max_wh;
         p.w_wh = alloc((halves + 1) / 2);
         p.w_wl = alloc((halves + 1) / 2);
     }

@@ -6,10 +6,11 @@
 // train-mode BN, 640x480) the descriptor map is 1.3e-5 from a float64 run -- the fp32 CPU reference itself is 1.5e-5 --
 // and every parameter gradient deviates from float64 exactly as much as the fp32 reference does (3.1e-2 max / 7.0e-3 L2,
 // ill-conditioning, not precision).  bf16 cannot do this (a 2-way bf16 split is 2.3e-4 off, above the 1e-4 parity bar).
-//   forward : activations s = 1, weights s = 64 (pre-split once per call: `split_rows_kernel`)
-//   dgrad   : the incoming gradient tensor is scaled by 2^e with e from its abs-max (a device scalar written by the
-//             kernel that produced the tensor) so that tiny gradients stay inside fp16's range; weights s = 64
-//   wgrad   : dy (dynamic scale) x activations (s = 1), reduction over pixels, register-transposed into k-major LDS
+//   forward : activations s = 1, weights s = 64 (all weight tensors pre-split by one launch per call)
+//   dgrad   : the incoming gradient tensor is scaled by 2^e with e from an upper bound of its abs-max (a device scalar
+//             written by the kernels that produce the tensor) so that tiny gradients stay inside fp16's range; weights s = 64
+//   wgrad   : dy (same scale) x activations (s = 1), reduction over pixels; both operands pre-split once per tensor
+//             (the gradient "pixel-blocked" by the BN backward pass itself), transposed into k-major LDS rows
 // MFMA work per K drops 5.3x (3 x 32 cycles per 16 K vs 8 x 64 cycles), so the kernels are designed around the
 // operand path: 128x128 tiles, 32-K stages, fp32->(hi,lo) conversion once per element at staging time (v_cvt_pk_f16_f32),
 // conflict-free 80-byte-pitch fp16 LDS images, one ds_read_b128 per 32x16 fragment.
