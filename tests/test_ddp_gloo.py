@@ -20,7 +20,7 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, q):
+def _worker(rank, world, port, q, pair=False):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HIPEMU_THREADS="2")
     torch.set_num_threads(2)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -42,8 +42,9 @@ def _worker(rank, world, port, q):
     img_a, img_b, lists = synth.make_batch(B, H, W, 40, 20, 20, seed=1 + rank)
     pcl = PixelwiseContrastiveLoss([H, W], synth.LOSS_CONFIG)
     grads.zero_()
-    pa = m(img_a).permute(0, 2, 3, 1).reshape(B, H * W, D)
-    pb = m(img_b).permute(0, 2, 3, 1).reshape(B, H * W, D)
+    ya, yb = m.forward_pair(img_a, img_b) if pair else (m(img_a), m(img_b))   # bench.py's default is the grouped call
+    pa = ya.permute(0, 2, 3, 1).reshape(B, H * W, D)
+    pb = yb.permute(0, 2, 3, 1).reshape(B, H * W, D)
     L = lists[0]
     tup = [(L["matches_a"], L["matches_b"], L["masked_non_matches_a"], L["masked_non_matches_b"],
             L["background_non_matches_a"], L["background_non_matches_b"], L["blind_non_matches_a"],
@@ -71,11 +72,12 @@ def _worker(rank, world, port, q):
 
 
 @pytest.mark.timeout(600)
-def test_two_rank_gradient_average_matches_oracle():
+@pytest.mark.parametrize("pair", [False, True], ids=["two_forward_calls", "forward_pair"])
+def test_two_rank_gradient_average_matches_oracle(pair):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q, pair)) for r in range(2)]
     for p in procs:
         p.start()
     res = [q.get(timeout=540) for _ in procs]
