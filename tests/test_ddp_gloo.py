@@ -31,7 +31,7 @@ def _worker(rank, world, port, q, pair=False):
     from dense_correspondence.loss_functions.pixelwise_contrastive_loss import PixelwiseContrastiveLoss
     from oracle import resnet_dilated_oracle as orc, step as ostep, synth
     from pytorch_segmentation_detection.models import resnet_dilated as prod
-    H, W, D, B = 32, 32, 3, 1
+    H, W, D, B = (64, 64, 3, 1) if pair else (32, 32, 3, 1)   # (a group's rows must be tile-aligned for the grouped plan)
     torch.manual_seed(100 + rank)  # different init per rank: the broadcast must fix that
     m = prod.Resnet18_8s(num_classes=D, base_width=8)
     if rank == 0:
@@ -43,6 +43,9 @@ def _worker(rank, world, port, q, pair=False):
     pcl = PixelwiseContrastiveLoss([H, W], synth.LOSS_CONFIG)
     grads.zero_()
     ya, yb = m.forward_pair(img_a, img_b) if pair else (m(img_a), m(img_b))   # bench.py's default is the grouped call
+    if pair:
+        from dcn_hip import backbone as _bb
+        assert any(k[-1] == 2 for k in _bb._PLANS), "forward_pair fell back to two calls"
     pa = ya.permute(0, 2, 3, 1).reshape(B, H * W, D)
     pb = yb.permute(0, 2, 3, 1).reshape(B, H * W, D)
     L = lists[0]
