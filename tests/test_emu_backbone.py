@@ -177,6 +177,8 @@ def test_grouped_pair_forward_equals_two_forward_calls(arch, bw, shape):
     gb = torch.randn(N, D, H, W, generator=g)
     m.train(); m2.train(); o.train()
     ya, yb = m.forward_pair(xa, xb)
+    from dcn_hip import backbone as _bb
+    assert any(k[-1] == 2 and k[2] == 2 * N for k in _bb._PLANS), "forward_pair fell back to two calls"
     za, zb = m2(xa), m2(xb)
     oa, ob = o(xa), o(xb)
     assert ya.shape == oa.shape and rel_err(ya, oa) < 2e-5 and rel_err(yb, ob) < 2e-5
