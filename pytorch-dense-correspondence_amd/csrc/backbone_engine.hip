@@ -78,7 +78,7 @@ struct dcn_plan {
     size_t s_in4 = 0, s_stem_y = 0, s_pool = 0, s_argmax = 0, s_low = 0, saved_floats = 0;
     // workspace offsets (floats)
     size_t w_buf[6] = {0, 0, 0, 0, 0, 0}, w_wt = 0, w_slab = 0, w_part = 0, w_k123 = 0, w_wstem = 0, w_dwstem = 0,
-           w_glow = 0, w_ups = 0, w_sk = 0, w_gnorm = 0, w_wh = 0, w_wl = 0, w_amax = 0, w_xs = 0, w_dq = 0, ws_floats = 0;
+           w_glow = 0, w_ups = 0, w_sk = 0, w_gnorm = 0, w_wh = 0, w_wl = 0, w_amax = 0, w_dq = 0, ws_floats = 0;
     int conv_mode = DCN_CONV_F16X3;
     size_t max_act = 0;
     double flops = 0;
@@ -316,13 +316,10 @@ int build_plan(dcn_plan& p) {
         p.w_wl = alloc((halves + 1) / 2);
     }
     p.w_amax = alloc(p.convs.size());   // abs-max of the gradient w.r.t. each convolution's output
-    {   // split (fp16 hi | lo) copies of one activation tensor and one gradient tensor: wgrad operands, split once per tensor
-        size_t max_x = 0, max_dq = 0;
-        for (const ConvL& c : p.convs) {
-            max_x = std::max(max_x, (size_t)c.d.n * c.d.hin * c.d.win * c.d.cin);
+    {   // pixel-blocked split (fp16 hi | lo) copy of one gradient tensor: wgrad's dy operand, written by the BN backward pass
+        size_t max_dq = 0;
+        for (const ConvL& c : p.convs)
             max_dq = std::max(max_dq, dcn_grad_blocked_bytes(c.d.n * c.d.hout * c.d.wout, c.d.ldc) / sizeof(float));
-        }
-        p.w_xs = alloc(max_x);
         p.w_dq = alloc(max_dq);
     }
     p.ws_floats = ws;
@@ -640,20 +637,14 @@ extern "C" int dcn_backbone_backward(dcn_plan* plan, const float* grad_descripto
                            grads[b.b], k123, dx, g_out, f16 ? amax + c.idx : nullptr, f16 ? (void*)R.Wk(p.w_dq) : nullptr, st);
         dq_of = f16 ? dx : nullptr;   // the pixel-blocked split copy of this dx now sits in w_dq
     };
-    const float* planes_of = nullptr;   // activation tensor whose split copy is in w_xs (block input: two consumers)
     auto wgrad = [&](const ConvL& c, const float* in, const float* dx, float* dw) -> int {
         if (!f16) return R.timed(1, c.flops, [&] { return dcn_conv_wgrad(&c.d, in, dx, dw, slab, st); });
-        // an activation element is used by taps x (Cout / tile) wgrad tiles: pre-split it once when that is worth a pass
-        const bool presplit = c.d.kh * c.d.kw * ceil_div(c.d.cout, c.d.cout <= 64 ? 64 : 128) >= 4;
-        if (presplit && planes_of != in) {
-            DCN_TRY(dcn_split_act_f16(in, R.Wk(p.w_xs), (int64_t)c.d.n * c.d.hin * c.d.win * c.d.cin, st));
-            planes_of = in;
-        }
+        // The activation operand is the fp32 tensor itself, split on the fly inside the kernel: measured faster than a
+        // split pass + pre-split operand on every layer of ResNet34 / ResNet50 (the pass costs more than the conversions).
         if (dq_of != dx)   // (BN backward emits it directly; only the scoring layer's gradient needs the separate pass)
             DCN_TRY(dcn_split_grad_blocked_f16(dx, c.d.n * c.d.hout * c.d.wout, c.d.ldc, amax + c.idx, R.Wk(p.w_dq), st));
         return R.timed(1, c.flops, [&] {
-            return dcn_conv_wgrad_f16(&c.d, presplit ? (const void*)R.Wk(p.w_xs) : (const void*)in, presplit ? 0 : 1,
-                                      R.Wk(p.w_dq), amax + c.idx, dw, slab, st);
+            return dcn_conv_wgrad_f16(&c.d, in, 1, R.Wk(p.w_dq), amax + c.idx, dw, slab, st);
         });
     };
     auto dgrad = [&](const ConvL& c, const float* dx, const float* add, float* din) -> int {

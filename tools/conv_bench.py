@@ -36,6 +36,7 @@ def main():
     ap.add_argument("--json", default="")
     ap.add_argument("--only", default="", help="substring filter on the shape name")
     ap.add_argument("--kinds", default="fwd,dgrad,wgrad")
+    ap.add_argument("--x-direct", action="store_true", help="f16 wgrad: fp32 activation operand split on the fly")
     ap.add_argument("--no-split", action="store_true", help="f16 wgrad: time the GEMM kernel alone (planes prepared once)")
     ap.add_argument("--check", action="store_true", help="with --mode f16: compare against the fp32 kernels")
     ap.add_argument("--mode", default="fp32", choices=["fp32", "f16"], help="fp32 MFMA kernels or the split-fp16 (f16x3) ones")
@@ -92,6 +93,11 @@ def main():
 
             def wgrad_f16(split=not a.no_split):   # the two split passes are part of the cost unless --no-split
                 rc = 0
+                if a.x_direct:   # activation operand = the fp32 tensor, split on the fly (no split pass)
+                    if split:
+                        rc |= lib.dcn_split_grad_blocked_f16(_lib.ptr(dy), M, cout, _lib.ptr(amax), _lib.ptr(dq), st)
+                    return rc | lib.dcn_conv_wgrad_f16(ctypes.byref(d), _lib.ptr(x), 1, _lib.ptr(dq), _lib.ptr(amax), _lib.ptr(dw),
+                                                       _lib.ptr(slab), st)
                 if split:
                     rc |= lib.dcn_split_act_f16(_lib.ptr(x), _lib.ptr(xs), x.numel(), st)
                     rc |= lib.dcn_split_grad_blocked_f16(_lib.ptr(dy), M, cout, _lib.ptr(amax), _lib.ptr(dq), st)
