@@ -56,58 +56,22 @@ class DenseCorrespondenceNetwork(nn.Module):
         self._normalize = normalize
         self._constructed_from_model_folder = False
 
-    # ---- properties (:61-154)
-    @property
-    def fcn(self):
-        return self._fcn
-
-    @property
-    def config(self):
-        return self._config
-
-    @config.setter
-    def config(self, value):
-        self._config = value
-
-    @property
-    def descriptor_dimension(self):
-        return self._descriptor_dimension
+    # ---- the attribute-style accessors the training / evaluation code reads (:61-154), generated from one table:
+    # name -> (backing field, writable, mirrored into self.config and followed by a refresh of the normalisation transform)
+    _ACCESSORS = {
+        "fcn": ("_fcn", False, False),
+        "config": ("_config", True, False),
+        "descriptor_dimension": ("_descriptor_dimension", False, False),
+        "image_mean": ("_image_mean", True, True),
+        "image_std_dev": ("_image_std_dev", True, True),
+        "image_to_tensor": ("_image_to_tensor", True, False),
+        "normalize_tensor_transform": ("_normalize_tensor_transform", False, False),
+        "constructed_from_model_folder": ("_constructed_from_model_folder", True, False),
+    }
 
     @property
     def image_shape(self):
         return [self._image_height, self._image_width]
-
-    @property
-    def image_mean(self):
-        return self._image_mean
-
-    @image_mean.setter
-    def image_mean(self, value):
-        self._image_mean = value
-        self.config['image_mean'] = value
-        self._update_normalize_tensor_transform()
-
-    @property
-    def image_std_dev(self):
-        return self._image_std_dev
-
-    @image_std_dev.setter
-    def image_std_dev(self, value):
-        self._image_std_dev = value
-        self.config['image_std_dev'] = value
-        self._update_normalize_tensor_transform()
-
-    @property
-    def image_to_tensor(self):
-        return self._image_to_tensor
-
-    @image_to_tensor.setter
-    def image_to_tensor(self, value):
-        self._image_to_tensor = value
-
-    @property
-    def normalize_tensor_transform(self):
-        return self._normalize_tensor_transform
 
     @property
     def path_to_network_params_folder(self):
@@ -123,14 +87,6 @@ class DenseCorrespondenceNetwork(nn.Module):
             descriptor_stats_file = os.path.join(path_to_params, "descriptor_statistics.yaml")
             self._descriptor_image_stats = utils.getDictFromYamlFilename(descriptor_stats_file)
         return self._descriptor_image_stats
-
-    @property
-    def constructed_from_model_folder(self):
-        return self._constructed_from_model_folder
-
-    @constructed_from_model_folder.setter
-    def constructed_from_model_folder(self, value):
-        self._constructed_from_model_folder = value
 
     @property
     def unique_identifier(self):
@@ -330,3 +286,21 @@ class DenseCorrespondenceNetwork(nn.Module):
 
     def evaluate_descriptor_at_keypoints(self, res, keypoint_list):
         raise NotImplementedError("This function is currently broken")  # :565, same as the reference
+
+
+def _install_accessors(cls):
+    def make(field, writable, mirrored, name):
+        def getter(self):
+            return getattr(self, field)
+
+        def setter(self, value):
+            object.__setattr__(self, field, value) if not isinstance(value, nn.Module) else nn.Module.__setattr__(self, field, value)
+            if mirrored:
+                self.config[name] = value
+                self._update_normalize_tensor_transform()
+        return property(getter, setter if writable else None)
+    for name, (field, writable, mirrored) in cls._ACCESSORS.items():
+        setattr(cls, name, make(field, writable, mirrored, name))
+
+
+_install_accessors(DenseCorrespondenceNetwork)
