@@ -315,3 +315,25 @@ def test_match_statistics_vs_reference_golden(L):
     s2 = DCN.compute_match_statistics(uv, uv, res_a, res_b)
     assert torch.equal(s2["uv_b_pred"], s2["uv_b_pred_masked"])
     assert torch.equal(s2["num_pixels_closer_than_ground_truth"], s2["num_pixels_closer_than_ground_truth_masked"])
+
+
+def test_match_statistics_wide_descriptors_and_degenerate_masks(L):
+    """D = 16 (specialised instance) and D = 5 (runtime width); a mask of one pixel; the oracle per query."""
+    from dense_correspondence.network.dense_correspondence_network import DenseCorrespondenceNetwork as DCN
+    from oracle import evaluation_oracle as eo
+    g = torch.Generator().manual_seed(1)
+    for D in (16, 5):
+        H, W, Q = 20, 28, 6
+        res_a = torch.randn(H, W, D, generator=g)
+        res_b = res_a + 0.4 * torch.randn(H, W, D, generator=g)
+        mask = torch.zeros(H, W)
+        mask[7, 9] = 1
+        uv = torch.stack([torch.randint(0, W, (Q,), generator=g), torch.randint(0, H, (Q,), generator=g)], 1)
+        s = DCN.compute_match_statistics(uv, uv, res_a, res_b, mask)
+        for q in range(Q):
+            o = eo.match_statistics((int(uv[q, 0]), int(uv[q, 1])), (int(uv[q, 0]), int(uv[q, 1])), res_a.numpy(), res_b.numpy(),
+                                    mask.numpy())
+            assert tuple(s["uv_b_pred"][q].tolist()) == tuple(int(x) for x in o["uv_b_pred"])
+            assert tuple(s["uv_b_pred_masked"][q].tolist()) == (9, 7)
+            assert abs(int(s["num_pixels_closer_than_ground_truth"][q]) - o["num_pixels_closer_than_ground_truth"]) <= 1
+            assert int(s["num_pixels_closer_than_ground_truth_masked"][q]) in (0, 1)

@@ -158,3 +158,25 @@ def test_mismatched_lists_raise():
     from dcn_hip import loss as K
     with pytest.raises(ValueError):
         K.PairLists.from_lists([(torch.tensor([1, 2]), torch.tensor([1]), None, None, None, None, None, None)], "cpu")
+
+
+@pytest.mark.parametrize("D,mult", [(1, 1), (5, 3), (32, 2)])
+def test_triplet_kernel_shapes_vs_oracle(D, mult):
+    """Descriptor widths without a specialised kernel instance, multiplier 1, gradient accumulation onto repeated pixels."""
+    from dense_correspondence.loss_functions.pixelwise_contrastive_loss import PixelwiseContrastiveLoss as PCL
+    from oracle import loss_oracle
+    g = torch.Generator().manual_seed(D)
+    HW, Pm = 200, 17
+    A0, B0 = torch.randn(1, HW, D, generator=g), torch.randn(1, HW, D, generator=g)
+    ma = torch.randint(0, HW, (Pm,), generator=g)
+    mb = torch.randint(0, 8, (Pm,), generator=g)                 # few distinct pixels: many atomic adds per address
+    na = ma.repeat_interleave(mult)
+    nb = torch.randint(0, HW, (Pm * mult,), generator=g)
+    res = []
+    for fn in (PCL.get_triplet_loss, loss_oracle.PixelwiseContrastiveLoss.get_triplet_loss):
+        A, B = A0.clone().requires_grad_(True), B0.clone().requires_grad_(True)
+        l = fn(A, B, ma, mb, na, nb, 0.1)
+        l.backward()
+        res.append((l.item(), A.grad, B.grad))
+    assert abs(res[0][0] - res[1][0]) <= 1e-6 * abs(res[1][0])
+    assert rel_err(res[0][1], res[1][1]) < 1e-5 and rel_err(res[0][2], res[1][2]) < 1e-5

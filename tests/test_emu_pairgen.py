@@ -69,3 +69,23 @@ def test_edge_cases():
     one = pairgen.find_correspondences(_depth(z["depth_a"]), _depth(z["depth_b"]), co.get_default_K_matrix(), z["pose_a"],
                                        z["pose_b"], torch.tensor(z["uv_a_u"][:1]), torch.tensor(z["uv_a_v"][:1]))
     assert one[0].numel() == 1 and int(one[0]) == int(z["uv_a_u"][0])
+
+
+def test_out_of_image_candidates_and_mirrored_api_shapes():
+    """Candidates outside the image are dropped (the reference would index out of bounds); the mirrored
+    correspondence_finder API returns the reference's tuple-of-tensors shapes."""
+    from dcn_hip import pairgen
+    from oracle import correspondence_oracle as co
+    z = np.load(CORR_GOLDENS[0])
+    H, W = z["depth_a"].shape
+    good_u, good_v = torch.tensor(z["uv_a_u"][:5]), torch.tensor(z["uv_a_v"][:5])
+    cu = torch.cat([torch.tensor([-1, W, 3, 7]), good_u])
+    cv = torch.cat([torch.tensor([5, 5, -2, H]), good_v])
+    ua, va, ub, vb = pairgen.find_correspondences(_depth(z["depth_a"]), _depth(z["depth_b"]), co.get_default_K_matrix(),
+                                                  z["pose_a"], z["pose_b"], cu, cv)
+    assert np.array_equal(ua.numpy(), good_u.numpy()) and np.array_equal(va.numpy(), good_v.numpy())
+    np.testing.assert_allclose(ub.numpy(), z["uv_b_u"][:5], rtol=0, atol=3e-4)
+    # uniform sampling stays inside the image for random numbers arbitrarily close to 1
+    r = torch.tensor([[0.0, 0.5, 0.99999994], [0.99999994, 0.0, 0.5]])
+    u, v = pairgen.sample_pixels(r, 3, W, H)
+    assert u.tolist() == [0.0, W // 2, W - 1] and v.tolist() == [H - 1, 0.0, H // 2]
