@@ -240,6 +240,7 @@ def main():
                          "them every step; measured: no gain -- the step is kernel-bound, the host stays ahead of the GPU")
     ap.add_argument("--separate-forwards", action="store_true",
                     help="forward(img_a) and forward(img_b) as two engine calls (default: one grouped call with identical results)")
+    ap.add_argument("--torch-adam", action="store_true", help="optimizer.step() through torch.optim.Adam instead of dcn_adam_step")
     ap.add_argument("--force-dist", action="store_true", help="initialise RCCL even with one rank (smoke-tests the collective path)")
     args = ap.parse_args()
 
@@ -287,7 +288,8 @@ def main():
     broadcast_module(dcn)
     pcl = PixelwiseContrastiveLoss(image_shape=dcn.image_shape, config=LOSS_CONFIG)
     grads = FlatGradients(dcn)
-    opt = torch.optim.Adam(dcn.parameters(), lr=1.0e-4, weight_decay=1.0e-4)
+    from dcn_hip.optim import Adam
+    opt = (torch.optim.Adam if args.torch_adam else Adam)(dcn.parameters(), lr=1.0e-4, weight_decay=1.0e-4)   # training.py:133-145
     img_a, img_b, lists = make_batch(B, H, W, wl["Pm"], wl["Pk"], wl["Pg"], seed=1 + rank, masked=wl.get("masked", False))
     img_a, img_b = img_a.to(dev), img_b.to(dev)
     pair_lists = PairLists.from_lists(as_tuples(lists), dev)
@@ -454,7 +456,7 @@ def main():
                           "conv_mode": args.conv_mode, "hip_graph": graph_note,
                           "forward_calls": "forward(img_a), forward(img_b)" if args.separate_forwards else
                           "forward_pair(img_a, img_b): both network calls of the step as one grouped launch sequence, batch-norm "
-                          "statistics / running statistics / gradients per image batch (identical results)", "optimizer": "Adam lr 1e-4 wd 1e-4", "parallelism": "dp%d" % world,
+                          "statistics / running statistics / gradients per image batch (identical results)", "optimizer": "Adam lr 1e-4 wd 1e-4 (%s)" % ("torch.optim.Adam" if args.torch_adam else "dcn_adam_step, one pass"), "parallelism": "dp%d" % world,
                           "library": info["version"], "final_loss": final_loss,
                           "train_gflop_per_image": 3 * bb.get_plan(wl["backbone"], 64, B, H, W, D).forward_flops / B / 1e9},
                "roofline": roofline, "roofline_loss_gather": loss_roof}

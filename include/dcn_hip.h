@@ -345,6 +345,19 @@ int dcn_mask_nonzero(const float* mask, int64_t hw, int64_t* list, int64_t* coun
 int dcn_sample_pixels(const float* rand, int64_t n, int w, int h, const int64_t* list, const int64_t* count, float* u,
                       float* v, void* stream);
 
+/* =====================================================================================================
+ * 6. Optimizer step -- replaces `optimizer.step()` (dense_correspondence/training/training.py:346) of the
+ *    torch.optim.Adam built at training.py:133-145 (lr 1e-4, weight_decay 1e-4 from training.yaml:3,6; default betas,
+ *    eps; no amsgrad): one pass over n dense fp32 tensors, ceil(n / 80) launches.
+ *      g' = g + weight_decay * p;  m = m + (1 - beta1)(g' - m);  v = beta2 v + (1 - beta2) g'^2
+ *      p  = p - lr / (1 - beta1^step) * m / (sqrt(v) / sqrt(1 - beta2^step) + eps)
+ *    param / grad / exp_avg / exp_avg_sq: HOST arrays of n device pointers (element i of each addresses numel[i] floats in
+ *    the same memory order); they travel as kernel arguments.  step >= 1 is the count INCLUDING this update.
+ * ===================================================================================================== */
+int dcn_adam_step(int n, void* const* param, const void* const* grad, void* const* exp_avg, void* const* exp_avg_sq,
+                  const int64_t* numel, double lr, double beta1, double beta2, double eps, double weight_decay,
+                  int64_t step, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -82,6 +82,8 @@ SYMBOLS = {
     "dcn_mask_nonzero_workspace": (c_size_t, [c_int64]),
     "dcn_mask_nonzero": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p]),
     "dcn_sample_pixels": (c_int, [c_void_p, c_int64, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "dcn_adam_step": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, ctypes.c_double, ctypes.c_double,
+                              ctypes.c_double, ctypes.c_double, ctypes.c_double, c_int64, c_void_p]),
     "dcn_plan_create_grouped": (c_int, [c_char_p, c_int, c_int, c_int, c_int, c_int, c_int, ctypes.POINTER(c_void_p)]),
     "dcn_plan_set_conv_mode": (c_int, [c_void_p, c_int]),
     "dcn_plan_conv_mode": (c_int, [c_void_p]),

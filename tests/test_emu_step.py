@@ -68,7 +68,8 @@ def test_training_step_matches_oracle(B):
             net.fc.weight.mul_(FC_SCALE)
     o.train(); dcn.train()
     opt_o = torch.optim.Adam(o.parameters(), lr=1e-4, weight_decay=1e-4)
-    opt_m = torch.optim.Adam(dcn.parameters(), lr=1e-4, weight_decay=1e-4)
+    from dcn_hip.optim import Adam
+    opt_m = Adam(dcn.parameters(), lr=1e-4, weight_decay=1e-4)
     pcl = PixelwiseContrastiveLoss(image_shape=dcn.image_shape, config=synth.LOSS_CONFIG)
     for it in range(2):
         loss_o, terms_o, da_o, db_o = ostep.train_step(o, opt_o, img_a, img_b, lists, synth.LOSS_CONFIG)

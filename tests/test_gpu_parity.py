@@ -324,7 +324,8 @@ def test_batched_step_small_images_vs_oracle(L, conv_mode):
     dcn, o = _dcn_and_oracle("Resnet34_8s", D, H, W)
     img_a, img_b, lists = synth.make_batch(B, H, W, 300, 200, 200, seed=4)
     opt_o = torch.optim.Adam(o.parameters(), lr=1e-4, weight_decay=1e-4)
-    opt = torch.optim.Adam(dcn.parameters(), lr=1e-4, weight_decay=1e-4)
+    from dcn_hip.optim import Adam
+    opt = Adam(dcn.parameters(), lr=1e-4, weight_decay=1e-4)
     o.train()
     loss_o, _, da_o, _ = ostep.train_step(o, opt_o, img_a, img_b, lists, synth.LOSS_CONFIG)
     opt.zero_grad()
@@ -638,3 +639,46 @@ def test_match_statistics_vs_reference_golden_and_full_size(L):
         assert abs(int(s["num_pixels_closer_than_ground_truth"][q]) - o["num_pixels_closer_than_ground_truth"]) <= 1
         assert abs(int(s["num_pixels_closer_than_ground_truth_masked"][q]) - o["num_pixels_closer_than_ground_truth_masked"]) <= 1
         assert abs(float(s["norm_diff_descriptor_ground_truth"][q]) - float(o["norm_diff_descriptor_ground_truth"])) < 1e-5
+
+
+# ------------------------------------------------------------------------------------------------ optimizer step (F16)
+def test_adam_step_vs_torch_adam_on_cpu_and_full_model(L):
+    """dcn_adam_step against torch.optim.Adam -- the reference's optimizer (training.py:133-145) -- run on the CPU:
+    (1) mixed shapes / alignments / layouts over 10 steps, (2) every parameter of Resnet34_8s (21.3 M floats) for 3 steps
+    with the engine's channels_last weights; a checksum over all parameters as the size-independent property."""
+    from dcn_hip.optim import Adam
+    g = torch.Generator().manual_seed(0)
+    shapes = [(64,), (7,), (1,), (5, 3), (64, 64, 3, 3), (8200,), (4097,)]
+    base = [torch.randn(*s, generator=g) for s in shapes]
+    base.append(torch.randn(16, 8, 3, 3, generator=g).contiguous(memory_format=torch.channels_last))
+    ref = [torch.nn.Parameter(p.clone(memory_format=torch.preserve_format)) for p in base]
+    ours = [torch.nn.Parameter(p.cuda()) for p in base] + [torch.nn.Parameter(torch.randn(4099, generator=g).cuda()[3:])]
+    ref.append(torch.nn.Parameter(ours[-1].detach().cpu().clone()))
+    assert ours[7].stride() == ref[7].stride() and ours[-1].data_ptr() % 16 != 0
+    o, r = Adam(ours, lr=1e-3, weight_decay=1e-4), torch.optim.Adam(ref, lr=1e-3, weight_decay=1e-4, foreach=False)
+    for it in range(10):
+        for a, b in zip(ours, ref):
+            b.grad = torch.empty_like(b).copy_(torch.randn(b.shape, generator=g) * [1.0, 1e-8, 1e3, 1e-3][it % 4])
+            a.grad = b.grad.cuda()
+        o.step(); r.step()
+    for a, b in zip(ours, ref):
+        assert rel_err(a.detach().cpu(), b.detach()) < 2e-6
+        assert rel_err(o.state[a]["exp_avg_sq"].cpu(), r.state[b]["exp_avg_sq"]) < 2e-6
+
+    from dense_correspondence.network.dense_correspondence_network import DenseCorrespondenceNetwork
+    cfg = {"descriptor_dimension": 3, "image_width": 64, "image_height": 64}
+    torch.manual_seed(0)
+    dcn = DenseCorrespondenceNetwork.from_config(cfg, load_stored_params=False).cuda()
+    cpu = [torch.nn.Parameter(p.detach().cpu().clone(memory_format=torch.preserve_format)) for p in dcn.parameters()]
+    o, r = Adam(dcn.parameters(), lr=1e-4, weight_decay=1e-4), torch.optim.Adam(cpu, lr=1e-4, weight_decay=1e-4)
+    for it in range(3):
+        for a, b in zip(dcn.parameters(), cpu):
+            b.grad = torch.empty_like(b).copy_(torch.randn(b.shape, generator=g) * 1e-2)
+            a.grad = b.grad.cuda()
+            assert a.grad.stride() == a.stride()
+        o.step(); r.step()
+    tot = sum(float(p.detach().double().sum()) for p in dcn.parameters())
+    tot_ref = sum(float(p.detach().double().sum()) for p in cpu)
+    assert abs(tot - tot_ref) <= 1e-6 * abs(tot_ref) + 1e-4
+    worst = max(rel_err(a.detach().cpu(), b.detach()) for a, b in zip(dcn.parameters(), cpu))
+    assert worst < 2e-6, worst
