@@ -122,9 +122,13 @@ transpose_split_batched_kernel(SplitTable t) {
 }
 
 // ----------------------------------------------------------------------------------------------- gather-GEMM, f16x3
-template <int TM, int TN> struct F16Geo {
-    static constexpr int BM = 64 * TM, BN = 64 * TN, PA = BM / 32, PB = BN / 64,
+// WR: wavefront rows of the workgroup (WR x 2 wavefronts, 128 WR work-items): 2 -> tiles of 64 TM x 64 TN, two workgroups
+// per CU; 4 -> 128 TM x 64 TN on 8 wavefronts, ONE workgroup per CU (same 8 wavefronts per CU, but a quarter fewer
+// operand bytes per MFMA through the vector-memory path and the LDS store path).
+template <int TM, int TN, int WR = 2> struct F16Geo {
+    static constexpr int NTH = 128 * WR, BM = 32 * TM * WR, BN = 64 * TN, RA = 16 * WR, RB = 32 * WR, PA = BM / RA, PB = BN / RB,
                          kStageHalves = 2 * (BM + BN) * LDH;   // A hi, A lo, B hi, B lo
+    static_assert(BN % RB == 0, "WR = 4 needs TN = 2");
 };
 
 constexpr int kOob = (int)0x80000000;   // voffset that fails the bounds check of any buffer <= 2 GiB: the load returns 0
@@ -133,17 +137,17 @@ constexpr int kOob = (int)0x80000000;   // voffset that fails the bounds check o
 // gather is `buffer_load_dwordx4 voffset[row] + soffset(channel chunk)` with per-row byte offsets that only change when
 // the tap does; out-of-image taps, rows past M and weight rows past cd get an out-of-range voffset and come back as
 // zeros from the bounds check (no address clamps, no zero-fill selects in the K loop).
-template <int TM, int TN, bool TR, bool UNI>
+template <int TM, int TN, bool TR, bool UNI, int WR = 2>
 __device__ __forceinline__ void gemm_segment_f16(const GemmConv& p, _Float16* lds, int tile, int k0, int k1, int nk,
                                                  float* slot) {
-    using G = F16Geo<TM, TN>;
+    using G = F16Geo<TM, TN, WR>;
     constexpr int BM = G::BM, BN = G::BN, PA = G::PA, PB = G::PB, kStage = G::kStageHalves;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int wm_ = wv >> 1, wn_ = wv & 1;
     const int mt = fdiv(tile, p.div_nt), nt = tile - mt * p.ntiles;
     const int m0 = mt * BM, n0 = nt * BN;
 
-    // A staging: float4 (4 k) at k-quad kq of rows ra0 + 32 j;  B staging: 8 halves at k-octet ko of rows rb0 + 64 j
+    // A staging: float4 (4 k) at k-quad kq of rows ra0 + RA j;  B staging: 8 halves at k-octet ko of rows rb0 + RB j
     // Row order within a store lane-group: the 16 lanes of a ds_write_b64 group (8 of a ds_write_b128 group) cover two
     // rows; rows r and r + 4 are 320 bytes = 16 banks apart, so the two 64-byte runs tile all 32 banks exactly (rows r and
     // r + 1 would overlap on 4 banks: measured as SQ_LDS_BANK_CONFLICT = 50 % extra LDS cycles).
@@ -152,7 +156,7 @@ __device__ __forceinline__ void gemm_segment_f16(const GemmConv& p, _Float16* ld
     int by[PA], bx[PA], pixbase[PA];
 #pragma unroll
     for (int j = 0; j < PA; ++j) {
-        const int m = m0 + ra0 + 32 * j;
+        const int m = m0 + ra0 + G::RA * j;
         const int mm = m < p.M ? m : 0;
         const int img = fdiv(mm, p.div_hw), rem = mm - img * p.div_hw.d;
         const int y = fdiv(rem, p.div_w), x = rem - y * p.div_w.d;
@@ -165,7 +169,7 @@ __device__ __forceinline__ void gemm_segment_f16(const GemmConv& p, _Float16* ld
     unsigned wokm = 0;
 #pragma unroll
     for (int j = 0; j < PB; ++j) {
-        const int n = n0 + rb0 + 64 * j;
+        const int n = n0 + rb0 + G::RB * j;
         const bool ok = n < p.cd;
         wokm |= (ok ? 1u : 0u) << j;
         wrow[j] = (ok ? n : 0) * p.kp + ko * 8;
@@ -302,8 +306,8 @@ __device__ __forceinline__ void gemm_segment_f16(const GemmConv& p, _Float16* ld
             h4 hi, lo;
             if (TR) split4(v, sa, hi, lo);
             else split4_unscaled(v, hi, lo);   // forward: activations are taken as they are
-            *reinterpret_cast<h4*>(ah + (ra0 + 32 * j) * LDH + kq * 4) = hi;
-            *reinterpret_cast<h4*>(al + (ra0 + 32 * j) * LDH + kq * 4) = lo;
+            *reinterpret_cast<h4*>(ah + (ra0 + G::RA * j) * LDH + kq * 4) = hi;
+            *reinterpret_cast<h4*>(al + (ra0 + G::RA * j) * LDH + kq * 4) = lo;
         }
 #pragma unroll
         for (int j = 0; j < PB; ++j) {
@@ -311,8 +315,8 @@ __device__ __forceinline__ void gemm_segment_f16(const GemmConv& p, _Float16* ld
             h8 z;
 #pragma unroll
             for (int e = 0; e < 8; ++e) z[e] = (_Float16)0.f;
-            *reinterpret_cast<h8*>(bh + (rb0 + 64 * j) * LDH + ko * 8) = ok ? rbh[set][j] : z;
-            *reinterpret_cast<h8*>(bl + (rb0 + 64 * j) * LDH + ko * 8) = ok ? rbl[set][j] : z;
+            *reinterpret_cast<h8*>(bh + (rb0 + G::RB * j) * LDH + ko * 8) = ok ? rbh[set][j] : z;
+            *reinterpret_cast<h8*>(bl + (rb0 + G::RB * j) * LDH + ko * 8) = ok ? rbl[set][j] : z;
         }
     };
 
@@ -431,7 +435,7 @@ __device__ __forceinline__ void gemm_segment_f16(const GemmConv& p, _Float16* ld
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[tm][tn][r] *= inv;
     if (k0 == 0 && k1 == nk) {
-        gemm_epilogue<2, TM, TN, 16>(p, acc, mt, nt, reinterpret_cast<float*>(lds));
+        gemm_epilogue<WR, TM, TN, 16, 2>(p, acc, mt, nt, reinterpret_cast<float*>(lds));
     } else {
         float* o = slot + wv * (TM * TN * 16 * 64) + lane;
 #pragma unroll
@@ -443,20 +447,20 @@ __device__ __forceinline__ void gemm_segment_f16(const GemmConv& p, _Float16* ld
     }
 }
 
-template <int TM, int TN, bool TR, bool SK, bool UNI>
-__global__ void __launch_bounds__(NT, 2)
+template <int TM, int TN, bool TR, bool SK, bool UNI, int WR = 2>
+__global__ void __launch_bounds__(128 * WR, WR == 4 ? 1 : 2)
 conv_gemm_f16_kernel(GemmConv p) {
-    using G = F16Geo<TM, TN>;
+    using G = F16Geo<TM, TN, WR>;
     __shared__ __attribute__((aligned(16))) _Float16 lds[2 * G::kStageHalves];
     const int nk = (p.K + HBK - 1) / HBK;
     if (!SK) {
-        gemm_segment_f16<TM, TN, TR, UNI>(p, lds, xcd_remap(blockIdx.x, p.mtiles * p.ntiles), 0, nk, nk, nullptr);
+        gemm_segment_f16<TM, TN, TR, UNI, WR>(p, lds, xcd_remap(blockIdx.x, p.mtiles * p.ntiles), 0, nk, nk, nullptr);
     } else {
         // hybrid schedule: whole rounds of tiles data-parallel (all workgroups of an XCD walk K in step and share their
         // operands through L2), then ONE stream-K pass that splits the K stages of the leftover tiles evenly
         const int g = xcd_remap(blockIdx.x, gridDim.x);
         for (int tile = g; tile < p.sk_dp; tile += gridDim.x) {
-            gemm_segment_f16<TM, TN, TR, UNI>(p, lds, tile, 0, nk, nk, nullptr);
+            gemm_segment_f16<TM, TN, TR, UNI, WR>(p, lds, tile, 0, nk, nk, nullptr);
             __syncthreads();
         }
         int u = p.sk_dp * nk + g * p.sk_units;
@@ -466,7 +470,7 @@ conv_gemm_f16_kernel(GemmConv p) {
         while (u < u_end) {
             const int tile = fdiv(u, p.div_nk), k0 = u - tile * nk;
             const int k1 = min(nk, k0 + (u_end - u));
-            gemm_segment_f16<TM, TN, TR, UNI>(p, lds, tile, k0, k1, nk,
+            gemm_segment_f16<TM, TN, TR, UNI, WR>(p, lds, tile, k0, k1, nk,
                                          p.sk_partial + (int64_t)(2 * g + (first ? 0 : 1)) * (G::BM * G::BN));
             u += k1 - k0;
             first = false;
@@ -476,11 +480,11 @@ conv_gemm_f16_kernel(GemmConv p) {
 }
 
 // completes stream-K tiles (same slot layout / arithmetic as conv_gemm_fixup_kernel of the fp32 path, 32-K stages)
-template <int TM, int TN>
-__global__ void __launch_bounds__(NT)
+template <int TM, int TN, int WR = 2>
+__global__ void __launch_bounds__(128 * WR)
 conv_gemm_f16_fixup_kernel(GemmConv p) {
-    using G = F16Geo<TM, TN>;
-    __shared__ float red[4 * G::BN];
+    using G = F16Geo<TM, TN, WR>;
+    __shared__ float red[2 * WR * G::BN];
     const int nk = (p.K + HBK - 1) / HBK;
     const int tile = p.sk_dp + blockIdx.x;               // only the leftover tiles were stream-K'd
     const int ua = blockIdx.x * nk, ub = ua + nk - 1;    // unit range relative to the start of the stream-K pass
@@ -506,11 +510,11 @@ conv_gemm_f16_fixup_kernel(GemmConv p) {
                 for (int r = 0; r < 16; ++r) acc[tm][tn][r] += o[((tm * TN + tn) * 16 + r) * 64];
     }
     const int mt = tile / p.ntiles, nt = tile - mt * p.ntiles;
-    gemm_epilogue<2, TM, TN, 16>(p, acc, mt, nt, red);
+    gemm_epilogue<WR, TM, TN, 16, 2>(p, acc, mt, nt, red);
 }
 
 struct F16Shape {
-    int tm, tn, mtiles, ntiles, nk, sk_wgs, sk_units, sk_dp;
+    int tm, tn, wr, mtiles, ntiles, nk, sk_wgs, sk_units, sk_dp;   // tile = (32 tm wr) x (64 tn), 128 wr work-items
     bool sk;
     size_t ws_bytes;
 };
@@ -520,22 +524,29 @@ F16Shape f16_shape(int M, int cd, int K, int align = 0) {
     g.tn = cd <= 64 ? 1 : 2;
     const int ntiles128 = dcn::ceil_div(cd, 64 * g.tn);
     g.tm = dcn::ceil_div(M, 128) * ntiles128 < 2 * 256 ? 1 : 2;
+    // 256 x 128 on 8 wavefronts wherever the channel count fills a 128-wide tile: measured +4-5 % on every such layer of
+    // configs 1-3 against the best 64 / 128-row choice (a quarter fewer operand bytes per MFMA at the same 8 wavefronts per CU)
+    g.wr = 2;
+    if (g.tn == 2 && M >= 4096) { g.tm = 2; g.wr = 4; }
     if (const char* e = getenv("DCN_GEMM_TILE_M")) {
         const int v = atoi(e);
-        if (v == 64) g.tm = 1;
-        if (v == 128) g.tm = 2;
+        if (v == 64) { g.tm = 1; g.wr = 2; }
+        if (v == 128) { g.tm = 2; g.wr = 2; }
+        if (v == 256 && g.tn == 2) { g.tm = 2; g.wr = 4; }
     }
-    if (align > 0 && (align % (64 * g.tm)) != 0) g.tm = 1;
-    g.mtiles = dcn::ceil_div(M, 64 * g.tm);
+    if (align > 0 && (align % (32 * g.tm * g.wr)) != 0) { g.wr = 2; if ((align % (64 * g.tm)) != 0) g.tm = 1; }
+    const int bm = 32 * g.tm * g.wr;
+    g.mtiles = dcn::ceil_div(M, bm);
     g.ntiles = dcn::ceil_div(cd, 64 * g.tn);
     g.nk = dcn::ceil_div(K, HBK);
     const int tiles = g.mtiles * g.ntiles;
+    const int resident = g.wr == 4 ? 256 : 512;   // workgroups the chip holds at once
     const double rounds = tiles / 256.0;
     const double waste = 1.0 - rounds / (double)(int)(rounds + 0.999999);
     int sk_min_nk = 32;   // measured: below ~32 K stages the fix-up pass costs more than the tail it removes
     if (const char* e = getenv("DCN_GEMM_SK_MIN_NK")) sk_min_nk = atoi(e);
     g.sk = tiles < 8 * 256 && waste > 0.08 && g.nk >= sk_min_nk;
-    int wgs = 512;
+    int wgs = resident;
     if (const char* e = getenv("DCN_GEMM_SK")) {
         const int v = atoi(e);
         if (v == 0) g.sk = false;
@@ -550,7 +561,7 @@ F16Shape f16_shape(int M, int cd, int K, int align = 0) {
         if (g.sk_dp == 0 && wgs > total / 2) wgs = (int)(total / 2) > 0 ? (int)(total / 2) : 1;
         g.sk_units = (int)((total + wgs - 1) / wgs);
         g.sk_wgs = g.sk_dp > 0 ? wgs : (int)((total + g.sk_units - 1) / g.sk_units);
-        g.ws_bytes = (size_t)2 * g.sk_wgs * (64 * g.tm) * (64 * g.tn) * sizeof(float);
+        g.ws_bytes = (size_t)2 * g.sk_wgs * bm * (64 * g.tn) * sizeof(float);
     }
     return g;
 }
@@ -580,25 +591,26 @@ int launch_gemm_f16(GemmConv& p, void* workspace, hipStream_t st, int align = 0)
     if (const char* e = getenv("DCN_GEMM_UNI")) uni = uni && atoi(e) != 0;
     p.src_bytes = uni ? (unsigned)src_bytes : 0u;
     p.w_bytes = uni ? (unsigned)w_bytes : 0u;
-    const dim3 grid(sk ? g.sk_wgs : g.mtiles * g.ntiles), fgrid(g.mtiles * g.ntiles - g.sk_dp), block(NT);
-#define DCN_GEMM16_K(TM, TN, TR, SK)                                                                        \
-    do {                                                                                                    \
-        if (uni) hipLaunchKernelGGL((conv_gemm_f16_kernel<TM, TN, TR, SK, true>), grid, block, 0, st, p);   \
-        else hipLaunchKernelGGL((conv_gemm_f16_kernel<TM, TN, TR, SK, false>), grid, block, 0, st, p);      \
+    const dim3 grid(sk ? g.sk_wgs : g.mtiles * g.ntiles), fgrid(g.mtiles * g.ntiles - g.sk_dp), block(128 * g.wr);
+#define DCN_GEMM16_K(TM, TN, WR, TR, SK)                                                                        \
+    do {                                                                                                        \
+        if (uni) hipLaunchKernelGGL((conv_gemm_f16_kernel<TM, TN, TR, SK, true, WR>), grid, block, 0, st, p);   \
+        else hipLaunchKernelGGL((conv_gemm_f16_kernel<TM, TN, TR, SK, false, WR>), grid, block, 0, st, p);      \
     } while (0)
-#define DCN_GEMM16(TM, TN)                                                                     \
-    do {                                                                                       \
-        if (sk) {                                                                              \
-            if (p.transposed) DCN_GEMM16_K(TM, TN, true, true);                                \
-            else DCN_GEMM16_K(TM, TN, false, true);                                            \
-            hipLaunchKernelGGL((conv_gemm_f16_fixup_kernel<TM, TN>), fgrid, block, 0, st, p);  \
-        } else {                                                                               \
-            if (p.transposed) DCN_GEMM16_K(TM, TN, true, false);                               \
-            else DCN_GEMM16_K(TM, TN, false, false);                                           \
-        }                                                                                      \
+#define DCN_GEMM16(TM, TN, WR)                                                                     \
+    do {                                                                                           \
+        if (sk) {                                                                                  \
+            if (p.transposed) DCN_GEMM16_K(TM, TN, WR, true, true);                                \
+            else DCN_GEMM16_K(TM, TN, WR, false, true);                                            \
+            hipLaunchKernelGGL((conv_gemm_f16_fixup_kernel<TM, TN, WR>), fgrid, block, 0, st, p);  \
+        } else {                                                                                   \
+            if (p.transposed) DCN_GEMM16_K(TM, TN, WR, true, false);                               \
+            else DCN_GEMM16_K(TM, TN, WR, false, false);                                           \
+        }                                                                                          \
     } while (0)
-    if (g.tm == 1) { if (g.tn == 1) DCN_GEMM16(1, 1); else DCN_GEMM16(1, 2); }
-    else { if (g.tn == 1) DCN_GEMM16(2, 1); else DCN_GEMM16(2, 2); }
+    if (g.wr == 4) DCN_GEMM16(2, 2, 4);
+    else if (g.tm == 1) { if (g.tn == 1) DCN_GEMM16(1, 1, 2); else DCN_GEMM16(1, 2, 2); }
+    else { if (g.tn == 1) DCN_GEMM16(2, 1, 2); else DCN_GEMM16(2, 2, 2); }
 #undef DCN_GEMM16_K
 #undef DCN_GEMM16
     return dcn::check_launch();

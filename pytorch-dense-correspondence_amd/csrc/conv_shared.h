@@ -64,12 +64,13 @@ template <int WM, int TM, int TN, int BK> struct GemmGeo {
 };
 
 // Epilogue: C/D fragments -> NHWC rows (32 consecutive channels per half-wave = 128 B segments), + bias, + residual
-// gradient, + per-M-tile batch-norm partial sums (fixed order).  `red` = at least 4*BN floats of LDS, free to use.
-template <int WM, int TM, int TN, int BK>
+// gradient, + per-M-tile batch-norm partial sums (fixed order).  `red` = at least 2*WM*BN floats of LDS, free to use.
+// WN: wavefronts along N (WM * WN wavefronts per workgroup; 4 for every kernel but the 8-wavefront f16x3 tile).
+template <int WM, int TM, int TN, int BK, int WN = 4 / WM>
 __device__ __forceinline__ void gemm_epilogue(const GemmConv& p, f32x16 (&acc)[TM][TN], int mt, int nt, float* red) {
-    using G = GemmGeo<WM, TM, TN, BK>;
+    struct G { enum { BM = 32 * TM * WM, BN = 32 * TN * WN }; };
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const int wm_ = WM == 2 ? (wv >> 1) : 0, wn_ = WM == 2 ? (wv & 1) : wv;
+    const int wm_ = wv / WN, wn_ = wv % WN;
     const int fi = lane & 31, fh = lane >> 5;
     const int m0 = mt * G::BM, n0 = nt * G::BN;
     float csum[TN], csq[TN];
@@ -109,8 +110,12 @@ __device__ __forceinline__ void gemm_epilogue(const GemmConv& p, f32x16 (&acc)[T
         }
         __syncthreads();
         if (tid < G::BN && n0 + tid < p.cd) {
-            const float s = red[(0 * 2 + 0) * G::BN + tid] + (WM == 2 ? red[(1 * 2 + 0) * G::BN + tid] : 0.f);
-            const float q = red[(0 * 2 + 1) * G::BN + tid] + (WM == 2 ? red[(1 * 2 + 1) * G::BN + tid] : 0.f);
+            float s = red[(0 * 2 + 0) * G::BN + tid], q = red[(0 * 2 + 1) * G::BN + tid];
+#pragma unroll
+            for (int w = 1; w < WM; ++w) {   // fixed order
+                s += red[(w * 2 + 0) * G::BN + tid];
+                q += red[(w * 2 + 1) * G::BN + tid];
+            }
             p.bn_partial[((int64_t)mt * 2 + 0) * p.cd + n0 + tid] = s;
             p.bn_partial[((int64_t)mt * 2 + 1) * p.cd + n0 + tid] = q;
         }

@@ -180,7 +180,8 @@ F16_CASES = [
 ]
 
 
-@pytest.mark.parametrize("tile_m,sk", [("64", "0"), ("128", "0"), ("64", "3"), ("128", "2")])
+# tile_m 256 = the 8-wavefront 256 x 128 tile (only taken when the destination has more than 64 channels)
+@pytest.mark.parametrize("tile_m,sk", [("64", "0"), ("128", "0"), ("64", "3"), ("128", "2"), ("256", "0"), ("256", "3")])
 @pytest.mark.parametrize("case", F16_CASES, ids=[str(c) for c in F16_CASES])
 def test_conv_f16x3_forward_dgrad(L, case, tile_m, sk, monkeypatch):
     """Split-fp16 gather-GEMM (fp16 MFMA, hi/lo operands): must reproduce the fp32 convolution to ~1e-6."""
