@@ -437,13 +437,16 @@ __device__ __forceinline__ void gemm_segment_f16(const GemmConv& p, _Float16* ld
     if (k0 == 0 && k1 == nk) {
         gemm_epilogue<WR, TM, TN, 16, 2>(p, acc, mt, nt, reinterpret_cast<float*>(lds));
     } else {
-        float* o = slot + wv * (TM * TN * 16 * 64) + lane;
+        // slot layout [wavefront][tm][tn][r / 4][lane][r % 4]: one 16-byte store per lane, 1 KB per wave-instruction
+        float4* o = reinterpret_cast<float4*>(slot + wv * (TM * TN * 16 * 64)) + lane;
 #pragma unroll
         for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
             for (int tn = 0; tn < TN; ++tn)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) o[((tm * TN + tn) * 16 + r) * 64] = acc[tm][tn][r];
+                for (int q = 0; q < 4; ++q)
+                    o[((tm * TN + tn) * 4 + q) * 64] = make_float4(acc[tm][tn][4 * q], acc[tm][tn][4 * q + 1],
+                                                                   acc[tm][tn][4 * q + 2], acc[tm][tn][4 * q + 3]);
     }
 }
 
@@ -479,18 +482,21 @@ conv_gemm_f16_kernel(GemmConv p) {
     }
 }
 
-// completes stream-K tiles (same slot layout / arithmetic as conv_gemm_fixup_kernel of the fp32 path, 32-K stages)
+// completes stream-K tiles (32-K stages).  TWO workgroups per tile, one per wavefront column (the WR wavefronts that own
+// one half of the tile's columns): batch-norm partial sums are per column, so the halves are independent, and the pass
+// -- a few dozen leftover tiles -- spreads over twice as many CUs.
 template <int TM, int TN, int WR = 2>
-__global__ void __launch_bounds__(128 * WR)
+__global__ void __launch_bounds__(64 * WR)
 conv_gemm_f16_fixup_kernel(GemmConv p) {
     using G = F16Geo<TM, TN, WR>;
-    __shared__ float red[2 * WR * G::BN];
+    __shared__ float red[WR * G::BN];                    // 2 WR x (BN / 2)
     const int nk = (p.K + HBK - 1) / HBK;
-    const int tile = p.sk_dp + blockIdx.x;               // only the leftover tiles were stream-K'd
-    const int ua = blockIdx.x * nk, ub = ua + nk - 1;    // unit range relative to the start of the stream-K pass
+    const int rel = blockIdx.x >> 1, half = blockIdx.x & 1;
+    const int tile = p.sk_dp + rel;                      // only the leftover tiles were stream-K'd
+    const int ua = rel * nk, ub = ua + nk - 1;           // unit range relative to the start of the stream-K pass
     const int ga = ua / p.sk_units, gb = ub / p.sk_units;
     if (ga == gb) return;
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wv = 2 * (threadIdx.x >> 6) + half;   // wavefront index inside the GEMM workgroup
     f32x16 acc[TM][TN];
 #pragma unroll
     for (int i = 0; i < TM; ++i)
@@ -500,17 +506,22 @@ conv_gemm_f16_fixup_kernel(GemmConv p) {
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
     for (int g = ga; g <= gb; ++g) {
         const int first_tile = (g * p.sk_units) / nk;
-        const float* o = p.sk_partial + (int64_t)(2 * g + (first_tile == (int)blockIdx.x ? 0 : 1)) * (G::BM * G::BN) +
-                         wv * (TM * TN * 16 * 64) + lane;
+        const float4* o = reinterpret_cast<const float4*>(
+                              p.sk_partial + (int64_t)(2 * g + (first_tile == rel ? 0 : 1)) * (G::BM * G::BN) +
+                              wv * (TM * TN * 16 * 64)) + lane;
 #pragma unroll
         for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
             for (int tn = 0; tn < TN; ++tn)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) acc[tm][tn][r] += o[((tm * TN + tn) * 16 + r) * 64];
+                for (int q = 0; q < 4; ++q) {
+                    const float4 v = o[((tm * TN + tn) * 4 + q) * 64];
+                    acc[tm][tn][4 * q] += v.x; acc[tm][tn][4 * q + 1] += v.y;
+                    acc[tm][tn][4 * q + 2] += v.z; acc[tm][tn][4 * q + 3] += v.w;
+                }
     }
     const int mt = tile / p.ntiles, nt = tile - mt * p.ntiles;
-    gemm_epilogue<WR, TM, TN, 16, 2>(p, acc, mt, nt, red);
+    gemm_epilogue<WR, TM, TN, 16, 1>(p, acc, mt, 2 * nt + half, red);   // a (32 TM WR) x (32 TN) "tile" of one wavefront column
 }
 
 struct F16Shape {
@@ -591,7 +602,7 @@ int launch_gemm_f16(GemmConv& p, void* workspace, hipStream_t st, int align = 0)
     if (const char* e = getenv("DCN_GEMM_UNI")) uni = uni && atoi(e) != 0;
     p.src_bytes = uni ? (unsigned)src_bytes : 0u;
     p.w_bytes = uni ? (unsigned)w_bytes : 0u;
-    const dim3 grid(sk ? g.sk_wgs : g.mtiles * g.ntiles), fgrid(g.mtiles * g.ntiles - g.sk_dp), block(128 * g.wr);
+    const dim3 grid(sk ? g.sk_wgs : g.mtiles * g.ntiles), fgrid(2 * (g.mtiles * g.ntiles - g.sk_dp)), block(128 * g.wr), fblock(64 * g.wr);
 #define DCN_GEMM16_K(TM, TN, WR, TR, SK)                                                                        \
     do {                                                                                                        \
         if (uni) hipLaunchKernelGGL((conv_gemm_f16_kernel<TM, TN, TR, SK, true, WR>), grid, block, 0, st, p);   \
@@ -602,7 +613,7 @@ int launch_gemm_f16(GemmConv& p, void* workspace, hipStream_t st, int align = 0)
         if (sk) {                                                                                  \
             if (p.transposed) DCN_GEMM16_K(TM, TN, WR, true, true);                                \
             else DCN_GEMM16_K(TM, TN, WR, false, true);                                            \
-            hipLaunchKernelGGL((conv_gemm_f16_fixup_kernel<TM, TN, WR>), fgrid, block, 0, st, p);  \
+            hipLaunchKernelGGL((conv_gemm_f16_fixup_kernel<TM, TN, WR>), fgrid, fblock, 0, st, p);  \
         } else {                                                                                   \
             if (p.transposed) DCN_GEMM16_K(TM, TN, WR, true, false);                               \
             else DCN_GEMM16_K(TM, TN, WR, false, false);                                           \
