@@ -390,11 +390,11 @@ def main():
             # MI355X_MICROARCH.md's HBM section), attached only when workload / arithmetic / call pattern match
             traffic, traffic_note = None, None
             try:
-                rec = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r1f_hbm_counters.json")))
+                rec = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r1g_hbm_counters.json")))
                 if (rec["workload"] == args.workload and rec["conv_mode"] == args.conv_mode and not args.batch and
                         (rec["forward_calls"] == "pair") == (not args.separate_forwards)):
                     traffic = rec["hbm_bytes_per_launch"]
-                    traffic_note = "profiles/r1f_hbm_counters.json: " + rec["correction"]
+                    traffic_note = "profiles/r1g_hbm_counters.json: " + rec["correction"]
             except (OSError, KeyError, ValueError):
                 pass
             roofline = {"bound": "mfma", "kernel": kern,
