@@ -907,12 +907,12 @@ int wgrad_splits_f16(const dcn_conv_desc* c, int* rows_per_split) {
     const int tiles = dcn::ceil_div(c->cout, narrow ? 64 : 128) * dcn::ceil_div(K, 128);
     const int slots = 512;
     const int max_by_rows = (M / (8 * HBK)) > 1 ? (M / (8 * HBK)) : 1;
-    int cap = narrow ? 256 : 64;
+    int cap = narrow ? 256 : (tiles < 16 ? 128 : 64);   // (slab traffic grows with the split count; few-tile layers need more splits to fill the chip)
     if (cap > max_by_rows) cap = max_by_rows;
     const int target = dcn::ceil_div(3 * slots, tiles);
     int lo = target / 2 > 1 ? target / 2 : 1, hi = target + target / 2;
     if (hi > cap) hi = cap;
-    if (lo > hi) lo = hi;
+    if (lo > hi / 2) lo = hi / 2 > 1 ? hi / 2 : 1;   // capped: still search below the cap (e.g. 9 tiles x 64 splits = 1.125 rounds, x 55 = one)
     int best = hi;
     double best_score = -1.0;
     for (int s = lo; s <= hi; ++s) {
