@@ -899,8 +899,8 @@ conv_wgrad_f16_kernel(WgradF16 p) {
 }
 
 // Pixel-range splits: enough workgroups to fill the chip (2 resident per CU), chosen so that the LAST round of
-// workgroups is nearly full -- e.g. 144 tiles x 11 splits = 1584 workgroups = 3.09 rounds of 512 wastes a quarter of the
-// machine, 144 x 10 = 2.81 rounds does not.  Fewer splits win ties (less slab traffic for the reduce pass).
+// workgroups is nearly full -- e.g. 144 tiles x 4 splits = 576 workgroups = 1.125 rounds of 512 wastes almost half of the
+// machine, 144 x 7 = 1.97 rounds does not.  Fewer splits win ties (less slab traffic for the reduce pass).
 int wgrad_splits_f16(const dcn_conv_desc* c, int* rows_per_split) {
     const int M = c->n * c->hout * c->wout, K = c->kh * c->kw * c->cin;
     const bool narrow = c->cout <= 64;
@@ -909,8 +909,11 @@ int wgrad_splits_f16(const dcn_conv_desc* c, int* rows_per_split) {
     const int max_by_rows = (M / (8 * HBK)) > 1 ? (M / (8 * HBK)) : 1;
     int cap = narrow ? 256 : (tiles < 16 ? 128 : 64);   // (slab traffic grows with the split count; few-tile layers need more splits to fill the chip)
     if (cap > max_by_rows) cap = max_by_rows;
-    const int target = dcn::ceil_div(3 * slots, tiles);
-    int lo = target / 2 > 1 ? target / 2 : 1, hi = target + target / 2;
+    // search from half a round to three rounds of workgroups; the score prefers FULL rounds and, among those, few splits:
+    // measured (N = 8): one full round beats two -- layer 1: 100 splits 107 us vs 200 splits 120 us, layer 3: 14 splits
+    // 223 us vs 28 splits 243 us -- every workgroup pays its prologue and its 64 KB slab once
+    const int target = dcn::ceil_div(slots, tiles);
+    int lo = target / 2 > 1 ? target / 2 : 1, hi = 3 * target;
     if (hi > cap) hi = cap;
     if (lo > hi / 2) lo = hi / 2 > 1 ? hi / 2 : 1;   // capped: still search below the cap (e.g. 9 tiles x 64 splits = 1.125 rounds, x 55 = one)
     int best = hi;
@@ -923,6 +926,7 @@ int wgrad_splits_f16(const dcn_conv_desc* c, int* rows_per_split) {
         const double score = eff - 0.004 * real - (wgs < slots ? 0.5 * (1.0 - (double)wgs / slots) : 0.0);
         if (score > best_score) { best_score = score; best = s; }
     }
+    if (const char* e = getenv("DCN_WGRAD_SPLITS")) { const int v = atoi(e); if (v >= 1 && v <= max_by_rows) best = v; }
     int rps = dcn::ceil_div(dcn::ceil_div(M, best), HBK) * HBK;
     *rows_per_split = rps;
     return dcn::ceil_div(M, rps);
