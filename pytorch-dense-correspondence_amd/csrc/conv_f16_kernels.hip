@@ -554,9 +554,14 @@ F16Shape f16_shape(int M, int cd, int K, int align = 0) {
     const int resident = g.wr == 4 ? 256 : 512;   // workgroups the chip holds at once
     const double rounds = tiles / 256.0;
     const double waste = 1.0 - rounds / (double)(int)(rounds + 0.999999);
-    int sk_min_nk = 32;   // measured: below ~32 K stages the fix-up pass costs more than the tail it removes
-    if (const char* e = getenv("DCN_GEMM_SK_MIN_NK")) sk_min_nk = atoi(e);
-    g.sk = tiles < 8 * 256 && waste > 0.08 && g.nk >= sk_min_nk;
+    // Stream-K removes the idle part of the last round -- (ceil(rounds) - rounds) * nk stage times -- and costs the
+    // partial-tile writes plus the fix-up pass (25-30 us ~ 20 stage times).  Measured at N = 8: 128-channel layer (150
+    // tiles of 36 stages, 15 stage times to gain) 50 us data-parallel vs 62 us stream-K; 256-channel layer (300 tiles of 72
+    // stages, 60 to gain) 189 vs 156 us.
+    double sk_min_gain = 20.0;
+    if (const char* e = getenv("DCN_GEMM_SK_MIN_GAIN")) sk_min_gain = atof(e);
+    const double gain = ((double)(int)(rounds + 0.999999) - rounds) * g.nk;
+    g.sk = tiles < 8 * 256 && waste > 0.08 && g.nk >= 8 && gain >= sk_min_gain;
     int wgs = resident;
     if (const char* e = getenv("DCN_GEMM_SK")) {
         const int v = atoi(e);
