@@ -1,8 +1,9 @@
 #!/usr/bin/env python3
 """Per-shape micro-benchmark of the matrix-core kernels through the C ABI (GPU only): every distinct convolution
 of Resnet34_8s at a given batch, forward / dgrad / wgrad, timed with events on the launch stream.
-    python tools/conv_bench.py [--n 4] [--reps 10]
-Prints TFLOP/s (algorithmic) and the fraction of the fp32-MFMA peak (157.3 TF)."""
+    python tools/conv_bench.py [--n 4] [--reps 10] [--mode f16 [--check] [--x-direct] [--no-split]] [--only NAME] [--kinds fwd,dgrad,wgrad]
+Prints TFLOP/s (algorithmic; the totals also as a fraction of the fp32-MFMA peak, 157.3 TF -- the f16x3 kernels exceed it).
+Use one process for a whole sweep: a fresh process measures the first layers at clocks that have not ramped up yet."""
 import argparse
 import ctypes
 import json
