@@ -78,7 +78,7 @@ struct dcn_plan {
     size_t s_in4 = 0, s_stem_y = 0, s_pool = 0, s_argmax = 0, s_low = 0, saved_floats = 0;
     // workspace offsets (floats)
     size_t w_buf[6] = {0, 0, 0, 0, 0, 0}, w_wt = 0, w_slab = 0, w_part = 0, w_k123 = 0, w_wstem = 0, w_dwstem = 0,
-           w_glow = 0, w_ups = 0, w_sk = 0, w_gnorm = 0, w_wh = 0, w_wl = 0, w_amax = 0, w_dq = 0, ws_floats = 0;
+           w_glow = 0, w_ups = 0, w_sk = 0, w_gnorm = 0, w_wh = 0, w_wl = 0, w_amax = 0, w_dq = 0, w_dq2 = 0, ws_floats = 0;
     int conv_mode = DCN_CONV_F16X3;
     size_t max_act = 0;
     double flops = 0;
@@ -88,6 +88,11 @@ struct dcn_plan {
     std::vector<int> prof_cat;
     std::vector<double> prof_flops;
     size_t prof_used = 0;
+    // backward pass, split-fp16 mode: the weight-gradient GEMMs run on a second, low-priority stream next to the
+    // dgrad -> BN-backward chain of the following layer (created on first use; DCN_BACKWARD_OVERLAP=0 disables)
+    hipStream_t side = nullptr;
+    hipEvent_t ev_dq[2] = {nullptr, nullptr}, ev_wg[2] = {nullptr, nullptr}, ev_join = nullptr;
+    int side_state = 0;   // 0: not tried, 1: ready, -1: unavailable
 };
 
 namespace {
@@ -321,6 +326,7 @@ int build_plan(dcn_plan& p) {
         for (const ConvL& c : p.convs)
             max_dq = std::max(max_dq, dcn_grad_blocked_bytes(c.d.n * c.d.hout * c.d.wout, c.d.ldc) / sizeof(float));
         p.w_dq = alloc(max_dq);
+        p.w_dq2 = alloc(max_dq);   // second image: wgrad of layer k reads one while BN backward of layer k - 1 writes the other
     }
     p.ws_floats = ws;
     return DCN_OK;
@@ -463,6 +469,9 @@ extern "C" int dcn_plan_create_grouped(const char* arch, int base_width, int n, 
 extern "C" void dcn_plan_destroy(dcn_plan* plan) {
     if (!plan) return;
     for (hipEvent_t e : plan->prof_ev) hipEventDestroy(e);
+    for (hipEvent_t e : {plan->ev_dq[0], plan->ev_dq[1], plan->ev_wg[0], plan->ev_wg[1], plan->ev_join})
+        if (e) hipEventDestroy(e);
+    if (plan->side) hipStreamDestroy(plan->side);
     delete plan;
 }
 extern "C" int dcn_plan_set_conv_mode(dcn_plan* plan, int mode) {
@@ -626,25 +635,60 @@ extern "C" int dcn_backbone_backward(dcn_plan* plan, const float* grad_descripto
     float* amax = R.Wk(p.w_amax);
     const bool f16 = p.conv_mode == DCN_CONV_F16X3;
 
-    const float* dq_of = nullptr;       // gradient tensor whose pixel-blocked split copy is in w_dq
+    // Overlap (split-fp16 mode, not while launches are being timed one by one): wgrad of layer k only feeds the optimizer,
+    // so it runs on the plan's side stream while the main stream goes on with dgrad(k) -> BN backward(k - 1) -> ...; the
+    // gradient's pixel-blocked image alternates between two buffers and events order writer and reader of each.
+    bool overlap = f16 && !p.prof_on;
+    if (overlap && p.side_state == 0) {
+        const char* e = getenv("DCN_BACKWARD_OVERLAP");
+        bool ok = !(e && atoi(e) == 0);
+        int lo_prio = 0, hi_prio = 0;
+        if (ok && hipDeviceGetStreamPriorityRange(&lo_prio, &hi_prio) != hipSuccess) lo_prio = 0;
+        ok = ok && hipStreamCreateWithPriority(&p.side, hipStreamNonBlocking, lo_prio) == hipSuccess;
+        for (hipEvent_t* ev : {&p.ev_dq[0], &p.ev_dq[1], &p.ev_wg[0], &p.ev_wg[1], &p.ev_join})
+            ok = ok && hipEventCreateWithFlags(ev, hipEventDisableTiming) == hipSuccess;
+        p.side_state = ok ? 1 : -1;
+    }
+    overlap = overlap && p.side_state == 1;
+    if (overlap) {   // inside a hipGraph capture the fork / join pattern replays slower than the serial chain (measured): stay serial
+        hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+        if (hipStreamIsCapturing(st, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) overlap = false;
+    }
+    int n_bn = 0, cur = 0;              // BN-backward launches so far; buffer holding the newest split gradient
+    bool wg_pending[2] = {false, false};
+    float* const dqbuf[2] = {R.Wk(p.w_dq), R.Wk(p.w_dq2)};
+    const float* dq_of = nullptr;       // gradient tensor whose pixel-blocked split copy is in dqbuf[cur]
     // BN backward of conv c's batch norm: dy (+ optional relu mask from relu_out) -> dx; g_out optional
     auto bn_bwd = [&](const ConvL& c, const float* dy, const float* relu_out, float* dx, float* g_out) {
         const BnL& b = p.bns[c.bn];
         const float* s = R.S(b.stats);
         // (the mask bytes the forward wrote next to that activation; relu_out itself is then not read)
         const unsigned char* mask = relu_out ? R.M((size_t)(relu_out - R.saved)) : nullptr;
+        cur = overlap ? (n_bn & 1) : 0;
+        if (overlap && wg_pending[cur]) hipStreamWaitEvent(st, p.ev_wg[cur], 0);   // the wgrad that read this buffer two layers ago
         dcn::launch_bn_bwd(dy, relu_out, mask, R.S(c.x), s, R.P(b.g), b.C, b.rows, p.groups, part, grads[b.g],
-                           grads[b.b], k123, dx, g_out, f16 ? amax + c.idx : nullptr, f16 ? (void*)R.Wk(p.w_dq) : nullptr, st);
-        dq_of = f16 ? dx : nullptr;   // the pixel-blocked split copy of this dx now sits in w_dq
+                           grads[b.b], k123, dx, g_out, f16 ? amax + c.idx : nullptr, f16 ? (void*)dqbuf[cur] : nullptr, st);
+        if (overlap) hipEventRecord(p.ev_dq[cur], st);
+        ++n_bn;
+        dq_of = f16 ? dx : nullptr;   // the pixel-blocked split copy of this dx now sits in dqbuf[cur]
     };
     auto wgrad = [&](const ConvL& c, const float* in, const float* dx, float* dw) -> int {
         if (!f16) return R.timed(1, c.flops, [&] { return dcn_conv_wgrad(&c.d, in, dx, dw, slab, st); });
         // The activation operand is the fp32 tensor itself, split on the fly inside the kernel: measured faster than a
         // split pass + pre-split operand on every layer of ResNet34 / ResNet50 (the pass costs more than the conversions).
-        if (dq_of != dx)   // (BN backward emits it directly; only the scoring layer's gradient needs the separate pass)
-            DCN_TRY(dcn_split_grad_blocked_f16(dx, c.d.n * c.d.hout * c.d.wout, c.d.ldc, amax + c.idx, R.Wk(p.w_dq), st));
+        if (dq_of != dx) {   // (BN backward emits it directly; only the scoring layer's gradient needs the separate pass)
+            DCN_TRY(dcn_split_grad_blocked_f16(dx, c.d.n * c.d.hout * c.d.wout, c.d.ldc, amax + c.idx, dqbuf[0], st));
+            return R.timed(1, c.flops, [&] { return dcn_conv_wgrad_f16(&c.d, in, 1, dqbuf[0], amax + c.idx, dw, slab, st); });
+        }
+        if (overlap) {
+            hipStreamWaitEvent(p.side, p.ev_dq[cur], 0);
+            DCN_TRY(dcn_conv_wgrad_f16(&c.d, in, 1, dqbuf[cur], amax + c.idx, dw, slab, p.side));
+            hipEventRecord(p.ev_wg[cur], p.side);
+            wg_pending[cur] = true;
+            return DCN_OK;
+        }
         return R.timed(1, c.flops, [&] {
-            return dcn_conv_wgrad_f16(&c.d, in, 1, R.Wk(p.w_dq), amax + c.idx, dw, slab, st);
+            return dcn_conv_wgrad_f16(&c.d, in, 1, dqbuf[cur], amax + c.idx, dw, slab, st);
         });
     };
     auto dgrad = [&](const ConvL& c, const float* dx, const float* add, float* din) -> int {
@@ -720,6 +764,10 @@ extern "C" int dcn_backbone_backward(dcn_plan* plan, const float* grad_descripto
                             st);
     bn_bwd(stem, dnext, R.S(p.s_stem_y), dxa, nullptr);
     DCN_TRY(wgrad(stem, R.S(p.s_in4), dxa, R.Wk(p.w_dwstem)));
+    if (overlap) {   // join: everything the side stream produced is ordered before whatever follows on the caller's stream
+        hipEventRecord(p.ev_join, p.side);
+        hipStreamWaitEvent(st, p.ev_join, 0);
+    }
     dcn::launch_unpad_c4_to_c3(R.Wk(p.w_dwstem), grads[stem.w], (int64_t)p.base * 49, st);
     return dcn::check_launch();
 }
