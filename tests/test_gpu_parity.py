@@ -682,3 +682,44 @@ def test_adam_step_vs_torch_adam_on_cpu_and_full_model(L):
     assert abs(tot - tot_ref) <= 1e-6 * abs(tot_ref) + 1e-4
     worst = max(rel_err(a.detach().cpu(), b.detach()) for a, b in zip(dcn.parameters(), cpu))
     assert worst < 2e-6, worst
+
+
+def test_backward_side_stream_equals_serial_schedule_bitwise(L, monkeypatch):
+    """The weight-gradient GEMMs run on the plan's side stream next to the dgrad / BN-backward chain (two alternating
+    gradient images ordered by events).  With a FIXED output gradient (no loss atomics) the backward pass is deterministic,
+    so every parameter gradient must be bit-identical to the serial schedule (DCN_BACKWARD_OVERLAP=0, a fresh plan) --
+    three times in a row at the full config-2 size, where the two streams really do overlap."""
+    from dcn_hip import backbone as bb
+    from oracle import synth
+    c = synth.CONFIGS[2]
+    B = 4
+    bb.set_conv_mode("f16x3")
+    dcn, _ = _dcn_and_oracle(c["backbone"], c["D"], c["H"], c["W"])
+    img_a, img_b, _ = synth.make_batch(B, c["H"], c["W"], 10, 10, 10, seed=5)
+    img_a, img_b = img_a.cuda(), img_b.cuda()
+    g = torch.Generator(device="cuda").manual_seed(0)
+    ga = torch.randn(B, c["D"], c["H"], c["W"], device="cuda", generator=g).contiguous(memory_format=torch.channels_last)
+    gb = torch.randn(B, c["D"], c["H"], c["W"], device="cuda", generator=g).contiguous(memory_format=torch.channels_last)
+    params = list(dcn.parameters())
+
+    def grads():
+        for p in params:
+            p.grad = None
+        dcn.train()
+        ya, yb = dcn.forward_pair(img_a, img_b)
+        torch.autograd.backward([ya, yb], [ga, gb])
+        torch.cuda.synchronize()
+        return [p.grad.clone() for p in params]
+
+    runs = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("DCN_BACKWARD_OVERLAP", mode)
+        bb._PLANS.clear()                       # the schedule is fixed at a plan's first backward pass
+        runs[mode] = [grads() for _ in range(3)]
+    bb._PLANS.clear()
+    bb.set_conv_mode(None)
+    ref = runs["0"][0]
+    assert all(torch.isfinite(t).all() for t in ref)
+    for mode in ("0", "1"):
+        for r in runs[mode]:
+            assert all(torch.equal(a, b) for a, b in zip(r, ref)), mode
