@@ -454,6 +454,9 @@ def main():
                           "image": "%dx%d" % (W, H), "descriptor_dim": D, "backbone": wl["backbone"],
                           "pixel_pairs_per_image_pair": [wl["Pm"], wl["Pk"], wl["Pg"]],
                           "conv_mode": args.conv_mode, "hip_graph": graph_note,
+                          "backward_schedule": ("serial (DCN_BACKWARD_OVERLAP=0)" if os.environ.get("DCN_BACKWARD_OVERLAP") == "0" or args.conv_mode != "f16x3" or graph is not None
+                                                else "weight-gradient GEMMs on the engine's side stream next to dgrad / BN backward; the roofline "
+                                                     "steps time every launch alone (serial schedule), see profiles/r1g_kernel_stats*.txt"),
                           "forward_calls": "forward(img_a), forward(img_b)" if args.separate_forwards else
                           "forward_pair(img_a, img_b): both network calls of the step as one grouped launch sequence, batch-norm "
                           "statistics / running statistics / gradients per image batch (identical results)", "optimizer": "Adam lr 1e-4 wd 1e-4 (%s)" % ("torch.optim.Adam" if args.torch_adam else "dcn_adam_step, one pass"), "parallelism": "dp%d" % world,
