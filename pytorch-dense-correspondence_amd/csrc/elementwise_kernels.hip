@@ -183,6 +183,7 @@ bn_bwd_reduce_kernel(const float* __restrict__ dy, const float* __restrict__ rel
         const int64_t r0 = g * rows_per_group + (int64_t)((int)blockIdx.y - g * chunks_per_group) * rows_per_chunk;
         int64_t r1 = r0 + rows_per_chunk;
         if (r1 > (g + 1) * rows_per_group) r1 = (g + 1) * rows_per_group;
+#pragma unroll 4   // (8 loads in flight per work-item instead of 2: 27 -> 23 us per launch)
         for (int64_t r = r0 + rl; r < r1; r += 16) {
             const int64_t o = r * C + c;
             const float4 g = relu_masked(*reinterpret_cast<const float4*>(dy + o), relu_out, relu_mask, o >> 2);
