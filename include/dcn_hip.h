@@ -12,8 +12,10 @@
  *   - plain C: pointers + sizes, no torch / C++ types.  All tensor pointers are DEVICE pointers owned
  *     by the caller (the PyTorch caching allocator in practice); the library allocates no device
  *     memory.  Pointer *arrays* (params / grads) are HOST arrays of device pointers.
- *   - every call is asynchronous on the caller's stream (`hipStream_t` passed as void*), performs no
- *     host synchronisation and keeps no global state: re-entrant per stream, one process per GPU.
+ *   - every call is asynchronous on the caller's stream (`hipStream_t` passed as void*) and performs no host
+ *     synchronisation.  The only process-wide state is the table of DCN_* environment overrides (read once, see
+ *     dcn_reload_env).  A dcn_plan carries per-plan state (a side stream, events, profiling slots, the conv mode):
+ *     use ONE plan per stream -- two streams driving the same plan concurrently would race; one process per GPU.
  *   - return value: 0 on success, negative DCN_E_* otherwise (never throws across the ABI).  The
  *     Python wrapper raises RuntimeError / ValueError like the reference does
  *     (dense_correspondence/network/dense_correspondence_network.py:381).
@@ -41,6 +43,12 @@ extern "C" {
 /* Build identification: "dcn_hip <version> gfx950" for the shipped library, "... hostemu" for the
  * test-only host emulation build (tests/hostemu). */
 const char* dcn_version(void);
+
+/* The DCN_* environment overrides (csrc/dcn_tuning.h: DCN_CONV_MODE, DCN_BACKWARD_OVERLAP, DCN_GEMM_TILE_M, DCN_GEMM_SK,
+ * DCN_GEMM_SK_MIN_GAIN, DCN_GEMM_UNI, DCN_WGRAD_SPLITS) are read ONCE, at the first call that needs them -- never on the
+ * launch path.  dcn_reload_env re-reads them (tests / tuning scripts that change a variable in-process); not to be called
+ * while another thread is inside the library. */
+void dcn_reload_env(void);
 
 /* =====================================================================================================
  * 1. Pixelwise contrastive loss  (kernel K9)
@@ -165,9 +173,11 @@ void dcn_plan_destroy(dcn_plan* plan);
  *   DCN_CONV_FP32  : fp32 MFMA (v_mfma_f32_32x32x2_f32), 157 TFLOP/s peak.
  *   DCN_CONV_F16X3 : split-fp16 -- every operand element x is split on the fly into fp16 hi + lo with
  *                    s*x = hi + lo (s a power of two: 64 for weights, chosen from the tensor's abs-max for
- *                    gradients, 1 for activations) and hi*hi + hi*lo + lo*hi runs on the fp16 MFMA pipe.
- *                    ~22 mantissa bits per operand: indistinguishable from fp32 on this network,
- *                    ~2x faster.  Operand range: |activation| < 65504, |weight| < 1023.
+ *                    gradients AND activations -- every tensor that feeds a convolution carries a device scalar
+ *                    with (a bound of) its abs-max, written by the kernel that produced it) and
+ *                    hi*hi + hi*lo + lo*hi runs on the fp16 MFMA pipe.  ~22 mantissa bits per operand:
+ *                    indistinguishable from fp32 on this network, ~2x faster.  Operand range: any finite
+ *                    fp32 tensor (the pre-scale brings its abs-max to <= 4096); |weight| < 1023.
  * Default: DCN_CONV_F16X3, or the environment variable DCN_CONV_MODE = "fp32" | "f16x3" at plan creation.
  * The saved / workspace arenas are sized for either mode, so the mode may be switched between steps (not between a
  * forward and its backward). */
@@ -182,6 +192,25 @@ int dcn_plan_num_bn(const dcn_plan* plan);
 int dcn_plan_param_info(const dcn_plan* plan, int i, char* name, int name_cap, int64_t shape[4], int* ndim);
 /* name prefix ("layer1.0.bn1") and channel count of batch-norm j. */
 int dcn_plan_bn_info(const dcn_plan* plan, int j, char* name, int name_cap, int64_t* channels);
+
+/* Inside the `saved` buffer of a forward call, at byte offset dcn_plan_activation_absmax_offset: one float per
+ * activation tensor that feeds a convolution (dcn_plan_num_activation_slots of them; slot 0 = the input image) with its
+ * abs-max as the split-fp16 kernels used it (all zero in fp32 mode), followed by one int32 STATUS word: bit 0 = some
+ * convolution input was not finite (inf / NaN) in that call.  Read it after the call (device memory; no sync is forced). */
+int dcn_plan_num_activation_slots(const dcn_plan* plan);
+size_t dcn_plan_activation_absmax_offset(const dcn_plan* plan);
+
+/* Gradient buckets for data-parallel training: the parameters split into
+ * dcn_plan_num_grad_buckets contiguous ranges of the state-dict order -- bucket k = parameters
+ * [first_param(k), first_param(k - 1)), bucket 0 ending at the last parameter -- numbered in the order the backward pass
+ * completes them (k = 0: fc + layer4, 62 % of Resnet34_8s; 1: layer3; 2: the rest).  dcn_backbone_backward records an
+ * event per bucket on its stream once every launch that writes one of the bucket's gradients has been enqueued;
+ * dcn_plan_stream_wait_grad_bucket makes `stream` wait for that event, so that a communication stream can all-reduce
+ * bucket k (RCCL) while the caller's stream is still computing buckets k + 1, ...  Call it after
+ * dcn_backbone_backward has returned; DCN_E_UNSUPPORTED before the plan's first backward pass. */
+int dcn_plan_num_grad_buckets(const dcn_plan* plan);
+int dcn_plan_grad_bucket_first_param(const dcn_plan* plan, int k);
+int dcn_plan_stream_wait_grad_bucket(dcn_plan* plan, int k, void* stream);
 
 size_t dcn_plan_saved_bytes(const dcn_plan* plan);     /* activations kept from forward to backward */
 size_t dcn_plan_workspace_bytes(const dcn_plan* plan); /* scratch shared by forward and backward */
@@ -252,8 +281,9 @@ int dcn_f16_kpad(int k);
 int dcn_split_rows_f16(const float* w, void* hi, void* lo, int64_t rows, int k, float scale, void* stream);
 int dcn_conv_num_mtiles_f16(const dcn_conv_desc* c);
 size_t dcn_conv_gemm_workspace_f16(const dcn_conv_desc* c, int dgrad);
-int dcn_conv_forward_f16(const dcn_conv_desc* c, const float* in, const void* w_hi, const void* w_lo, float w_scale,
-                         const float* bias, float* out, float* bn_partial, void* workspace, void* stream);
+/* in_absmax: device scalar >= max|in| (picks the power-of-two pre-scale of the activation tensor) or NULL for scale 1 */
+int dcn_conv_forward_f16(const dcn_conv_desc* c, const float* in, const float* in_absmax, const void* w_hi, const void* w_lo,
+                         float w_scale, const float* bias, float* out, float* bn_partial, void* workspace, void* stream);
 /* dout_absmax: device scalar >= max|dout| (picks the power-of-two pre-scale of the gradient tensor) or NULL */
 int dcn_conv_dgrad_f16(const dcn_conv_desc* c, const float* dout, const void* wt_hi, const void* wt_lo, float w_scale,
                        const float* dout_absmax, const float* add, float* din, void* workspace, void* stream);
@@ -268,9 +298,11 @@ int dcn_split_weights_f16(int n, const float* const* w, void* const* hi, void* c
 int dcn_split_weights_scaled_f16(int n, const float* const* w, const float* const* row_scale, void* const* hi,
                                  void* const* lo, const int* cout, const int* taps, const int* cin, const int* ldn,
                                  int transposed, float scale, void* stream);
-/* inference: out = [relu](conv(in, w) + bias [+ add]) in one pass (eval-mode batch norm folded into w and bias) */
-int dcn_conv_forward_fused_f16(const dcn_conv_desc* c, const float* in, const void* w_hi, const void* w_lo, float w_scale,
-                               const float* bias, const float* add, int relu, float* out, void* workspace, void* stream);
+/* inference: out = [relu](conv(in, w) + bias [+ add]) in one pass (eval-mode batch norm folded into w and bias);
+ * out_absmax (nullable): device scalar raised to max|out| -- the in_absmax of the convolution that reads `out` next */
+int dcn_conv_forward_fused_f16(const dcn_conv_desc* c, const float* in, const float* in_absmax, const void* w_hi,
+                               const void* w_lo, float w_scale, const float* bias, const float* add, int relu, float* out,
+                               float* out_absmax, void* workspace, void* stream);
 
 /* wgrad consumes PRE-SPLIT operands (every element takes part in many tiles, so the fp32 -> fp16 hi/lo split is done
  * once per tensor).  Both split tensors have the byte size of their fp32 source:
@@ -281,10 +313,31 @@ int dcn_split_act_f16(const float* src, void* xs, int64_t n, void* stream);
 size_t dcn_grad_blocked_bytes(int m, int ld);
 int dcn_split_grad_blocked_f16(const float* dy, int m, int ld, const float* absmax, void* dq, void* stream);
 /* xs_is_fp32 != 0: `xs` is the fp32 activation tensor itself, split on the fly (cheaper than a split pass when every
- * element is only used by a few tiles, e.g. 1x1 convolutions) */
-int dcn_conv_wgrad_f16(const dcn_conv_desc* c, const void* xs, int xs_is_fp32, const void* dq, const float* dout_absmax,
-                       float* dw, void* slabs, void* stream);
+ * element is only used by a few tiles, e.g. 1x1 convolutions); x_absmax (nullable, fp32 operand only): device scalar
+ * >= max|xs| for its power-of-two pre-scale */
+int dcn_conv_wgrad_f16(const dcn_conv_desc* c, const void* xs, int xs_is_fp32, const float* x_absmax, const void* dq,
+                       const float* dout_absmax, float* dw, void* slabs, void* stream);
 size_t dcn_conv_wgrad_workspace_f16(const dcn_conv_desc* c);
+
+/* Train-mode batch norm (+ residual) (+ ReLU) of a convolution output x [rows][c] (kernel K7; nn.BatchNorm2d as the
+ * backbone uses it): statistics from the per-M-tile partial sums the convolution's epilogue wrote (bn_partial
+ * [mtiles][2][c], dcn_conv_forward), running statistics updated with `momentum` (unbiased variance); training == 0: the
+ * running statistics are used instead.  y = [relu](x * scale + shift [+ res]); relu_mask (nullable): one byte per
+ * float4 of y, bit j = y[4 i + j] > 0.  stats [4][c] receives scale, shift, mean, invstd (read by dcn_bn_backward). */
+int dcn_bn_forward(const float* x, const float* bn_partial, int mtiles, int c, int64_t rows, const float* gamma,
+                   const float* beta, float* running_mean, float* running_var, float momentum, float eps, int training,
+                   const float* res, int relu, float* y, unsigned char* relu_mask, float* stats, void* stream);
+/* dx, dgamma, dbeta of the above given dy (masked by relu_mask when given); g_out (nullable) receives the masked dy
+ * (the residual branch's gradient).  workspace: dcn_bn_backward_workspace(rows, c) bytes. */
+size_t dcn_bn_backward_workspace(int64_t rows, int c);
+int dcn_bn_backward(const float* dy, const unsigned char* relu_mask, const float* x, const float* stats, const float* gamma,
+                    int c, int64_t rows, float* dgamma, float* dbeta, float* dx, float* g_out, void* workspace,
+                    void* stream);
+/* 3x3 / stride 2 / pad 1 max pool (kernel K2) of in [n,hin,win,c] -> out [n,(hin+1)/2,(win+1)/2,c]; argmax (nullable in
+ * forward): one byte per output element (window position 0..8); backward gathers with it (deterministic). */
+int dcn_maxpool_forward(const float* in, int n, int hin, int win, int c, float* out, unsigned char* argmax, void* stream);
+int dcn_maxpool_backward(const float* gout, const unsigned char* argmax, int n, int hin, int win, int c, float* gin,
+                         void* stream);
 
 /* bilinear xS upsample, align_corners=True (F.upsample_bilinear): low [n,hl,wl,ldl] -> out [n,h,w,d] */
 int dcn_upsample_forward(const float* low, int n, int hl, int wl, int ldl, int d, int h, int w, int normalize,

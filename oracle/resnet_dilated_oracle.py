@@ -135,9 +135,17 @@ class DilatedResNet(nn.Module):
             layers.append(block(self.inplanes, planes, dilation=self.current_dilation))
         return nn.Sequential(*layers)
 
+    use_checkpoint = False   # set_checkpointing(): recompute every block in backward (same arithmetic, ~8x less memory)
+
     def forward(self, x):
         x = self.maxpool(self.relu(self.bn1(self.conv1(x))))
-        x = self.layer4(self.layer3(self.layer2(self.layer1(x))))
+        if self.use_checkpoint and torch.is_grad_enabled():
+            from torch.utils.checkpoint import checkpoint
+            for layer in (self.layer1, self.layer2, self.layer3, self.layer4):
+                for blk in layer:
+                    x = checkpoint(blk, x, use_reentrant=False, preserve_rng_state=False)
+        else:
+            x = self.layer4(self.layer3(self.layer2(self.layer1(x))))
         return self.fc(x)
 
 
@@ -178,6 +186,13 @@ class Resnet50_8s(_Resnet8s):
 
 class Resnet101_8s(_Resnet8s):
     arch = "Resnet101_8s"
+
+
+def set_checkpointing(model, on=True):
+    """Per-block activation checkpointing for the full-size fixture runs that do not fit the authoring container's
+    memory (tests/golden/make_backbone_goldens.py).  Outputs and gradients are unchanged; BN running statistics are
+    updated once more by the recomputation."""
+    getattr(model, model._attr).use_checkpoint = bool(on)
 
 
 def build(name, num_classes, seed=0, base_width=64):

@@ -21,6 +21,7 @@
 #include <string>
 #include <vector>
 
+#include "dcn_tuning.h"
 #include "elementwise_kernels.h"
 
 namespace {
@@ -37,6 +38,7 @@ struct ConvL {
     int mtiles[2] = {0, 0};   // BN partial-sum rows of the forward kernel, per conv mode
     size_t wsplit = 0;        // offset (halves) of this conv's fp16 weight image inside w_wh / w_wl (forward or dgrad image)
     int idx = 0;
+    int in_act = -1;          // abs-max slot of the activation tensor this convolution reads (split-fp16 operand pre-scale)
     std::string name;
 };
 struct BnL {
@@ -53,6 +55,7 @@ struct BlockL {
     int64_t out_rows = 0;
     int out_c = 0, in_c = 0;
     int64_t in_rows = 0;
+    int act_in = -1, act_mid[2] = {-1, -1}, act_out = -1;   // abs-max slots of the block's input / mid / output activations
 };
 struct ParamInfo {
     std::string name;
@@ -75,7 +78,8 @@ struct dcn_plan {
     int stem = -1, fc = -1;
     int hl = 0, wl = 0, feat_c = 0;
     // saved arena offsets (floats)
-    size_t s_in4 = 0, s_stem_y = 0, s_pool = 0, s_argmax = 0, s_low = 0, saved_floats = 0;
+    size_t s_in4 = 0, s_stem_y = 0, s_pool = 0, s_argmax = 0, s_low = 0, s_actmax = 0, saved_floats = 0;
+    int n_act = 0;    // activation tensors that feed a convolution: s_actmax[n_act] abs-max scalars + one status word behind them
     // workspace offsets (floats)
     size_t w_buf[6] = {0, 0, 0, 0, 0, 0}, w_wt = 0, w_slab = 0, w_part = 0, w_k123 = 0, w_wstem = 0, w_dwstem = 0,
            w_glow = 0, w_ups = 0, w_sk = 0, w_gnorm = 0, w_wh = 0, w_wl = 0, w_amax = 0, w_dq = 0, w_dq2 = 0, ws_floats = 0;
@@ -93,6 +97,13 @@ struct dcn_plan {
     hipStream_t side = nullptr;
     hipEvent_t ev_dq[2] = {nullptr, nullptr}, ev_wg[2] = {nullptr, nullptr}, ev_join = nullptr;
     int side_state = 0;   // 0: not tried, 1: ready, -1: unavailable
+    // gradient buckets (data-parallel training): bucket k = parameters [bucket_first[k], bucket_first[k - 1]) in
+    // state-dict order (bucket 0 ends at the last parameter); backward finishes them in the order 0, 1, ... and records
+    // ev_bucket[k] on the caller's stream as soon as every gradient of bucket k has been enqueued
+    std::vector<int> bucket_first, bucket_block;
+    std::vector<hipEvent_t> ev_bucket;
+    hipEvent_t ev_bucket_side = nullptr;
+    int bucket_state = 0;   // 0: events not created yet, 1: ready, -1: unavailable
 };
 
 namespace {
@@ -187,8 +198,11 @@ int build_plan(dcn_plan& p) {
     p.Dp = (p.D + 3) / 4 * 4;
 
     p.s_in4 = B.alloc_saved((size_t)N * p.H * p.W * 4);
+    int n_act = 0;
     // stem
     p.stem = B.add_conv("conv1", N, p.H, p.W, 3, w, 7, 2, 3, 1, false);
+    p.convs[p.stem].in_act = n_act++;              // slot 0: the input image
+    const int act_pool = n_act++;                   // slot 1: max |stem activation| >= max |max-pool output|
     B.conv_out(p.stem);
     {
         ConvL& c = p.convs[p.stem];
@@ -201,6 +215,7 @@ int build_plan(dcn_plan& p) {
     p.s_argmax = B.alloc_saved(((size_t)N * hp * wp * w + 3) / 4);
     h = hp; wd = wp;
     size_t cur = p.s_pool;
+    int cur_act = act_pool;
     int inplanes = w, cur_stride = 4, cur_dil = 1;
     for (int li = 0; li < 4; ++li) {
         const int planes = w << li;
@@ -208,6 +223,7 @@ int build_plan(dcn_plan& p) {
         for (int bi = 0; bi < layers[li]; ++bi) {
             const std::string bname = "layer" + std::to_string(li + 1) + "." + std::to_string(bi);
             BlockL blk;
+            blk.act_in = cur_act;
             blk.in = cur;
             blk.in_c = inplanes;
             blk.in_rows = (int64_t)N * h * wd;
@@ -246,11 +262,17 @@ int build_plan(dcn_plan& p) {
                 B.conv_out(blk.conv[2]);
                 p.convs[blk.conv[2]].bn = B.add_bn(bname + ".bn3", planes * 4, B.rows_of(p.convs[blk.conv[2]]));
             }
+            for (int i = 0; i < blk.nconv; ++i) {
+                if (i + 1 < blk.nconv) blk.act_mid[i] = n_act++;
+                p.convs[blk.conv[i]].in_act = i == 0 ? blk.act_in : blk.act_mid[i - 1];
+            }
+            blk.act_out = n_act++;
             const ConvL last = p.convs[blk.conv[blk.nconv - 1]];
             if (need_down) {
                 blk.down = B.add_conv(bname + ".downsample.0", N, h, wd, inplanes, planes * exp, 1, bstride, 0, 1, false);
                 B.conv_out(blk.down);
                 p.convs[blk.down].bn = B.add_bn(bname + ".downsample.1", planes * exp, B.rows_of(p.convs[blk.down]));
+                p.convs[blk.down].in_act = blk.act_in;
             }
             blk.out_rows = B.rows_of(last);
             blk.out_c = planes * exp;
@@ -258,14 +280,24 @@ int build_plan(dcn_plan& p) {
             if ((size_t)blk.out_rows * blk.out_c > p.max_act) p.max_act = (size_t)blk.out_rows * blk.out_c;
             p.blocks.push_back(blk);
             cur = blk.out;
+            cur_act = blk.act_out;
             h = last.d.hout; wd = last.d.wout;
             inplanes = planes * exp;
         }
     }
     p.hl = h; p.wl = wd; p.feat_c = inplanes;
     p.fc = B.add_conv("fc", N, h, wd, inplanes, p.D, 1, 1, 0, 1, true, p.Dp);
+    p.convs[p.fc].in_act = cur_act;
     p.s_low = B.alloc_saved((size_t)N * h * wd * p.Dp);  // low-resolution descriptor map (needed by the normalise backward)
+    p.n_act = n_act;
+    p.s_actmax = B.alloc_saved((size_t)n_act + 1);        // abs-max of every convolution input (kept for wgrad) + status word
     p.saved_floats = B.saved;
+    {   // gradient buckets, in the order backward completes them: fc + layer4 | layer3 | layer2 + layer1 + stem
+        int first_block[4], b0 = 0;
+        for (int li = 0; li < 4; ++li) { first_block[li] = b0; b0 += layers[li]; }
+        p.bucket_block = {first_block[3], first_block[2], 0};
+        p.bucket_first = {p.convs[p.blocks[first_block[3]].conv[0]].w, p.convs[p.blocks[first_block[2]].conv[0]].w, 0};
+    }
     {
         const size_t in4 = (size_t)N * p.H * p.W * 4;
         if (in4 > p.max_act) p.max_act = in4;
@@ -332,6 +364,19 @@ int build_plan(dcn_plan& p) {
     return DCN_OK;
 }
 
+// status word behind the activation abs-max slots: bit 0 = some convolution input is not finite (inf / NaN abs-max)
+__global__ void __launch_bounds__(64)
+act_status_kernel(const float* __restrict__ actmax, int n, int* __restrict__ status) {
+    int bad = 0;
+    for (int i = threadIdx.x; i < n; i += 64) {
+        const float v = actmax[i];
+        bad |= (v != v || v > 3.0e38f) ? 1 : 0;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) bad |= __shfl_xor(bad, o);
+    if (threadIdx.x == 0) *status = bad;
+}
+
 // column sums of a [rows][ld] matrix (fc bias gradient): one workgroup per column, fixed-order reduction
 __global__ void __launch_bounds__(256)
 colsum_kernel(const float* __restrict__ m, int64_t rows, int ld, float* __restrict__ out) {
@@ -370,13 +415,15 @@ struct Run {
         p.prof_used += 2;
         p.prof_cat.push_back(cat);
         p.prof_flops.push_back(flops);
-        hipEventRecord(e0, st);
+        if (hipEventRecord(e0, st) != hipSuccess) return DCN_E_LAUNCH;
         const int rc = launch();
-        hipEventRecord(e1, st);
+        if (hipEventRecord(e1, st) != hipSuccess) return DCN_E_LAUNCH;
         return rc;
     }
 
     float* S(size_t off) const { return saved + off; }
+    // abs-max scalar of activation slot `a` (split-fp16 mode only: null otherwise, i.e. "no pre-scale")
+    float* A(int a) const { return (p.conv_mode == DCN_CONV_F16X3 && a >= 0) ? saved + p.s_actmax + a : nullptr; }
     // ReLU mask bytes of the post-ReLU activation at saved-arena offset `off`
     unsigned char* M(size_t off) const {
         for (const auto& m : p.relu_masks)
@@ -392,7 +439,8 @@ struct Run {
             return timed(0, c.flops, [&] { return dcn_conv_forward(&c.d, in, w, bias, out, part, Wk(p.w_sk), st); });
         (void)w;   // split-fp16 mode: the image was produced by split_all_weights at the start of the call
         return timed(0, c.flops, [&] {
-            return dcn_conv_forward_f16(&c.d, in, wimg(p.w_wh, c), wimg(p.w_wl, c), kWeightScale, bias, out, part, Wk(p.w_sk), st);
+            return dcn_conv_forward_f16(&c.d, in, A(c.in_act), wimg(p.w_wh, c), wimg(p.w_wl, c), kWeightScale, bias, out, part,
+                                        Wk(p.w_sk), st);
         });
     }
 
@@ -420,11 +468,12 @@ struct Run {
     }
 
     // inference: conv + folded batch norm (+ residual) (+ ReLU) in one pass; bias = the BN shift beta - mean * scale
-    int conv_fused(const ConvL& c, const float* in, const float* add, int relu, float* out) {
+    // out_act: abs-max slot of the tensor being produced (it is the next convolution's operand), or -1
+    int conv_fused(const ConvL& c, const float* in, const float* add, int relu, float* out, int out_act) {
         const float* shift = S(p.bns[c.bn].stats) + p.bns[c.bn].C;
         return timed(0, c.flops, [&] {
-            return dcn_conv_forward_fused_f16(&c.d, in, wimg(p.w_wh, c), wimg(p.w_wl, c), kWeightScale, shift, add, relu, out,
-                                              Wk(p.w_sk), st);
+            return dcn_conv_forward_fused_f16(&c.d, in, A(c.in_act), wimg(p.w_wh, c), wimg(p.w_wl, c), kWeightScale, shift, add,
+                                              relu, out, A(out_act), Wk(p.w_sk), st);
         });
     }
 
@@ -456,11 +505,9 @@ extern "C" int dcn_plan_create_grouped(const char* arch, int base_width, int n, 
         return DCN_E_INVALID;
     dcn_plan* p = new dcn_plan();
     p->arch = arch; p->N = n; p->H = h; p->W = w; p->D = d; p->base = base_width; p->groups = groups;
-    if (const char* m = getenv("DCN_CONV_MODE")) {
-        if (!strcmp(m, "fp32")) p->conv_mode = DCN_CONV_FP32;
-        else if (!strcmp(m, "f16x3")) p->conv_mode = DCN_CONV_F16X3;
-        else { delete p; return DCN_E_INVALID; }
-    }
+    const dcn::Tuning& tune = dcn::tuning();   // (environment read once: dcn_tuning.h)
+    if (tune.conv_mode_invalid) { delete p; return DCN_E_INVALID; }
+    if (tune.conv_mode >= 0) p->conv_mode = tune.conv_mode;
     const int rc = build_plan(*p);
     if (rc != DCN_OK) { delete p; return rc; }
     *out = p;
@@ -471,6 +518,9 @@ extern "C" void dcn_plan_destroy(dcn_plan* plan) {
     for (hipEvent_t e : plan->prof_ev) hipEventDestroy(e);
     for (hipEvent_t e : {plan->ev_dq[0], plan->ev_dq[1], plan->ev_wg[0], plan->ev_wg[1], plan->ev_join})
         if (e) hipEventDestroy(e);
+    for (hipEvent_t e : plan->ev_bucket)
+        if (e) hipEventDestroy(e);
+    if (plan->ev_bucket_side) hipEventDestroy(plan->ev_bucket_side);
     if (plan->side) hipStreamDestroy(plan->side);
     delete plan;
 }
@@ -523,6 +573,18 @@ extern "C" int dcn_plan_bn_info(const dcn_plan* plan, int j, char* name, int nam
     *channels = plan->bns[j].C;
     return DCN_OK;
 }
+extern "C" int dcn_plan_num_grad_buckets(const dcn_plan* plan) { return plan ? (int)plan->bucket_first.size() : DCN_E_INVALID; }
+extern "C" int dcn_plan_grad_bucket_first_param(const dcn_plan* plan, int k) {
+    if (!plan || k < 0 || k >= (int)plan->bucket_first.size()) return DCN_E_INVALID;
+    return plan->bucket_first[k];
+}
+extern "C" int dcn_plan_stream_wait_grad_bucket(dcn_plan* plan, int k, void* stream) {
+    if (!plan || k < 0 || k >= (int)plan->bucket_first.size()) return DCN_E_INVALID;
+    if (plan->bucket_state != 1) return DCN_E_UNSUPPORTED;   // no backward pass has run yet (or events unavailable)
+    return hipStreamWaitEvent((hipStream_t)stream, plan->ev_bucket[k], 0) == hipSuccess ? DCN_OK : DCN_E_LAUNCH;
+}
+extern "C" int dcn_plan_num_activation_slots(const dcn_plan* plan) { return plan ? plan->n_act : DCN_E_INVALID; }
+extern "C" size_t dcn_plan_activation_absmax_offset(const dcn_plan* plan) { return plan ? plan->s_actmax * sizeof(float) : 0; }
 extern "C" size_t dcn_plan_saved_bytes(const dcn_plan* plan) { return plan ? plan->saved_floats * sizeof(float) : 0; }
 extern "C" size_t dcn_plan_workspace_bytes(const dcn_plan* plan) { return plan ? plan->ws_floats * sizeof(float) : 0; }
 extern "C" double dcn_plan_forward_flops(const dcn_plan* plan) { return plan ? plan->flops : 0.0; }
@@ -536,9 +598,11 @@ extern "C" int dcn_backbone_forward(dcn_plan* plan, const float* image, const fl
     hipStream_t st = R.st;
     const int N = p.N;
 
+    // abs-max slots of the activation tensors (+ the status word behind them)
+    if (dcn::fill_bytes_async(R.S(p.s_actmax), 0, ((size_t)p.n_act + 1) * sizeof(float), st) != DCN_OK) return DCN_E_LAUNCH;
     // stem: NCHW(3) -> NHWC(4), weight [w][7][7][3] -> [w][7][7][4]
-    dcn::launch_nchw3_to_nhwc4(image, R.S(p.s_in4), N, p.H * p.W, st);
     const ConvL& stem = p.convs[p.stem];
+    dcn::launch_nchw3_to_nhwc4(image, R.S(p.s_in4), N, p.H * p.W, R.A(stem.in_act), st);
     dcn::launch_pad_c3_to_c4(R.P(stem.w), R.Wk(p.w_wstem), (int64_t)p.base * 49, st);
     const bool fused_eval = !training && p.conv_mode == DCN_CONV_F16X3;
     if (fused_eval) {
@@ -551,7 +615,7 @@ extern "C" int dcn_backbone_forward(dcn_plan* plan, const float* image, const fl
                                     bn_running[2 * b.idx], bn_running[2 * b.idx + 1], momentum, eps, 0, R.S(b.stats), st);
         }
         DCN_TRY(R.split_all_weights(false, R.Wk(p.w_wstem), true));
-        DCN_TRY(R.conv_fused(stem, R.S(p.s_in4), nullptr, 1, R.S(p.s_stem_y)));
+        DCN_TRY(R.conv_fused(stem, R.S(p.s_in4), nullptr, 1, R.S(p.s_stem_y), p.blocks[0].act_in));
         {
             const BnL& b = p.bns[stem.bn];
             const int hp = (stem.d.hout + 2 - 3) / 2 + 1, wp = (stem.d.wout + 2 - 3) / 2 + 1;
@@ -562,17 +626,17 @@ extern "C" int dcn_backbone_forward(dcn_plan* plan, const float* image, const fl
             const float* in = R.S(blk.in);
             const float* cur = in;
             for (int i = 0; i + 1 < blk.nconv; ++i) {
-                DCN_TRY(R.conv_fused(p.convs[blk.conv[i]], cur, nullptr, 1, R.S(blk.mid[i])));
+                DCN_TRY(R.conv_fused(p.convs[blk.conv[i]], cur, nullptr, 1, R.S(blk.mid[i]), blk.act_mid[i]));
                 cur = R.S(blk.mid[i]);
             }
             const ConvL& last = p.convs[blk.conv[blk.nconv - 1]];
             const float* res = in;
             if (blk.down >= 0) {
                 const ConvL& dc = p.convs[blk.down];
-                DCN_TRY(R.conv_fused(dc, in, nullptr, 0, R.S(dc.x)));
+                DCN_TRY(R.conv_fused(dc, in, nullptr, 0, R.S(dc.x), -1));
                 res = R.S(dc.x);
             }
-            DCN_TRY(R.conv_fused(last, cur, res, 1, R.S(blk.out)));
+            DCN_TRY(R.conv_fused(last, cur, res, 1, R.S(blk.out), blk.act_out));
         }
     } else {
     if (p.conv_mode == DCN_CONV_F16X3) DCN_TRY(R.split_all_weights(false, R.Wk(p.w_wstem)));
@@ -580,7 +644,8 @@ extern "C" int dcn_backbone_forward(dcn_plan* plan, const float* image, const fl
     {
         const BnL& b = p.bns[stem.bn];
         const float* s = R.S(b.stats);
-        dcn::launch_bn_apply(R.S(stem.x), s, nullptr, nullptr, 1, R.S(p.s_stem_y), R.M(p.s_stem_y), b.C, b.rows, p.groups, st);
+        dcn::launch_bn_apply(R.S(stem.x), s, nullptr, nullptr, 1, R.S(p.s_stem_y), R.M(p.s_stem_y), b.C, b.rows, p.groups,
+                             R.A(p.blocks[0].act_in), st);
         const int hp = (stem.d.hout + 2 - 3) / 2 + 1, wp = (stem.d.wout + 2 - 3) / 2 + 1;
         dcn::launch_maxpool_fwd(R.S(p.s_stem_y), R.S(p.s_pool), (unsigned char*)R.S(p.s_argmax), N, stem.d.hout,
                                 stem.d.wout, hp, wp, b.C, st);
@@ -594,7 +659,8 @@ extern "C" int dcn_backbone_forward(dcn_plan* plan, const float* image, const fl
             if (i + 1 < blk.nconv) {
                 const BnL& b = p.bns[c.bn];
                 const float* s = R.S(b.stats);
-                dcn::launch_bn_apply(R.S(c.x), s, nullptr, nullptr, 1, R.S(blk.mid[i]), R.M(blk.mid[i]), b.C, b.rows, p.groups, st);
+                dcn::launch_bn_apply(R.S(c.x), s, nullptr, nullptr, 1, R.S(blk.mid[i]), R.M(blk.mid[i]), b.C, b.rows, p.groups,
+                                     R.A(blk.act_mid[i]), st);
                 cur = R.S(blk.mid[i]);
             }
         }
@@ -605,9 +671,11 @@ extern "C" int dcn_backbone_forward(dcn_plan* plan, const float* image, const fl
             const ConvL& dc = p.convs[blk.down];
             DCN_TRY(R.conv_bn(dc, in, R.P(dc.w), bn_running, momentum, eps, training));
             const float* sd = R.S(p.bns[dc.bn].stats);
-            dcn::launch_bn_apply(R.S(last.x), sl, R.S(dc.x), sd, 1, R.S(blk.out), R.M(blk.out), bl.C, bl.rows, p.groups, st);
+            dcn::launch_bn_apply(R.S(last.x), sl, R.S(dc.x), sd, 1, R.S(blk.out), R.M(blk.out), bl.C, bl.rows, p.groups,
+                                 R.A(blk.act_out), st);
         } else {
-            dcn::launch_bn_apply(R.S(last.x), sl, in, nullptr, 1, R.S(blk.out), R.M(blk.out), bl.C, bl.rows, p.groups, st);
+            dcn::launch_bn_apply(R.S(last.x), sl, in, nullptr, 1, R.S(blk.out), R.M(blk.out), bl.C, bl.rows, p.groups,
+                                 R.A(blk.act_out), st);
         }
     }
     }   // !fused_eval
@@ -617,6 +685,8 @@ extern "C" int dcn_backbone_forward(dcn_plan* plan, const float* image, const fl
     if (dcn::fill_bytes_async(R.S(p.s_low), 0, low_bytes, st) != DCN_OK) return DCN_E_LAUNCH;
     DCN_TRY(R.conv_fwd(fc, R.S(p.blocks.back().out), R.P(fc.w), R.P(fc.b), R.S(p.s_low), nullptr));
     dcn::launch_upsample_fwd(R.S(p.s_low), N, p.hl, p.wl, p.Dp, p.D, p.H, p.W, normalize, descriptors, st);
+    hipLaunchKernelGGL(act_status_kernel, dim3(1), dim3(64), 0, st, (const float*)R.S(p.s_actmax), p.n_act,
+                       (int*)(R.S(p.s_actmax) + p.n_act));
     return dcn::check_launch();
 }
 
@@ -640,8 +710,7 @@ extern "C" int dcn_backbone_backward(dcn_plan* plan, const float* grad_descripto
     // gradient's pixel-blocked image alternates between two buffers and events order writer and reader of each.
     bool overlap = f16 && !p.prof_on;
     if (overlap && p.side_state == 0) {
-        const char* e = getenv("DCN_BACKWARD_OVERLAP");
-        bool ok = !(e && atoi(e) == 0);
+        bool ok = dcn::tuning().backward_overlap != 0;
         int lo_prio = 0, hi_prio = 0;
         if (ok && hipDeviceGetStreamPriorityRange(&lo_prio, &hi_prio) != hipSuccess) lo_prio = 0;
         ok = ok && hipStreamCreateWithPriority(&p.side, hipStreamNonBlocking, lo_prio) == hipSuccess;
@@ -650,6 +719,17 @@ extern "C" int dcn_backbone_backward(dcn_plan* plan, const float* grad_descripto
         p.side_state = ok ? 1 : -1;
     }
     overlap = overlap && p.side_state == 1;
+    if (p.bucket_state == 0) {   // events behind dcn_plan_stream_wait_grad_bucket
+        bool ok = true;
+        p.ev_bucket.assign(p.bucket_first.size(), nullptr);
+        for (hipEvent_t& ev : p.ev_bucket) ok = ok && hipEventCreateWithFlags(&ev, hipEventDisableTiming) == hipSuccess;
+        ok = ok && hipEventCreateWithFlags(&p.ev_bucket_side, hipEventDisableTiming) == hipSuccess;
+        p.bucket_state = ok ? 1 : -1;
+    }
+    // event / stream-dependency calls of the overlap and bucket logic: a failure must not pass silently (a missed
+    // dependency is a data race), so every one is checked
+    int rt_fail = 0;
+    auto RT = [&](hipError_t e) { if (e != hipSuccess) rt_fail = 1; };
     if (overlap) {   // inside a hipGraph capture the fork / join pattern replays slower than the serial chain (measured): stay serial
         hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
         if (hipStreamIsCapturing(st, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) overlap = false;
@@ -665,10 +745,10 @@ extern "C" int dcn_backbone_backward(dcn_plan* plan, const float* grad_descripto
         // (the mask bytes the forward wrote next to that activation; relu_out itself is then not read)
         const unsigned char* mask = relu_out ? R.M((size_t)(relu_out - R.saved)) : nullptr;
         cur = overlap ? (n_bn & 1) : 0;
-        if (overlap && wg_pending[cur]) hipStreamWaitEvent(st, p.ev_wg[cur], 0);   // the wgrad that read this buffer two layers ago
+        if (overlap && wg_pending[cur]) RT(hipStreamWaitEvent(st, p.ev_wg[cur], 0));   // the wgrad that read this buffer two layers ago
         dcn::launch_bn_bwd(dy, relu_out, mask, R.S(c.x), s, R.P(b.g), b.C, b.rows, p.groups, part, grads[b.g],
                            grads[b.b], k123, dx, g_out, f16 ? amax + c.idx : nullptr, f16 ? (void*)dqbuf[cur] : nullptr, st);
-        if (overlap) hipEventRecord(p.ev_dq[cur], st);
+        if (overlap) RT(hipEventRecord(p.ev_dq[cur], st));
         ++n_bn;
         dq_of = f16 ? dx : nullptr;   // the pixel-blocked split copy of this dx now sits in dqbuf[cur]
     };
@@ -678,17 +758,19 @@ extern "C" int dcn_backbone_backward(dcn_plan* plan, const float* grad_descripto
         // split pass + pre-split operand on every layer of ResNet34 / ResNet50 (the pass costs more than the conversions).
         if (dq_of != dx) {   // (BN backward emits it directly; only the scoring layer's gradient needs the separate pass)
             DCN_TRY(dcn_split_grad_blocked_f16(dx, c.d.n * c.d.hout * c.d.wout, c.d.ldc, amax + c.idx, dqbuf[0], st));
-            return R.timed(1, c.flops, [&] { return dcn_conv_wgrad_f16(&c.d, in, 1, dqbuf[0], amax + c.idx, dw, slab, st); });
+            return R.timed(1, c.flops, [&] {
+                return dcn_conv_wgrad_f16(&c.d, in, 1, R.A(c.in_act), dqbuf[0], amax + c.idx, dw, slab, st);
+            });
         }
         if (overlap) {
-            hipStreamWaitEvent(p.side, p.ev_dq[cur], 0);
-            DCN_TRY(dcn_conv_wgrad_f16(&c.d, in, 1, dqbuf[cur], amax + c.idx, dw, slab, p.side));
-            hipEventRecord(p.ev_wg[cur], p.side);
+            RT(hipStreamWaitEvent(p.side, p.ev_dq[cur], 0));
+            DCN_TRY(dcn_conv_wgrad_f16(&c.d, in, 1, R.A(c.in_act), dqbuf[cur], amax + c.idx, dw, slab, p.side));
+            RT(hipEventRecord(p.ev_wg[cur], p.side));
             wg_pending[cur] = true;
             return DCN_OK;
         }
         return R.timed(1, c.flops, [&] {
-            return dcn_conv_wgrad_f16(&c.d, in, 1, dqbuf[cur], amax + c.idx, dw, slab, st);
+            return dcn_conv_wgrad_f16(&c.d, in, 1, R.A(c.in_act), dqbuf[cur], amax + c.idx, dw, slab, st);
         });
     };
     auto dgrad = [&](const ConvL& c, const float* dx, const float* add, float* din) -> int {
@@ -755,6 +837,16 @@ extern "C" int dcn_backbone_backward(dcn_plan* plan, const float* grad_descripto
             DCN_TRY(dgrad(dc, dxa, dpart, dnext));
         }
         float* t = dout; dout = dnext; dnext = t;
+        // gradient bucket complete?  (every launch that writes one of its gradients has been enqueued: the side stream's
+        // weight-gradient GEMMs are joined into the caller's stream first)
+        for (size_t k = 0; k + 1 < p.bucket_block.size(); ++k)
+            if (p.bucket_block[k] == bi && p.bucket_state == 1) {
+                if (overlap) {
+                    RT(hipEventRecord(p.ev_bucket_side, p.side));
+                    RT(hipStreamWaitEvent(st, p.ev_bucket_side, 0));
+                }
+                RT(hipEventRecord(p.ev_bucket[k], st));
+            }
     }
     // ---- max pool, stem
     const ConvL& stem = p.convs[p.stem];
@@ -765,9 +857,11 @@ extern "C" int dcn_backbone_backward(dcn_plan* plan, const float* grad_descripto
     bn_bwd(stem, dnext, R.S(p.s_stem_y), dxa, nullptr);
     DCN_TRY(wgrad(stem, R.S(p.s_in4), dxa, R.Wk(p.w_dwstem)));
     if (overlap) {   // join: everything the side stream produced is ordered before whatever follows on the caller's stream
-        hipEventRecord(p.ev_join, p.side);
-        hipStreamWaitEvent(st, p.ev_join, 0);
+        RT(hipEventRecord(p.ev_join, p.side));
+        RT(hipStreamWaitEvent(st, p.ev_join, 0));
     }
     dcn::launch_unpad_c4_to_c3(R.Wk(p.w_dwstem), grads[stem.w], (int64_t)p.base * 49, st);
+    if (p.bucket_state == 1) RT(hipEventRecord(p.ev_bucket.back(), st));   // last bucket: the whole backward pass
+    if (rt_fail) return DCN_E_LAUNCH;
     return dcn::check_launch();
 }

@@ -15,6 +15,7 @@
 // operand path: 128x128 tiles, 32-K stages, fp32->(hi,lo) conversion once per element at staging time (v_cvt_pk_f16_f32),
 // conflict-free 80-byte-pitch fp16 LDS images, one ds_read_b128 per 32x16 fragment.
 #include "conv_shared.h"
+#include "dcn_tuning.h"
 #include "f16_split.h"
 
 namespace {
@@ -175,7 +176,9 @@ __device__ __forceinline__ void gemm_segment_f16(const GemmConv& p, _Float16* ld
         wrow[j] = (ok ? n : 0) * p.kp + ko * 8;
     }
     const int smask = p.stride - 1;
-    const float sa = (TR && p.a_absmax) ? pow2_scale(*p.a_absmax) : 1.f;   // only gradient tensors are pre-scaled
+    // power-of-two pre-scale of the gathered operand from an upper bound of its abs-max (a device scalar written by the
+    // kernel that produced the tensor): gradients AND activations, so that neither tiny nor huge tensors leave fp16's range
+    const float sa = p.a_absmax ? pow2_scale(*p.a_absmax) : 1.f;
     // two register sets: global loads run TWO 32-K stages ahead of the MFMAs (a stage of fp16 MFMA work is ~0.3 us,
     // shorter than a trip to L2 / HBM under load)
     float4 ra[2][PA];
@@ -304,8 +307,7 @@ __device__ __forceinline__ void gemm_segment_f16(const GemmConv& p, _Float16* ld
             float4 v = ra[set][j];
             v = make_float4(ok ? v.x : 0.f, ok ? v.y : 0.f, ok ? v.z : 0.f, ok ? v.w : 0.f);
             h4 hi, lo;
-            if (TR) split4(v, sa, hi, lo);
-            else split4_unscaled(v, hi, lo);   // forward: activations are taken as they are
+            split4(v, sa, hi, lo);
             *reinterpret_cast<h4*>(ah + (ra0 + G::RA * j) * LDH + kq * 4) = hi;
             *reinterpret_cast<h4*>(al + (ra0 + G::RA * j) * LDH + kq * 4) = lo;
         }
@@ -539,8 +541,9 @@ F16Shape f16_shape(int M, int cd, int K, int align = 0) {
     // configs 1-3 against the best 64 / 128-row choice (a quarter fewer operand bytes per MFMA at the same 8 wavefronts per CU)
     g.wr = 2;
     if (g.tn == 2 && M >= 4096) { g.tm = 2; g.wr = 4; }
-    if (const char* e = getenv("DCN_GEMM_TILE_M")) {
-        const int v = atoi(e);
+    const dcn::Tuning& tune = dcn::tuning();
+    if (tune.gemm_tile_m) {
+        const int v = tune.gemm_tile_m;
         if (v == 64) { g.tm = 1; g.wr = 2; }
         if (v == 128) { g.tm = 2; g.wr = 2; }
         if (v == 256 && g.tn == 2) { g.tm = 2; g.wr = 4; }
@@ -558,13 +561,12 @@ F16Shape f16_shape(int M, int cd, int K, int align = 0) {
     // partial-tile writes plus the fix-up pass (25-30 us ~ 20 stage times).  Measured at N = 8: 128-channel layer (150
     // tiles of 36 stages, 15 stage times to gain) 50 us data-parallel vs 62 us stream-K; 256-channel layer (300 tiles of 72
     // stages, 60 to gain) 189 vs 156 us.
-    double sk_min_gain = 20.0;
-    if (const char* e = getenv("DCN_GEMM_SK_MIN_GAIN")) sk_min_gain = atof(e);
+    const double sk_min_gain = tune.gemm_sk_min_gain;
     const double gain = ((double)(int)(rounds + 0.999999) - rounds) * g.nk;
     g.sk = tiles < 8 * 256 && waste > 0.08 && g.nk >= 8 && gain >= sk_min_gain;
     int wgs = resident;
-    if (const char* e = getenv("DCN_GEMM_SK")) {
-        const int v = atoi(e);
+    if (tune.gemm_sk >= 0) {
+        const int v = tune.gemm_sk;
         if (v == 0) g.sk = false;
         if (v > 1) { g.sk = g.nk >= 2; wgs = v; }
     }
@@ -604,7 +606,7 @@ int launch_gemm_f16(GemmConv& p, void* workspace, hipStream_t st, int align = 0)
     // uniform-tap fast path: whole 32-K stages inside one filter tap, tensors addressable through 2 GiB buffer resources
     const int64_t src_bytes = (int64_t)p.M / (p.hd * p.wd) * p.hs * p.ws * p.cs * 4, w_bytes = (int64_t)p.cd * p.kp * 2;
     bool uni = (p.cs % HBK) == 0 && src_bytes <= ((int64_t)1 << 31) && w_bytes <= ((int64_t)1 << 31);
-    if (const char* e = getenv("DCN_GEMM_UNI")) uni = uni && atoi(e) != 0;
+    uni = uni && dcn::tuning().gemm_uni != 0;
     p.src_bytes = uni ? (unsigned)src_bytes : 0u;
     p.w_bytes = uni ? (unsigned)w_bytes : 0u;
     const dim3 grid(sk ? g.sk_wgs : g.mtiles * g.ntiles), fgrid(2 * (g.mtiles * g.ntiles - g.sk_dp)), block(128 * g.wr), fblock(64 * g.wr);
@@ -681,6 +683,7 @@ struct WgradF16 {
     const void* dq;       // split gradient, pixel-blocked (layout above), pre-scaled by pow2_scale(*d_absmax)
     float* slab;          // [splits][cout][K]
     const float* d_absmax;
+    const float* x_absmax;   // abs-max bound of the fp32 activation operand (null, or ignored with a pre-split operand: scale 1)
     unsigned x_bytes, d_bytes;
     int hin, win, cin, hout, wout, cout, kh, kw, stride, pad, dil, ldo, M, K, splits, rows_per_split, ntiles_n, ntiles_k;
     FastDiv div_hw, div_w, div_cin, div_kw;
@@ -780,6 +783,7 @@ conv_wgrad_f16_kernel(WgradF16 p) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) rx[i] = __builtin_amdgcn_raw_buffer_load_b128(rs_x, xoff[i], 0, 0);
     };
+    const float sx = (!XPRE && p.x_absmax) ? pow2_scale(*p.x_absmax) : 1.f;
     auto store_tile = [&](int stage) {
         _Float16* dh = lds + stage * kStage;
         _Float16* dl = dh + BM * LDH;
@@ -789,7 +793,7 @@ conv_wgrad_f16_kernel(WgradF16 p) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 h4 a, b;
-                split4_unscaled(__builtin_bit_cast(float4, rx[i]), a, b);
+                split4(__builtin_bit_cast(float4, rx[i]), sx, a, b);
                 const u32x2 ua = __builtin_bit_cast(u32x2, a), ub = __builtin_bit_cast(u32x2, b);
                 rx[i] = u32x4{ua[0], ua[1], ub[0], ub[1]};
             }
@@ -888,7 +892,7 @@ conv_wgrad_f16_kernel(WgradF16 p) {
         }
     }
     // C fragment: row (r) <-> output channel, column (lane & 31) <-> K column: 128-byte coalesced rows
-    const float inv = 1.f / (p.d_absmax ? pow2_scale(*p.d_absmax) : 1.f);
+    const float inv = 1.f / (p.d_absmax ? pow2_scale(*p.d_absmax) : 1.f) / sx;
     float* out = p.slab + (int64_t)split * p.cout * p.K;
 #pragma unroll
     for (int tm = 0; tm < 2; ++tm)
@@ -931,7 +935,7 @@ int wgrad_splits_f16(const dcn_conv_desc* c, int* rows_per_split) {
         const double score = eff - 0.004 * real - (wgs < slots ? 0.5 * (1.0 - (double)wgs / slots) : 0.0);
         if (score > best_score) { best_score = score; best = s; }
     }
-    if (const char* e = getenv("DCN_WGRAD_SPLITS")) { const int v = atoi(e); if (v >= 1 && v <= max_by_rows) best = v; }
+    if (const int v = dcn::tuning().wgrad_splits) { if (v >= 1 && v <= max_by_rows) best = v; }
     int rps = dcn::ceil_div(dcn::ceil_div(M, best), HBK) * HBK;
     *rows_per_split = rps;
     return dcn::ceil_div(M, rps);
@@ -1011,13 +1015,13 @@ extern "C" size_t dcn_conv_gemm_workspace_f16(const dcn_conv_desc* c, int dgrad)
 }
 
 // w_hi / w_lo: [cout][kpad(K)] fp16 from dcn_split_rows_f16(w, ..., scale = w_scale)
-extern "C" int dcn_conv_forward_f16(const dcn_conv_desc* c, const float* in, const void* w_hi, const void* w_lo,
-                                    float w_scale, const float* bias, float* out, float* bn_partial, void* workspace,
-                                    void* stream) {
+extern "C" int dcn_conv_forward_f16(const dcn_conv_desc* c, const float* in, const float* in_absmax, const void* w_hi,
+                                    const void* w_lo, float w_scale, const float* bias, float* out, float* bn_partial,
+                                    void* workspace, void* stream) {
     if (!valid_desc16(c) || !in || !w_hi || !w_lo || !out || !(w_scale > 0.f)) return DCN_E_INVALID;
     GemmConv p;
-    p.src = in; p.wm = nullptr; p.bias = bias; p.add = nullptr; p.dst = out; p.bn_partial = bn_partial;
-    p.wh = (const _Float16*)w_hi; p.wl = (const _Float16*)w_lo; p.a_absmax = nullptr; p.b_inv_scale = 1.f / w_scale;
+    p.src = in; p.wm = nullptr; p.bias = bias; p.add = nullptr; p.dst = out; p.bn_partial = bn_partial; p.out_absmax = nullptr;
+    p.wh = (const _Float16*)w_hi; p.wl = (const _Float16*)w_lo; p.a_absmax = in_absmax; p.b_inv_scale = 1.f / w_scale;
     p.hs = c->hin; p.ws = c->win; p.cs = c->cin; p.hd = c->hout; p.wd = c->wout; p.cd = c->cout;
     p.kh = c->kh; p.kw = c->kw; p.stride = c->stride; p.pad = c->pad; p.dil = c->dil; p.ldc = c->ldc;
     p.M = c->n * c->hout * c->wout; p.K = c->kh * c->kw * c->cin; p.kp = dcn_f16_kpad(p.K); p.transposed = 0; p.relu = 0;
@@ -1026,13 +1030,13 @@ extern "C" int dcn_conv_forward_f16(const dcn_conv_desc* c, const float* in, con
 
 // Inference form: out = [relu](conv(in, w) + bias [+ add]) in one pass (w / bias with the eval-mode batch norm folded in:
 // dcn_split_weights_scaled_f16 with row_scale = gamma / sqrt(var + eps), bias = beta - mean * that).  add: [M][ldc] or NULL.
-extern "C" int dcn_conv_forward_fused_f16(const dcn_conv_desc* c, const float* in, const void* w_hi, const void* w_lo,
-                                          float w_scale, const float* bias, const float* add, int relu, float* out,
-                                          void* workspace, void* stream) {
+extern "C" int dcn_conv_forward_fused_f16(const dcn_conv_desc* c, const float* in, const float* in_absmax, const void* w_hi,
+                                          const void* w_lo, float w_scale, const float* bias, const float* add, int relu,
+                                          float* out, float* out_absmax, void* workspace, void* stream) {
     if (!valid_desc16(c) || !in || !w_hi || !w_lo || !out || !(w_scale > 0.f)) return DCN_E_INVALID;
     GemmConv p;
-    p.src = in; p.wm = nullptr; p.bias = bias; p.add = add; p.dst = out; p.bn_partial = nullptr;
-    p.wh = (const _Float16*)w_hi; p.wl = (const _Float16*)w_lo; p.a_absmax = nullptr; p.b_inv_scale = 1.f / w_scale;
+    p.src = in; p.wm = nullptr; p.bias = bias; p.add = add; p.dst = out; p.bn_partial = nullptr; p.out_absmax = out_absmax;
+    p.wh = (const _Float16*)w_hi; p.wl = (const _Float16*)w_lo; p.a_absmax = in_absmax; p.b_inv_scale = 1.f / w_scale;
     p.hs = c->hin; p.ws = c->win; p.cs = c->cin; p.hd = c->hout; p.wd = c->wout; p.cd = c->cout;
     p.kh = c->kh; p.kw = c->kw; p.stride = c->stride; p.pad = c->pad; p.dil = c->dil; p.ldc = c->ldc;
     p.M = c->n * c->hout * c->wout; p.K = c->kh * c->kw * c->cin; p.kp = dcn_f16_kpad(p.K); p.transposed = 0;
@@ -1047,7 +1051,7 @@ extern "C" int dcn_conv_dgrad_f16(const dcn_conv_desc* c, const float* dout, con
                                   void* stream) {
     if (!valid_desc16(c) || !dout || !wt_hi || !wt_lo || !din || (c->ldc % 4) != 0 || !(w_scale > 0.f)) return DCN_E_INVALID;
     GemmConv p;
-    p.src = dout; p.wm = nullptr; p.bias = nullptr; p.add = add; p.dst = din; p.bn_partial = nullptr;
+    p.src = dout; p.wm = nullptr; p.bias = nullptr; p.add = add; p.dst = din; p.bn_partial = nullptr; p.out_absmax = nullptr;
     p.wh = (const _Float16*)wt_hi; p.wl = (const _Float16*)wt_lo; p.a_absmax = dout_absmax; p.b_inv_scale = 1.f / w_scale;
     p.hs = c->hout; p.ws = c->wout; p.cs = c->ldc;
     p.hd = c->hin; p.wd = c->win; p.cd = c->cin;
@@ -1083,15 +1087,15 @@ extern "C" size_t dcn_conv_wgrad_workspace_f16(const dcn_conv_desc* c) {
     return (size_t)splits * c->cout * c->kh * c->kw * c->cin * sizeof(float);
 }
 
-extern "C" int dcn_conv_wgrad_f16(const dcn_conv_desc* c, const void* xs, int xs_is_fp32, const void* dq,
-                                  const float* dout_absmax, float* dw, void* slabs, void* stream) {
+extern "C" int dcn_conv_wgrad_f16(const dcn_conv_desc* c, const void* xs, int xs_is_fp32, const float* x_absmax,
+                                  const void* dq, const float* dout_absmax, float* dw, void* slabs, void* stream) {
     if (!valid_desc16(c) || !xs || !dq || !dw || !slabs || (c->ldc % 4) != 0) return DCN_E_INVALID;
     const int64_t x_bytes = (int64_t)c->n * c->hin * c->win * c->cin * 4;
     const int64_t d_bytes = (int64_t)dcn_grad_blocked_bytes(c->n * c->hout * c->wout, c->ldc);
     if (x_bytes > ((int64_t)1 << 31) || d_bytes > ((int64_t)1 << 31)) return DCN_E_UNSUPPORTED;
     WgradF16 p;
     p.xs = xs; p.dq = dq;
-    p.d_absmax = dout_absmax; p.x_bytes = (unsigned)x_bytes; p.d_bytes = (unsigned)d_bytes;
+    p.d_absmax = dout_absmax; p.x_absmax = xs_is_fp32 ? x_absmax : nullptr; p.x_bytes = (unsigned)x_bytes; p.d_bytes = (unsigned)d_bytes;
     p.hin = c->hin; p.win = c->win; p.cin = c->cin; p.hout = c->hout; p.wout = c->wout; p.cout = c->cout;
     p.kh = c->kh; p.kw = c->kw; p.stride = c->stride; p.pad = c->pad; p.dil = c->dil; p.ldo = c->ldc;
     p.M = c->n * c->hout * c->wout; p.K = c->kh * c->kw * c->cin;

@@ -22,6 +22,7 @@
 //   wgrad LDS image: [pixel][128 channels], fragments by ds_read_b64 (lane i holds channels 2i, 2i+1 of
 //   pixel 2q + (lane >> 5)): 64 consecutive dwords per half-wave, conflict-free without padding.
 #include "conv_shared.h"
+#include "dcn_tuning.h"
 
 namespace {
 
@@ -281,8 +282,7 @@ int gemm_tile_m(int M, int cd, int align) {
     int bm;
     const int ntiles = dcn::ceil_div(cd, cd <= 64 ? 64 : 128);
     bm = dcn::ceil_div(M, 128) * ntiles < 3 * 256 ? 64 : 128;
-    if (const char* e = getenv("DCN_GEMM_TILE_M")) {  // tuning / test override
-        const int v = atoi(e);
+    if (const int v = dcn::tuning().gemm_tile_m) {  // tuning / test override (dcn_tuning.h)
         if (v == 32 || v == 64 || v == 128) bm = (v == 32 && cd <= 64) ? 64 : v;
     }
     if (align > 0 && (align % bm) != 0) bm = 64;   // rows per batch-norm group: a multiple of 64 (checked by the launcher)
@@ -309,8 +309,8 @@ GemmShape gemm_shape(int M, int cd, int K, int align = 0) {
     const double waste = 1.0 - rounds / (double)(int)(rounds + 0.999999);
     g.sk = tiles < 8 * 256 && waste > 0.08 && g.nk >= 32;  // short K loops (1x1 convs) do not amortise the fix-up pass
     int wgs = 512;
-    if (const char* e = getenv("DCN_GEMM_SK")) {  // tuning / test override: 0 = off, 1 = as decided, N > 1 = force N workgroups
-        const int v = atoi(e);
+    if (dcn::tuning().gemm_sk >= 0) {  // tuning / test override: 0 = off, 1 = as decided, N > 1 = force N workgroups
+        const int v = dcn::tuning().gemm_sk;
         if (v == 0) g.sk = false;
         if (v > 1) { g.sk = g.nk >= 2; wgs = v; }
     }
@@ -617,7 +617,7 @@ extern "C" int dcn_conv_forward(const dcn_conv_desc* c, const float* in, const f
                                 float* bn_partial, void* workspace, void* stream) {
     if (!valid_desc(c) || !in || !w || !out) return DCN_E_INVALID;
     GemmConv p;
-    p.src = in; p.wm = w; p.bias = bias; p.add = nullptr; p.dst = out; p.bn_partial = bn_partial;
+    p.src = in; p.wm = w; p.bias = bias; p.add = nullptr; p.dst = out; p.bn_partial = bn_partial; p.out_absmax = nullptr;
     p.hs = c->hin; p.ws = c->win; p.cs = c->cin; p.hd = c->hout; p.wd = c->wout; p.cd = c->cout;
     p.kh = c->kh; p.kw = c->kw; p.stride = c->stride; p.pad = c->pad; p.dil = c->dil; p.ldc = c->ldc;
     p.M = c->n * c->hout * c->wout; p.K = c->kh * c->kw * c->cin; p.transposed = 0; p.relu = 0;
@@ -629,7 +629,7 @@ extern "C" int dcn_conv_dgrad(const dcn_conv_desc* c, const float* dout, const f
                               void* workspace, void* stream) {
     if (!valid_desc(c) || !dout || !wt || !din || (c->ldc % 4) != 0) return DCN_E_INVALID;
     GemmConv p;
-    p.src = dout; p.wm = wt; p.bias = nullptr; p.add = add; p.dst = din; p.bn_partial = nullptr;
+    p.src = dout; p.wm = wt; p.bias = nullptr; p.add = add; p.dst = din; p.bn_partial = nullptr; p.out_absmax = nullptr;
     p.hs = c->hout; p.ws = c->wout; p.cs = c->ldc;   // source channels = (padded) forward output channels
     p.hd = c->hin; p.wd = c->win; p.cd = c->cin;
     p.kh = c->kh; p.kw = c->kw; p.stride = c->stride; p.pad = c->pad; p.dil = c->dil; p.ldc = c->cin;

@@ -37,6 +37,7 @@ struct GemmConv {
     float* dst;         // [M][ldc]
     float* bn_partial;  // [mtiles][2][cd] or null
     float* sk_partial;  // stream-K: [2 * workgroups][BM*BN] parked accumulators (fragment order)
+    float* out_absmax;  // null, or device scalar raised to max |dst| (fused inference path: the next layer's operand pre-scale)
     // split-fp16 path only: pre-split weights [cd][kp] (hi, lo), device scalar with max|src| (or null), 1 / weight scale
     const _Float16* wh;
     const _Float16* wl;
@@ -74,6 +75,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmConv& p, f32x16 (&acc)[T
     const int fi = lane & 31, fh = lane >> 5;
     const int m0 = mt * G::BM, n0 = nt * G::BN;
     float csum[TN], csq[TN];
+    float vmax = 0.f;
 #pragma unroll
     for (int tn = 0; tn < TN; ++tn) {
         csum[tn] = 0.f; csq[tn] = 0.f;
@@ -91,10 +93,20 @@ __device__ __forceinline__ void gemm_epilogue(const GemmConv& p, f32x16 (&acc)[T
                     if (p.add) v += p.add[o];
                     if (p.relu) v = fmaxf(v, 0.f);   // (inference: conv + folded BN + residual + ReLU in one pass)
                     p.dst[o] = v;
+                    vmax = fmaxf(vmax, fabsf(v));
                 }
                 csum[tn] += acc[tm][tn][r];
                 csq[tn] = fmaf(acc[tm][tn][r], acc[tm][tn][r], csq[tn]);
             }
+        }
+    }
+    if (p.out_absmax) {   // one atomic per wavefront at most (look before the atomic: the value only grows)
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) vmax = fmaxf(vmax, __shfl_xor(vmax, o, 64));
+        if (lane == 0 && vmax > 0.f) {
+            const unsigned bits = __float_as_uint(vmax);
+            if (bits > __atomic_load_n(reinterpret_cast<unsigned*>(p.out_absmax), __ATOMIC_RELAXED))
+                atomicMax(reinterpret_cast<unsigned*>(p.out_absmax), bits);
         }
     }
     if (p.bn_partial) {

@@ -1,0 +1,27 @@
+// Process-wide tuning / test overrides of the convolution launchers.  The environment is read ONCE (first use), not on
+// every launch; dcn_reload_env() (include/dcn_hip.h) re-reads it -- the test-suite calls it after changing a variable.
+//   DCN_CONV_MODE           fp32 | f16x3    default arithmetic of new plans
+//   DCN_BACKWARD_OVERLAP    0: weight-gradient GEMMs stay on the caller's stream
+//   DCN_GEMM_TILE_M         32 | 64 | 128 | 256   workgroup-tile height of the gather-GEMM kernels
+//   DCN_GEMM_SK             0: no stream-K, 1: as decided, N > 1: force N workgroups
+//   DCN_GEMM_SK_MIN_GAIN    stage times stream-K must save to be chosen (split-fp16 kernel)
+//   DCN_GEMM_UNI            0: disable the uniform-tap fast path
+//   DCN_WGRAD_SPLITS        force the pixel-range split count of the split-fp16 wgrad kernel
+#pragma once
+
+namespace dcn {
+
+struct Tuning {
+    int conv_mode = -1;          // -1: unset
+    int conv_mode_invalid = 0;   // DCN_CONV_MODE holds something else than fp32 / f16x3
+    int backward_overlap = 1;
+    int gemm_tile_m = 0;         // 0: unset
+    int gemm_sk = -1;            // -1: unset
+    double gemm_sk_min_gain = 20.0;
+    int gemm_uni = 1;
+    int wgrad_splits = 0;        // 0: unset
+};
+
+const Tuning& tuning();
+
+}  // namespace dcn

@@ -1,0 +1,45 @@
+// Environment overrides, read once (dcn_tuning.h).
+#include <atomic>
+#include <cstdlib>
+#include <cstring>
+#include <mutex>
+
+#include "dcn_common.h"
+#include "dcn_tuning.h"
+
+namespace dcn {
+namespace {
+
+Tuning g_tuning;
+std::once_flag g_once;
+std::mutex g_mu;
+
+void read_env(Tuning& t) {
+    t = Tuning();
+    if (const char* m = getenv("DCN_CONV_MODE")) {
+        if (!strcmp(m, "fp32")) t.conv_mode = DCN_CONV_FP32;
+        else if (!strcmp(m, "f16x3")) t.conv_mode = DCN_CONV_F16X3;
+        else t.conv_mode_invalid = 1;
+    }
+    if (const char* e = getenv("DCN_BACKWARD_OVERLAP")) t.backward_overlap = atoi(e) != 0;
+    if (const char* e = getenv("DCN_GEMM_TILE_M")) t.gemm_tile_m = atoi(e);
+    if (const char* e = getenv("DCN_GEMM_SK")) t.gemm_sk = atoi(e);
+    if (const char* e = getenv("DCN_GEMM_SK_MIN_GAIN")) t.gemm_sk_min_gain = atof(e);
+    if (const char* e = getenv("DCN_GEMM_UNI")) t.gemm_uni = atoi(e) != 0;
+    if (const char* e = getenv("DCN_WGRAD_SPLITS")) t.wgrad_splits = atoi(e);
+}
+
+}  // namespace
+
+const Tuning& tuning() {
+    std::call_once(g_once, [] { read_env(g_tuning); });
+    return g_tuning;
+}
+
+}  // namespace dcn
+
+extern "C" void dcn_reload_env(void) {
+    (void)dcn::tuning();   // make sure the one-time read cannot run after (and undo) this one
+    std::lock_guard<std::mutex> lock(dcn::g_mu);
+    dcn::read_env(dcn::g_tuning);
+}

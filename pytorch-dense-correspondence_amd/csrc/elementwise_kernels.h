@@ -4,7 +4,8 @@
 
 namespace dcn {
 
-void launch_nchw3_to_nhwc4(const float* img, float* out, int n, int hw, hipStream_t st);
+// absmax (optional): raised to max |img|
+void launch_nchw3_to_nhwc4(const float* img, float* out, int n, int hw, float* absmax, hipStream_t st);
 void launch_pad_c3_to_c4(const float* w, float* wp, int64_t rows, hipStream_t st);
 void launch_unpad_c4_to_c3(const float* wp, float* w, int64_t rows, hipStream_t st);
 void launch_pad_rows(const float* src, float* dst, int64_t rows, int d, int ld, hipStream_t st);
@@ -18,8 +19,9 @@ void launch_bn_finalize(const float* partial, int tiles_per_group, int groups, i
                         int training, float* stats, hipStream_t st);
 // y = [relu](x*scale1 + shift1 + (res ? (stats2 ? res*scale2 + shift2 : res) : 0))
 // relu_mask (optional, with relu): one byte per float4 of y, bit j = y[4i + j] > 0 (read back by launch_bn_bwd)
+// absmax (optional): device scalar raised to max |y| (pre-scale of the split-fp16 convolution that consumes y)
 void launch_bn_apply(const float* x, const float* stats1, const float* res, const float* stats2, int relu, float* y,
-                     unsigned char* relu_mask, int C, int64_t rows, int groups, hipStream_t st);
+                     unsigned char* relu_mask, int C, int64_t rows, int groups, float* absmax, hipStream_t st);
 int bn_bwd_chunks(int64_t rows_per_group);
 // partial: groups*bn_bwd_chunks(rows/groups)*4*C floats, k123: groups*3*C floats.  g_out (nullable) receives the
 // relu-masked dy.  absmax (optional): raised to an upper bound of max |dx|

@@ -13,14 +13,36 @@
 
 namespace dcn {
 
+// max |.| over a wavefront, then one atomic per wavefront (non-negative floats order like their bit patterns).
+// The abs-max of every tensor that feeds a split-fp16 convolution (activations in forward, gradients in backward) selects
+// that operand's power-of-two pre-scale; a NaN anywhere propagates through the scaled products exactly as it would
+// through the fp32 ones.  EVERY lane of the wavefront must call this (shuffles).
+__device__ __forceinline__ void wave_atomic_absmax(float amax, float* absmax) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) amax = fmaxf(amax, __shfl_xor(amax, o));
+    // thousands of wavefronts target one address: look first (plain load, served by L2) and only the few wavefronts that
+    // would actually raise the value issue the atomic -- the value only ever grows, so a stale look is merely conservative
+    if ((threadIdx.x & 63) == 0 && amax > 0.f) {
+        const unsigned bits = __float_as_uint(amax);
+        if (bits > __atomic_load_n(reinterpret_cast<unsigned*>(absmax), __ATOMIC_RELAXED))
+            atomicMax(reinterpret_cast<unsigned*>(absmax), bits);
+    }
+}
+
 // ---------------------------------------------------------------------------------------------- layout
 __global__ void __launch_bounds__(256)
-nchw3_to_nhwc4_kernel(const float* __restrict__ img, float* __restrict__ out, int hw, int64_t total) {
+nchw3_to_nhwc4_kernel(const float* __restrict__ img, float* __restrict__ out, int hw, int64_t total,
+                      float* __restrict__ absmax) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;  // over n*hw
-    if (i >= total) return;
-    const int64_t n = i / hw, p = i - n * hw;
-    const float* s = img + n * 3 * hw + p;
-    reinterpret_cast<float4*>(out)[i] = make_float4(s[0], s[hw], s[2 * (int64_t)hw], 0.f);
+    float m = 0.f;
+    if (i < total) {
+        const int64_t n = i / hw, p = i - n * hw;
+        const float* s = img + n * 3 * hw + p;
+        const float4 v = make_float4(s[0], s[hw], s[2 * (int64_t)hw], 0.f);
+        reinterpret_cast<float4*>(out)[i] = v;
+        m = fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fabsf(v.z));
+    }
+    if (absmax) wave_atomic_absmax(m, absmax);
 }
 
 // wp[o][tap][4] = (w[o][tap][0..2], 0)   and back (gradient): w[o][tap][c] = wp[o][tap][c], c < 3
@@ -121,7 +143,8 @@ __global__ void __launch_bounds__(256)
 bn_apply_kernel(const float* __restrict__ x, const float* __restrict__ s1, const float* __restrict__ b1,
                 const float* __restrict__ res, const float* __restrict__ s2, const float* __restrict__ b2, int relu,
                 float* __restrict__ y, unsigned char* __restrict__ relu_mask, int c4n, int64_t total4, int64_t group4,
-                int gstride) {
+                int gstride, float* __restrict__ absmax) {
+    float amax = 0.f;   // max |y| of this work-item: the pre-scale of the split-fp16 convolution that reads y
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total4; i += (int64_t)gridDim.x * 256) {
         const int c = (int)(i % c4n) * 4 + (i >= group4 ? gstride : 0);   // (at most two groups: second group's statistics)
         const float4 v = reinterpret_cast<const float4*>(x)[i];
@@ -139,11 +162,13 @@ bn_apply_kernel(const float* __restrict__ x, const float* __restrict__ s1, const
         }
         if (relu) { o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f); }
         reinterpret_cast<float4*>(y)[i] = o;
+        amax = fmaxf(fmaxf(amax, fmaxf(fabsf(o.x), fabsf(o.y))), fmaxf(fabsf(o.z), fabsf(o.w)));
         // which of the four outputs are positive: ONE byte per float4, so that the backward passes read 1 byte instead
         // of 16 to rebuild the ReLU mask
         if (relu_mask)
             relu_mask[i] = (unsigned char)((o.x > 0.f ? 1 : 0) | (o.y > 0.f ? 2 : 0) | (o.z > 0.f ? 4 : 0) | (o.w > 0.f ? 8 : 0));
     }
+    if (absmax) wave_atomic_absmax(amax, absmax);
 }
 
 // relu-masked upstream gradient: from the one-byte-per-float4 mask written by the forward apply pass when there is one,
@@ -286,21 +311,6 @@ bn_bwd_finalize_kernel(const float* __restrict__ partial, int chunks, int groups
             if (bound > 0.f && bits > __atomic_load_n(reinterpret_cast<unsigned*>(absmax), __ATOMIC_RELAXED))
                 atomicMax(reinterpret_cast<unsigned*>(absmax), bits);
         }
-    }
-}
-
-// max |.| over a wavefront, then one atomic per wavefront (non-negative floats order like their bit patterns).
-// The abs-max of every gradient tensor feeds the power-of-two pre-scale of the split-fp16 convolutions; a NaN
-// anywhere propagates through the scaled products exactly as it would through the fp32 ones.
-__device__ __forceinline__ void wave_atomic_absmax(float amax, float* absmax) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) amax = fmaxf(amax, __shfl_xor(amax, o));
-    // thousands of wavefronts target one address: look first (plain load, served by L2) and only the few wavefronts that
-    // would actually raise the value issue the atomic -- the value only ever grows, so a stale look is merely conservative
-    if ((threadIdx.x & 63) == 0 && amax > 0.f) {
-        const unsigned bits = __float_as_uint(amax);
-        if (bits > __atomic_load_n(reinterpret_cast<unsigned*>(absmax), __ATOMIC_RELAXED))
-            atomicMax(reinterpret_cast<unsigned*>(absmax), bits);
     }
 }
 
@@ -603,9 +613,9 @@ static inline unsigned blocks_for(int64_t n, int cap = 0) {
 }
 constexpr int kGridCap = 256 * 8;  // grid-stride kernels: 8 workgroups per CU
 
-void launch_nchw3_to_nhwc4(const float* img, float* out, int n, int hw, hipStream_t st) {
+void launch_nchw3_to_nhwc4(const float* img, float* out, int n, int hw, float* absmax, hipStream_t st) {
     const int64_t total = (int64_t)n * hw;
-    hipLaunchKernelGGL(nchw3_to_nhwc4_kernel, dim3(blocks_for(total)), dim3(256), 0, st, img, out, hw, total);
+    hipLaunchKernelGGL(nchw3_to_nhwc4_kernel, dim3(blocks_for(total)), dim3(256), 0, st, img, out, hw, total, absmax);
 }
 void launch_pad_c3_to_c4(const float* w, float* wp, int64_t rows, hipStream_t st) {
     hipLaunchKernelGGL(pad_c3_to_c4_kernel, dim3(blocks_for(rows)), dim3(256), 0, st, w, wp, rows);
@@ -624,10 +634,11 @@ void launch_bn_finalize(const float* partial, int tiles_per_group, int groups, i
                        stats + 3 * C, 4 * C);
 }
 void launch_bn_apply(const float* x, const float* stats1, const float* res, const float* stats2, int relu, float* y,
-                     unsigned char* relu_mask, int C, int64_t rows, int groups, hipStream_t st) {
+                     unsigned char* relu_mask, int C, int64_t rows, int groups, float* absmax, hipStream_t st) {
     const int64_t total4 = rows * (C / 4);
     hipLaunchKernelGGL(bn_apply_kernel, dim3(blocks_for(total4, kGridCap)), dim3(256), 0, st, x, stats1, stats1 + C, res,
-                       stats2, stats2 ? stats2 + C : nullptr, relu, y, relu_mask, C / 4, total4, total4 / groups, 4 * C);
+                       stats2, stats2 ? stats2 + C : nullptr, relu, y, relu_mask, C / 4, total4, total4 / groups, 4 * C,
+                       absmax);
 }
 int bn_bwd_chunks(int64_t rows_per_group) {
     // enough row chunks that even a 64-channel layer launches >= ~1000 workgroups (HBM-bound pass: fill all 256 CUs)
@@ -718,5 +729,50 @@ extern "C" int dcn_upsample_backward(const float* gout, int n, int hl, int wl, i
                                      float* tmp, void* stream) {
     if (!gout || !glow || !tmp || n < 1 || hl < 1 || wl < 1 || d < 1 || ldl < d || h < 1 || w < 1) return DCN_E_INVALID;
     dcn::launch_upsample_bwd(gout, n, hl, wl, ldl, d, h, w, tmp, glow, nullptr, (hipStream_t)stream);
+    return dcn::check_launch();
+}
+
+// ---- batch norm / max pool as stand-alone calls (unit tests; the engine uses the launchers above directly)
+extern "C" int dcn_bn_forward(const float* x, const float* bn_partial, int mtiles, int c, int64_t rows, const float* gamma,
+                              const float* beta, float* running_mean, float* running_var, float momentum, float eps,
+                              int training, const float* res, int relu, float* y, unsigned char* relu_mask, float* stats,
+                              void* stream) {
+    if (!x || !gamma || !beta || !y || !stats || c < 4 || (c % 4) != 0 || rows < 1) return DCN_E_INVALID;
+    if (training ? (!bn_partial || mtiles < 1) : (!running_mean || !running_var)) return DCN_E_INVALID;
+    hipStream_t st = (hipStream_t)stream;
+    dcn::launch_bn_finalize(bn_partial, mtiles, 1, c, (double)rows, gamma, beta, running_mean, running_var, momentum, eps,
+                            training, stats, st);
+    dcn::launch_bn_apply(x, stats, res, nullptr, relu, y, relu_mask, c, rows, 1, nullptr, st);
+    return dcn::check_launch();
+}
+
+extern "C" size_t dcn_bn_backward_workspace(int64_t rows, int c) {
+    if (rows < 1 || c < 4) return 0;
+    return ((size_t)dcn::bn_bwd_chunks(rows) * 4 * (size_t)c + 3 * (size_t)c) * sizeof(float);
+}
+
+extern "C" int dcn_bn_backward(const float* dy, const unsigned char* relu_mask, const float* x, const float* stats,
+                               const float* gamma, int c, int64_t rows, float* dgamma, float* dbeta, float* dx, float* g_out,
+                               void* workspace, void* stream) {
+    if (!dy || !x || !stats || !gamma || !dgamma || !dbeta || !dx || !workspace || c < 4 || (c % 4) != 0 || rows < 1)
+        return DCN_E_INVALID;
+    float* partial = (float*)workspace;
+    float* k123 = partial + (size_t)dcn::bn_bwd_chunks(rows) * 4 * c;
+    dcn::launch_bn_bwd(dy, nullptr, relu_mask, x, stats, gamma, c, rows, 1, partial, dgamma, dbeta, k123, dx, g_out, nullptr,
+                       nullptr, (hipStream_t)stream);
+    return dcn::check_launch();
+}
+
+extern "C" int dcn_maxpool_forward(const float* in, int n, int hin, int win, int c, float* out, unsigned char* argmax,
+                                   void* stream) {
+    if (!in || !out || n < 1 || hin < 1 || win < 1 || c < 4 || (c % 4) != 0) return DCN_E_INVALID;
+    dcn::launch_maxpool_fwd(in, out, argmax, n, hin, win, (hin + 2 - 3) / 2 + 1, (win + 2 - 3) / 2 + 1, c, (hipStream_t)stream);
+    return dcn::check_launch();
+}
+
+extern "C" int dcn_maxpool_backward(const float* gout, const unsigned char* argmax, int n, int hin, int win, int c,
+                                    float* gin, void* stream) {
+    if (!gout || !argmax || !gin || n < 1 || hin < 1 || win < 1 || c < 4 || (c % 4) != 0) return DCN_E_INVALID;
+    dcn::launch_maxpool_bwd(gout, argmax, gin, n, hin, win, (hin + 2 - 3) / 2 + 1, (win + 2 - 3) / 2 + 1, c, (hipStream_t)stream);
     return dcn::check_launch();
 }

@@ -32,6 +32,19 @@ class ConvDesc(ctypes.Structure):
 SYMBOLS = {
     # name: (restype, argtypes)
     "dcn_version": (c_char_p, []),
+    "dcn_reload_env": (None, []),
+    "dcn_plan_num_activation_slots": (c_int, [c_void_p]),
+    "dcn_plan_activation_absmax_offset": (c_size_t, [c_void_p]),
+    "dcn_plan_num_grad_buckets": (c_int, [c_void_p]),
+    "dcn_plan_grad_bucket_first_param": (c_int, [c_void_p, c_int]),
+    "dcn_plan_stream_wait_grad_bucket": (c_int, [c_void_p, c_int, c_void_p]),
+    "dcn_bn_forward": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_float,
+                               c_float, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "dcn_bn_backward_workspace": (c_size_t, [c_int64, c_int]),
+    "dcn_bn_backward": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int64, c_void_p, c_void_p, c_void_p,
+                                c_void_p, c_void_p, c_void_p]),
+    "dcn_maxpool_forward": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
+    "dcn_maxpool_backward": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
     "dcn_loss_workspace_bytes": (c_size_t, [c_int, c_int64]),
     "dcn_contrastive_loss_forward": (c_int, [c_void_p, c_void_p, c_int, c_int64, c_int, c_void_p, c_void_p, c_void_p,
                                              c_void_p, ctypes.POINTER(LossConfig), c_void_p, c_void_p, c_void_p,
@@ -66,8 +79,8 @@ SYMBOLS = {
     "dcn_split_rows_f16": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_float, c_void_p]),
     "dcn_conv_num_mtiles_f16": (c_int, [ctypes.POINTER(ConvDesc)]),
     "dcn_conv_gemm_workspace_f16": (c_size_t, [ctypes.POINTER(ConvDesc), c_int]),
-    "dcn_conv_forward_f16": (c_int, [ctypes.POINTER(ConvDesc), c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_void_p,
-                                     c_void_p, c_void_p, c_void_p]),
+    "dcn_conv_forward_f16": (c_int, [ctypes.POINTER(ConvDesc), c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_void_p,
+                                     c_void_p, c_void_p, c_void_p, c_void_p]),
     "dcn_conv_dgrad_f16": (c_int, [ctypes.POINTER(ConvDesc), c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_void_p,
                                    c_void_p, c_void_p, c_void_p]),
     "dcn_triplet_loss_workspace_bytes": (c_size_t, [c_int64]),
@@ -87,14 +100,14 @@ SYMBOLS = {
     "dcn_plan_create_grouped": (c_int, [c_char_p, c_int, c_int, c_int, c_int, c_int, c_int, ctypes.POINTER(c_void_p)]),
     "dcn_plan_set_conv_mode": (c_int, [c_void_p, c_int]),
     "dcn_plan_conv_mode": (c_int, [c_void_p]),
-    "dcn_conv_wgrad_f16": (c_int, [ctypes.POINTER(ConvDesc), c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
+    "dcn_conv_wgrad_f16": (c_int, [ctypes.POINTER(ConvDesc), c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                    c_void_p]),
     "dcn_split_weights_f16": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int,
                                       c_float, c_void_p]),
     "dcn_split_weights_scaled_f16": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                              c_void_p, c_int, c_float, c_void_p]),
-    "dcn_conv_forward_fused_f16": (c_int, [ctypes.POINTER(ConvDesc), c_void_p, c_void_p, c_void_p, c_float, c_void_p,
-                                           c_void_p, c_int, c_void_p, c_void_p, c_void_p]),
+    "dcn_conv_forward_fused_f16": (c_int, [ctypes.POINTER(ConvDesc), c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_void_p,
+                                           c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
     "dcn_split_act_f16": (c_int, [c_void_p, c_void_p, c_int64, c_void_p]),
     "dcn_grad_blocked_bytes": (c_size_t, [c_int, c_int]),
     "dcn_split_grad_blocked_f16": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p]),

@@ -46,6 +46,12 @@ class Plan(object):
         self.grad_offsets = [0]
         for nmel in self.param_numel:
             self.grad_offsets.append((self.grad_offsets[-1] + nmel + 3) // 4 * 4)  # keep every gradient 16-B aligned
+        # gradient buckets in the order backward completes them: (first float, one-past-last float) of the flat buffer
+        firsts = [lib.dcn_plan_grad_bucket_first_param(handle, k) for k in range(lib.dcn_plan_num_grad_buckets(handle))]
+        ends = [len(self.param_numel)] + firsts[:-1]
+        self.grad_buckets = [(self.grad_offsets[a], self.grad_offsets[b]) for a, b in zip(firsts, ends)]
+        self.num_activation_slots = int(lib.dcn_plan_num_activation_slots(handle))
+        self.activation_absmax_offset = int(lib.dcn_plan_activation_absmax_offset(handle))
 
     @property
     def conv_mode(self):
@@ -54,6 +60,16 @@ class Plan(object):
 
     def set_conv_mode(self, mode):
         _lib.check(_lib.get().dcn_plan_set_conv_mode(self.handle, CONV_MODES.index(mode)), "dcn_plan_set_conv_mode")
+
+    def stream_wait_grad_bucket(self, k, stream_ptr):
+        """Make the stream wait until every gradient of bucket k of the LAST backward pass has been computed."""
+        _lib.check(_lib.get().dcn_plan_stream_wait_grad_bucket(self.handle, k, stream_ptr), "dcn_plan_stream_wait_grad_bucket")
+
+    def activation_range(self, saved):
+        """(abs-max per activation slot [n] fp32, status int) of the forward call that filled ``saved`` (device tensors are
+        sliced, not synchronised: call .item() / .cpu() to look).  Status bit 0: a convolution input was not finite."""
+        o, n = self.activation_absmax_offset, self.num_activation_slots
+        return saved[o:o + 4 * n].view(torch.float32), saved[o + 4 * n:o + 4 * n + 4].view(torch.int32)
 
     def profile_begin(self):
         _lib.check(_lib.get().dcn_plan_profile_begin(self.handle), "dcn_plan_profile_begin")
@@ -140,7 +156,9 @@ class _BackboneFn(torch.autograd.Function):
                                       _lib.ptr(ws), _lib.stream_ptr())
         _lib.check(rc, "dcn_backbone_forward")
         ctx.plan = plan
+        plan.last_activation_range = plan.activation_range(saved)   # views into this call's arena (no sync)
         ctx.grad_sink = getattr(bn_running, "grad_sink", None)
+        ctx.grad_owner = getattr(bn_running, "grad_owner", None)
         ctx.grad_probe = (params[0], params[-1])  # to verify at backward time that .grad still aliases the sink
         ctx.saved_arena = saved
         ctx.kparams = kparams
@@ -175,6 +193,9 @@ class _BackboneFn(torch.autograd.Function):
         dev = g.device
         ws = torch.empty(plan.workspace_bytes, dtype=torch.uint8, device=dev)
         flat = torch.empty(plan.grad_offsets[-1], dtype=torch.float32, device=dev)
+        for i, nmel in enumerate(plan.param_numel):   # the <= 3 alignment floats behind a tensor are never written by the
+            if nmel % 4:                              # engine: keep them zero, the buffer is ADDED into the shared sink
+                flat[plan.grad_offsets[i] + nmel:plan.grad_offsets[i + 1]].zero_()
         base = flat.data_ptr()
         gptr = (ctypes.c_void_p * len(plan.param_numel))(*[base + 4 * o for o in plan.grad_offsets[:-1]])
         pptr = (ctypes.c_void_p * len(ctx.kparams))(*[p.data_ptr() for p in ctx.kparams])
@@ -189,21 +210,31 @@ class _BackboneFn(torch.autograd.Function):
                    last.grad.data_ptr() == sink.data_ptr() + 4 * plan.grad_offsets[-2])
         if aliased:
             # the parameters' .grad are views of ONE flat buffer with this very layout (dcn_hip.distributed.FlatGradients):
-            # accumulate with a single kernel instead of ~110 autograd AccumulateGrad launches
-            sink.add_(flat)
+            # accumulate with a single kernel instead of ~110 autograd AccumulateGrad launches -- or, data-parallel, bucket
+            # by bucket on the communication stream as the engine's grad-ready events fire, each followed by its all-reduce
+            owner = ctx.grad_owner
+            if owner is not None and owner.wants_buckets():
+                owner.accumulate_and_reduce_buckets(plan, flat)
+            else:
+                sink.add_(flat)
             return (None,) * (7 + len(plan.param_numel))
+        if sink is not None and ctx.grad_owner is not None:
+            ctx.grad_owner.note_detached()   # e.g. optimizer.zero_grad(set_to_none=True) dropped the views: see all_reduce_mean
         return (None, None, None, None, None, None, None) + tuple(_grad_views(flat, plan))
 
 
 class _RunningList(list):
     """bn running-statistic tensors + an optional flat gradient sink (non-tensor payload of the autograd call)."""
     grad_sink = None
+    grad_owner = None
 
 
-def backbone_forward(image, plan, params, bn_running, training, normalize=False, momentum=0.1, eps=1e-5, grad_sink=None):
+def backbone_forward(image, plan, params, bn_running, training, normalize=False, momentum=0.1, eps=1e-5, grad_sink=None,
+                     grad_owner=None):
     """image [N,3,H,W] -> descriptors, logical [N,D,H,W] in channels_last memory.
     ``params`` / ``bn_running`` follow ``plan.param_names`` / ``plan.bn_names`` (running_mean, running_var per BN).
     ``grad_sink``: flat fp32 buffer laid out like ``plan.grad_offsets`` that the parameters' ``.grad`` alias."""
     rl = _RunningList(bn_running)
     rl.grad_sink = grad_sink
+    rl.grad_owner = grad_owner   # dcn_hip.distributed.FlatGradients that owns grad_sink (bucketed all-reduce), or None
     return _BackboneFn.apply(image, plan, rl, training, normalize, momentum, eps, *params)

@@ -37,9 +37,12 @@ class PairLists(object):
         self.total = self.offsets_host[-1]
 
     @staticmethod
-    def from_lists(pairs, device):
+    def from_lists(pairs, device, hw=None):
         """pairs: sequence of 8-tuples (matches_a, matches_b, masked_a, masked_b, background_a, background_b,
-        blind_a, blind_b) -- the order loss_composer.get_loss takes them (loss_composer.py:7-12)."""
+        blind_a, blind_b) -- the order loss_composer.get_loss takes them (loss_composer.py:7-12).
+        ``hw`` (optional): pixels per image; lists that arrive on the HOST are then range-checked here (the reference's
+        index_select raises IndexError on an out-of-range index; device-resident lists are checked by the kernel, which
+        skips such pairs and raises the status word -- see loss_composer.get_loss_batched)."""
         chunks_a, chunks_b, offsets = [], [], [0]
         for lists in pairs:
             assert len(lists) == 8
@@ -50,6 +53,11 @@ class PairLists(object):
                     continue
                 if a.numel() != b.numel():
                     raise ValueError("pair list %d: a has %d entries, b has %d" % (t, a.numel(), b.numel()))
+                if hw is not None:
+                    for side in (a, b):
+                        if side.device.type == "cpu" and side.numel() and (int(side.max()) >= hw or int(side.min()) < 0):
+                            raise IndexError("pair list %d holds a pixel index outside [0, %d) (lists built for another "
+                                             "image size?)" % (t, hw))
                 chunks_a.append(a.reshape(-1))
                 chunks_b.append(b.reshape(-1))
                 offsets.append(offsets[-1] + a.numel())
@@ -85,6 +93,9 @@ def _run_forward(desc_a, desc_b, lists, cfg, want_per_term):
     lib = _lib.get()
     _lib.require_device(desc_a, desc_b, lists.idx_a, lists.idx_b)
     P, HW, D = desc_a.shape
+    if desc_a.dtype != torch.float32 or desc_b.dtype != torch.float32:
+        raise TypeError("dcn_hip loss kernels take float32 descriptor maps, got %s / %s (cast with .float(); the gradient "
+                        "then flows back through the cast)" % (desc_a.dtype, desc_b.dtype))
     if desc_b.shape != desc_a.shape or P != lists.num_pairs:
         raise ValueError("descriptor maps %s / %s do not match %d pair lists" %
                          (tuple(desc_a.shape), tuple(desc_b.shape), lists.num_pairs))

@@ -12,7 +12,7 @@ def find_best_matches(res, queries, mask=None, return_norm_diffs=False):
     d = int(shape[-1])
     res2 = res.reshape(-1, d).contiguous().float()
     q = queries.reshape(-1, d).contiguous().float()
-    m = None if mask is None else mask.reshape(-1).to(torch.uint8).contiguous()
+    m = None if mask is None else (mask.reshape(-1) != 0).to(torch.uint8).contiguous()   # non-zero == object, like the reference
     _lib.require_device(res2, q, m)
     hw, nq = res2.shape[0], q.shape[0]
     dev = res2.device

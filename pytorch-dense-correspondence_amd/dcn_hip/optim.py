@@ -56,6 +56,16 @@ class Adam(torch.optim.Optimizer):
         super(Adam, self).__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, amsgrad=False,
                                                 maximize=False))
 
+    def zero_grad(self, set_to_none=True):
+        """``optimizer.zero_grad()`` of training.py:325.  When the gradients are views of a flat buffer
+        (``dcn_hip.distributed.FlatGradients(...).attach(optimizer)``) they are zeroed IN PLACE with one kernel whatever
+        ``set_to_none`` says -- dropping the views would detach ``p.grad`` from the buffer the collective averages."""
+        flat = getattr(self, "_flat_gradients", None)
+        if flat is not None:
+            flat.zero_()
+            return
+        super(Adam, self).zero_grad(set_to_none=set_to_none)
+
     @torch.no_grad()
     def step(self, closure=None):
         loss = None

@@ -65,11 +65,18 @@ def get_loss_batched(pixelwise_contrastive_loss, match_type, image_a_pred, image
     """image_*_pred: [B, W*H, D]; pair_lists: ``dcn_hip.loss.PairLists`` for the B pairs (or a sequence of 8-tuples).
     Returns (loss, terms [B,5], hard_negatives int32 [B,4]) -- all device tensors, no sync."""
     if not isinstance(pair_lists, _k.PairLists):
-        pair_lists = _k.PairLists.from_lists(pair_lists, image_a_pred.device)
+        pair_lists = _k.PairLists.from_lists(pair_lists, image_a_pred.device, hw=int(image_a_pred.shape[1]))
     cfg = _kernel_config(pixelwise_contrastive_loss, _match_type_code(match_type))
     if cfg.compose == _k.COMPOSE_WITHIN_SCENE:
         _check_pixel_layout(pixelwise_contrastive_loss, pair_lists)
     loss, terms, sums, hard, status, _ = _k.contrastive_loss(image_a_pred, image_b_pred, pair_lists, cfg)
+    # status (device int32): 1 if a device-resident list held an index outside [0, H*W) -- the kernel skips such pairs where
+    # the reference's index_select raises.  Kept on the loss object (no sync on the hot path); with `debug` on it is read
+    # and raised immediately.
+    pixelwise_contrastive_loss.last_status = status
+    if getattr(pixelwise_contrastive_loss, "debug", False) and int(status.item()) != 0:
+        raise IndexError("pixel index outside [0, %d) in a pair list (pixelwise_contrastive_loss.debug check)"
+                         % int(image_a_pred.shape[1]))
     return loss, terms, hard
 
 
@@ -79,7 +86,8 @@ def get_loss(pixelwise_contrastive_loss, match_type, image_a_pred, image_b_pred,
     """:7-67.  -> (loss, match_loss, masked_non_match_loss, background_non_match_loss, blind_non_match_loss)"""
     lists = _k.PairLists.from_lists([(matches_a, matches_b, masked_non_matches_a, masked_non_matches_b,
                                       background_non_matches_a, background_non_matches_b,
-                                      blind_non_matches_a, blind_non_matches_b)], image_a_pred.device)
+                                      blind_non_matches_a, blind_non_matches_b)], image_a_pred.device,
+                                    hw=int(image_a_pred.shape[1]))
     loss, terms, _hard = get_loss_batched(pixelwise_contrastive_loss, match_type, image_a_pred, image_b_pred, lists)
     t = terms[0]
     return loss, t[1], t[2], t[3], t[4]

@@ -41,10 +41,11 @@ def add_dense_correspondence_to_python_path():
 
 
 def convert_to_absolute_path(path):
-    # utils.py: paths relative to the data dir
-    if os.path.isabs(path) or get_data_dir() is None:
+    # utils.py:145-159 -- an existing directory is returned as it is, anything else is taken relative to the HOME
+    # directory (the relative paths stored in training.yaml files: path_to_network_params_folder, model folders)
+    if os.path.isdir(path):
         return path
-    return os.path.join(get_data_dir(), path)
+    return os.path.join(os.path.expanduser("~"), path)
 
 
 def getPaddedString(idx, width=6):

@@ -8,6 +8,7 @@ Each class is an ``nn.Module`` whose parameters / buffers carry the reference ch
 run any torch operator on the activations: it hands the parameter pointers to the MI355X backbone
 engine (dcn_hip / csrc/backbone_engine.hip).  There is no CPU path."""
 import math
+import warnings
 
 import torch
 import torch.nn as nn
@@ -60,6 +61,7 @@ class _DilatedResnet8s(nn.Module):
             node.register_buffer("num_batches_tracked", torch.tensor(0, dtype=torch.long))
         self.bn_momentum = 0.1
         self.bn_eps = 1e-5
+        self._pair_fallback_warned = set()
         self.reset_parameters()
 
     def reset_parameters(self):
@@ -101,9 +103,19 @@ class _DilatedResnet8s(nn.Module):
         params, running, tracked = self._tables()
         if self.training:
             torch._foreach_add_(tracked, int(groups))
-        sink = getattr(self, "_flat_grad_sink", None)
+        owner = getattr(self, "_flat_grad_owner", None)   # dcn_hip.distributed.FlatGradients, if one manages the gradients
+        self._last_plan = plan
         return _bb.backbone_forward(x, plan, params, running, self.training, normalize, self.bn_momentum, self.bn_eps,
-                                    grad_sink=sink)
+                                    grad_sink=owner.flat if owner is not None else None, grad_owner=owner)
+
+    def last_forward_status(self):
+        """(abs-max of every convolution input, status word) of the most recent forward call, as device tensors (reading
+        them synchronises).  Status bit 0 set: an activation was not finite (inf / NaN) -- every finite fp32 range is handled
+        by the split-fp16 kernels' power-of-two operand pre-scales."""
+        plan = getattr(self, "_last_plan", None)
+        if plan is None or getattr(plan, "last_activation_range", None) is None:
+            raise RuntimeError("no forward call yet")
+        return plan.last_activation_range
 
     def forward_pair(self, x_a, x_b, normalize=False):
         """forward(x_a), forward(x_b) of the reference's training step (training.py:329-333) as one grouped engine call.
@@ -111,8 +123,13 @@ class _DilatedResnet8s(nn.Module):
         if x_a.shape == x_b.shape:
             try:
                 y = self.forward(torch.cat([x_a, x_b], 0), normalize, groups=2)
-            except ValueError:
+            except ValueError as e:
                 y = None
+                key = tuple(x_a.shape)
+                if key not in self._pair_fallback_warned:   # once per shape: the fallback is correct but ~10-15 % slower
+                    self._pair_fallback_warned.add(key)
+                    warnings.warn("forward_pair: grouped launch unavailable for input %s (%s); running two forward calls"
+                                  % (key, e))
             if y is not None:
                 return y
         return self.forward(x_a, normalize), self.forward(x_b, normalize)

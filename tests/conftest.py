@@ -18,3 +18,18 @@ def pytest_configure(config):
 @pytest.fixture(scope="session")
 def golden_dir():
     return os.path.join(ROOT, "tests", "golden")
+
+
+@pytest.fixture
+def dcn_env(monkeypatch):
+    """Set DCN_* overrides for one test.  The library reads the environment ONCE (csrc/dcn_tuning.h), so: set -> reload,
+    and after the test: restore -> reload."""
+    from dcn_hip import _lib
+
+    def set_env(**kw):
+        for k, v in kw.items():
+            monkeypatch.setenv(k, str(v))
+        _lib.get().dcn_reload_env()
+    yield set_env
+    monkeypatch.undo()
+    _lib.get().dcn_reload_env()

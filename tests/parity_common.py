@@ -1,0 +1,106 @@
+"""Shared by tests/test_gpu_configs.py and tools/parity_report.py (not a test module): one full-size training step of a
+BASELINE config on the MI355X against its committed oracle fixture (tests/golden/config<N>_oracle.npz, made by
+tests/golden/make_backbone_goldens.py).  Returns the measured deviations; the caller asserts / prints."""
+import os
+
+import numpy as np
+import torch
+
+GOLDEN_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+KEYS = ("matches_a", "matches_b", "masked_non_matches_a", "masked_non_matches_b", "background_non_matches_a",
+        "background_non_matches_b", "blind_non_matches_a", "blind_non_matches_b")
+
+
+NUM_PROBES = 32
+
+
+def probe_vectors(tensor_index, numel):
+    """NUM_PROBES reproducible +-1 vectors (float64) for gradient tensor `tensor_index` (CPU mt19937: platform independent).
+    For any two gradients g, g' of the tensor, E_r (<g' - g, r>)^2 = ||g' - g||_2^2: the fixtures store <g64, r_j>, the test
+    computes <g_gpu, r_j>, and the root mean square of the differences estimates the L2 error of the WHOLE tensor."""
+    g = torch.Generator().manual_seed(7919 + tensor_index)
+    return [(torch.randint(0, 2, (numel,), generator=g, dtype=torch.int8).double() * 2 - 1) for _ in range(NUM_PROBES)]
+
+
+def fixture_path(config):
+    return os.path.join(GOLDEN_DIR, "config%d_oracle.npz" % config)
+
+
+def build_dcn(arch, D, H, W):
+    """DenseCorrespondenceNetwork on the GPU carrying the oracle's seeded weights (same state-dict keys)."""
+    from dense_correspondence.network.dense_correspondence_network import DenseCorrespondenceNetwork
+    from oracle import resnet_dilated_oracle
+    cfg = {"descriptor_dimension": D, "image_width": W, "image_height": H,
+           "backbone": {"model_class": "Resnet", "resnet_name": arch}}
+    dcn = DenseCorrespondenceNetwork.from_config(cfg, load_stored_params=False)
+    o = resnet_dilated_oracle.build(arch, D, seed=0)
+    dcn.fcn.load_state_dict(o.state_dict())
+    return dcn, o
+
+
+def run_config_against_fixture(config, pair_call=False):
+    """-> dict of measured deviations of one full-size step of BASELINE config `config` from its oracle fixture."""
+    from dense_correspondence.loss_functions import loss_composer
+    from dense_correspondence.loss_functions.pixelwise_contrastive_loss import PixelwiseContrastiveLoss
+    from oracle import synth
+    z = np.load(fixture_path(config))
+    c = synth.CONFIGS[config]
+    B = c["B"]
+    dcn, _ = build_dcn(c["backbone"], c["D"], c["H"], c["W"])
+    img_a, img_b, lists = synth.make_batch(B, c["H"], c["W"], c["Pm"], c["Pk"], c["Pg"], seed=1, masked=c.get("masked", False))
+    pcl = PixelwiseContrastiveLoss(image_shape=dcn.image_shape, config=synth.LOSS_CONFIG)
+    img_a, img_b = img_a.cuda(), img_b.cuda()
+    if pair_call:
+        ya, yb = dcn.forward_pair(img_a, img_b)
+    else:
+        ya, yb = dcn.forward(img_a), dcn.forward(img_b)
+    pa, pb = dcn.process_network_output(ya, B), dcn.process_network_output(yb, B)
+    assert pa.is_contiguous()
+    tup = [tuple(Ld[k].cuda() for k in KEYS) for Ld in lists]
+    loss, terms, hard = loss_composer.get_loss_batched(pcl, 0, pa, pb, tup)
+    loss.backward()
+    torch.cuda.synchronize()
+    s = int(z["desc_stride"])
+    scale = float(z["desc_a_absmax"])
+    out = {"config": config, "desc_err32_vs_64": float(z["desc_err32_vs_64"])}
+    out["desc_a"] = float((ya.detach().cpu()[:, :, ::s, ::s] - torch.tensor(z["desc_a"])).abs().max()) / scale
+    out["desc_b"] = float((yb.detach().cpu()[:, :, ::s, ::s] - torch.tensor(z["desc_b"])).abs().max()) / scale
+    out["loss"] = abs(loss.item() - float(z["loss"])) / abs(float(z["loss"]))
+    zt = z["terms"].reshape(B, 5)
+    t = terms.cpu().numpy().astype(np.float64)
+    out["terms"] = float(np.max(np.abs(t - zt) / np.maximum(np.abs(zt), 1e-12)))
+    h = hard.cpu().numpy()
+    zh = z["hard"]
+    out["hard_diff"] = int(np.max(np.abs(h[:, 1:3].astype(np.int64) - zh[:, :2])))
+    out["hard_tie_band"] = int(zh[:, 2].max())
+    out["hard_match_len_ok"] = bool((h[:, 0] == c["Pm"]).all())
+    # gradients against the float64 run of the oracle, in units of the float32 oracle's own deviation from it
+    names = [str(n) for n in z["grad_names"]]
+    params = dict(dcn.fcn.named_parameters())
+    worst_l2, worst_max, per = 0.0, 0.0, []
+    for i, k in enumerate(names):
+        if k.endswith("fc.bias"):
+            continue   # mathematically zero (the loss only sees descriptor differences): round-off only
+        gq = params[k].grad.detach().cpu().double()
+        n64, m64 = float(z["grad_norms64"][i]), float(z["grad_max64"][i])
+        e_nrm = abs(float(gq.norm()) - n64)
+        flat = gq.reshape(-1)
+        idx = torch.linspace(0, flat.numel() - 1, 16).long()
+        e_smp = float((flat[idx] - torch.tensor(z["grad_samples64"][i])).abs().max())
+        # unbiased estimate of ||g_gpu - g64||_2 from the random-sign probes
+        pr = torch.tensor([float((flat * r).sum()) for r in probe_vectors(i, flat.numel())], dtype=torch.float64)
+        e_l2 = float(((pr - torch.tensor(z["grad_probes64"][i])) ** 2).mean().sqrt())
+        err32_l2, err32_mx = float(z["grad_err32_l2"][i]), float(z["grad_err32_max"][i])
+        per.append((k, e_l2 / n64, e_l2 / (err32_l2 + 1e-30), e_smp / m64, e_smp / (err32_mx + 1e-30), e_nrm / n64))
+        # excess over a 2e-4 relative floor (tensors the float32 oracle happens to get almost exactly), in yard-sticks
+        worst_l2 = max(worst_l2, (e_l2 - 2e-4 * n64) / (err32_l2 + 1e-30))
+        worst_max = max(worst_max, (e_smp - 2e-4 * m64) / (err32_mx + 1e-30))
+    out["grad_l2_ratio"] = worst_l2        # (est. ||g - g64|| - 2e-4 ||g64||) / float32-oracle's ||g32 - g64||, worst tensor
+    out["grad_sample_ratio"] = worst_max   # (max sampled |g - g64| - 2e-4 max|g64|) / float32-oracle's max error, worst tensor
+    out["per_tensor"] = per   # (name, est. L2 rel err, in yard-sticks, sampled max rel err, in yard-sticks, |norm diff| rel)
+    if "running_mean_bn1" in z.files:
+        attr = getattr(dcn.fcn, dcn.fcn.attr)
+        rm = attr.bn1.running_mean.cpu()
+        out["running_mean_bn1"] = float((rm - torch.tensor(z["running_mean_bn1"])).abs().max() /
+                                        np.abs(z["running_mean_bn1"]).max())
+    return out

@@ -1,6 +1,7 @@
-"""Multi-GPU path on CPU: world_size 2, gloo.  Every rank runs the step on its own image pairs (kernels
-host-emulated), FlatGradients averages with one all-reduce; the result must equal the oracle run per shard with
-averaged gradients (BN statistics are per rank, no SyncBN)."""
+"""Multi-GPU path on CPU: gloo, world size 2 and 4.  Every rank runs the step on its own image pairs (kernels
+host-emulated), FlatGradients averages -- bucket by bucket as the backbone's backward completes them (the default with
+world size > 1), or with one all-reduce; the result must equal the oracle run per shard with averaged gradients
+(BN statistics are per rank, no SyncBN), and the two schedules must agree."""
 import os
 import socket
 
@@ -55,6 +56,7 @@ def _worker(rank, world, port, q, pair=False):
     loss, _, _ = loss_composer.get_loss_batched(pcl, 0, pa, pb, tup)
     loss.backward()
     grads.all_reduce_mean()
+    assert grads.stats["bucketed_steps"] == (1 if pair else 2) and grads.stats["monolithic_steps"] == 0   # world 2: bucketed
     # oracle: both shards on this rank, averaged
     ref = None
     for r in range(world):
@@ -91,3 +93,77 @@ def test_two_rank_gradient_average_matches_oracle(pair):
         assert err < 5e-4, (rank, err)
         assert spread == 0.0, "ranks disagree after the all-reduce"
         assert views
+
+
+def _bucket_worker(rank, world, port, q):
+    """Same step twice on every rank -- monolithic all-reduce, then the bucketed schedule -- and the exact-arithmetic check of
+    the slicing: integer-valued "engine gradients" whose sums are exact in fp32 whatever order gloo adds them in."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HIPEMU_THREADS="1")   # 1: deterministic atomics order
+    torch.set_num_threads(1)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from helpers import use_emulation_library
+    use_emulation_library()
+    from dcn_hip import backbone as bb
+    from dcn_hip.distributed import FlatGradients, broadcast_module
+    from oracle import resnet_dilated_oracle as orc, synth
+    from pytorch_segmentation_detection.models import resnet_dilated as prod
+    H, W, D = 64, 64, 3
+    torch.manual_seed(7)
+    m = prod.Resnet18_8s(num_classes=D, base_width=8)
+    m.load_state_dict(orc.build("Resnet18_8s", D, seed=0, base_width=8).state_dict())
+    broadcast_module(m, src=0)
+    m.train()
+    img_a, img_b, _ = synth.make_batch(1, H, W, 4, 4, 4, seed=1 + rank)
+    g = torch.Generator().manual_seed(50 + rank)
+    ga, gb = torch.randn(1, D, H, W, generator=g), torch.randn(1, D, H, W, generator=g)
+    flats = {}
+    for mode in (False, True):
+        grads = FlatGradients(m, bucketed=mode)
+        grads.zero_()
+        ya, yb = m.forward_pair(img_a, img_b)
+        torch.autograd.backward([ya, yb], [ga, gb])
+        grads.all_reduce_mean()
+        assert grads.stats["bucketed_steps"] == int(mode) and grads.stats["monolithic_steps"] == int(not mode)
+        flats[mode] = grads.flat.clone()
+    same_bits = bool(torch.equal(flats[False], flats[True]))
+    close = float((flats[False] - flats[True]).abs().max() / flats[False].abs().max())
+    # exact-arithmetic check of the bucket slicing / coverage
+    plan = bb.get_plan("Resnet18_8s", 8, 2, H, W, D, 2)
+    n = plan.grad_offsets[-1]
+    eng = ((torch.arange(n) % 251) * world * (rank + 1)).float()        # multiples of `world`: the pre-division is exact
+    grads = FlatGradients(m, bucketed=True)
+    grads.zero_()
+    grads.accumulate_and_reduce_buckets(plan, eng.clone())
+    grads.all_reduce_mean()
+    expect = (torch.arange(n) % 251).float() * sum(r + 1 for r in range(world))
+    mono = FlatGradients(m, bucketed=False)
+    mono.zero_()
+    mono.flat.copy_(eng)
+    mono.all_reduce_mean()
+    exact = bool(torch.equal(grads.flat, expect)) and bool(torch.equal(mono.flat, expect))
+    covered = sorted(plan.grad_buckets) == sorted(set(plan.grad_buckets)) and \
+        sum(hi - lo for lo, hi in plan.grad_buckets) == n
+    q.put((rank, same_bits, close, exact, covered))
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+@pytest.mark.parametrize("world", [2, 4])
+def test_bucketed_all_reduce_equals_monolithic(world):
+    """world 2: bit for bit on real gradients (a + b is commutative, so gloo's chunking cannot matter); world 4: within fp32
+    summation-order noise on real gradients, and bit for bit on integer-valued buffers whose sums are exact."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_bucket_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=540) for _ in procs]
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    for rank, same_bits, close, exact, covered in res:
+        assert covered and exact, rank
+        assert close < 1e-6, (rank, close)
+        if world == 2:
+            assert same_bits, rank

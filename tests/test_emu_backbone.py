@@ -74,9 +74,9 @@ def test_gradient_scale_invariance(gscale, conv_mode):
         assert rel_err(p.grad, po.grad) < 2e-4, (k, conv_mode)
 
 
-def test_forward_backward_with_stream_k_forced(monkeypatch):
+def test_forward_backward_with_stream_k_forced(dcn_env):
     """Same network with every gather-GEMM launch forced through the stream-K split + fix-up path (engine workspace)."""
-    monkeypatch.setenv("DCN_GEMM_SK", "5")
+    dcn_env(DCN_GEMM_SK=5)
     m, o = _pair("Resnet18_8s", 3, 8)
     g = torch.Generator().manual_seed(11)
     x = torch.randn(2, 3, 32, 40, generator=g)

@@ -34,9 +34,9 @@ CONV_CASES = [
 @pytest.mark.parametrize("tile_m,sk", [("32", "0"), ("64", "0"), ("128", "0"), ("32", "3"), ("64", "5"), ("128", "2"),
                                        ("64", "7")])
 @pytest.mark.parametrize("case", CONV_CASES, ids=[str(c) for c in CONV_CASES])
-def test_conv_forward_dgrad_wgrad(L, case, tile_m, sk, monkeypatch):
-    monkeypatch.setenv("DCN_GEMM_TILE_M", tile_m)   # every workgroup-tile height of the gather-GEMM kernel
-    monkeypatch.setenv("DCN_GEMM_SK", sk)           # 0: one workgroup per tile; N: stream-K over N workgroups
+def test_conv_forward_dgrad_wgrad(L, case, tile_m, sk, dcn_env):
+    # every workgroup-tile height of the gather-GEMM kernel; SK 0: one workgroup per tile; N: stream-K over N workgroups
+    dcn_env(DCN_GEMM_TILE_M=tile_m, DCN_GEMM_SK=sk)
     lib = L.get()
     n, hin, win, cin, cout, k, stride, pad, dil = case
     hout = (hin + 2 * pad - dil * (k - 1) - 1) // stride + 1
@@ -183,10 +183,9 @@ F16_CASES = [
 # tile_m 256 = the 8-wavefront 256 x 128 tile (only taken when the destination has more than 64 channels)
 @pytest.mark.parametrize("tile_m,sk", [("64", "0"), ("128", "0"), ("64", "3"), ("128", "2"), ("256", "0"), ("256", "3")])
 @pytest.mark.parametrize("case", F16_CASES, ids=[str(c) for c in F16_CASES])
-def test_conv_f16x3_forward_dgrad(L, case, tile_m, sk, monkeypatch):
+def test_conv_f16x3_forward_dgrad(L, case, tile_m, sk, dcn_env):
     """Split-fp16 gather-GEMM (fp16 MFMA, hi/lo operands): must reproduce the fp32 convolution to ~1e-6."""
-    monkeypatch.setenv("DCN_GEMM_TILE_M", tile_m)
-    monkeypatch.setenv("DCN_GEMM_SK", sk)
+    dcn_env(DCN_GEMM_TILE_M=tile_m, DCN_GEMM_SK=sk)
     lib = L.get()
     n, hin, win, cin, cout, k, stride, pad, dil = case
     hout = (hin + 2 * pad - dil * (k - 1) - 1) // stride + 1
@@ -209,11 +208,20 @@ def test_conv_f16x3_forward_dgrad(L, case, tile_m, sk, monkeypatch):
     part = torch.full((mt, 2, cout), float("nan"))
     ws_f = torch.empty(max(lib.dcn_conv_gemm_workspace_f16(ctypes.byref(d), 0), 4) // 4)
     ws_d = torch.empty(max(lib.dcn_conv_gemm_workspace_f16(ctypes.byref(d), 1), 4) // 4)
-    assert lib.dcn_conv_forward_f16(ctypes.byref(d), L.ptr(x_nhwc), L.ptr(wh), L.ptr(wl), 64.0, None, L.ptr(out),
+    assert lib.dcn_conv_forward_f16(ctypes.byref(d), L.ptr(x_nhwc), None, L.ptr(wh), L.ptr(wl), 64.0, None, L.ptr(out),
                                     L.ptr(part), L.ptr(ws_f), None) == 0
     ref = F.conv2d(x, w, None, stride, pad, dil)
     refn = ref.detach().permute(0, 2, 3, 1)
     assert rel_err(out, refn) < 3e-6
+    # activations far outside fp16's range (2e5 overflows, 1e-7 is below its subnormals): the abs-max driven power-of-two
+    # pre-scale of the operand keeps the result at fp32 accuracy
+    for big in (2.0e5, 1.0e-7):
+        xb = (x_nhwc * big).contiguous()
+        xmax = xb.abs().max().reshape(1).clone()
+        outb = torch.full((n, hout, wout, cout), float("nan"))
+        assert lib.dcn_conv_forward_f16(ctypes.byref(d), L.ptr(xb), L.ptr(xmax), L.ptr(wh), L.ptr(wl), 64.0, None,
+                                        L.ptr(outb), None, L.ptr(ws_f), None) == 0
+        assert rel_err(outb, refn * big) < 3e-6, big
     assert rel_err(part.sum(0)[0], refn.sum((0, 1, 2))) < 1e-5
     assert rel_err(part.sum(0)[1], (refn ** 2).sum((0, 1, 2))) < 1e-5
     # dgrad with a TINY gradient tensor (1e-7 scale): the abs-max driven power-of-two pre-scale keeps it inside fp16
@@ -249,12 +257,18 @@ def test_conv_f16x3_forward_dgrad(L, case, tile_m, sk, monkeypatch):
     scale = float(rec[:M].abs().max() / dout.abs().max())
     assert abs(math.log2(scale) - round(math.log2(scale))) < 1e-3 and 1024 < scale * float(amax) <= 4096
     assert rel_err(rec[:M] / scale, dout.reshape(M, cout)) < 1e-6 and float(rec[M:].abs().sum()) == 0
-    assert lib.dcn_conv_wgrad_f16(ctypes.byref(d), L.ptr(xs), 0, L.ptr(dq), L.ptr(amax), L.ptr(dw), L.ptr(slabs), None) == 0
+    assert lib.dcn_conv_wgrad_f16(ctypes.byref(d), L.ptr(xs), 0, None, L.ptr(dq), L.ptr(amax), L.ptr(dw), L.ptr(slabs), None) == 0
     # same result when the activation operand is the fp32 tensor itself, split on the fly
     dw_direct = torch.full((cout, k, k, cin), float("nan"))
-    assert lib.dcn_conv_wgrad_f16(ctypes.byref(d), L.ptr(x_nhwc), 1, L.ptr(dq), L.ptr(amax), L.ptr(dw_direct), L.ptr(slabs),
-                                  None) == 0
+    assert lib.dcn_conv_wgrad_f16(ctypes.byref(d), L.ptr(x_nhwc), 1, None, L.ptr(dq), L.ptr(amax), L.ptr(dw_direct),
+                                  L.ptr(slabs), None) == 0
     assert torch.equal(dw_direct, dw)
+    xb = (x_nhwc * 2.0e5).contiguous()     # out-of-range activations with their abs-max: pre-scaled operand
+    xmax = xb.abs().max().reshape(1).clone()
+    dw_big = torch.full((cout, k, k, cin), float("nan"))
+    assert lib.dcn_conv_wgrad_f16(ctypes.byref(d), L.ptr(xb), 1, L.ptr(xmax), L.ptr(dq), L.ptr(amax), L.ptr(dw_big),
+                                  L.ptr(slabs), None) == 0
+    assert rel_err(dw_big, w.grad.permute(0, 2, 3, 1) * 2.0e5) < 5e-6
     assert rel_err(dw, w.grad.permute(0, 2, 3, 1)) < 5e-6
 
 

@@ -154,6 +154,33 @@ def test_index_out_of_range_sets_status_and_is_skipped():
     np.testing.assert_allclose(out[0].item(), ref.item(), rtol=1e-6)
 
 
+def test_host_lists_are_range_checked_and_debug_surfaces_the_device_status():
+    """an index >= H*W (lists built for another image size) must not silently train on a partial loss.  Lists
+    that arrive on the host raise IndexError like the reference's index_select; for device-resident lists the kernel's
+    status word is kept on the loss object and raised when `debug` is on."""
+    from dcn_hip import loss as K
+    from dense_correspondence.loss_functions import loss_composer
+    from dense_correspondence.loss_functions.pixelwise_contrastive_loss import PixelwiseContrastiveLoss
+    from oracle import synth
+    A = torch.rand(1, 100, 3)
+    B = torch.rand(1, 100, 3)
+    good, bad = torch.tensor([1, 2, 3]), torch.tensor([1, 100, 3])
+    e = torch.tensor([-1])
+    pcl = PixelwiseContrastiveLoss([10, 10], synth.LOSS_CONFIG)
+    with pytest.raises(IndexError):
+        loss_composer.get_loss(pcl, 0, A, B, good, bad, e, e, e, e, e, e)
+    with pytest.raises(IndexError):
+        K.PairLists.from_lists([(good, torch.tensor([1, -7, 3]), None, None, None, None, None, None)], "cpu", hw=100)
+    raw = K.PairLists.from_lists([(good, bad, None, None, None, None, None, None)], "cpu")   # unchecked (as if on the GPU)
+    loss_composer.get_loss_batched(pcl, 0, A, B, raw)
+    assert int(pcl.last_status) == 1
+    pcl.debug = True
+    with pytest.raises(IndexError):
+        loss_composer.get_loss_batched(pcl, 0, A, B, raw)
+    with pytest.raises(TypeError):
+        loss_composer.get_loss_batched(pcl, 0, A.double(), B.double(), raw)
+
+
 def test_mismatched_lists_raise():
     from dcn_hip import loss as K
     with pytest.raises(ValueError):

@@ -189,9 +189,16 @@ def test_conv_f16x3_kernels_vs_torch_cpu(L, case):
     part = torch.full((lib.dcn_conv_num_mtiles_f16(ctypes.byref(d)), 2, cout), float("nan"), device="cuda")
     ws_f = torch.empty(max(lib.dcn_conv_gemm_workspace_f16(ctypes.byref(d), 0), 4) // 4, device="cuda")
     ws_d = torch.empty(max(lib.dcn_conv_gemm_workspace_f16(ctypes.byref(d), 1), 4) // 4, device="cuda")
-    assert lib.dcn_conv_forward_f16(ctypes.byref(d), L.ptr(xg), L.ptr(wh), L.ptr(wl), 64.0, None, L.ptr(out), L.ptr(part),
-                                    L.ptr(ws_f), st) == 0
+    assert lib.dcn_conv_forward_f16(ctypes.byref(d), L.ptr(xg), None, L.ptr(wh), L.ptr(wl), 64.0, None, L.ptr(out),
+                                    L.ptr(part), L.ptr(ws_f), st) == 0
     assert rel_err(out.cpu(), refn) < 1e-5
+    for big in (2.0e5, 1.0e-7):   # activations outside fp16's range: the operand pre-scale from the abs-max scalar
+        xb = xg * big
+        xmax = xb.abs().max().reshape(1)
+        outb = torch.full((n, hout, wout, cout), float("nan"), device="cuda")
+        assert lib.dcn_conv_forward_f16(ctypes.byref(d), L.ptr(xb), L.ptr(xmax), L.ptr(wh), L.ptr(wl), 64.0, None,
+                                        L.ptr(outb), None, L.ptr(ws_f), st) == 0
+        assert rel_err(outb.cpu(), refn * big) < 1e-5, big
     assert rel_err(part.sum(0)[0].cpu(), refn.sum((0, 1, 2))) < 2e-5
     assert rel_err(part.sum(0)[1].cpu(), (refn ** 2).sum((0, 1, 2))) < 2e-5
     wt = torch.empty(cin, k * k, cout, device="cuda")
@@ -213,14 +220,19 @@ def test_conv_f16x3_kernels_vs_torch_cpu(L, case):
     assert lib.dcn_split_act_f16(L.ptr(xg), L.ptr(xs), xg.numel(), st) == 0
     dq = torch.empty(lib.dcn_grad_blocked_bytes(M, cout) // 4, dtype=torch.float32, device="cuda")
     assert lib.dcn_split_grad_blocked_f16(L.ptr(dg), M, cout, L.ptr(amax), L.ptr(dq), st) == 0
-    wg_args = (ctypes.byref(d), L.ptr(xs), 0, L.ptr(dq), L.ptr(amax))
+    wg_args = (ctypes.byref(d), L.ptr(xs), 0, None, L.ptr(dq), L.ptr(amax))
     assert lib.dcn_conv_wgrad_f16(*wg_args, L.ptr(dw), L.ptr(slab), st) == 0
     assert rel_err(dw.cpu(), w.grad.permute(0, 2, 3, 1)) < 1e-5
     dw2 = torch.empty_like(dw)
     assert lib.dcn_conv_wgrad_f16(*wg_args, L.ptr(dw2), L.ptr(slab), st) == 0
     dw3 = torch.empty_like(dw)   # activation operand = the fp32 tensor, split on the fly: same bits
-    assert lib.dcn_conv_wgrad_f16(ctypes.byref(d), L.ptr(xg), 1, L.ptr(dq), L.ptr(amax), L.ptr(dw3), L.ptr(slab), st) == 0
+    assert lib.dcn_conv_wgrad_f16(ctypes.byref(d), L.ptr(xg), 1, None, L.ptr(dq), L.ptr(amax), L.ptr(dw3), L.ptr(slab), st) == 0
     assert torch.equal(dw, dw3)
+    xb = xg * 2.0e5
+    xmax = xb.abs().max().reshape(1)
+    dw4 = torch.empty_like(dw)
+    assert lib.dcn_conv_wgrad_f16(ctypes.byref(d), L.ptr(xb), 1, L.ptr(xmax), L.ptr(dq), L.ptr(amax), L.ptr(dw4), L.ptr(slab), st) == 0
+    assert rel_err(dw4.cpu(), w.grad.permute(0, 2, 3, 1) * 2.0e5) < 1e-5
     assert torch.equal(dw, dw2)
 
 
@@ -684,7 +696,7 @@ def test_adam_step_vs_torch_adam_on_cpu_and_full_model(L):
     assert worst < 2e-6, worst
 
 
-def test_backward_side_stream_equals_serial_schedule_bitwise(L, monkeypatch):
+def test_backward_side_stream_equals_serial_schedule_bitwise(L, dcn_env):
     """The weight-gradient GEMMs run on the plan's side stream next to the dgrad / BN-backward chain (two alternating
     gradient images ordered by events).  With a FIXED output gradient (no loss atomics) the backward pass is deterministic,
     so every parameter gradient must be bit-identical to the serial schedule (DCN_BACKWARD_OVERLAP=0, a fresh plan) --
@@ -713,7 +725,7 @@ def test_backward_side_stream_equals_serial_schedule_bitwise(L, monkeypatch):
 
     runs = {}
     for mode in ("1", "0"):
-        monkeypatch.setenv("DCN_BACKWARD_OVERLAP", mode)
+        dcn_env(DCN_BACKWARD_OVERLAP=mode)
         bb._PLANS.clear()                       # the schedule is fixed at a plan's first backward pass
         runs[mode] = [grads() for _ in range(3)]
     bb._PLANS.clear()

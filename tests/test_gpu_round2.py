@@ -1,0 +1,403 @@
+"""-m gpu tests added in round 2: activation range of the split-fp16 arithmetic, inverted
+hinge / across-scene loss, checkpoint round trip on the device, stand-alone batch-norm / max-pool / upsample kernels at
+layer shapes vs torch CPU ops, gradient buckets + bucketed accumulate on one rank."""
+import ctypes
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from helpers import lists_from_golden, load_golden_loss, rel_err, use_gfx950_library
+import parity_common as pc
+
+pytestmark = pytest.mark.gpu
+GOLDEN_DIR = os.path.join(os.path.dirname(__file__), "golden")
+TOL = 1e-4
+
+
+@pytest.fixture(scope="module")
+def L():
+    lib = use_gfx950_library()
+    assert torch.cuda.is_available()
+    return lib
+
+
+@pytest.fixture(params=["f16x3", "fp32"])
+def conv_mode(request):
+    from dcn_hip import backbone
+    backbone.set_conv_mode(request.param)
+    yield request.param
+    backbone.set_conv_mode(None)
+
+
+# ------------------------------------------------------------------------------------------------ f16x3 operand range
+@pytest.mark.parametrize("scale", [1.0e4, 1.0e-5, 3.0e6])
+def test_activation_range_forward_backward(L, conv_mode, scale):
+    """Activations far outside fp16's range (bn1's gamma / beta scaled so that the stem activation, the max-pool output and
+    layer1's residual stream sit at ~1e4, ~3e6 -- beyond fp16's 65504 -- or ~1e-5 -- below fp16's normal range): the
+    split-fp16 kernels pre-scale every convolution operand by a power of two from its abs-max scalar, so descriptors and
+    gradients keep fp32-level parity with the oracle, and the status word stays clear."""
+    import copy
+    H, W, D = 96, 128, 3
+    dcn, o = pc.build_dcn("Resnet34_8s", D, H, W)
+    with torch.no_grad():
+        o.resnet34_8s.bn1.weight.mul_(scale)
+        o.resnet34_8s.bn1.bias.fill_(0.1 * scale)
+    dcn.fcn.load_state_dict(o.state_dict())
+    o64 = copy.deepcopy(o).double()
+    g = torch.Generator().manual_seed(21)
+    x = torch.randn(2, 3, H, W, generator=g)
+    gy = torch.randn(2, D, H, W, generator=g)
+    o.train(); o64.train()
+    y = dcn.forward(x.cuda())
+    yo, y64 = o(x), o64(x.double())
+    amax, status = dcn.fcn.last_forward_status()
+    assert int(status.item()) == 0
+    if conv_mode == "f16x3":
+        a = amax.cpu()
+        assert float(a[1]) > 0.5 * scale, a[:4]       # the stem activation really is at that scale
+    assert rel_err(y.detach().cpu(), y64) < 3 * rel_err(yo, y64) + 2e-5, (rel_err(y.detach().cpu(), y64), rel_err(yo, y64))
+    assert rel_err(y.detach().cpu(), yo.detach()) < TOL
+    (y * gy.cuda()).sum().backward(); (yo * gy).sum().backward(); (y64 * gy.double()).sum().backward()
+    worst = 0.0
+    for (k, p), (_, po), (_, p6) in zip(dcn.fcn.named_parameters(), o.named_parameters(), o64.named_parameters()):
+        n6 = float(p6.grad.norm().clamp_min(1e-300))
+        e_gpu = float((p.grad.double().cpu() - p6.grad).norm()) / n6
+        e_o32 = float((po.grad.double() - p6.grad).norm()) / n6
+        worst = max(worst, (e_gpu - 5e-4) / max(e_o32, 1e-12))
+        assert e_gpu < 3 * e_o32 + 5e-4, (k, e_gpu, e_o32)
+    print("activation range %g (%s): worst gradient error %.2f float32-oracle yard-sticks" % (scale, conv_mode, worst))
+
+
+def test_non_finite_activation_raises_status(L):
+    """A convolution input that is not finite (here: an inf pixel in the image) cannot be rescued by any pre-scale: the
+    status word behind the activation abs-max slots reports it."""
+    from dcn_hip import backbone
+    backbone.set_conv_mode("f16x3")
+    dcn, _ = pc.build_dcn("Resnet34_8s", 3, 64, 96)
+    x = torch.randn(1, 3, 64, 96)
+    dcn.train()
+    dcn.forward(x.cuda())
+    assert int(dcn.fcn.last_forward_status()[1].item()) == 0
+    x[0, 1, 5, 7] = float("inf")
+    dcn.forward(x.cuda())
+    assert int(dcn.fcn.last_forward_status()[1].item()) == 1
+    backbone.set_conv_mode(None)
+
+
+# ------------------------------------------------------------------------------------------------ loss variants (F13 / f4)
+def test_inverted_hinge_vs_reference_golden(L):
+    """pcl.py:205-208 `invert=True` (what get_same_object_across_scene_loss uses, loss_composer.py:193-212): the reference's
+    own golden vector (f7_vec_invert), hard-negative count exact."""
+    from dense_correspondence.loss_functions.pixelwise_contrastive_loss import PixelwiseContrastiveLoss as PCL
+    z, cfg = load_golden_loss(os.path.join(GOLDEN_DIR, "loss_ref_within_d16.npz"))
+    A = torch.tensor(z["A"], device="cuda", requires_grad=True)
+    B = torch.tensor(z["B"], device="cuda", requires_grad=True)
+    ka, kb = torch.tensor(z["masked_a"], device="cuda"), torch.tensor(z["masked_b"], device="cuda")
+    vec, hn, _, _ = PCL.non_match_descriptor_loss(A, B, ka, kb, M=cfg["M_masked"], invert=True)
+    np.testing.assert_allclose(vec.detach().cpu().numpy(), z["f7_vec_invert"], rtol=1e-5, atol=1e-8)
+    assert hn == int(z["f7_hard_invert"])
+
+
+@pytest.mark.parametrize("D,P", [(3, 5000), (16, 100000)])
+def test_across_scene_loss_vs_oracle(L, D, P):
+    """SINGLE_OBJECT_ACROSS_SCENE (loss_composer.py:193-212: blind list only, inverted hinge, margin M_masked, scaled by the
+    hard-negative count) through get_loss and through get_same_object_across_scene_loss at 640x480: value, 5-tuple and
+    gradients vs the oracle; plus DIFFERENT_OBJECT at the same size."""
+    from dense_correspondence.loss_functions import loss_composer
+    from dense_correspondence.loss_functions.pixelwise_contrastive_loss import PixelwiseContrastiveLoss
+    from oracle import loss_oracle, synth
+    H, W = 480, 640
+    g = torch.Generator().manual_seed(31 + D)
+    A = (torch.rand(1, H * W, D, generator=g) * 2 - 1) * (0.6 / D ** 0.5)
+    Bd = (torch.rand(1, H * W, D, generator=g) * 2 - 1) * (0.6 / D ** 0.5)
+    ba = torch.randint(0, H * W, (P,), generator=g)
+    bb_ = torch.randint(0, H * W, (P,), generator=g)
+    e = torch.tensor([-1], dtype=torch.int64)
+    pcl = PixelwiseContrastiveLoss([H, W], synth.LOSS_CONFIG)
+    opcl = loss_oracle.PixelwiseContrastiveLoss([H, W], synth.LOSS_CONFIG)
+    for mtype in (1, 2):   # SINGLE_OBJECT_ACROSS_SCENE, DIFFERENT_OBJECT
+        Ag, Bg = A.cuda().requires_grad_(True), Bd.cuda().requires_grad_(True)
+        Ao, Bo = A.clone().requires_grad_(True), Bd.clone().requires_grad_(True)
+        out = loss_composer.get_loss(pcl, torch.tensor([mtype]), Ag, Bg, e, e, e, e, e, e, ba.cuda(), bb_.cuda())
+        ref = loss_oracle.get_loss(opcl, torch.tensor([mtype]), Ao, Bo, e, e, e, e, e, e, ba, bb_)
+        got = np.array([float(t.sum().item()) for t in out])
+        want = np.array([float(t.sum().item()) for t in ref])
+        assert want[0] > 0, "hinge must be active"
+        np.testing.assert_allclose(got, want, rtol=TOL, atol=1e-9)
+        out[0].backward(); ref[0].sum().backward()
+        assert rel_err(Ag.grad.cpu(), Ao.grad) < TOL and rel_err(Bg.grad.cpu(), Bo.grad) < TOL, mtype
+    Ag, Bg = A.cuda(), Bd.cuda()
+    direct = loss_composer.get_same_object_across_scene_loss(pcl, Ag, Bg, ba.cuda(), bb_.cuda())
+    via = loss_composer.get_loss(pcl, torch.tensor([1]), Ag, Bg, e, e, e, e, e, e, ba.cuda(), bb_.cuda())
+    assert float(direct[0].sum()) == float(via[0].sum())
+
+
+def test_within_scene_wrapper_and_legacy_loss_on_gpu(L):
+    """F9 `get_loss_matched_and_non_matched_with_l2` (pcl.py:35-101) on the device against the reference goldens' building
+    blocks, and `get_loss_original` against the oracle."""
+    from dense_correspondence.loss_functions.pixelwise_contrastive_loss import PixelwiseContrastiveLoss as PCL
+    z, cfg = load_golden_loss(os.path.join(GOLDEN_DIR, "loss_ref_within_d16.npz"))
+    A = torch.tensor(z["A"], device="cuda")
+    B = torch.tensor(z["B"], device="cuda")
+    t = lambda k: torch.tensor(z[k], device="cuda")
+    pcl = PCL([int(z["H"]), int(z["W"])], cfg)
+    ml, nml, hn = pcl.get_loss_matched_and_non_matched_with_l2(A, B, t("matches_a"), t("matches_b"), t("masked_a"), t("masked_b"),
+                                                               M_descriptor=cfg["M_masked"])
+    np.testing.assert_allclose(float(ml), z["f6_match_loss"], rtol=5e-6)
+    np.testing.assert_allclose(float(nml), z["f7_vec"].sum(), rtol=2e-5)
+    assert int(hn) == int(z["f7_hard"])
+
+
+# ------------------------------------------------------------------------------------------------ checkpoints (f3)
+def test_checkpoint_round_trip_on_device(L, tmp_path):
+    """training.py:501-521 / network.py:426-485 with the real Resnet34_8s on the GPU: `%06d.pth` + `.pth.opt` written after
+    two training steps, reloaded through from_model_folder -> identical eval-mode descriptors; the optimizer state loads
+    into torch.optim.Adam and back, and the next step from the restored pair (model, optimizer) equals the next step of
+    the original bit for bit."""
+    import copy
+    import yaml
+    from dcn_hip import backbone
+    from dcn_hip.optim import Adam
+    from dense_correspondence.loss_functions import loss_composer
+    from dense_correspondence.loss_functions.pixelwise_contrastive_loss import PixelwiseContrastiveLoss
+    from dense_correspondence.network.dense_correspondence_network import DenseCorrespondenceNetwork
+    from oracle import synth
+    backbone.set_conv_mode(None)
+    H, W, D, B = 96, 128, 3, 2
+    dcn, _ = pc.build_dcn("Resnet34_8s", D, H, W)
+    opt = Adam(dcn.parameters(), lr=1e-4, weight_decay=1e-4)
+    img_a, img_b, lists = synth.make_batch(B, H, W, 300, 150, 150, seed=6)
+    img_a, img_b = img_a.cuda(), img_b.cuda()
+    tup = [tuple(Ld[k].cuda() for k in pc.KEYS) for Ld in lists]
+    pcl = PixelwiseContrastiveLoss(image_shape=dcn.image_shape, config=synth.LOSS_CONFIG)
+    gen = torch.Generator(device="cuda").manual_seed(0)
+    ga = torch.randn(B, D, H, W, device="cuda", generator=gen).contiguous(memory_format=torch.channels_last)
+
+    def step(model, optimizer, fixed_grad=False):
+        optimizer.zero_grad()
+        ya, yb = model.forward(img_a), model.forward(img_b)
+        if fixed_grad:   # (no loss atomics: the step is then deterministic to the bit)
+            torch.autograd.backward([ya, yb], [ga, ga])
+        else:
+            loss_composer.get_loss_batched(pcl, 0, model.process_network_output(ya, B), model.process_network_output(yb, B),
+                                           tup)[0].backward()
+        optimizer.step()
+
+    for _ in range(2):
+        step(dcn, opt)
+    sd = dcn.state_dict()
+    assert all(k.startswith("_fcn.resnet34_8s.") for k in sd) and all(v.is_cuda for v in sd.values())
+    torch.save(sd, str(tmp_path / "000002.pth"))
+    torch.save(opt.state_dict(), str(tmp_path / "000002.pth.opt"))
+    cfg = {"dense_correspondence_network": {"descriptor_dimension": D, "image_width": W, "image_height": H,
+                                            "backbone": {"model_class": "Resnet", "resnet_name": "Resnet34_8s"}}}
+    (tmp_path / "training.yaml").write_text(yaml.safe_dump(cfg))
+    loaded = DenseCorrespondenceNetwork.from_model_folder(str(tmp_path))
+    assert next(loaded.parameters()).is_cuda
+    dcn.eval(); loaded.eval()
+    with torch.no_grad():
+        assert torch.equal(loaded.forward(img_a), dcn.forward(img_a))
+    w = loaded.fcn.resnet34_8s.get_parameter("layer4.2.conv2.weight")
+    assert w.is_contiguous(memory_format=torch.channels_last)
+    # optimizer state: dcn_hip.optim.Adam <-> torch.optim.Adam share the state_dict layout
+    t_opt = torch.optim.Adam(loaded.parameters(), lr=1e-4, weight_decay=1e-4)
+    t_opt.load_state_dict(torch.load(str(tmp_path / "000002.pth.opt")))
+    opt2 = Adam(loaded.parameters(), lr=1e-4, weight_decay=1e-4)
+    opt2.load_state_dict(t_opt.state_dict())
+    dcn.train(); loaded.train()
+    step(dcn, opt, fixed_grad=True)
+    step(loaded, opt2, fixed_grad=True)
+    for (k, p), p2 in zip(dcn.named_parameters(), loaded.parameters()):
+        assert torch.equal(p, p2), k
+    for (k, b), b2 in zip(dcn.named_buffers(), loaded.buffers()):
+        assert torch.equal(b, b2), k
+
+
+# ------------------------------------------------------------------------------------------------ stand-alone kernels
+BN_SHAPES = [(2 * 120 * 160, 64), (2 * 60 * 80, 256), (60 * 80, 512), (1000, 12)]
+
+
+@pytest.mark.parametrize("rows,C", BN_SHAPES, ids=[str(s) for s in BN_SHAPES])
+@pytest.mark.parametrize("residual", [False, True])
+def test_batch_norm_kernels_vs_torch_cpu(L, rows, C, residual):
+    """K7 at layer shapes: statistics from the convolution epilogue's partial sums (an identity 1x1 convolution in the exact
+    fp32 mode produces them), normalise (+ residual) + ReLU + mask, running statistics, and the backward pass
+    (dgamma, dbeta, dx, masked residual gradient) against nn.BatchNorm2d / autograd on the CPU."""
+    lib = L.get()
+    st = L.stream_ptr()
+    g = torch.Generator().manual_seed(rows + C)
+    x = (torch.randn(rows, C, generator=g) * (1 + torch.arange(C) % 5) + 0.3 * (torch.arange(C) % 3)).contiguous()
+    res = torch.randn(rows, C, generator=g) if residual else None
+    gamma = torch.rand(C, generator=g) + 0.5
+    beta = torch.randn(C, generator=g) * 0.2
+    dy = torch.randn(rows, C, generator=g)
+    # reference
+    bn = torch.nn.BatchNorm2d(C)
+    with torch.no_grad():
+        bn.weight.copy_(gamma); bn.bias.copy_(beta)
+    bn.train()
+    xr = x.clone().requires_grad_(True)
+    rr = res.clone().requires_grad_(True) if residual else None
+    yr = bn(xr.t().reshape(1, C, rows, 1))
+    if residual:
+        yr = yr + rr.t().reshape(1, C, rows, 1)
+    yr = F.relu(yr)
+    yr.backward(dy.t().reshape(1, C, rows, 1))
+    y_ref = yr.detach().reshape(C, rows).t()
+    # device: identity conv -> x copy + partial sums
+    d = L.ConvDesc(1, rows, 1, C, rows, 1, C, 1, 1, 1, 0, 1, C)
+    xg = x.cuda()
+    eye = torch.eye(C).reshape(C, 1, 1, C).contiguous().cuda()
+    xc = torch.empty(rows, C, device="cuda")
+    mt = lib.dcn_conv_num_mtiles(ctypes.byref(d))
+    part = torch.empty(mt, 2, C, device="cuda")
+    assert lib.dcn_conv_forward(ctypes.byref(d), L.ptr(xg), L.ptr(eye), None, L.ptr(xc), L.ptr(part), None, st) == 0
+    assert torch.equal(xc, xg)
+    rm, rv = torch.zeros(C, device="cuda"), torch.ones(C, device="cuda")
+    y = torch.empty(rows, C, device="cuda")
+    mask = torch.empty(rows * C // 4, dtype=torch.uint8, device="cuda")
+    stats = torch.empty(4, C, device="cuda")
+    resg = res.cuda() if residual else None
+    assert lib.dcn_bn_forward(L.ptr(xc), L.ptr(part), mt, C, rows, L.ptr(gamma.cuda()), L.ptr(beta.cuda()), L.ptr(rm), L.ptr(rv),
+                              0.1, 1e-5, 1, L.ptr(resg), 1, L.ptr(y), L.ptr(mask), L.ptr(stats), st) == 0
+    assert rel_err(y.cpu(), y_ref) < 1e-5
+    assert rel_err(rm.cpu(), bn.running_mean) < 1e-5 and rel_err(rv.cpu(), bn.running_var) < 1e-5
+    bits = (y.reshape(-1, 4) > 0).to(torch.uint8)
+    assert torch.equal(mask, bits[:, 0] | (bits[:, 1] << 1) | (bits[:, 2] << 2) | (bits[:, 3] << 3))
+    ws = torch.empty(lib.dcn_bn_backward_workspace(rows, C), dtype=torch.uint8, device="cuda")
+    dgamma, dbeta = torch.empty(C, device="cuda"), torch.empty(C, device="cuda")
+    dx, gout = torch.empty(rows, C, device="cuda"), torch.empty(rows, C, device="cuda")
+    assert lib.dcn_bn_backward(L.ptr(dy.cuda()), L.ptr(mask), L.ptr(xc), L.ptr(stats), L.ptr(gamma.cuda()), C, rows, L.ptr(dgamma),
+                               L.ptr(dbeta), L.ptr(dx), L.ptr(gout), L.ptr(ws), st) == 0
+    assert rel_err(dgamma.cpu(), bn.weight.grad) < 2e-5 and rel_err(dbeta.cpu(), bn.bias.grad) < 2e-5
+    assert rel_err(dx.cpu(), xr.grad) < 2e-5
+    if residual:
+        assert rel_err(gout.cpu(), rr.grad) < 1e-6
+    # eval mode: running statistics
+    bn.eval()
+    ye = F.relu(bn(x.t().reshape(1, C, rows, 1))).reshape(C, rows).t()
+    y2 = torch.empty(rows, C, device="cuda")
+    assert lib.dcn_bn_forward(L.ptr(xc), None, 0, C, rows, L.ptr(gamma.cuda()), L.ptr(beta.cuda()), L.ptr(rm), L.ptr(rv), 0.1, 1e-5,
+                              0, None, 1, L.ptr(y2), None, L.ptr(stats), st) == 0
+    assert rel_err(y2.cpu(), ye.detach()) < 1e-5
+
+
+@pytest.mark.parametrize("shape", [(2, 240, 320, 64), (1, 480, 640, 64), (1, 9, 7, 8)], ids=str)
+def test_max_pool_kernels_vs_torch_cpu(L, shape):
+    """K2 at the stem's shape (64 channels, 240x320 -> 120x160) and the ResNet50 / 1280x960 one: values, and the backward
+    gather against autograd (ties: random floats have none; the first-maximum rule is covered by the emulator suite)."""
+    lib = L.get()
+    st = L.stream_ptr()
+    n, h, w, C = shape
+    g = torch.Generator().manual_seed(h)
+    x = torch.randn(n, C, h, w, generator=g, requires_grad=True)
+    yr = F.max_pool2d(x, 3, 2, 1)
+    ho, wo = yr.shape[2:]
+    gy = torch.randn(n, C, ho, wo, generator=g)
+    yr.backward(gy)
+    xg = x.detach().permute(0, 2, 3, 1).contiguous().cuda()
+    y = torch.empty(n, ho, wo, C, device="cuda")
+    am = torch.empty(n * ho * wo * C, dtype=torch.uint8, device="cuda")
+    assert lib.dcn_maxpool_forward(L.ptr(xg), n, h, w, C, L.ptr(y), L.ptr(am), st) == 0
+    assert torch.equal(y.cpu(), yr.detach().permute(0, 2, 3, 1))
+    gx = torch.empty(n, h, w, C, device="cuda")
+    assert lib.dcn_maxpool_backward(L.ptr(gy.permute(0, 2, 3, 1).contiguous().cuda()), L.ptr(am), n, h, w, C, L.ptr(gx), st) == 0
+    assert rel_err(gx.cpu(), x.grad.permute(0, 2, 3, 1)) < 1e-6
+
+
+@pytest.mark.parametrize("shape", [(2, 60, 80, 3, 480, 640), (1, 60, 80, 16, 480, 640), (1, 120, 160, 32, 960, 1280)], ids=str)
+@pytest.mark.parametrize("normalize", [0, 1])
+def test_upsample_kernels_vs_torch_cpu(L, shape, normalize):
+    """K8 / K10 at the networks' real shapes: bilinear x8 (align_corners=True) forward (+ per-pixel L2 normalisation) and the
+    separable gather backward against F.interpolate / autograd."""
+    lib = L.get()
+    st = L.stream_ptr()
+    n, hl, wl, D, H, W = shape
+    ld = (D + 3) // 4 * 4
+    g = torch.Generator().manual_seed(D)
+    low = torch.randn(n, D, hl, wl, generator=g, requires_grad=True)
+    ref = F.interpolate(low, size=(H, W), mode="bilinear", align_corners=True)
+    if normalize:
+        ref = ref / torch.norm(ref, 2, 1, keepdim=True)
+    lowp = torch.zeros(n, hl, wl, ld)
+    lowp[..., :D] = low.detach().permute(0, 2, 3, 1)
+    out = torch.empty(n, H, W, D, device="cuda")
+    assert lib.dcn_upsample_forward(L.ptr(lowp.cuda()), n, hl, wl, ld, D, H, W, normalize, L.ptr(out), st) == 0
+    assert rel_err(out.cpu(), ref.detach().permute(0, 2, 3, 1)) < 1e-5
+    if not normalize:
+        gout = torch.randn(n, H, W, D, generator=g)
+        ref.backward(gout.permute(0, 3, 1, 2))
+        glow = torch.full((n, hl, wl, ld), float("nan"), device="cuda")
+        tmp = torch.empty(lib.dcn_upsample_backward_tmp_bytes(n, hl, W, D) // 4, device="cuda")
+        assert lib.dcn_upsample_backward(L.ptr(gout.cuda()), n, hl, wl, ld, D, H, W, L.ptr(glow), L.ptr(tmp), st) == 0
+        assert rel_err(glow[..., :D].cpu(), low.grad.permute(0, 2, 3, 1)) < 1e-5
+        assert float(glow[..., D:].abs().sum()) == 0.0
+
+
+# ------------------------------------------------------------------------------------------------ gradient buckets (8e)
+def test_bucketed_gradient_accumulation_equals_monolithic_bitwise(L):
+    """One rank, config-2 shapes: the bucketed schedule (engine grad-ready events -> communication stream -> per-bucket
+    accumulate, include/dcn_hip.h dcn_plan_stream_wait_grad_bucket) leaves exactly the bits of the monolithic one in the
+    flat gradient buffer, three steps in a row, while the compute stream keeps running ahead."""
+    from dcn_hip import backbone as bb
+    from dcn_hip.distributed import FlatGradients
+    from oracle import synth
+    bb.set_conv_mode("f16x3")
+    c = synth.CONFIGS[2]
+    B = 2
+    dcn, _ = pc.build_dcn(c["backbone"], c["D"], c["H"], c["W"])
+    img_a, img_b, _ = synth.make_batch(B, c["H"], c["W"], 10, 10, 10, seed=5)
+    img_a, img_b = img_a.cuda(), img_b.cuda()
+    gen = torch.Generator(device="cuda").manual_seed(0)
+    ga = torch.randn(B, c["D"], c["H"], c["W"], device="cuda", generator=gen).contiguous(memory_format=torch.channels_last)
+    gb = torch.randn(B, c["D"], c["H"], c["W"], device="cuda", generator=gen).contiguous(memory_format=torch.channels_last)
+    plan = bb.get_plan(c["backbone"], 64, 2 * B, c["H"], c["W"], c["D"], 2)
+    assert len(plan.grad_buckets) == 3 and plan.grad_buckets[0][1] == plan.grad_offsets[-1] and plan.grad_buckets[-1][0] == 0
+    assert [lo for lo, _ in plan.grad_buckets[:-1]] == [hi for _, hi in plan.grad_buckets[1:]]
+    results = {}
+    for mode in (False, True):
+        grads = FlatGradients(dcn, bucketed=mode)
+        runs = []
+        for _ in range(3):
+            grads.zero_()
+            ya, yb = dcn.forward_pair(img_a, img_b)
+            torch.autograd.backward([ya, yb], [ga, gb])
+            grads.all_reduce_mean()
+            torch.cuda.synchronize()
+            runs.append(grads.flat.clone())
+        results[mode] = runs
+        assert grads.stats["bucketed_steps"] == (3 if mode else 0)
+    for r in results[True] + results[False]:
+        assert torch.equal(r, results[False][0])
+    assert float(results[False][0].abs().max()) > 0
+    bb.set_conv_mode(None)
+
+
+def test_zero_grad_set_to_none_keeps_flat_buffer_consistent(L):
+    """optimizer.zero_grad() with torch's default set_to_none=True drops the p.grad views of the flat
+    buffer.  FlatGradients re-installs them before the collective (and dcn_hip.optim.Adam zeroes in place once attached),
+    so the buffer the all-reduce averages is always what the optimizer reads."""
+    from dcn_hip.distributed import FlatGradients
+    from dcn_hip.optim import Adam
+    dcn, _ = pc.build_dcn("Resnet34_8s", 3, 64, 96)
+    grads = FlatGradients(dcn)
+    topt = torch.optim.Adam(dcn.parameters(), lr=1e-4)
+    x = torch.randn(1, 3, 64, 96).cuda()
+    topt.zero_grad()                                    # set_to_none=True: views dropped
+    assert all(p.grad is None for p in dcn.parameters())
+    dcn.forward(x).sum().backward()
+    detached = sum(p.grad.data_ptr() < grads.flat.data_ptr() or p.grad.data_ptr() >= grads.flat.data_ptr() + 4 * grads.flat.numel()
+                   for p in dcn.parameters())
+    assert detached > 0
+    ref = [p.grad.clone() for p in dcn.parameters()]
+    grads.all_reduce_mean()                             # world size 1: only the re-installation happens
+    assert grads.stats["reinstalled_views"] == len(ref)
+    lo, hi = grads.flat.data_ptr(), grads.flat.data_ptr() + 4 * grads.flat.numel()
+    for p, r in zip(dcn.parameters(), ref):
+        assert lo <= p.grad.data_ptr() < hi and torch.equal(p.grad, r)
+    opt = grads.attach(Adam(dcn.parameters(), lr=1e-4))
+    opt.zero_grad()                                     # in place: still views, all zero
+    assert all(lo <= p.grad.data_ptr() < hi for p in dcn.parameters()) and float(grads.flat.abs().max()) == 0.0

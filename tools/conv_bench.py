@@ -83,7 +83,7 @@ def main():
             "wgrad": lambda: lib.dcn_conv_wgrad(ctypes.byref(d), _lib.ptr(x), _lib.ptr(dy), _lib.ptr(dw), _lib.ptr(slab), st),
         }
         if a.mode == "f16":
-            calls["fwd"] = lambda: lib.dcn_conv_forward_f16(ctypes.byref(d), _lib.ptr(x), _lib.ptr(wh), _lib.ptr(wl), 64.0,
+            calls["fwd"] = lambda: lib.dcn_conv_forward_f16(ctypes.byref(d), _lib.ptr(x), None, _lib.ptr(wh), _lib.ptr(wl), 64.0,
                                                             None, _lib.ptr(y), _lib.ptr(part), _lib.ptr(wsf), st)
             calls["dgrad"] = lambda: lib.dcn_conv_dgrad_f16(ctypes.byref(d), _lib.ptr(dy), _lib.ptr(wth), _lib.ptr(wtl), 64.0,
                                                             _lib.ptr(amax), None, _lib.ptr(dx), _lib.ptr(wsd), st)
@@ -97,12 +97,12 @@ def main():
                 if a.x_direct:   # activation operand = the fp32 tensor, split on the fly (no split pass)
                     if split:
                         rc |= lib.dcn_split_grad_blocked_f16(_lib.ptr(dy), M, cout, _lib.ptr(amax), _lib.ptr(dq), st)
-                    return rc | lib.dcn_conv_wgrad_f16(ctypes.byref(d), _lib.ptr(x), 1, _lib.ptr(dq), _lib.ptr(amax), _lib.ptr(dw),
+                    return rc | lib.dcn_conv_wgrad_f16(ctypes.byref(d), _lib.ptr(x), 1, None, _lib.ptr(dq), _lib.ptr(amax), _lib.ptr(dw),
                                                        _lib.ptr(slab), st)
                 if split:
                     rc |= lib.dcn_split_act_f16(_lib.ptr(x), _lib.ptr(xs), x.numel(), st)
                     rc |= lib.dcn_split_grad_blocked_f16(_lib.ptr(dy), M, cout, _lib.ptr(amax), _lib.ptr(dq), st)
-                return rc | lib.dcn_conv_wgrad_f16(ctypes.byref(d), _lib.ptr(xs), 0, _lib.ptr(dq), _lib.ptr(amax), _lib.ptr(dw),
+                return rc | lib.dcn_conv_wgrad_f16(ctypes.byref(d), _lib.ptr(xs), 0, None, _lib.ptr(dq), _lib.ptr(amax), _lib.ptr(dw),
                                                    _lib.ptr(slab), st)
             assert wgrad_f16(True) == 0
             calls["wgrad"] = wgrad_f16
