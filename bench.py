@@ -1,20 +1,23 @@
 #!/usr/bin/env python3
 """Training throughput of the dense-correspondence hot path on MI355X.
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W          (N > 1 without a launcher: bench.py starts the N ranks itself)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 
 One step = one pass of the reference's training iteration (dense_correspondence/training/training.py:325-346)
 over one synthetic batch already resident in HBM:
-    zero grads -> dcn.forward(img_a), dcn.forward(img_b) (by default as ONE grouped engine call, forward_pair: identical
-    values, batch-norm statistics per image batch; --separate-forwards for two calls) -> process_network_output x2 ->
-    loss_composer (match + masked + background non-match lists, hard-negative scaling) -> backward ->
-    gradient all-reduce (RCCL, N > 1) -> Adam step (lr 1e-4, weight decay 1e-4, training.yaml:3,6).
-Workload at N = 1: BASELINE.json configs[1] -- B = 4 image pairs (8 images / step), 640x480, D = 3,
-Resnet34_8s, 5000 match + 2500 masked + 2500 background non-match pixel pairs per image pair.  For N > 1 every
-rank runs that same per-GPU workload on its own pairs (weak scaling, BN statistics per rank: the reference has no
-SyncBN); `value` is the whole-job images / second.
+    optimizer.zero_grad() -> dcn.forward(img_a), dcn.forward(img_b) (by default as ONE grouped engine call, forward_pair:
+    identical values, batch-norm statistics per image batch; --separate-forwards for two calls) -> process_network_output x2
+    -> loss_composer (match + masked + background non-match lists, hard-negative scaling) -> backward, with the gradient
+    buckets all-reduced over RCCL on a communication stream as the backbone's backward completes them (N > 1) ->
+    Adam step (lr 1e-4, weight decay 1e-4, training.yaml:3,6).
+Workload at N = 1: BASELINE.json configs[1] -- B = 4 image pairs (8 images / step), 640x480, D = 3, Resnet34_8s, 5000 match
++ 2500 masked + 2500 background non-match pixel pairs per image pair.  At N > 1: BASELINE configs[3] -- global batch
+8 N image pairs, every rank runs B = 8 pairs of its own (weak scaling, BN statistics per rank: the reference has no
+SyncBN); `value` is the whole-job images / second.  The same line carries, as `variants`, the measurements that complete
+the picture: the fp32-MFMA arithmetic and configs[3]'s per-GPU share on ONE GPU (N = 1), the fixed-global-batch-64
+strong-scaling point (N > 1), and `allreduce_ms` / `communication` (collective alone, exposed per step, RCCL rank count).
 
 Prints ONE JSON line on rank 0 (contract in the task description) with `roofline` (dominant kernel = the gather-GEMM
 convolution, conv_gemm_f16_kernel in the default split-fp16 arithmetic / conv_gemm_kernel with --conv-mode fp32;
@@ -139,19 +142,23 @@ def usable_cpus():
 
 def cpu_baseline(wl, steps, warmup):
     """The oracle's training step (oracle/step.py, the CPU restatement of the reference) on this box's host cores.
-    Bounded sample: ONE image pair of the workload's shapes."""
+    Bounded sample (~10-30 s of CPU work): the workload's FULL batch when it has at most 4 image pairs (config 1, config 2),
+    otherwise ONE image pair of its shapes (BN statistics then over 1 image instead of B: same FLOPs per image)."""
     from oracle import resnet_dilated_oracle, step as ostep, synth
     cores = usable_cpus()
     torch.set_num_threads(cores)
     model = resnet_dilated_oracle.build(wl["backbone"], wl["D"], seed=0)
     model.train()
-    img_a, img_b, lists = synth.make_batch(1, wl["H"], wl["W"], wl["Pm"], wl["Pk"], wl["Pg"], seed=1,
+    Bc = wl["B"] if wl["B"] <= 4 else 1
+    img_a, img_b, lists = synth.make_batch(Bc, wl["H"], wl["W"], wl["Pm"], wl["Pk"], wl["Pg"], seed=1,
                                            masked=wl.get("masked", False))
     sec = ostep.time_cpu_step(model, img_a, img_b, lists, synth.LOSS_CONFIG, steps=steps, warmup=warmup)
-    return {"value": 2.0 / sec, "unit": "images/s", "cores": cores, "host_logical_cpus": os.cpu_count(), "kind": "port",
-            "sample": "oracle (py3 CPU restatement of training.py:325-346, torch %s, fp32) on 1 image pair of the "
-                      "workload's shapes (%dx%d, D=%d, %d/%d/%d pairs), %d warm-up + median of %d steps, %.2f s/step"
-                      % (torch.__version__.split("+")[0], wl["W"], wl["H"], wl["D"], wl["Pm"], wl["Pk"], wl["Pg"],
+    return {"value": 2.0 * Bc / sec, "unit": "images/s", "cores": cores, "host_logical_cpus": os.cpu_count(), "kind": "port",
+            "sample": "oracle (py3 CPU restatement of training.py:325-346, torch %s, fp32, forward + loss + backward + Adam) on "
+                      "%s of the workload's shapes (%dx%d, D=%d, %d/%d/%d pixel pairs per image pair), %d warm-up + median "
+                      "of up to %d steps (30 s budget), %.2f s/step"
+                      % (torch.__version__.split("+")[0], "the full batch of %d image pairs" % Bc if Bc == wl["B"] else
+                         "1 of the %d image pairs" % wl["B"], wl["W"], wl["H"], wl["D"], wl["Pm"], wl["Pk"], wl["Pg"],
                          warmup, steps, sec)}
 
 
@@ -223,14 +230,133 @@ def pairgen_bench(args):
     print(json.dumps(out), flush=True)
 
 
+def respawn_under_torchrun(n):
+    """`python bench.py --gpus N` with no torch.distributed.run around it: start the N ranks ourselves (one process per
+    GPU, RCCL over xGMI) and relay rank 0's JSON line."""
+    import socket
+    import subprocess
+    if not torch.cuda.is_available() or torch.cuda.device_count() < n:
+        raise SystemExit("bench.py --gpus %d: only %d GPU(s) visible on this node" %
+                         (n, torch.cuda.device_count() if torch.cuda.is_available() else 0))
+    sock = socket.socket()
+    sock.bind(("127.0.0.1", 0))
+    port = sock.getsockname()[1]
+    sock.close()
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # the host driver only supports dmabuf IPC (RCCL across processes)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr",
+           "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    raise SystemExit(subprocess.call(cmd, env=env))
+
+
+class Job(object):
+    """One workload on this rank: model, optimizer, flat gradients, resident synthetic batch, and the step closure."""
+
+    def __init__(self, args, wl, B, dev, rank, use_dist):
+        from dcn_hip.distributed import FlatGradients, broadcast_module
+        from dcn_hip.loss import PairLists
+        from dcn_hip.optim import Adam
+        from dense_correspondence.loss_functions import loss_composer
+        from dense_correspondence.loss_functions.pixelwise_contrastive_loss import PixelwiseContrastiveLoss
+        from dense_correspondence.network.dense_correspondence_network import DenseCorrespondenceNetwork
+        self.args, self.wl, self.B, self.dev = args, wl, B, dev
+        H, W, D = wl["H"], wl["W"], wl["D"]
+        torch.manual_seed(0)
+        cfg = {"descriptor_dimension": D, "image_width": W, "image_height": H,
+               "backbone": {"model_class": "Resnet", "resnet_name": wl["backbone"]}}
+        self.dcn = dcn = DenseCorrespondenceNetwork.from_config(cfg, load_stored_params=False)  # .cuda().train() like network.py:435
+        dcn.to(dev)
+        broadcast_module(dcn)
+        self.pcl = pcl = PixelwiseContrastiveLoss(image_shape=dcn.image_shape, config=LOSS_CONFIG)
+        self.grads = grads = FlatGradients(dcn, bucketed=False if args.monolithic_allreduce else None)
+        self.opt = opt = grads.attach((torch.optim.Adam if args.torch_adam else Adam)(
+            dcn.parameters(), lr=1.0e-4, weight_decay=1.0e-4))   # training.py:133-145
+        img_a, img_b, lists = make_batch(B, H, W, wl["Pm"], wl["Pk"], wl["Pg"], seed=1 + rank, masked=wl.get("masked", False))
+        self.img_a, self.img_b = img_a, img_b = img_a.to(dev), img_b.to(dev)
+        self.pair_lists = pair_lists = PairLists.from_lists(as_tuples(lists), dev, hw=H * W)
+        self.match_type = match_type = 0  # SINGLE_OBJECT_WITHIN_SCENE
+        self.comm = True
+
+        def forward_backward():
+            opt.zero_grad()              # training.py:325 (the attached flat buffer is zeroed in place, one kernel)
+            if args.separate_forwards:   # literally training.py:329-333
+                ya, yb = dcn.forward(img_a), dcn.forward(img_b)
+            else:                        # the same two network calls as ONE grouped launch sequence (BN statistics per image batch)
+                ya, yb = dcn.forward_pair(img_a, img_b)
+            pa = dcn.process_network_output(ya, B)
+            pb = dcn.process_network_output(yb, B)
+            loss, terms, hard = loss_composer.get_loss_batched(pcl, match_type, pa, pb, pair_lists)
+            loss.backward()              # (world > 1: the gradient buckets are all-reduced on the communication stream from
+            return loss                  #  inside this call, as the backbone's backward completes them)
+        self.forward_backward = forward_backward
+
+        # The ~600 launches of forward + loss + backward are captured ONCE into a hipGraph (inputs, lists, parameters and
+        # the flat gradient buffer are static tensors; a training loop copies each new batch into them) and replayed per
+        # step; the gradient all-reduce and the optimizer stay eager.  Falls back to eager launches if capture fails.
+        self.graph, self.static_loss, self.graph_note = None, None, "off"
+        if args.hip_graph:
+            try:
+                side = torch.cuda.Stream()
+                side.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(side):
+                    for _ in range(2):
+                        forward_backward()
+                torch.cuda.current_stream().wait_stream(side)
+                torch.cuda.synchronize()
+                self.graph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(self.graph):
+                    self.static_loss = forward_backward()
+                self.graph_note = "forward + loss + backward replayed from one captured hipGraph"
+            except Exception as e:  # noqa: BLE001 -- any capture problem: run eagerly, say so in the JSON
+                self.graph, self.graph_note = None, "capture failed (%s): eager launches" % (str(e).splitlines()[0][:120],)
+                torch.cuda.synchronize()
+
+    def step(self, it, eager=False):
+        if it % 250 == 0 and it > 0:  # training.yaml:4-5 step decay
+            for g in self.opt.param_groups:
+                g["lr"] *= 0.9
+        if self.graph is not None and not eager:
+            self.graph.replay()
+            loss = self.static_loss
+        else:
+            loss = self.forward_backward()
+        if self.comm:
+            self.grads.all_reduce_mean()   # joins the communication stream (bucketed) or ONE collective (monolithic)
+        self.opt.step()
+        return loss
+
+    def timed(self, warmup, steps, first_it, use_dist):
+        """W untimed steps, then exactly K steps between barrier + synchronize; max over ranks.  -> (seconds, last loss)"""
+        loss = None
+        for it in range(warmup):
+            loss = self.step(first_it + it)
+        if use_dist:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for it in range(steps):
+            loss = self.step(first_it + warmup + it)
+        torch.cuda.synchronize()
+        if use_dist:
+            dist.barrier()
+        torch.cuda.synchronize()
+        elapsed = time.perf_counter() - t0
+        if use_dist:
+            t = torch.tensor([elapsed], dtype=torch.float64, device=self.dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            elapsed = float(t.item())
+        return elapsed, loss
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--workload", default="config2", choices=sorted(WORKLOADS) + ["pairgen"])
+    ap.add_argument("--workload", default=None, choices=sorted(WORKLOADS) + ["pairgen"],
+                    help="default: config2 (BASELINE configs[1]) on one GPU, config4 (configs[3]: B = 8 pairs per GPU) on several")
     ap.add_argument("--batch", type=int, default=0, help="override image pairs per GPU per step")
-    ap.add_argument("--cpu-baseline-steps", type=int, default=3, help="0 disables the CPU baseline leg")
+    ap.add_argument("--cpu-baseline-steps", type=int, default=5, help="0 disables the CPU baseline leg")
     ap.add_argument("--profile-steps", type=int, default=3, help="extra steps with per-launch HIP events (roofline)")
     ap.add_argument("--conv-mode", default="f16x3", choices=["f16x3", "fp32"],
                     help="convolution arithmetic (include/dcn_hip.h): split-fp16 on the fp16 MFMA pipe with fp32-level "
@@ -242,18 +368,25 @@ def main():
                     help="forward(img_a) and forward(img_b) as two engine calls (default: one grouped call with identical results)")
     ap.add_argument("--torch-adam", action="store_true", help="optimizer.step() through torch.optim.Adam instead of dcn_adam_step")
     ap.add_argument("--force-dist", action="store_true", help="initialise RCCL even with one rank (smoke-tests the collective path)")
+    ap.add_argument("--monolithic-allreduce", action="store_true",
+                    help="ONE all-reduce after backward instead of the bucketed, overlapped schedule")
+    ap.add_argument("--no-variants", action="store_true", help="skip the extra measurements (fp32-MFMA mode, config 4 on one "
+                                                                "GPU, strong-scaling point) that ride on the JSON line")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        respawn_under_torchrun(args.gpus)   # does not return
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and world > 1:
+    if world != args.gpus:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the dense-correspondence hot path has no CPU fallback")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     use_dist = world > 1 or args.force_dist
+    rccl = None
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
@@ -261,18 +394,18 @@ def main():
         dist.barrier()
         import ctypes
         ctypes.CDLL(None).fflush(None)  # RCCL's version banner sits in the C stdio buffer: emit it now, not after the JSON line
+        rccl = {"backend": dist.get_backend(), "ranks": dist.get_world_size(),
+                "nccl_version": ".".join(str(v) for v in torch.cuda.nccl.version())}
 
+    if args.workload is None:
+        args.workload = "config2" if world == 1 else "config4"
     if args.workload == "pairgen":
         if world > 1:
             raise SystemExit("--workload pairgen is a single-GPU measurement")
         return pairgen_bench(args)
     from dcn_hip import _lib, backbone as bb
     bb.set_conv_mode(args.conv_mode)
-    from dcn_hip.distributed import FlatGradients, broadcast_module
-    from dcn_hip.loss import PairLists
     from dense_correspondence.loss_functions import loss_composer
-    from dense_correspondence.loss_functions.pixelwise_contrastive_loss import PixelwiseContrastiveLoss
-    from dense_correspondence.network.dense_correspondence_network import DenseCorrespondenceNetwork
     info = _lib.library_info()
     assert not info["hostemu"], "bench.py must run the gfx950 library"
 
@@ -280,134 +413,100 @@ def main():
     if args.batch:
         wl["B"] = args.batch
     B, H, W, D = wl["B"], wl["H"], wl["W"], wl["D"]
-    torch.manual_seed(0)
-    cfg = {"descriptor_dimension": D, "image_width": W, "image_height": H,
-           "backbone": {"model_class": "Resnet", "resnet_name": wl["backbone"]}}
-    dcn = DenseCorrespondenceNetwork.from_config(cfg, load_stored_params=False)  # .cuda().train() like network.py:435
-    dcn.to(dev)
-    broadcast_module(dcn)
-    pcl = PixelwiseContrastiveLoss(image_shape=dcn.image_shape, config=LOSS_CONFIG)
-    grads = FlatGradients(dcn)
-    from dcn_hip.optim import Adam
-    opt = (torch.optim.Adam if args.torch_adam else Adam)(dcn.parameters(), lr=1.0e-4, weight_decay=1.0e-4)   # training.py:133-145
-    img_a, img_b, lists = make_batch(B, H, W, wl["Pm"], wl["Pk"], wl["Pg"], seed=1 + rank, masked=wl.get("masked", False))
-    img_a, img_b = img_a.to(dev), img_b.to(dev)
-    pair_lists = PairLists.from_lists(as_tuples(lists), dev)
-    match_type = 0  # SINGLE_OBJECT_WITHIN_SCENE
+    job = Job(args, wl, B, dev, rank, use_dist)
+    dcn, pcl, grads, pair_lists, match_type = job.dcn, job.pcl, job.grads, job.pair_lists, job.match_type
+    img_a, img_b = job.img_a, job.img_b
+    graph = job.graph
+    graph_note = job.graph_note
+    step = job.step
 
-    def forward_backward():
-        grads.zero_()
-        if args.separate_forwards:   # literally training.py:329-333
-            ya, yb = dcn.forward(img_a), dcn.forward(img_b)
-        else:                        # the same two network calls as ONE grouped launch sequence (BN statistics per image batch)
-            ya, yb = dcn.forward_pair(img_a, img_b)
-        pa = dcn.process_network_output(ya, B)
-        pb = dcn.process_network_output(yb, B)
-        loss, terms, hard = loss_composer.get_loss_batched(pcl, match_type, pa, pb, pair_lists)
-        loss.backward()
-        return loss
-
-    # The ~600 launches of forward + loss + backward are captured ONCE into a hipGraph (inputs, lists, parameters and
-    # the flat gradient buffer are static tensors; a training loop copies each new batch into them) and replayed per
-    # step; the gradient all-reduce and the optimizer stay eager.  Falls back to eager launches if capture fails.
-    graph, static_loss, graph_note = None, None, "off"
-    if args.hip_graph:
-        try:
-            side = torch.cuda.Stream()
-            side.wait_stream(torch.cuda.current_stream())
-            with torch.cuda.stream(side):
-                for _ in range(2):
-                    forward_backward()
-            torch.cuda.current_stream().wait_stream(side)
-            torch.cuda.synchronize()
-            graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph):
-                static_loss = forward_backward()
-            graph_note = "forward + loss + backward replayed from one captured hipGraph"
-        except Exception as e:  # noqa: BLE001 -- any capture problem: run eagerly, say so in the JSON
-            graph, graph_note = None, "capture failed (%s): eager launches" % (str(e).splitlines()[0][:120],)
-            torch.cuda.synchronize()
-
-    def step(it, eager=False):
-        if it % 250 == 0 and it > 0:  # training.yaml:4-5 step decay
-            for g in opt.param_groups:
-                g["lr"] *= 0.9
-        if graph is not None and not eager:
-            graph.replay()
-            loss = static_loss
-        else:
-            loss = forward_backward()
-        grads.all_reduce_mean()
-        opt.step()
-        return loss
-
-    def fence():
-        if use_dist:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    for it in range(args.warmup):
-        loss = step(it)
-    fence()
-    t0 = time.perf_counter()
-    for it in range(args.steps):
-        loss = step(args.warmup + it)
-    torch.cuda.synchronize()
-    if use_dist:
-        dist.barrier()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    if use_dist:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    elapsed, loss = job.timed(args.warmup, args.steps, 0, use_dist)
     final_loss = float(loss.item())
 
+    # ---- gradient all-reduce: the collective alone (whole flat buffer, RCCL), and what the step really pays for it
+    # (same steps with the communication switched off; the bucketed schedule hides all but the last bucket)
+    comm = None
+    if use_dist:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        reps = 10
+        for _ in range(3):
+            dist.all_reduce(grads.flat)
+        dist.barrier()
+        e0.record()
+        for _ in range(reps):
+            dist.all_reduce(grads.flat)
+        e1.record()
+        torch.cuda.synchronize()
+        ar_ms = e0.elapsed_time(e1) / reps
+        job.comm = False
+        grads.bucketed = False
+        nocomm, _ = job.timed(2, max(4, args.steps // 2), args.warmup + args.steps, use_dist)
+        job.comm = True
+        grads.bucketed = False if args.monolithic_allreduce else None
+        broadcast = __import__("dcn_hip.distributed", fromlist=["broadcast_module"]).broadcast_module
+        broadcast(dcn)   # the un-synchronised steps let the replicas drift: re-align before anything else is measured
+        comm = {"allreduce_ms": ar_ms, "allreduce_bytes": grads.flat.numel() * 4,
+                "allreduce_busbw_GBps": (grads.flat.numel() * 4 * 2 * (world - 1) / max(world, 1)) / (ar_ms * 1e-3) / 1e9 if world > 1 else None,
+                "schedule": "monolithic: one all-reduce after backward" if args.monolithic_allreduce or graph is not None else
+                "bucketed: fc+layer4 | layer3 | rest, each all-reduced on a communication stream as soon as the backbone's "
+                "backward has produced it (dcn_plan_stream_wait_grad_bucket)",
+                "ms_per_step_without_allreduce": 1e3 * nocomm / max(4, args.steps // 2),
+                "allreduce_exposed_ms": 1e3 * elapsed / args.steps - 1e3 * nocomm / max(4, args.steps // 2),
+                "bucketed_steps": grads.stats["bucketed_steps"], "monolithic_steps": grads.stats["monolithic_steps"]}
+        comm.update(rccl)
+
     # ---- roofline of the dominant kernel: extra steps, every conv_gemm / conv_wgrad launch bracketed by HIP events
-    roofline = None
-    if args.profile_steps > 0:
-        plan = bb.get_plan(wl["backbone"], 64, B, H, W, D) if args.separate_forwards else \
-            bb.get_plan(wl["backbone"], 64, 2 * B, H, W, D, 2)
+    def measure_roofline(job_, conv_mode, first_it):
+        wl_, B_ = job_.wl, job_.B
+        plan = bb.get_plan(wl_["backbone"], 64, B_, wl_["H"], wl_["W"], wl_["D"]) if args.separate_forwards else \
+            bb.get_plan(wl_["backbone"], 64, 2 * B_, wl_["H"], wl_["W"], wl_["D"], 2)
         plan.profile_begin()
         for it in range(args.profile_steps):
-            step(args.warmup + args.steps + it, eager=True)   # the engine's per-launch events do not exist inside a graph
+            job_.step(first_it + it, eager=True)   # the engine's per-launch events do not exist inside a graph
         prof = plan.profile_end()
         ms, n, fl = prof["conv_gemm"]
         wms, wn, wfl = prof["conv_wgrad"]
-        if n > 0 and ms > 0:
-            achieved = fl / (ms * 1e-3) / 1e12
-            if args.conv_mode == "fp32":
-                peak, kern = FP32_MFMA_PEAK_TFLOPS, "conv_gemm_kernel (fp32 v_mfma_f32_32x32x2_f32; forward + dgrad)"
-                peak_note = "fp32 MFMA dense peak"
-            else:
-                # one fp32-accurate multiply-add = 3 fp16 MFMA products (hi*hi + hi*lo + lo*hi): the ceiling for
-                # ALGORITHMIC flops is a third of the fp16 pipe's dense peak
-                peak, kern = F16X3_PEAK_TFLOPS, "conv_gemm_f16_kernel (3x v_mfma_f32_32x32x16_f16 per product; forward + dgrad)"
-                peak_note = "fp16 MFMA dense peak %.1f / 3 products per fp32-accurate MAC (fp32 MFMA peak: %.1f)" % (
-                    F16_MFMA_PEAK_TFLOPS, FP32_MFMA_PEAK_TFLOPS)
-            # HBM-side traffic of the dominant kernel cannot be measured from inside the process (PMC counters need
-            # rocprofv3): it is the committed measurement of this very command (profiles/, collected and corrected per
-            # MI355X_MICROARCH.md's HBM section), attached only when workload / arithmetic / call pattern match
-            traffic, traffic_note = None, None
+        if not (n > 0 and ms > 0):
+            return None
+        achieved = fl / (ms * 1e-3) / 1e12
+        if conv_mode == "fp32":
+            peak, kern = FP32_MFMA_PEAK_TFLOPS, "conv_gemm_kernel (fp32 v_mfma_f32_32x32x2_f32; forward + dgrad)"
+            peak_note = "fp32 MFMA dense peak"
+        else:
+            # one fp32-accurate multiply-add = 3 fp16 MFMA products (hi*hi + hi*lo + lo*hi): the ceiling for
+            # ALGORITHMIC flops is a third of the fp16 pipe's dense peak
+            peak, kern = F16X3_PEAK_TFLOPS, "conv_gemm_f16_kernel (3x v_mfma_f32_32x32x16_f16 per product; forward + dgrad)"
+            peak_note = "fp16 MFMA dense peak %.1f / 3 products per fp32-accurate MAC (fp32 MFMA peak: %.1f)" % (
+                F16_MFMA_PEAK_TFLOPS, FP32_MFMA_PEAK_TFLOPS)
+        # HBM-side traffic of the dominant kernel cannot be measured from inside the process (PMC counters need
+        # rocprofv3): it is the COMMITTED measurement of this very command (profiles/, collected and corrected per
+        # MI355X_MICROARCH.md's HBM section), attached only when workload / arithmetic / call pattern match -- the
+        # field name says so: it was not measured in this run
+        traffic, traffic_src = None, None
+        for name in ("r2_hbm_counters.json", "r1g_hbm_counters.json"):
             try:
-                rec = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r1g_hbm_counters.json")))
-                if (rec["workload"] == args.workload and rec["conv_mode"] == args.conv_mode and not args.batch and
+                rec = json.load(open(os.path.join(ROOT, "profiles", name)))
+                if (rec["workload"] == args.workload and rec["conv_mode"] == conv_mode and not args.batch and job_ is job and
                         (rec["forward_calls"] == "pair") == (not args.separate_forwards)):
                     traffic = rec["hbm_bytes_per_launch"]
-                    traffic_note = "profiles/r1g_hbm_counters.json: " + rec["correction"]
+                    traffic_src = "committed rocprofv3 --pmc measurement of this command, profiles/%s: %s" % (name, rec["correction"])
+                    break
             except (OSError, KeyError, ValueError):
                 pass
-            roofline = {"bound": "mfma", "kernel": kern,
-                        "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "peak_note": peak_note,
-                        "frac": achieved / peak, "traffic": traffic, "traffic_note": traffic_note,
-                        "launches_per_step": n / args.profile_steps, "avg_launch_us": 1e3 * ms / n,
-                        "algorithmic_gflop_per_launch": fl / n / 1e9,
-                        "kernel_ms_per_step": ms / args.profile_steps,
-                        "conv_wgrad": {"achieved": (wfl / (wms * 1e-3) / 1e12) if wms > 0 else None,
-                                       "frac": (wfl / (wms * 1e-3) / 1e12 / peak) if wms > 0 else None,
-                                       "launches_per_step": wn / args.profile_steps,
-                                       "avg_launch_us": (1e3 * wms / wn) if wn else None,
-                                       "kernel_ms_per_step": wms / args.profile_steps}}
+        return {"bound": "mfma", "kernel": kern,
+                "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "peak_note": peak_note,
+                "frac": achieved / peak, "traffic": traffic, "traffic_from_committed_profile": traffic_src,
+                "launches_per_step": n / args.profile_steps, "avg_launch_us": 1e3 * ms / n,
+                "algorithmic_gflop_per_launch": fl / n / 1e9,
+                "kernel_ms_per_step": ms / args.profile_steps,
+                "conv_wgrad": {"achieved": (wfl / (wms * 1e-3) / 1e12) if wms > 0 else None,
+                               "frac": (wfl / (wms * 1e-3) / 1e12 / peak) if wms > 0 else None,
+                               "launches_per_step": wn / args.profile_steps,
+                               "avg_launch_us": (1e3 * wms / wn) if wn else None,
+                               "kernel_ms_per_step": wms / args.profile_steps}}
+
+    it_next = args.warmup + args.steps + 64
+    roofline = measure_roofline(job, args.conv_mode, it_next) if args.profile_steps > 0 else None
 
     # ---- HBM roofline of the loss gather (K9): forward + backward of the fused contrastive loss alone, on the
     # descriptor maps of the last step, timed with events on the launch stream
@@ -439,6 +538,45 @@ def main():
                      "pixel_pairs": npairs, "algorithmic_bytes": {"pairs": pair_bytes, "zero_fill": fill_bytes},
                      "note": "latency-bound at this size: %d random %d-byte gathers per call" % (2 * npairs, 4 * D)}
 
+    # ---- measurements that ride on the same line (driver-timed): the same-precision fp32-MFMA arithmetic, BASELINE
+    # configs[3]'s per-GPU share on ONE GPU (the 1-GPU point of the weak-scaling curve the multi-GPU runs trace), and for
+    # N > 1 the fixed-global-batch-64 strong-scaling point
+    variants = {}
+    short = max(5, args.steps // 2)
+
+    def summarize(job_, sec, steps_, extra=None):
+        d = {"value": 2 * job_.B * world * steps_ / sec, "unit": "images/s", "ms_per_step": 1e3 * sec / steps_, "steps": steps_,
+             "pairs_per_gpu": job_.B, "global_pairs": job_.B * world}
+        d.update(extra or {})
+        return d
+
+    if not args.no_variants and graph is None:
+        if world == 1 and args.conv_mode == "f16x3":
+            bb.set_conv_mode("fp32")
+            sec, _ = job.timed(2, short, it_next + 16, use_dist)
+            r32 = measure_roofline(job, "fp32", it_next + 64) if args.profile_steps > 0 else None
+            variants["fp32_mfma"] = summarize(job, sec, short, {
+                "arithmetic": "fp32 MFMA (v_mfma_f32_32x32x2_f32): the same-precision comparison point of the default",
+                "roofline": None if r32 is None else {k: r32[k] for k in ("kernel", "achieved", "peak", "frac", "kernel_ms_per_step")}})
+            bb.set_conv_mode(args.conv_mode)
+        if world == 1 and args.workload == "config2" and not args.batch:
+            wl4 = dict(WORKLOADS["config4"])
+            job4 = Job(args, wl4, wl4["B"], dev, rank, use_dist)
+            sec, _ = job4.timed(3, short, 0, use_dist)
+            variants["config4_one_gpu"] = summarize(job4, sec, short, {"workload": wl4["desc"]})
+            del job4
+        if world > 1 and 64 % world == 0 and args.workload == "config4" and not args.batch:
+            Bs = 64 // world
+            if Bs == B:
+                variants["strong_scaling_global64"] = summarize(job, elapsed, args.steps, {"note": "same as the headline at this N"})
+            else:
+                jobs = Job(args, wl, Bs, dev, rank, use_dist)
+                sec, _ = jobs.timed(2, short, 0, use_dist)
+                variants["strong_scaling_global64"] = summarize(jobs, sec, short, {
+                    "workload": "BASELINE configs[3]: global batch 64 image pairs split over %d GPUs" % world})
+                del jobs
+        torch.cuda.empty_cache()
+
     if rank == 0:
         images_per_step = 2 * B * world
         ms_per_step = 1e3 * elapsed / args.steps
@@ -446,7 +584,8 @@ def main():
                else "training images/sec (%s)" % args.workload,
                "value": images_per_step * args.steps / elapsed, "unit": "images/s", "n_gpus": world,
                "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
-               "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+               "scaling": "weak", "vs_baseline": None,
+               "dtype": "f32 (f16x3 products)" if args.conv_mode == "f16x3" else "f32", "data": "synthetic",
                "arithmetic": ("fp32 tensors and accumulation; convolution products as 3 fp16 MFMAs on exact hi/lo operand "
                               "splits (~22 mantissa bits per operand; parity with the fp32 reference at 1e-4, tests/test_gpu_parity.py)"
                               if args.conv_mode == "f16x3" else "fp32 MFMA"),
@@ -456,13 +595,14 @@ def main():
                           "conv_mode": args.conv_mode, "hip_graph": graph_note,
                           "backward_schedule": ("serial (DCN_BACKWARD_OVERLAP=0)" if os.environ.get("DCN_BACKWARD_OVERLAP") == "0" or args.conv_mode != "f16x3" or graph is not None
                                                 else "weight-gradient GEMMs on the engine's side stream next to dgrad / BN backward; the roofline "
-                                                     "steps time every launch alone (serial schedule), see profiles/r1g_kernel_stats*.txt"),
+                                                     "steps time every launch alone (serial schedule), see profiles/r2_kernel_stats*.txt"),
                           "forward_calls": "forward(img_a), forward(img_b)" if args.separate_forwards else
                           "forward_pair(img_a, img_b): both network calls of the step as one grouped launch sequence, batch-norm "
                           "statistics / running statistics / gradients per image batch (identical results)", "optimizer": "Adam lr 1e-4 wd 1e-4 (%s)" % ("torch.optim.Adam" if args.torch_adam else "dcn_adam_step, one pass"), "parallelism": "dp%d" % world,
                           "library": info["version"], "final_loss": final_loss,
                           "train_gflop_per_image": 3 * bb.get_plan(wl["backbone"], 64, B, H, W, D).forward_flops / B / 1e9},
-               "roofline": roofline, "roofline_loss_gather": loss_roof}
+               "roofline": roofline, "roofline_loss_gather": loss_roof, "variants": variants,
+               "allreduce_ms": comm["allreduce_ms"] if comm else None, "communication": comm}
         if world == 1 and args.cpu_baseline_steps > 0:
             out["cpu_baseline"] = cpu_baseline(wl, args.cpu_baseline_steps, 1)
         else:

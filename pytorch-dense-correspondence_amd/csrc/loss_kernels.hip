@@ -7,43 +7,35 @@
 //   pixelwise_contrastive_loss.py:307-352  l2_pixel_loss               w_j = min(||uv(gt_j)-uv(b_j)||, M_pixel)/M_pixel
 //   loss_composer.py:70-212                composition + hard-negative scaling
 //
-// HBM-bound, latency-dominated gather: one work-item per pixel pair reads its two int64 indices
-// (coalesced), then the two D-float descriptors straight from the [pairs, HW, D] descriptor maps (one
-// contiguous 4*D-byte read each thanks to the channels_last descriptor layout), reduces across the
-// 64-lane wavefront with shuffles, across the workgroup through LDS, and writes ONE partial per
-// workgroup.  A single-workgroup finalize kernel adds the partials in a fixed order in fp64 (run-to-run
-// deterministic forward) and composes the 5-tuple on the device, so the hard-negative count never
-// travels to the host (the reference syncs twice per step at pcl.py:210-211).
+// HBM-bound gather: a group of LP = 4 / 8 / 16 / 32 lanes per pixel pair reads the pair's two int64 indices, then the two
+// D-float descriptors straight from the [pairs, HW, D] descriptor maps as ONE contiguous 4*D-byte run each (the
+// channels_last descriptor layout makes a descriptor contiguous; lane k of the group takes component k), reduces the
+// squared distance inside the group with xor-shuffles, the loss terms across the 64-lane wavefront with shuffles and
+// across the workgroup through LDS, and writes ONE partial per workgroup.  A single-workgroup finalize kernel adds the
+// partials in a fixed order in fp64 (run-to-run deterministic forward) and composes the 5-tuple on the device, so the
+// hard-negative count never travels to the host (the reference syncs twice per step at pcl.py:210-211).  The backward
+// scatter-adds a pair's gradient as D consecutive fp32 atomics per descriptor (one cache line per group).
 // Algorithmic traffic per pair, fwd+bwd: 2*8 B indices + 2*4D B reads (x2, fwd and bwd) + 2*4D B atomics.
 #include "dcn_common.h"
 
 namespace {
 
 constexpr int kThreads = 256;
-constexpr int kItems = 4;  // pairs per work-item
-constexpr int kPairsPerBlock = kThreads * kItems;
+constexpr int kItems = 8;  // pairs per lane group
 
-template <int DT> struct Desc {
-    static __device__ __forceinline__ float dist2(const float* a, const float* b, int d_rt, float* diff) {
-        float s = 0.f;
-        if (DT % 4 == 0 && DT > 0) {
+// Lane mapping: LP = 4 / 8 / 16 / 32 consecutive lanes share one pixel pair and each owns the descriptor components
+// sub, sub + LP, ... -- so the two gathers of a pair are ONE contiguous 4*D-byte run across the group (not D strided
+// loads of one lane), the squared distance is a log2(LP)-step xor-shuffle reduction inside the group, and the backward
+// scatter-add of a pair's gradient is one run of D consecutive fp32 atomics per descriptor: a wave-instruction touches
+// 64 / LP cache lines with LP dwords each instead of 64 lines with one dword each (16x fewer L2 atomic line operations
+// at D = 16).  SINGLE: D <= LP, every lane holds at most one component (kept in a register between the two phases).
+template <int LP> __device__ __forceinline__ float group_sum(float v) {
 #pragma unroll
-            for (int k = 0; k < DT; k += 4) {
-                const float4 x = *reinterpret_cast<const float4*>(a + k);
-                const float4 y = *reinterpret_cast<const float4*>(b + k);
-                diff[k] = x.x - y.x; diff[k + 1] = x.y - y.y; diff[k + 2] = x.z - y.z; diff[k + 3] = x.w - y.w;
-            }
-#pragma unroll
-            for (int k = 0; k < DT; ++k) s = fmaf(diff[k], diff[k], s);
-        } else if (DT > 0) {
-#pragma unroll
-            for (int k = 0; k < DT; ++k) { diff[k] = a[k] - b[k]; s = fmaf(diff[k], diff[k], s); }
-        } else {
-            for (int k = 0; k < d_rt; ++k) { const float t = a[k] - b[k]; s = fmaf(t, t, s); }
-        }
-        return s;
-    }
-};
+    for (int o = LP / 2; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+constexpr int pairs_per_block(int lp) { return kThreads / lp * kItems; }
+inline int lanes_per_pair(int d) { return d <= 4 ? 4 : (d <= 8 ? 8 : (d <= 16 ? 16 : 32)); }
 
 __device__ __forceinline__ float pixel_weight(int64_t gt, int64_t nb, int width, float m_pixel) {
     const float du = (float)((gt % width) - (nb % width));
@@ -52,18 +44,19 @@ __device__ __forceinline__ float pixel_weight(int64_t gt, int64_t nb, int width,
 }
 
 // grid = (chunks, 4*num_pairs).  Every workgroup writes its partial, chunks beyond the list's end write zeros.
-template <int DT>
+template <int LP, bool SINGLE>
 __global__ void __launch_bounds__(kThreads)
-loss_fwd_kernel(const float* __restrict__ A, const float* __restrict__ B, int64_t hw, int d_rt,
+loss_fwd_kernel(const float* __restrict__ A, const float* __restrict__ B, int64_t hw, int D,
                 const int64_t* __restrict__ idx_a, const int64_t* __restrict__ idx_b,
                 const int64_t* __restrict__ offsets, dcn_loss_config cfg, double* __restrict__ part_sum,
                 int* __restrict__ part_cnt, float* __restrict__ per_term, int* __restrict__ status) {
     __shared__ double s_sum[kThreads / dcn::kWave];
     __shared__ int s_cnt[kThreads / dcn::kWave];
-    const int D = DT > 0 ? DT : d_rt;
+    constexpr int GROUPS = kThreads / LP, PPB = GROUPS * kItems;
     const int seg = blockIdx.y, p = seg >> 2, t = seg & 3;
     const int64_t beg = offsets[seg], len = offsets[seg + 1] - beg;
-    const int64_t chunk0 = (int64_t)blockIdx.x * kPairsPerBlock;
+    const int64_t chunk0 = (int64_t)blockIdx.x * PPB;
+    const int grp = threadIdx.x / LP, sub = threadIdx.x % LP;
     double sum = 0.0;
     int cnt = 0;
     if (chunk0 < len) {
@@ -75,36 +68,45 @@ loss_fwd_kernel(const float* __restrict__ A, const float* __restrict__ B, int64_
         float acc = 0.f;
 #pragma unroll
         for (int it = 0; it < kItems; ++it) {
-            const int64_t j = chunk0 + (int64_t)it * kThreads + threadIdx.x;
-            if (j < len) {
-                const int64_t ia = idx_a[beg + j], ib = idx_b[beg + j];
-                float term = 0.f;
-                if (ia < 0 || ib < 0) {
-                    // the reference's `[-1]` "empty list" sentinel (dense_correspondence_dataset_masked.py:209-223)
-                    // left in place by a caller that did not want a host sync to test for it: contributes nothing
-                } else if (ia >= hw || ib >= hw) {
-                    *status = 1;
+            const int64_t j = chunk0 + (int64_t)it * GROUPS + grp;
+            // (every lane of a group takes the same branches: j, ia, ib are group-uniform; the shuffles below only mix
+            //  lanes of one group, and all 64 lanes of the wavefront reach them)
+            const bool live = j < len;
+            const int64_t ia = live ? idx_a[beg + j] : -1, ib = live ? idx_b[beg + j] : -1;
+            const bool skip = ia < 0 || ib < 0;        // the reference's `[-1]` "empty list" sentinel
+            const bool oob = !skip && (ia >= hw || ib >= hw);
+            if (oob && sub == 0) *status = 1;
+            const bool ok = !skip && !oob;
+            float s = 0.f;
+            if (ok) {
+                const float* a = Ap + ia * D;
+                const float* b = Bp + ib * D;
+                if (SINGLE) {
+                    if (sub < D) { const float df = a[sub] - b[sub]; s = df * df; }
                 } else {
-                    float diff[DT > 0 ? DT : 1];
-                    const float d2 = Desc<DT>::dist2(Ap + ia * D, Bp + ib * D, d_rt, diff);
-                    if (t == DCN_LIST_MATCH) {
-                        term = d2;
-                        acc += term;
-                    } else {
-                        const float dist = sqrtf(d2);
-                        const float h = fmaxf(cfg.invert[t] ? dist - M : M - dist, 0.f);
-                        term = h * h;
-                        cnt += (term != 0.f) ? 1 : 0;
-                        float w = 1.f;
-                        if (per > 0) {
-                            const int64_t mi = j / per;
-                            w = mi < mlen ? pixel_weight(idx_b[mbeg + mi], ib, cfg.image_width, cfg.m_pixel) : 0.f;
-                        }
-                        acc += term * w;
-                    }
+                    for (int c = sub; c < D; c += LP) { const float df = a[c] - b[c]; s = fmaf(df, df, s); }
                 }
-                if (per_term) per_term[beg + j] = term;
             }
+            const float d2 = group_sum<LP>(s);
+            float term = 0.f;
+            if (ok) {
+                if (t == DCN_LIST_MATCH) {
+                    term = d2;
+                    acc += sub == 0 ? term : 0.f;
+                } else {
+                    const float dist = sqrtf(d2);
+                    const float h = fmaxf(cfg.invert[t] ? dist - M : M - dist, 0.f);
+                    term = h * h;
+                    cnt += (sub == 0 && term != 0.f) ? 1 : 0;
+                    float w = 1.f;
+                    if (per > 0) {
+                        const int64_t mi = j / per;
+                        w = mi < mlen ? pixel_weight(idx_b[mbeg + mi], ib, cfg.image_width, cfg.m_pixel) : 0.f;
+                    }
+                    acc += sub == 0 ? term * w : 0.f;
+                }
+            }
+            if (per_term && live && sub == 0) per_term[beg + j] = term;
         }
         sum = (double)acc;
     }
@@ -209,19 +211,20 @@ loss_finalize_kernel(const double* __restrict__ part_sum, const int* __restrict_
     if (threadIdx.x == 0) loss[0] = (float)(total / (double)num_pairs);
 }
 
-// grid = (chunks, 4*num_pairs).  Scatter-adds d loss / d descriptor with hardware fp32 atomics.
-template <int DT>
+// grid = (chunks, 4*num_pairs).  Scatter-adds d loss / d descriptor with hardware fp32 atomics (lane mapping above).
+template <int LP, bool SINGLE>
 __global__ void __launch_bounds__(kThreads)
-loss_bwd_kernel(const float* __restrict__ A, const float* __restrict__ B, int64_t hw, int d_rt, int num_pairs,
+loss_bwd_kernel(const float* __restrict__ A, const float* __restrict__ B, int64_t hw, int D, int num_pairs,
                 const int64_t* __restrict__ idx_a, const int64_t* __restrict__ idx_b,
                 const int64_t* __restrict__ offsets, dcn_loss_config cfg, const int* __restrict__ hard_neg,
                 const float* __restrict__ grad_loss, const float* __restrict__ pair_grad,
                 float* __restrict__ gA, float* __restrict__ gB) {
-    const int D = DT > 0 ? DT : d_rt;
+    constexpr int GROUPS = kThreads / LP, PPB = GROUPS * kItems;
     const int seg = blockIdx.y, p = seg >> 2, t = seg & 3;
     const int64_t beg = offsets[seg], len = offsets[seg + 1] - beg;
-    const int64_t chunk0 = (int64_t)blockIdx.x * kPairsPerBlock;
+    const int64_t chunk0 = (int64_t)blockIdx.x * PPB;
     if (chunk0 >= len) return;
+    const int grp = threadIdx.x / LP, sub = threadIdx.x % LP;
     int64_t lens[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k) lens[k] = offsets[4 * p + k + 1] - offsets[4 * p + k];
@@ -244,14 +247,22 @@ loss_bwd_kernel(const float* __restrict__ A, const float* __restrict__ B, int64_
     const float M = cfg.margin[t];
 #pragma unroll
     for (int it = 0; it < kItems; ++it) {
-        const int64_t j = chunk0 + (int64_t)it * kThreads + threadIdx.x;
-        if (j >= len) continue;
-        const int64_t ia = idx_a[beg + j], ib = idx_b[beg + j];
-        if ((uint64_t)ia >= (uint64_t)hw || (uint64_t)ib >= (uint64_t)hw) continue;
-        const float* a = Ap + ia * D;
-        const float* b = Bp + ib * D;
-        float diff[DT > 0 ? DT : 1];
-        const float d2 = Desc<DT>::dist2(a, b, d_rt, diff);
+        const int64_t j = chunk0 + (int64_t)it * GROUPS + grp;
+        const bool live = j < len;
+        const int64_t ia = live ? idx_a[beg + j] : -1, ib = live ? idx_b[beg + j] : -1;
+        const bool ok = (uint64_t)ia < (uint64_t)hw && (uint64_t)ib < (uint64_t)hw;
+        const float* a = Ap + (ok ? ia : 0) * D;
+        const float* b = Bp + (ok ? ib : 0) * D;
+        float df = 0.f, s = 0.f;
+        if (ok) {
+            if (SINGLE) {
+                if (sub < D) { df = a[sub] - b[sub]; s = df * df; }
+            } else {
+                for (int c = sub; c < D; c += LP) { const float e = a[c] - b[c]; s = fmaf(e, e, s); }
+            }
+        }
+        const float d2 = group_sum<LP>(s);    // (all lanes of the wavefront get here)
+        if (!ok) continue;
         float g;  // d term / d diff = g * diff
         const float cj = pair_grad ? pair_grad[beg + j] : coef;
         if (t == DCN_LIST_MATCH) {
@@ -268,26 +279,26 @@ loss_bwd_kernel(const float* __restrict__ A, const float* __restrict__ B, int64_
             if (pair_grad) w = 1.f;  // per_term is the unweighted l_j
             g = (cfg.invert[t] ? 2.f : -2.f) * hinge / dist * w * cj;
         }
-        if (DT > 0) {
-#pragma unroll
-            for (int k = 0; k < (DT > 0 ? DT : 1); ++k) {
-                const float v = g * diff[k];
-                unsafeAtomicAdd(gAp + ia * D + k, v);
-                unsafeAtomicAdd(gBp + ib * D + k, -v);
+        if (SINGLE) {
+            if (sub < D) {
+                const float v = g * df;
+                unsafeAtomicAdd(gAp + ia * D + sub, v);
+                unsafeAtomicAdd(gBp + ib * D + sub, -v);
             }
         } else {
-            for (int k = 0; k < D; ++k) {
-                const float v = g * (a[k] - b[k]);
-                unsafeAtomicAdd(gAp + ia * D + k, v);
-                unsafeAtomicAdd(gBp + ib * D + k, -v);
+            for (int c = sub; c < D; c += LP) {
+                const float v = g * (a[c] - b[c]);
+                unsafeAtomicAdd(gAp + ia * D + c, v);
+                unsafeAtomicAdd(gBp + ib * D + c, -v);
             }
         }
     }
 }
 
-int chunks_for(int64_t max_list_len) {
-    int64_t c = dcn::ceil_div64(max_list_len > 0 ? max_list_len : 1, kPairsPerBlock);
-    return (int)c;
+// workgroups per list for descriptor dimension d (d <= 0: the worst case over all d, for workspace sizing)
+int chunks_for(int64_t max_list_len, int d) {
+    const int ppb = pairs_per_block(d > 0 ? lanes_per_pair(d) : 32);
+    return (int)dcn::ceil_div64(max_list_len > 0 ? max_list_len : 1, ppb);
 }
 
 int64_t max_len(const int64_t* offsets_host, int num_pairs) {
@@ -401,7 +412,7 @@ namespace {
 }  // namespace
 
 extern "C" size_t dcn_loss_workspace_bytes(int num_pairs, int64_t max_list_len) {
-    const size_t n = (size_t)4 * (size_t)num_pairs * (size_t)chunks_for(max_list_len);
+    const size_t n = (size_t)4 * (size_t)num_pairs * (size_t)chunks_for(max_list_len, 0);
     return n * sizeof(double) + n * sizeof(int) + 64;
 }
 
@@ -417,22 +428,23 @@ extern "C" int dcn_contrastive_loss_forward(const float* desc_a, const float* de
         if (offsets_host[s + 1] < offsets_host[s]) return DCN_E_INVALID;
     if (offsets_host[4 * num_pairs] > 0 && (!idx_a || !idx_b)) return DCN_E_INVALID;
     hipStream_t st = (hipStream_t)stream;
-    const int chunks = chunks_for(max_len(offsets_host, num_pairs));
+    const int chunks = chunks_for(max_len(offsets_host, num_pairs), d);
     const size_t n = (size_t)4 * num_pairs * chunks;
     double* part_sum = (double*)workspace;
     int* part_cnt = (int*)(part_sum + n);
     if (dcn::fill_bytes_async(status, 0, sizeof(int32_t), st) != DCN_OK) return DCN_E_LAUNCH;
     const dim3 grid(chunks, 4 * num_pairs), block(kThreads);
-#define DCN_LAUNCH_FWD(DT)                                                                                        \
-    hipLaunchKernelGGL((loss_fwd_kernel<DT>), grid, block, 0, st, desc_a, desc_b, hw, d, idx_a, idx_b, offsets_dev, \
+#define DCN_LAUNCH_FWD(LP, SINGLE)                                                                                       \
+    hipLaunchKernelGGL((loss_fwd_kernel<LP, SINGLE>), grid, block, 0, st, desc_a, desc_b, hw, d, idx_a, idx_b, offsets_dev, \
                        *cfg, part_sum, part_cnt, per_term, (int*)status)
-    switch (d) {
-        case 3: DCN_LAUNCH_FWD(3); break;
-        case 4: DCN_LAUNCH_FWD(4); break;
-        case 8: DCN_LAUNCH_FWD(8); break;
-        case 16: DCN_LAUNCH_FWD(16); break;
-        case 32: DCN_LAUNCH_FWD(32); break;
-        default: DCN_LAUNCH_FWD(0); break;
+    switch (lanes_per_pair(d)) {
+        case 4: DCN_LAUNCH_FWD(4, true); break;
+        case 8: DCN_LAUNCH_FWD(8, true); break;
+        case 16: DCN_LAUNCH_FWD(16, true); break;
+        default:
+            if (d <= 32) DCN_LAUNCH_FWD(32, true);
+            else DCN_LAUNCH_FWD(32, false);
+            break;
     }
 #undef DCN_LAUNCH_FWD
     hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), block, 0, st, part_sum, part_cnt, chunks, num_pairs, offsets_dev,
@@ -456,17 +468,18 @@ extern "C" int dcn_contrastive_loss_backward(const float* desc_a, const float* d
     if (dcn::fill_bytes_async(grad_b, 0, bytes, st) != DCN_OK) return DCN_E_LAUNCH;
     const int64_t ml = max_len(offsets_host, num_pairs);
     if (ml == 0) return DCN_OK;
-    const dim3 grid(chunks_for(ml), 4 * num_pairs), block(kThreads);
-#define DCN_LAUNCH_BWD(DT)                                                                                         \
-    hipLaunchKernelGGL((loss_bwd_kernel<DT>), grid, block, 0, st, desc_a, desc_b, hw, d, num_pairs, idx_a, idx_b,   \
+    const dim3 grid(chunks_for(ml, d), 4 * num_pairs), block(kThreads);
+#define DCN_LAUNCH_BWD(LP, SINGLE)                                                                                        \
+    hipLaunchKernelGGL((loss_bwd_kernel<LP, SINGLE>), grid, block, 0, st, desc_a, desc_b, hw, d, num_pairs, idx_a, idx_b,   \
                        offsets_dev, *cfg, (const int*)hard_neg, grad_loss, pair_grad, grad_a, grad_b)
-    switch (d) {
-        case 3: DCN_LAUNCH_BWD(3); break;
-        case 4: DCN_LAUNCH_BWD(4); break;
-        case 8: DCN_LAUNCH_BWD(8); break;
-        case 16: DCN_LAUNCH_BWD(16); break;
-        case 32: DCN_LAUNCH_BWD(32); break;
-        default: DCN_LAUNCH_BWD(0); break;
+    switch (lanes_per_pair(d)) {
+        case 4: DCN_LAUNCH_BWD(4, true); break;
+        case 8: DCN_LAUNCH_BWD(8, true); break;
+        case 16: DCN_LAUNCH_BWD(16, true); break;
+        default:
+            if (d <= 32) DCN_LAUNCH_BWD(32, true);
+            else DCN_LAUNCH_BWD(32, false);
+            break;
     }
 #undef DCN_LAUNCH_BWD
     return dcn::check_launch();

@@ -85,9 +85,13 @@ def make(config):
     print("config %d: float32 oracle step %.0f s" % (config, t1 - t0), flush=True)
     # float64 run of the same oracle: the yard-stick for gradient tolerances (gradients through 36 ReLU/BN layers are
     # ill-conditioned: the float32 oracle itself is only good to a few 1e-2 of max|g| on some tensors)
-    loss64, _, da64, _ = ostep.forward_loss(model64, img_a.double(), img_b.double(), lists, synth.LOSS_CONFIG)
+    loss64, _, da64, db64 = ostep.forward_loss(model64, img_a.double(), img_b.double(), lists, synth.LOSS_CONFIG)
     loss64.backward()
     rec["desc_err32_vs_64"] = float((da32.double() - da64.detach()).abs().max() / da64.detach().abs().max())
+    # the float64 oracle's maps ("truth" for the 1e-4 bound), stored as their float32 difference from the float32 maps
+    rec["desc_a64_minus_32"] = (da64.detach()[:, :, ::s, ::s].numpy() - rec["desc_a"].astype(np.float64)).astype(np.float32)
+    rec["desc_b64_minus_32"] = (db64.detach()[:, :, ::s, ::s].numpy() - rec["desc_b"].astype(np.float64)).astype(np.float32)
+    rec["desc64_absmax"] = float(np.abs(rec["desc_a"].astype(np.float64) + rec["desc_a64_minus_32"]).max())
     rec["loss64"] = float(loss64.detach())
     print("config %d: float64 oracle step %.0f s" % (config, time.time() - t1), flush=True)
     names, norms64, samples64, err32_max, err32_l2, gmax64, probes64 = [], [], [], [], [], [], []

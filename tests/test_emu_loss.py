@@ -76,16 +76,17 @@ def test_building_blocks_match_reference_goldens():
     np.testing.assert_allclose([o.item() for o in orig], z["original_loss"], rtol=1e-6)
 
 
-def test_batched_ragged_lists_vs_oracle():
+@pytest.mark.parametrize("D", [2, 3, 5, 8, 16, 32, 40])   # lane groups of 4 / 8 / 16 / 32 per pair; 40: two components per lane
+def test_batched_ragged_lists_vs_oracle(D):
     """B = 3 pairs with different list lengths, an empty background list, duplicates, a device-side sentinel."""
     from dense_correspondence.loss_functions import loss_composer
     from dense_correspondence.loss_functions.pixelwise_contrastive_loss import PixelwiseContrastiveLoss
     from oracle import loss_oracle, synth
-    H, W, D, B = 24, 32, 5, 3
+    H, W, B = 24, 32, 3
     g = torch.Generator().manual_seed(7)
-    A = ((torch.rand(B, H * W, D, generator=g) * 2 - 1) * 0.3).requires_grad_(True)
-    Bt = ((torch.rand(B, H * W, D, generator=g) * 2 - 1) * 0.3).requires_grad_(True)
-    sizes = [(50, 1100, 70), (1, 3, 2), (2049, 5, 1025)]   # crosses the 1024-pairs-per-workgroup chunk boundary
+    A = ((torch.rand(B, H * W, D, generator=g) * 2 - 1) * 0.6 / D ** 0.5).requires_grad_(True)
+    Bt = ((torch.rand(B, H * W, D, generator=g) * 2 - 1) * 0.6 / D ** 0.5).requires_grad_(True)
+    sizes = [(50, 1100, 70), (1, 3, 2), (2049, 5, 1025)]   # crosses the pairs-per-workgroup chunk boundaries (64 .. 512)
     lists = []
     for pm, pk, pg in sizes:
         L = synth.make_index_lists(1, H * W, pm, pk, pg, g)[0]

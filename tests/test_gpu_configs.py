@@ -47,7 +47,11 @@ def test_full_size_step_vs_oracle_fixture(L, conv_mode, config):
     if not os.path.exists(pc.fixture_path(config)):
         pytest.fail("missing fixture %s (python tests/golden/make_backbone_goldens.py --config %d)" % (pc.fixture_path(config), config))
     r = pc.run_config_against_fixture(config)
-    assert r["desc_a"] < TOL and r["desc_b"] < TOL, r
+    # within 1e-4 of the exact (float64) result; against the float32 oracle the bound widens by that oracle's own distance
+    # from float64 (1.5e-5 at configs 1-3, 7.8e-5 at config 5: D = 32 channels on a 1280x960 ResNet-50)
+    assert r["desc_a_vs_f64"] < TOL and r["desc_b_vs_f64"] < TOL and r["loss_vs_f64"] < TOL, r
+    slack = TOL + r["desc_err32_vs_64"] if config == 5 else TOL
+    assert r["desc_a"] < slack and r["desc_b"] < slack, r
     assert r["loss"] < TOL and r["terms"] < TOL, r
     assert r["hard_match_len_ok"] and r["hard_diff"] <= r["hard_tie_band"] + 2, r
     worst = sorted(r["per_tensor"], key=lambda t: -t[2])[:3]

@@ -272,40 +272,6 @@ def _gpu_step(dcn, img_a, img_b, lists, B):
     return loss, terms, hard, ya, yb
 
 
-def test_config1_full_size_vs_committed_oracle_fixture(L, conv_mode):
-    """BASELINE config 1 at full size (1 pair, 640x480, D=3, Resnet34_8s): descriptor maps, loss terms and every
-    parameter gradient against the committed oracle fixture -- no oracle run needed on the GPU box."""
-    from oracle import synth
-    z = np.load(os.path.join(GOLDEN_DIR, "config1_oracle.npz"))
-    c = synth.CONFIGS[1]
-    dcn, _ = _dcn_and_oracle(c["backbone"], c["D"], c["H"], c["W"])
-    img_a, img_b, lists = synth.make_batch(c["B"], c["H"], c["W"], c["Pm"], c["Pk"], c["Pg"], seed=1)
-    loss, terms, hard, ya, yb = _gpu_step(dcn, img_a, img_b, lists, c["B"])
-    scale = float(z["desc_a_absmax"])
-    assert float((ya.detach().cpu()[:, :, ::16, ::16] - torch.tensor(z["desc_a"])).abs().max()) < TOL * scale
-    assert float((yb.detach().cpu()[:, :, ::16, ::16] - torch.tensor(z["desc_b"])).abs().max()) < TOL * scale
-    np.testing.assert_allclose(terms[0].cpu().numpy(), z["terms"], rtol=TOL, atol=1e-9)
-    assert abs(loss.item() - float(z["loss"])) <= TOL * abs(float(z["loss"]))
-    loss.backward()
-    torch.cuda.synchronize()
-    # gradients: ill-conditioned through 36 ReLU/BN layers -- the float32 ORACLE is itself only within
-    # grad_err32_* of its float64 self (up to 3.6e-2 of max|g|), so that error is the yard-stick (x3 + 1e-3)
-    names = [str(s) for s in z["grad_names"]]
-    params = dict(dcn.fcn.named_parameters())
-    for i, k in enumerate(names):
-        if k.endswith("fc.bias"):
-            continue   # mathematically zero (the loss only sees descriptor differences): round-off only
-        gq = params[k].grad.detach().cpu().double()
-        gmax = float(z["grad_max64"][i])
-        nrm_err = abs(float(gq.norm()) - float(z["grad_norms64"][i]))
-        assert nrm_err <= 3 * float(z["grad_err32_l2"][i]) + 1e-3 * float(z["grad_norms64"][i]), k
-        flat = gq.reshape(-1)
-        idx = torch.linspace(0, flat.numel() - 1, 16).long()
-        err = float((flat[idx] - torch.tensor(z["grad_samples64"][i])).abs().max())
-        assert err <= 3 * float(z["grad_err32_max"][i]) + 1e-3 * gmax, (k, err / gmax)
-    assert rel_err(dcn.fcn.resnet34_8s.bn1.running_mean.cpu(), z["running_mean_bn1"]) < 1e-5
-
-
 def test_config1_full_size_vs_live_oracle(L, conv_mode):
     """Same configuration against the oracle run live on the host cores (takes a few seconds)."""
     from oracle import step as ostep, synth
@@ -319,14 +285,18 @@ def test_config1_full_size_vs_live_oracle(L, conv_mode):
     loss.backward()
     assert rel_err(ya.detach().cpu(), da_o) < TOL and rel_err(yb.detach().cpu(), db_o) < TOL
     assert abs(loss.item() - loss_o.item()) <= TOL * abs(loss_o.item())
-    # the float32 oracle's gradients are themselves only good to ~4e-2 (max) / ~7e-3 (L2) of their float64 values at
-    # this size (tests/golden/make_backbone_goldens.py prints it), so two float32 implementations may differ by that
+    # Gradients are NOT compared float32-against-float32 here: both sides carry their own ill-conditioning noise (the float32
+    # oracle is up to 3.6e-2 of max|g| away from its float64 self at this size).  tests/test_gpu_configs.py judges every
+    # gradient tensor against the FLOAT64 oracle with the float32 oracle's error as the yard-stick (<= 1.5 of them).
+    # Here: the two float32 results must at least be within the sum of two such yard-sticks of each other.
+    z = np.load(os.path.join(GOLDEN_DIR, "config1_oracle.npz"))
+    yard = {str(k): (float(e), float(n)) for k, e, n in zip(z["grad_names"], z["grad_err32_l2"], z["grad_norms64"])}
     for (k, p), (_, po) in zip(dcn.fcn.named_parameters(), o.named_parameters()):
         if k.endswith("fc.bias"):
             continue
-        l2 = float((p.grad.cpu() - po.grad).norm() / po.grad.norm())
-        assert l2 < 2e-2, (k, l2)
-        assert rel_err(p.grad.cpu(), po.grad) < 1e-1, (k, rel_err(p.grad.cpu(), po.grad))
+        e32, n64 = yard[k]
+        l2 = float((p.grad.cpu() - po.grad).norm())
+        assert l2 <= 2.5 * e32 + 4e-4 * n64, (k, l2 / n64, e32 / n64)
 
 
 def test_batched_step_small_images_vs_oracle(L, conv_mode):
@@ -374,7 +344,7 @@ def test_resnet50_8s_forward_backward_vs_oracle(L, conv_mode):
     (y * gy.cuda()).sum().backward(); (yo * gy).sum().backward(); (y64 * gy.double()).sum().backward()
     for (k, p), (_, po), (_, p6) in zip(dcn.fcn.named_parameters(), o.named_parameters(), o64.named_parameters()):
         l2 = lambda g: float((g.double().cpu() - p6.grad).norm() / p6.grad.norm().clamp_min(1e-30))
-        assert l2(p.grad) < 5 * l2(po.grad) + 2e-3, (k, l2(p.grad), l2(po.grad))
+        assert l2(p.grad) < 2 * l2(po.grad) + 1e-3, (k, l2(p.grad), l2(po.grad))
 
 
 def test_config2_full_size_properties(L, conv_mode):
@@ -442,10 +412,21 @@ def test_normalized_descriptor_training_step(L, conv_mode):
     scaled = ((y.detach().cpu() - yo.detach()).abs() * nv).max() / ro.detach().abs().max()
     assert float(scaled) < 2 * TOL, float(scaled)
     assert float((y.detach().norm(2, 1) - 1).abs().max()) < 1e-5
-    (y * gy.cuda()).sum().backward(); (yo * gy).sum().backward()
-    for (k, p), (_, po) in zip(dcn.fcn.named_parameters(), o.named_parameters()):
-        l2 = float((p.grad.cpu() - po.grad).norm() / po.grad.norm().clamp_min(1e-30))
-        assert l2 < 5e-2, (k, l2)
+    import copy
+    o64 = copy.deepcopy(o).double()
+    for p6 in o64.parameters():
+        p6.grad = None
+    o64.train()
+    r64 = o64(x.double())
+    y64 = r64 / torch.norm(r64, 2, 1, keepdim=True)
+    (y * gy.cuda()).sum().backward(); (yo * gy).sum().backward(); (y64 * gy.double()).sum().backward()
+    # against the float64 oracle, in units of the float32 oracle's own error (unit vectors of near-zero raw descriptors make
+    # this ill-conditioned: the float32 oracle itself is per cent off on some tensors)
+    for (k, p), (_, po), (_, p6) in zip(dcn.fcn.named_parameters(), o.named_parameters(), o64.named_parameters()):
+        n6 = float(p6.grad.norm().clamp_min(1e-300))
+        e_gpu = float((p.grad.double().cpu() - p6.grad).norm()) / n6
+        e_o32 = float((po.grad.double() - p6.grad).norm()) / n6
+        assert e_gpu < 2 * e_o32 + 1e-3, (k, e_gpu, e_o32)
 
 
 def test_forward_pair_equals_two_forward_calls_full_size(L, conv_mode):

@@ -1,0 +1,28 @@
+#!/bin/bash
+# One GPU-box session (run through gpurun from the repo root): parity report, GPU test-suite, smoke, bench lines, profile.
+# Usage: bash tools/gpu_session.sh <tag> [steps...]   steps: report tests smoke bench forcedist config3 prof pmc
+# Everything lands in gpurun_out/<tag>_*; nothing here reads /root/reference.
+tag=${1:-r2}; shift
+steps=${*:-report tests smoke bench forcedist config3 prof}
+mkdir -p gpurun_out
+export TMPDIR=/tmp
+for s in $steps; do
+  echo "=== $s $(date +%T)"
+  case $s in
+    report)    timeout 900 python tools/parity_report.py --json gpurun_out/${tag}_parity_report.json > gpurun_out/${tag}_parity_report.log 2>&1; tail -12 gpurun_out/${tag}_parity_report.log | cut -c1-600 ;;
+    tests)     timeout 1500 python -m pytest tests -m gpu -q -p no:cacheprovider > gpurun_out/${tag}_pytest.log 2>&1; tail -40 gpurun_out/${tag}_pytest.log | cut -c1-400 ;;
+    smoke)     timeout 300 python __graft_entry__.py smoke > gpurun_out/${tag}_smoke.log 2>&1; tail -3 gpurun_out/${tag}_smoke.log ;;
+    bench)     timeout 600 python bench.py > gpurun_out/${tag}_bench_default.json 2> gpurun_out/${tag}_bench_default.err; tail -c 1500 gpurun_out/${tag}_bench_default.json; tail -5 gpurun_out/${tag}_bench_default.err ;;
+    forcedist) timeout 600 env NCCL_DEBUG=VERSION python bench.py --force-dist --no-variants --cpu-baseline-steps 0 > gpurun_out/${tag}_bench_forcedist.log 2>&1; tail -c 1200 gpurun_out/${tag}_bench_forcedist.log ;;
+    config3)   timeout 600 python bench.py --workload config3 --no-variants --cpu-baseline-steps 0 --steps 10 --warmup 3 > gpurun_out/${tag}_bench_config3.json 2> gpurun_out/${tag}_bench_config3.err; tail -c 1200 gpurun_out/${tag}_bench_config3.json ;;
+    configs)   for c in config1 config4 config5; do timeout 600 python bench.py --workload $c --no-variants --cpu-baseline-steps 0 --steps 10 --warmup 3 > gpurun_out/${tag}_bench_$c.json 2> gpurun_out/${tag}_bench_$c.err; head -c 300 gpurun_out/${tag}_bench_$c.json; echo; done ;;
+    prof)      (cd /tmp && timeout 900 env DCN_BACKWARD_OVERLAP=0 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/${tag}_prof -- python $GRAFT_REPO_ROOT/bench.py --steps 10 --warmup 3 --cpu-baseline-steps 0 --no-variants --profile-steps 0 > $GRAFT_REPO_ROOT/gpurun_out/${tag}_prof_bench.log 2>&1); python tools/stats_summary.py gpurun_out/${tag}_prof > gpurun_out/${tag}_kernel_stats.txt 2>&1; head -45 gpurun_out/${tag}_kernel_stats.txt ;;
+    pmc)       for ctr in FETCH_SIZE WRITE_SIZE; do (cd /tmp && timeout 900 rocprofv3 --kernel-trace --pmc $ctr --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/${tag}_pmc_$ctr -- python $GRAFT_REPO_ROOT/bench.py --steps 4 --warmup 2 --cpu-baseline-steps 0 --no-variants --profile-steps 0 > $GRAFT_REPO_ROOT/gpurun_out/${tag}_pmc_$ctr.log 2>&1); done; python tools/pmc_summary.py gpurun_out/${tag}_pmc_FETCH_SIZE gpurun_out/${tag}_pmc_WRITE_SIZE gpurun_out/${tag}_hbm_counters.txt gpurun_out/${tag}_hbm_counters.json 2>&1 | tail -3; head -40 gpurun_out/${tag}_hbm_counters.txt ;;
+    pmc3)      for ctr in FETCH_SIZE WRITE_SIZE; do (cd /tmp && timeout 900 rocprofv3 --kernel-trace --pmc $ctr --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/${tag}_pmc3_$ctr -- python $GRAFT_REPO_ROOT/bench.py --workload config3 --steps 2 --warmup 1 --cpu-baseline-steps 0 --no-variants --profile-steps 0 > $GRAFT_REPO_ROOT/gpurun_out/${tag}_pmc3_$ctr.log 2>&1); done; DCN_PMC_WORKLOAD=config3 python tools/pmc_summary.py gpurun_out/${tag}_pmc3_FETCH_SIZE gpurun_out/${tag}_pmc3_WRITE_SIZE gpurun_out/${tag}_hbm_counters_config3.txt gpurun_out/${tag}_hbm_counters_config3.json 2>&1 | tail -3; grep -i "loss\|upsample\|fill" gpurun_out/${tag}_hbm_counters_config3.txt ;;
+    *) echo "unknown step $s" ;;
+  esac
+done
+# rocprof databases are large: keep only the summaries
+find gpurun_out -name "*.db" -size +20M -delete 2>/dev/null
+du -sh gpurun_out 2>/dev/null
+echo "=== done $(date +%T)"

@@ -8,6 +8,7 @@ import collections
 import csv
 import glob
 import json
+import os
 import re
 import sys
 
@@ -32,13 +33,14 @@ def main():
         for h in sys.argv[5:]:
             o.write("# " + h + "\n")
         o.write("# kernel | launches | FETCH_SIZE KiB / launch (raw) | WRITE_SIZE KiB / launch (raw)\n")
-        for k in rows[:28]:
+        shown = rows[:28] + [k for k in rows[28:] if "loss_" in k or "upsample" in k]   # the loss gather's kernels always
+        for k in shown:
             o.write("%-78s | %5d | %12.1f | %12.1f\n" % (k[:78], n_f[k], fetch[k] / n_f[k], write.get(k, 0.0) / max(n_w.get(k, 0), 1)))
     gemm = [k for k in fetch if "conv_gemm_f16_kernel" in k]
     launches = sum(n_f[k] for k in gemm)
     f_raw = sum(fetch[k] for k in gemm) / launches
     w_raw = sum(write.get(k, 0.0) for k in gemm) / launches
-    json.dump({"workload": "config2", "conv_mode": "f16x3", "forward_calls": "pair",
+    json.dump({"workload": os.environ.get("DCN_PMC_WORKLOAD", "config2"), "conv_mode": "f16x3", "forward_calls": "pair",
                "kernel": "conv_gemm_f16_kernel (all variants)", "launches": launches,
                "fetch_kib_per_launch_raw": f_raw, "write_kib_per_launch_raw": w_raw,
                "hbm_bytes_per_launch": 1024.0 * (2.0 * f_raw + w_raw),
