@@ -257,7 +257,7 @@ typedef struct dcn_conv_desc {
 } dcn_conv_desc;
 
 /* out = conv(in, w) [+ bias];  w: [cout][kh][kw][cin].  If bn_partial != NULL also writes per-M-tile
- * partial sums for batch-norm statistics: bn_partial[tile][2][cout] (sum, sum of squares); the number of
+ * partial sums for batch-norm statistics: bn_partial[tile][3][cout] (sum, sum of squares, max |x|); the number of
  * tiles is returned by dcn_conv_num_mtiles. */
 /* workspace (nullable): dcn_conv_gemm_workspace(c, dgrad) bytes; enables the stream-K work split used when the layer
  * has too few output tiles to load all 256 CUs evenly (small batch). */
@@ -321,7 +321,7 @@ size_t dcn_conv_wgrad_workspace_f16(const dcn_conv_desc* c);
 
 /* Train-mode batch norm (+ residual) (+ ReLU) of a convolution output x [rows][c] (kernel K7; nn.BatchNorm2d as the
  * backbone uses it): statistics from the per-M-tile partial sums the convolution's epilogue wrote (bn_partial
- * [mtiles][2][c], dcn_conv_forward), running statistics updated with `momentum` (unbiased variance); training == 0: the
+ * [mtiles][3][c], dcn_conv_forward), running statistics updated with `momentum` (unbiased variance); training == 0: the
  * running statistics are used instead.  y = [relu](x * scale + shift [+ res]); relu_mask (nullable): one byte per
  * float4 of y, bit j = y[4 i + j] > 0.  stats [4][c] receives scale, shift, mean, invstd (read by dcn_bn_backward). */
 int dcn_bn_forward(const float* x, const float* bn_partial, int mtiles, int c, int64_t rows, const float* gamma,

@@ -56,6 +56,7 @@ struct BlockL {
     int out_c = 0, in_c = 0;
     int64_t in_rows = 0;
     int act_in = -1, act_mid[2] = {-1, -1}, act_out = -1;   // abs-max slots of the block's input / mid / output activations
+    int act_down = -1;                                      // ... and of the downsample branch's batch-norm output
 };
 struct ParamInfo {
     std::string name;
@@ -273,6 +274,7 @@ int build_plan(dcn_plan& p) {
                 B.conv_out(blk.down);
                 p.convs[blk.down].bn = B.add_bn(bname + ".downsample.1", planes * exp, B.rows_of(p.convs[blk.down]));
                 p.convs[blk.down].in_act = blk.act_in;
+                blk.act_down = n_act++;
             }
             blk.out_rows = B.rows_of(last);
             blk.out_c = planes * exp;
@@ -322,7 +324,7 @@ int build_plan(dcn_plan& p) {
             const size_t sk = std::max(dcn_conv_gemm_workspace(&c.d, dg), dcn_conv_gemm_workspace_f16(&c.d, dg)) / sizeof(float);
             if (sk > max_sk) max_sk = sk;
         }
-        const size_t pf = (size_t)std::max(c.mtiles[0], c.mtiles[1]) * 2 * c.d.cout;
+        const size_t pf = (size_t)std::max(c.mtiles[0], c.mtiles[1]) * 3 * c.d.cout;
         if (pf > max_part) max_part = pf;
         if (c.d.cout > max_c) max_c = c.d.cout;
     }
@@ -477,9 +479,10 @@ struct Run {
         });
     }
 
-    // conv + BN statistics -> scale/shift in the saved arena
+    // conv + BN statistics -> scale/shift in the saved arena.  out_act: abs-max slot of the tensor the apply pass will
+    // produce from this batch norm (its bound is computed here, from the statistics); res_act: slot of the residual added there
     int conv_bn(const ConvL& c, const float* in, const float* w, float* const* bn_running, float momentum, float eps,
-                int training) {
+                int training, int out_act, int res_act = -1) {
         float* part = training ? Wk(p.w_part) : nullptr;
         DCN_TRY(conv_fwd(c, in, w, nullptr, S(c.x), part));
         const BnL& b = p.bns[c.bn];
@@ -488,7 +491,8 @@ struct Run {
         float* rv = bn_running ? bn_running[2 * b.idx + 1] : nullptr;
         if (!training && (!rm || !rv)) return DCN_E_INVALID;
         dcn::launch_bn_finalize(part, c.mtiles[p.conv_mode] / p.groups, p.groups, b.C, (double)(b.rows / p.groups), P(b.g),
-                                P(b.b), rm, rv, momentum, eps, training, stats, st);
+                                P(b.b), rm, rv, momentum, eps, training, stats, training ? A(out_act) : nullptr,
+                                training ? A(res_act) : nullptr, st);
         return DCN_OK;
     }
 };
@@ -612,7 +616,8 @@ extern "C" int dcn_backbone_forward(dcn_plan* plan, const float* image, const fl
         for (const BnL& b : p.bns) {
             if (!bn_running[2 * b.idx] || !bn_running[2 * b.idx + 1]) return DCN_E_INVALID;
             dcn::launch_bn_finalize(nullptr, 0, p.groups, b.C, (double)(b.rows / p.groups), R.P(b.g), R.P(b.b),
-                                    bn_running[2 * b.idx], bn_running[2 * b.idx + 1], momentum, eps, 0, R.S(b.stats), st);
+                                    bn_running[2 * b.idx], bn_running[2 * b.idx + 1], momentum, eps, 0, R.S(b.stats), nullptr,
+                                    nullptr, st);
         }
         DCN_TRY(R.split_all_weights(false, R.Wk(p.w_wstem), true));
         DCN_TRY(R.conv_fused(stem, R.S(p.s_in4), nullptr, 1, R.S(p.s_stem_y), p.blocks[0].act_in));
@@ -640,12 +645,11 @@ extern "C" int dcn_backbone_forward(dcn_plan* plan, const float* image, const fl
         }
     } else {
     if (p.conv_mode == DCN_CONV_F16X3) DCN_TRY(R.split_all_weights(false, R.Wk(p.w_wstem)));
-    DCN_TRY(R.conv_bn(stem, R.S(p.s_in4), R.Wk(p.w_wstem), bn_running, momentum, eps, training));
+    DCN_TRY(R.conv_bn(stem, R.S(p.s_in4), R.Wk(p.w_wstem), bn_running, momentum, eps, training, p.blocks[0].act_in));
     {
         const BnL& b = p.bns[stem.bn];
         const float* s = R.S(b.stats);
-        dcn::launch_bn_apply(R.S(stem.x), s, nullptr, nullptr, 1, R.S(p.s_stem_y), R.M(p.s_stem_y), b.C, b.rows, p.groups,
-                             R.A(p.blocks[0].act_in), st);
+        dcn::launch_bn_apply(R.S(stem.x), s, nullptr, nullptr, 1, R.S(p.s_stem_y), R.M(p.s_stem_y), b.C, b.rows, p.groups, st);
         const int hp = (stem.d.hout + 2 - 3) / 2 + 1, wp = (stem.d.wout + 2 - 3) / 2 + 1;
         dcn::launch_maxpool_fwd(R.S(p.s_stem_y), R.S(p.s_pool), (unsigned char*)R.S(p.s_argmax), N, stem.d.hout,
                                 stem.d.wout, hp, wp, b.C, st);
@@ -653,15 +657,21 @@ extern "C" int dcn_backbone_forward(dcn_plan* plan, const float* image, const fl
     for (const BlockL& blk : p.blocks) {
         const float* in = R.S(blk.in);
         const float* cur = in;
+        if (blk.down >= 0) {   // (first: the last batch norm's output bound needs the downsample branch's)
+            const ConvL& dc = p.convs[blk.down];
+            DCN_TRY(R.conv_bn(dc, in, R.P(dc.w), bn_running, momentum, eps, training, blk.act_down));
+        }
         for (int i = 0; i < blk.nconv; ++i) {
             const ConvL& c = p.convs[blk.conv[i]];
-            DCN_TRY(R.conv_bn(c, cur, R.P(c.w), bn_running, momentum, eps, training));
             if (i + 1 < blk.nconv) {
+                DCN_TRY(R.conv_bn(c, cur, R.P(c.w), bn_running, momentum, eps, training, blk.act_mid[i]));
                 const BnL& b = p.bns[c.bn];
                 const float* s = R.S(b.stats);
-                dcn::launch_bn_apply(R.S(c.x), s, nullptr, nullptr, 1, R.S(blk.mid[i]), R.M(blk.mid[i]), b.C, b.rows, p.groups,
-                                     R.A(blk.act_mid[i]), st);
+                dcn::launch_bn_apply(R.S(c.x), s, nullptr, nullptr, 1, R.S(blk.mid[i]), R.M(blk.mid[i]), b.C, b.rows, p.groups, st);
                 cur = R.S(blk.mid[i]);
+            } else {
+                DCN_TRY(R.conv_bn(c, cur, R.P(c.w), bn_running, momentum, eps, training, blk.act_out,
+                                  blk.down >= 0 ? blk.act_down : blk.act_in));
             }
         }
         const ConvL& last = p.convs[blk.conv[blk.nconv - 1]];
@@ -669,13 +679,10 @@ extern "C" int dcn_backbone_forward(dcn_plan* plan, const float* image, const fl
         const float* sl = R.S(bl.stats);
         if (blk.down >= 0) {
             const ConvL& dc = p.convs[blk.down];
-            DCN_TRY(R.conv_bn(dc, in, R.P(dc.w), bn_running, momentum, eps, training));
             const float* sd = R.S(p.bns[dc.bn].stats);
-            dcn::launch_bn_apply(R.S(last.x), sl, R.S(dc.x), sd, 1, R.S(blk.out), R.M(blk.out), bl.C, bl.rows, p.groups,
-                                 R.A(blk.act_out), st);
+            dcn::launch_bn_apply(R.S(last.x), sl, R.S(dc.x), sd, 1, R.S(blk.out), R.M(blk.out), bl.C, bl.rows, p.groups, st);
         } else {
-            dcn::launch_bn_apply(R.S(last.x), sl, in, nullptr, 1, R.S(blk.out), R.M(blk.out), bl.C, bl.rows, p.groups,
-                                 R.A(blk.act_out), st);
+            dcn::launch_bn_apply(R.S(last.x), sl, in, nullptr, 1, R.S(blk.out), R.M(blk.out), bl.C, bl.rows, p.groups, st);
         }
     }
     }   // !fused_eval

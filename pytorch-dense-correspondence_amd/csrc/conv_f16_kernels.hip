@@ -491,7 +491,7 @@ template <int TM, int TN, int WR = 2>
 __global__ void __launch_bounds__(64 * WR)
 conv_gemm_f16_fixup_kernel(GemmConv p) {
     using G = F16Geo<TM, TN, WR>;
-    __shared__ float red[WR * G::BN];                    // 2 WR x (BN / 2)
+    __shared__ float red[3 * WR * G::BN / 2];            // 3 WR x (BN / 2)
     const int nk = (p.K + HBK - 1) / HBK;
     const int rel = blockIdx.x >> 1, half = blockIdx.x & 1;
     const int tile = p.sk_dp + rel;                      // only the leftover tiles were stream-K'd

@@ -246,7 +246,7 @@ template <int WM, int TM, int TN, int BK>
 __global__ void __launch_bounds__(NT)
 conv_gemm_fixup_kernel(GemmConv p) {
     using G = GemmGeo<WM, TM, TN, BK>;
-    __shared__ float red[4 * G::BN];
+    __shared__ float red[6 * G::BN];
     const int nk = (p.K + BK - 1) / BK;
     const int tile = blockIdx.x;
     const int ua = tile * nk, ub = ua + nk - 1;

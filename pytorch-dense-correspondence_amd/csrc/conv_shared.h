@@ -35,7 +35,7 @@ struct GemmConv {
     const float* bias;  // [cd] or null
     const float* add;   // [M][ldc] or null
     float* dst;         // [M][ldc]
-    float* bn_partial;  // [mtiles][2][cd] or null
+    float* bn_partial;  // [mtiles][3][cd] (sum, sum of squares, max |x| per channel of the M tile) or null
     float* sk_partial;  // stream-K: [2 * workgroups][BM*BN] parked accumulators (fragment order)
     float* out_absmax;  // null, or device scalar raised to max |dst| (fused inference path: the next layer's operand pre-scale)
     // split-fp16 path only: pre-split weights [cd][kp] (hi, lo), device scalar with max|src| (or null), 1 / weight scale
@@ -65,7 +65,8 @@ template <int WM, int TM, int TN, int BK> struct GemmGeo {
 };
 
 // Epilogue: C/D fragments -> NHWC rows (32 consecutive channels per half-wave = 128 B segments), + bias, + residual
-// gradient, + per-M-tile batch-norm partial sums (fixed order).  `red` = at least 2*WM*BN floats of LDS, free to use.
+// gradient, + per-M-tile batch-norm partial statistics (sum, sum of squares, max |x|; fixed order).  `red` = at least
+// 3*WM*BN floats of LDS, free to use.
 // WN: wavefronts along N (WM * WN wavefronts per workgroup; 4 for every kernel but the 8-wavefront f16x3 tile).
 template <int WM, int TM, int TN, int BK, int WN = 4 / WM>
 __device__ __forceinline__ void gemm_epilogue(const GemmConv& p, f32x16 (&acc)[TM][TN], int mt, int nt, float* red) {
@@ -74,11 +75,11 @@ __device__ __forceinline__ void gemm_epilogue(const GemmConv& p, f32x16 (&acc)[T
     const int wm_ = wv / WN, wn_ = wv % WN;
     const int fi = lane & 31, fh = lane >> 5;
     const int m0 = mt * G::BM, n0 = nt * G::BN;
-    float csum[TN], csq[TN];
+    float csum[TN], csq[TN], cmax[TN];
     float vmax = 0.f;
 #pragma unroll
     for (int tn = 0; tn < TN; ++tn) {
-        csum[tn] = 0.f; csq[tn] = 0.f;
+        csum[tn] = 0.f; csq[tn] = 0.f; cmax[tn] = 0.f;
         const int col = n0 + wn_ * 32 * TN + tn * 32 + fi;
         const bool cok = col < p.cd;
         const float bv = (p.bias && cok) ? p.bias[col] : 0.f;
@@ -97,17 +98,23 @@ __device__ __forceinline__ void gemm_epilogue(const GemmConv& p, f32x16 (&acc)[T
                 }
                 csum[tn] += acc[tm][tn][r];
                 csq[tn] = fmaf(acc[tm][tn][r], acc[tm][tn][r], csq[tn]);
+                cmax[tn] = fmaxf(cmax[tn], fabsf(acc[tm][tn][r]));
             }
         }
     }
-    if (p.out_absmax) {   // one atomic per wavefront at most (look before the atomic: the value only grows)
+    if (p.out_absmax) {   // ONE atomic per workgroup at most (same-address atomics serialise in L2: thousands of them cost
+                          // tens of microseconds); look before the atomic: the value only grows
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) vmax = fmaxf(vmax, __shfl_xor(vmax, o, 64));
-        if (lane == 0 && vmax > 0.f) {
+        if (lane == 0) red[wv] = vmax;
+        __syncthreads();
+        if (tid == 0) {
+            for (int w = 1; w < WM * WN; ++w) vmax = fmaxf(vmax, red[w]);
             const unsigned bits = __float_as_uint(vmax);
-            if (bits > __atomic_load_n(reinterpret_cast<unsigned*>(p.out_absmax), __ATOMIC_RELAXED))
+            if (vmax > 0.f && bits > __atomic_load_n(reinterpret_cast<unsigned*>(p.out_absmax), __ATOMIC_RELAXED))
                 atomicMax(reinterpret_cast<unsigned*>(p.out_absmax), bits);
         }
+        __syncthreads();
     }
     if (p.bn_partial) {
         // rows >= M and columns >= cd are exactly zero in acc (zero-filled fragments), so no masking is needed
@@ -115,21 +122,25 @@ __device__ __forceinline__ void gemm_epilogue(const GemmConv& p, f32x16 (&acc)[T
         for (int tn = 0; tn < TN; ++tn) {
             csum[tn] += __shfl_xor(csum[tn], 32, 64);
             csq[tn] += __shfl_xor(csq[tn], 32, 64);
+            cmax[tn] = fmaxf(cmax[tn], __shfl_xor(cmax[tn], 32, 64));
             if (fh == 0) {
-                red[(wm_ * 2 + 0) * G::BN + wn_ * 32 * TN + tn * 32 + fi] = csum[tn];
-                red[(wm_ * 2 + 1) * G::BN + wn_ * 32 * TN + tn * 32 + fi] = csq[tn];
+                red[(wm_ * 3 + 0) * G::BN + wn_ * 32 * TN + tn * 32 + fi] = csum[tn];
+                red[(wm_ * 3 + 1) * G::BN + wn_ * 32 * TN + tn * 32 + fi] = csq[tn];
+                red[(wm_ * 3 + 2) * G::BN + wn_ * 32 * TN + tn * 32 + fi] = cmax[tn];
             }
         }
         __syncthreads();
         if (tid < G::BN && n0 + tid < p.cd) {
-            float s = red[(0 * 2 + 0) * G::BN + tid], q = red[(0 * 2 + 1) * G::BN + tid];
+            float s = red[0 * G::BN + tid], q = red[1 * G::BN + tid], mx = red[2 * G::BN + tid];
 #pragma unroll
             for (int w = 1; w < WM; ++w) {   // fixed order
-                s += red[(w * 2 + 0) * G::BN + tid];
-                q += red[(w * 2 + 1) * G::BN + tid];
+                s += red[(w * 3 + 0) * G::BN + tid];
+                q += red[(w * 3 + 1) * G::BN + tid];
+                mx = fmaxf(mx, red[(w * 3 + 2) * G::BN + tid]);
             }
-            p.bn_partial[((int64_t)mt * 2 + 0) * p.cd + n0 + tid] = s;
-            p.bn_partial[((int64_t)mt * 2 + 1) * p.cd + n0 + tid] = q;
+            p.bn_partial[((int64_t)mt * 3 + 0) * p.cd + n0 + tid] = s;
+            p.bn_partial[((int64_t)mt * 3 + 1) * p.cd + n0 + tid] = q;
+            p.bn_partial[((int64_t)mt * 3 + 2) * p.cd + n0 + tid] = mx;   // -> bound of max |BN output| (bn_finalize_kernel)
         }
     }
 }

@@ -13,15 +13,16 @@ void launch_pad_rows(const float* src, float* dst, int64_t rows, int d, int ld, 
 // Batch norm.  `groups` (1 or 2) = independent batches stacked along the rows of one launch (forward(img_a) and
 // forward(img_b) of a training step as one launch sequence): statistics per group; rows % groups == 0 and conv M tiles /
 // backward chunks never straddle a group boundary.  stats = [groups][4][C]: scale, shift, mean, invstd.
-// partial[groups * tiles_per_group][2][C] (sum, sum of squares) -> stats (+ running update, once per group, in order)
+// partial[groups * tiles_per_group][3][C] (sum, sum of squares, max |x|) -> stats (+ running update, once per group, in
+// order).  out_bound (optional, training only): device scalar raised to a bound of max |x scale + shift| (+ *res_bound when
+// given: the bound of the residual that the apply pass adds) -- the pre-scale of the split-fp16 convolution that reads y.
 void launch_bn_finalize(const float* partial, int tiles_per_group, int groups, int C, double count_per_group,
                         const float* gamma, const float* beta, float* rmean, float* rvar, float momentum, float eps,
-                        int training, float* stats, hipStream_t st);
+                        int training, float* stats, float* out_bound, const float* res_bound, hipStream_t st);
 // y = [relu](x*scale1 + shift1 + (res ? (stats2 ? res*scale2 + shift2 : res) : 0))
 // relu_mask (optional, with relu): one byte per float4 of y, bit j = y[4i + j] > 0 (read back by launch_bn_bwd)
-// absmax (optional): device scalar raised to max |y| (pre-scale of the split-fp16 convolution that consumes y)
 void launch_bn_apply(const float* x, const float* stats1, const float* res, const float* stats2, int relu, float* y,
-                     unsigned char* relu_mask, int C, int64_t rows, int groups, float* absmax, hipStream_t st);
+                     unsigned char* relu_mask, int C, int64_t rows, int groups, hipStream_t st);
 int bn_bwd_chunks(int64_t rows_per_group);
 // partial: groups*bn_bwd_chunks(rows/groups)*4*C floats, k123: groups*3*C floats.  g_out (nullable) receives the
 // relu-masked dy.  absmax (optional): raised to an upper bound of max |dx|

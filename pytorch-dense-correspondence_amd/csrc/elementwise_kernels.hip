@@ -33,16 +33,27 @@ __device__ __forceinline__ void wave_atomic_absmax(float amax, float* absmax) {
 __global__ void __launch_bounds__(256)
 nchw3_to_nhwc4_kernel(const float* __restrict__ img, float* __restrict__ out, int hw, int64_t total,
                       float* __restrict__ absmax) {
-    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;  // over n*hw
+    __shared__ float s_m[4];
     float m = 0.f;
-    if (i < total) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {  // over n*hw
         const int64_t n = i / hw, p = i - n * hw;
         const float* s = img + n * 3 * hw + p;
         const float4 v = make_float4(s[0], s[hw], s[2 * (int64_t)hw], 0.f);
         reinterpret_cast<float4*>(out)[i] = v;
-        m = fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fabsf(v.z));
+        m = fmaxf(m, fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fabsf(v.z)));
     }
-    if (absmax) wave_atomic_absmax(m, absmax);
+    if (absmax) {   // one atomic per workgroup (same-address atomics serialise in L2)
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+        if ((threadIdx.x & 63) == 0) s_m[threadIdx.x >> 6] = m;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            m = fmaxf(fmaxf(s_m[0], s_m[1]), fmaxf(s_m[2], s_m[3]));
+            const unsigned bits = __float_as_uint(m);
+            if (m > 0.f && bits > __atomic_load_n(reinterpret_cast<unsigned*>(absmax), __ATOMIC_RELAXED))
+                atomicMax(reinterpret_cast<unsigned*>(absmax), bits);
+        }
+    }
 }
 
 // wp[o][tap][4] = (w[o][tap][0..2], 0)   and back (gradient): w[o][tap][c] = wp[o][tap][c], c < 3
@@ -71,7 +82,11 @@ pad_rows_kernel(const float* __restrict__ src, float* __restrict__ dst, int64_t 
 }
 
 // ---------------------------------------------------------------------------------------------- batch norm
-// partial[tile][2][C] -> per-channel sums (fp64), then scale/shift + saved statistics + running update.
+// partial[tile][3][C] (sum, sum of squares, max |x| per channel of a convolution M tile) -> per-channel sums (fp64), then
+// scale/shift + saved statistics + running update, and -- when out_bound is given -- an upper bound of max |y| of the tensor
+// the apply pass is about to produce:  |x scale + shift (+ residual)| <= |scale| max|x| + |shift| (+ *res_bound),  raised
+// into *out_bound with ONE atomic per workgroup (no atomics in the big kernels; a ReLU only lowers it).  That bound is the
+// power-of-two pre-scale of the split-fp16 convolution that consumes y (f16_split.h).
 // GROUPS: the rows of one launch may hold several independent batches ("groups": forward(img_a) and forward(img_b) of a
 // training step run as ONE launch sequence over 2B images); batch statistics are per group -- group g owns tiles
 // [g*tiles, (g+1)*tiles) and the statistics block at offset g*gstride -- and the running statistics are updated once per
@@ -94,24 +109,31 @@ __global__ void __launch_bounds__(256)
 bn_finalize_kernel(const float* __restrict__ partial, int tiles, int groups, int C, double count,
                    const float* __restrict__ gamma, const float* __restrict__ beta, float* __restrict__ running_mean,
                    float* __restrict__ running_var, float momentum, float eps, int training, float* __restrict__ scale,
-                   float* __restrict__ shift, float* __restrict__ save_mean, float* __restrict__ save_invstd, int gstride) {
+                   float* __restrict__ shift, float* __restrict__ save_mean, float* __restrict__ save_invstd, int gstride,
+                   float* __restrict__ out_bound, const float* __restrict__ res_bound) {
     __shared__ double s_sum[4][4];
     __shared__ double s_sq[4][4];
+    __shared__ float s_mx[4][4];
+    __shared__ float s_bound[4];
     const int cl = threadIdx.x & 3, part = threadIdx.x >> 2, wv = threadIdx.x >> 6;
     const int c = blockIdx.x * 4 + cl;
+    float bound = 0.f;
     for (int g = 0; g < groups; ++g) {
         double a = 0.0, b = 0.0;
+        float mx = 0.f;
         if (training && c < C) {
 #pragma unroll 4
             for (int t = g * tiles + part; t < (g + 1) * tiles; t += 64) {
-                a += (double)partial[((int64_t)t * 2 + 0) * C + c];
-                b += (double)partial[((int64_t)t * 2 + 1) * C + c];
+                a += (double)partial[((int64_t)t * 3 + 0) * C + c];
+                b += (double)partial[((int64_t)t * 3 + 1) * C + c];
+                mx = fmaxf(mx, partial[((int64_t)t * 3 + 2) * C + c]);
             }
         }
         a = part_tree_sum(a);
         b = part_tree_sum(b);
+        mx = part_tree_max(mx);
         __syncthreads();
-        if ((threadIdx.x & 63) < 4) { s_sum[wv][cl] = a; s_sq[wv][cl] = b; }
+        if ((threadIdx.x & 63) < 4) { s_sum[wv][cl] = a; s_sq[wv][cl] = b; s_mx[wv][cl] = mx; }
         __syncthreads();
         if (threadIdx.x >= 4 || c >= C) continue;
         double mean, var;
@@ -132,9 +154,23 @@ bn_finalize_kernel(const float* __restrict__ partial, int tiles, int groups, int
         }
         const float invstd = (float)(1.0 / sqrt(var + (double)eps));
         const float sc = gamma[c] * invstd;
+        const float sh = beta[c] - (float)mean * sc;
         scale[g * gstride + c] = sc;
-        shift[g * gstride + c] = beta[c] - (float)mean * sc;
+        shift[g * gstride + c] = sh;
         if (save_mean) { save_mean[g * gstride + c] = (float)mean; save_invstd[g * gstride + c] = invstd; }
+        mx = fmaxf(fmaxf(s_mx[0][cl], s_mx[1][cl]), fmaxf(s_mx[2][cl], s_mx[3][cl]));
+        bound = fmaxf(bound, fabsf(sc) * mx + fabsf(sh));   // (a NaN statistic makes the products NaN anyway)
+    }
+    if (out_bound && training) {
+        __syncthreads();   // (every work-item reaches this: the loop above has no early exit)
+        if (threadIdx.x < 4) s_bound[threadIdx.x] = c < C ? bound : 0.f;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const float m = fmaxf(fmaxf(s_bound[0], s_bound[1]), fmaxf(s_bound[2], s_bound[3])) + (res_bound ? *res_bound : 0.f);
+            const unsigned bits = __float_as_uint(m);
+            if (m > 0.f && bits > __atomic_load_n(reinterpret_cast<unsigned*>(out_bound), __ATOMIC_RELAXED))
+                atomicMax(reinterpret_cast<unsigned*>(out_bound), bits);
+        }
     }
 }
 
@@ -143,8 +179,7 @@ __global__ void __launch_bounds__(256)
 bn_apply_kernel(const float* __restrict__ x, const float* __restrict__ s1, const float* __restrict__ b1,
                 const float* __restrict__ res, const float* __restrict__ s2, const float* __restrict__ b2, int relu,
                 float* __restrict__ y, unsigned char* __restrict__ relu_mask, int c4n, int64_t total4, int64_t group4,
-                int gstride, float* __restrict__ absmax) {
-    float amax = 0.f;   // max |y| of this work-item: the pre-scale of the split-fp16 convolution that reads y
+                int gstride) {
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total4; i += (int64_t)gridDim.x * 256) {
         const int c = (int)(i % c4n) * 4 + (i >= group4 ? gstride : 0);   // (at most two groups: second group's statistics)
         const float4 v = reinterpret_cast<const float4*>(x)[i];
@@ -162,13 +197,11 @@ bn_apply_kernel(const float* __restrict__ x, const float* __restrict__ s1, const
         }
         if (relu) { o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f); }
         reinterpret_cast<float4*>(y)[i] = o;
-        amax = fmaxf(fmaxf(amax, fmaxf(fabsf(o.x), fabsf(o.y))), fmaxf(fabsf(o.z), fabsf(o.w)));
         // which of the four outputs are positive: ONE byte per float4, so that the backward passes read 1 byte instead
         // of 16 to rebuild the ReLU mask
         if (relu_mask)
             relu_mask[i] = (unsigned char)((o.x > 0.f ? 1 : 0) | (o.y > 0.f ? 2 : 0) | (o.z > 0.f ? 4 : 0) | (o.w > 0.f ? 8 : 0));
     }
-    if (absmax) wave_atomic_absmax(amax, absmax);
 }
 
 // relu-masked upstream gradient: from the one-byte-per-float4 mask written by the forward apply pass when there is one,
@@ -615,7 +648,7 @@ constexpr int kGridCap = 256 * 8;  // grid-stride kernels: 8 workgroups per CU
 
 void launch_nchw3_to_nhwc4(const float* img, float* out, int n, int hw, float* absmax, hipStream_t st) {
     const int64_t total = (int64_t)n * hw;
-    hipLaunchKernelGGL(nchw3_to_nhwc4_kernel, dim3(blocks_for(total)), dim3(256), 0, st, img, out, hw, total, absmax);
+    hipLaunchKernelGGL(nchw3_to_nhwc4_kernel, dim3(blocks_for(total, kGridCap)), dim3(256), 0, st, img, out, hw, total, absmax);
 }
 void launch_pad_c3_to_c4(const float* w, float* wp, int64_t rows, hipStream_t st) {
     hipLaunchKernelGGL(pad_c3_to_c4_kernel, dim3(blocks_for(rows)), dim3(256), 0, st, w, wp, rows);
@@ -628,17 +661,16 @@ void launch_pad_rows(const float* src, float* dst, int64_t rows, int d, int ld, 
 }
 void launch_bn_finalize(const float* partial, int tiles_per_group, int groups, int C, double count_per_group,
                         const float* gamma, const float* beta, float* rmean, float* rvar, float momentum, float eps,
-                        int training, float* stats, hipStream_t st) {
+                        int training, float* stats, float* out_bound, const float* res_bound, hipStream_t st) {
     hipLaunchKernelGGL(bn_finalize_kernel, dim3(ceil_div(C, 4)), dim3(256), 0, st, partial, tiles_per_group, groups, C,
                        count_per_group, gamma, beta, rmean, rvar, momentum, eps, training, stats, stats + C, stats + 2 * C,
-                       stats + 3 * C, 4 * C);
+                       stats + 3 * C, 4 * C, out_bound, res_bound);
 }
 void launch_bn_apply(const float* x, const float* stats1, const float* res, const float* stats2, int relu, float* y,
-                     unsigned char* relu_mask, int C, int64_t rows, int groups, float* absmax, hipStream_t st) {
+                     unsigned char* relu_mask, int C, int64_t rows, int groups, hipStream_t st) {
     const int64_t total4 = rows * (C / 4);
     hipLaunchKernelGGL(bn_apply_kernel, dim3(blocks_for(total4, kGridCap)), dim3(256), 0, st, x, stats1, stats1 + C, res,
-                       stats2, stats2 ? stats2 + C : nullptr, relu, y, relu_mask, C / 4, total4, total4 / groups, 4 * C,
-                       absmax);
+                       stats2, stats2 ? stats2 + C : nullptr, relu, y, relu_mask, C / 4, total4, total4 / groups, 4 * C);
 }
 int bn_bwd_chunks(int64_t rows_per_group) {
     // enough row chunks that even a 64-channel layer launches >= ~1000 workgroups (HBM-bound pass: fill all 256 CUs)
@@ -741,8 +773,8 @@ extern "C" int dcn_bn_forward(const float* x, const float* bn_partial, int mtile
     if (training ? (!bn_partial || mtiles < 1) : (!running_mean || !running_var)) return DCN_E_INVALID;
     hipStream_t st = (hipStream_t)stream;
     dcn::launch_bn_finalize(bn_partial, mtiles, 1, c, (double)rows, gamma, beta, running_mean, running_var, momentum, eps,
-                            training, stats, st);
-    dcn::launch_bn_apply(x, stats, res, nullptr, relu, y, relu_mask, c, rows, 1, nullptr, st);
+                            training, stats, nullptr, nullptr, st);
+    dcn::launch_bn_apply(x, stats, res, nullptr, relu, y, relu_mask, c, rows, 1, st);
     return dcn::check_launch();
 }
 

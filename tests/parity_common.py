@@ -22,6 +22,33 @@ def probe_vectors(tensor_index, numel):
     return [(torch.randint(0, 2, (numel,), generator=g, dtype=torch.int8).double() * 2 - 1) for _ in range(NUM_PROBES)]
 
 
+def grad_error_stats(named_gpu, o32_params, o64_params, skip_suffix=("fc.bias",)):
+    """Relative L2 error of every gradient tensor against the float64 oracle, for the GPU and for the float32 oracle.
+    Two float32 implementations are two independent draws of the same ill-conditioning noise (ReLU kinks, hard-negative
+    boundaries): tensor by tensor their ratio is anything between 0.2 and 5 (wherever the oracle happens to be lucky), so the
+    meaningful statements are about the DISTRIBUTION: the root mean square over the tensors and the worst tensor."""
+    import math
+    e_gpu, e_o32, names = [], [], []
+    for (k, p), po, p6 in zip(named_gpu, o32_params, o64_params):
+        if k.endswith(tuple(skip_suffix)):
+            continue   # fc.bias: mathematically zero gradient (the loss only sees descriptor differences): round-off only
+        n6 = float(p6.grad.norm().clamp_min(1e-300))
+        e_gpu.append(float((p.grad.detach().double().cpu() - p6.grad).norm()) / n6)
+        e_o32.append(float((po.grad.double() - p6.grad).norm()) / n6)
+        names.append(k)
+    rms = lambda v: math.sqrt(sum(x * x for x in v) / len(v))
+    i = max(range(len(names)), key=lambda j: e_gpu[j])
+    return {"rms_gpu": rms(e_gpu), "rms_o32": rms(e_o32), "max_gpu": max(e_gpu), "max_o32": max(e_o32),
+            "worst": (names[i], e_gpu[i], e_o32[i])}
+
+
+def assert_as_accurate_as_float32(st, factor=1.5, floor=2e-4):
+    """GPU gradients vs float64 are no worse than `factor` x what the float32 CPU oracle manages, in the r.m.s. over the
+    tensors and on the worst tensor."""
+    assert st["rms_gpu"] <= factor * st["rms_o32"] + floor, st
+    assert st["max_gpu"] <= factor * st["max_o32"] + floor, st
+
+
 def fixture_path(config):
     return os.path.join(GOLDEN_DIR, "config%d_oracle.npz" % config)
 
@@ -103,9 +130,28 @@ def run_config_against_fixture(config, pair_call=False):
         # excess over a 2e-4 relative floor (tensors the float32 oracle happens to get almost exactly), in yard-sticks
         worst_l2 = max(worst_l2, (e_l2 - 2e-4 * n64) / (err32_l2 + 1e-30))
         worst_max = max(worst_max, (e_smp - 2e-4 * m64) / (err32_mx + 1e-30))
-    out["grad_l2_ratio"] = worst_l2        # (est. ||g - g64|| - 2e-4 ||g64||) / float32-oracle's ||g32 - g64||, worst tensor
-    out["grad_sample_ratio"] = worst_max   # (max sampled |g - g64| - 2e-4 max|g64|) / float32-oracle's max error, worst tensor
+    out["grad_l2_ratio"] = worst_l2        # diagnostic only (per-tensor ratios of two independent noise draws): see below
+    out["grad_sample_ratio"] = worst_max
     out["per_tensor"] = per   # (name, est. L2 rel err, in yard-sticks, sampled max rel err, in yard-sticks, |norm diff| rel)
+    # what is asserted: the distribution over the tensors -- r.m.s. and worst tensor of the relative L2 error against the
+    # float64 oracle, GPU vs the float32 oracle's own (grad_error_stats explains why not tensor by tensor)
+    keep = [i for i, k in enumerate(names) if not k.endswith("fc.bias")]
+    o32_rel = [float(z["grad_err32_l2"][i]) / float(z["grad_norms64"][i]) for i in keep]
+    o32_smp = [float(z["grad_err32_max"][i]) / float(z["grad_max64"][i]) for i in keep]
+    gpu_rel = [t[1] for t in per]
+    gpu_smp = [t[3] for t in per]
+    rms = lambda v: float(np.sqrt(np.mean(np.square(v))))
+    out["grad_rms_gpu"], out["grad_rms_o32"] = rms(gpu_rel), rms(o32_rel)
+    out["grad_max_gpu"], out["grad_max_o32"] = max(gpu_rel), max(o32_rel)
+    out["grad_sample_max_gpu"], out["grad_sample_max_o32"] = max(gpu_smp), max(o32_smp)   # (16 samples vs the whole tensor)
+    # per-pair loss terms: a non-match pair within round-off of its margin may flip its hard-negative status; its own loss
+    # term is ~0 but the normaliser 1 / #hard-negatives of that list moves by 1 / h  (config 3: h ~ 130 of 50 000)
+    tie = zh[:, 2:3].astype(np.float64) + np.abs(h[:, 1:3].astype(np.float64) - zh[:, :2])
+    hmin = np.maximum(np.minimum(h[:, 1:3], zh[:, :2]).astype(np.float64), 1.0)
+    slack = np.zeros_like(zt)
+    slack[:, 2:4] = tie / hmin
+    slack[:, 0] = (tie / hmin).max(axis=1)
+    out["terms_excess"] = float(np.max(np.abs(t - zt) / np.maximum(np.abs(zt), 1e-12) - slack))
     if "running_mean_bn1" in z.files:
         attr = getattr(dcn.fcn, dcn.fcn.attr)
         rm = attr.bn1.running_mean.cpu()

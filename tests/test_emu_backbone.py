@@ -74,6 +74,45 @@ def test_gradient_scale_invariance(gscale, conv_mode):
         assert rel_err(p.grad, po.grad) < 2e-4, (k, conv_mode)
 
 
+@pytest.mark.parametrize("scale", [1.0, 3.0e5, 1.0e-6])
+def test_activation_bounds_and_operand_prescale(scale):
+    """Split-fp16 mode: every convolution input carries an abs-max scalar -- the image's exact abs-max, and for batch-norm
+    outputs an upper BOUND computed from the statistics by bn_finalize (no atomics in the big kernels).  The bounds must hold
+    for the true activations (checked on the oracle's), the status word stays clear, and activations far outside fp16's range
+    (bn1 scaled by 3e5 / 1e-6) still give fp32-level results."""
+    from dcn_hip import backbone
+    backbone.set_conv_mode("f16x3")
+    try:
+        m, o = _pair("Resnet18_8s", 3, 8)
+        with torch.no_grad():
+            o.resnet18_8s.bn1.weight.mul_(scale)
+            o.resnet18_8s.bn1.bias.fill_(0.1 * scale)
+        m.load_state_dict(o.state_dict())
+        o64 = copy.deepcopy(o).double()
+        g = torch.Generator().manual_seed(5)
+        x = torch.randn(2, 3, 32, 40, generator=g) * 3
+        m.train(); o.train(); o64.train()
+        acts = {}
+        net = o.resnet18_8s
+        hooks = [net.maxpool.register_forward_hook(lambda mod, i, out: acts.__setitem__("pool", out.detach())),
+                 net.layer1[0].register_forward_hook(lambda mod, i, out: acts.__setitem__("l1.0", out.detach())),
+                 net.layer2[0].register_forward_hook(lambda mod, i, out: acts.__setitem__("l2.0", out.detach()))]
+        y, yo, y64 = m(x), o(x), o64(x.double())
+        for h in hooks:
+            h.remove()
+        amax, status = m.last_forward_status()
+        assert int(status) == 0 and bool((amax > 0).all()) and bool(torch.isfinite(amax).all())
+        assert float(amax[0]) == float(x.abs().max())                       # slot 0: the image, exact
+        assert float(amax[1]) >= float(acts["pool"].abs().max())             # slot 1: stem activation / max-pool output
+        # block outputs come right after the block's mid activation: slots (2: l1.0 mid, 3: l1.0 out, ...); the downsample
+        # block layer2.0 has one more slot (its shortcut branch)
+        assert float(amax[3]) >= float(acts["l1.0"].abs().max())
+        assert float(amax[3]) <= 8 * float(acts["l1.0"].abs().max()) + 1e-30  # ... and not absurdly loose
+        assert rel_err(y, y64) < 3 * rel_err(yo, y64) + 1e-5, (scale, rel_err(y, y64), rel_err(yo, y64))
+    finally:
+        backbone.set_conv_mode(None)
+
+
 def test_forward_backward_with_stream_k_forced(dcn_env):
     """Same network with every gather-GEMM launch forced through the stream-K split + fix-up path (engine workspace)."""
     dcn_env(DCN_GEMM_SK=5)

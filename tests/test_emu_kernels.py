@@ -50,7 +50,7 @@ def test_conv_forward_dgrad_wgrad(L, case, tile_m, sk, dcn_env):
     out = torch.full((n, hout, wout, cout), float("nan"))
     mt = lib.dcn_conv_num_mtiles(ctypes.byref(d))
     assert mt in [(n * hout * wout + b - 1) // b for b in (32, 64, 128)]
-    part = torch.full((mt, 2, cout), float("nan"))
+    part = torch.full((mt, 3, cout), float("nan"))
     ws_f = torch.empty(max(lib.dcn_conv_gemm_workspace(ctypes.byref(d), 0), 4) // 4)
     ws_d = torch.empty(max(lib.dcn_conv_gemm_workspace(ctypes.byref(d), 1), 4) // 4)
     if sk != "0" and k > 1:
@@ -61,6 +61,7 @@ def test_conv_forward_dgrad_wgrad(L, case, tile_m, sk, dcn_env):
     assert rel_err(out, refn) < 2e-6
     assert rel_err(part.sum(0)[0], refn.sum((0, 1, 2))) < 5e-6
     assert rel_err(part.sum(0)[1], (refn ** 2).sum((0, 1, 2))) < 5e-6
+    assert rel_err(part.max(0).values[2], refn.abs().amax((0, 1, 2))) < 2e-6   # third row: max |x| per channel (BN output bound)
     dout = torch.randn(n, hout, wout, cout, generator=g)
     ref.backward(dout.permute(0, 3, 1, 2))
     wt = torch.empty(cin, k * k, cout)
@@ -205,7 +206,7 @@ def test_conv_f16x3_forward_dgrad(L, case, tile_m, sk, dcn_env):
     assert rel_err(rec, w_k.reshape(cout, K)) < 1e-6 and float(wh[:, K:].abs().max() if kp > K else 0) == 0
     out = torch.full((n, hout, wout, cout), float("nan"))
     mt = lib.dcn_conv_num_mtiles_f16(ctypes.byref(d))
-    part = torch.full((mt, 2, cout), float("nan"))
+    part = torch.full((mt, 3, cout), float("nan"))
     ws_f = torch.empty(max(lib.dcn_conv_gemm_workspace_f16(ctypes.byref(d), 0), 4) // 4)
     ws_d = torch.empty(max(lib.dcn_conv_gemm_workspace_f16(ctypes.byref(d), 1), 4) // 4)
     assert lib.dcn_conv_forward_f16(ctypes.byref(d), L.ptr(x_nhwc), None, L.ptr(wh), L.ptr(wl), 64.0, None, L.ptr(out),

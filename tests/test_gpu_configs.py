@@ -21,10 +21,26 @@ import parity_common as pc
 
 pytestmark = pytest.mark.gpu
 TOL = 1e-4
-# measured on MI355X (profiles/r2_parity_report.json): the worst tensor of the worst config sits at GRAD_MEASURED x the
-# float32 oracle's own error; the bound leaves ~1.3x headroom over that
-GRAD_L2_YARDSTICKS = 1.5
-GRAD_SAMPLE_YARDSTICKS = 1.5
+# Gradients: relative L2 error of every tensor against the float64 oracle; asserted on the distribution over the tensors
+# (r.m.s. and worst tensor) against the float32 oracle's own -- measured on MI355X (profiles/r2_parity_report.json): r.m.s.
+# 0.96 - 1.24 x the float32 oracle's in both arithmetics on all four configs.
+GRAD_FACTOR = 1.5
+
+
+def _check(r, config):
+    # within 1e-4 of the exact (float64) result; against the float32 oracle the bound widens by that oracle's own distance
+    # from float64 at config 5 (7.8e-5 there: D = 32 channels on a 1280x960 ResNet-50; 1.5e-5 at configs 1-3)
+    assert r["desc_a_vs_f64"] < TOL and r["desc_b_vs_f64"] < TOL and r["loss_vs_f64"] < TOL, r
+    slack = TOL + r["desc_err32_vs_64"] if config == 5 else TOL
+    assert r["desc_a"] < slack and r["desc_b"] < slack, r
+    assert r["loss"] < TOL and r["terms_excess"] < TOL, r            # (terms: up to the hard-negative tie band, see parity_common)
+    assert r["hard_match_len_ok"] and r["hard_diff"] <= r["hard_tie_band"] + 2, r
+    worst = sorted(r["per_tensor"], key=lambda t: -t[1])[:3]
+    assert r["grad_rms_gpu"] <= GRAD_FACTOR * r["grad_rms_o32"], (r["grad_rms_gpu"], r["grad_rms_o32"], worst)
+    assert r["grad_max_gpu"] <= GRAD_FACTOR * r["grad_max_o32"], (r["grad_max_gpu"], r["grad_max_o32"], worst)
+    assert r["grad_sample_max_gpu"] <= GRAD_FACTOR * r["grad_sample_max_o32"], (r["grad_sample_max_gpu"], r["grad_sample_max_o32"])
+    if "running_mean_bn1" in r:
+        assert r["running_mean_bn1"] < 1e-5, r
 
 
 @pytest.fixture(scope="module")
@@ -47,25 +63,11 @@ def test_full_size_step_vs_oracle_fixture(L, conv_mode, config):
     if not os.path.exists(pc.fixture_path(config)):
         pytest.fail("missing fixture %s (python tests/golden/make_backbone_goldens.py --config %d)" % (pc.fixture_path(config), config))
     r = pc.run_config_against_fixture(config)
-    # within 1e-4 of the exact (float64) result; against the float32 oracle the bound widens by that oracle's own distance
-    # from float64 (1.5e-5 at configs 1-3, 7.8e-5 at config 5: D = 32 channels on a 1280x960 ResNet-50)
-    assert r["desc_a_vs_f64"] < TOL and r["desc_b_vs_f64"] < TOL and r["loss_vs_f64"] < TOL, r
-    slack = TOL + r["desc_err32_vs_64"] if config == 5 else TOL
-    assert r["desc_a"] < slack and r["desc_b"] < slack, r
-    assert r["loss"] < TOL and r["terms"] < TOL, r
-    assert r["hard_match_len_ok"] and r["hard_diff"] <= r["hard_tie_band"] + 2, r
-    worst = sorted(r["per_tensor"], key=lambda t: -t[2])[:3]
-    assert r["grad_l2_ratio"] <= GRAD_L2_YARDSTICKS, (r["grad_l2_ratio"], worst)
-    assert r["grad_sample_ratio"] <= GRAD_SAMPLE_YARDSTICKS, (r["grad_sample_ratio"], worst)
-    if "running_mean_bn1" in r:
-        assert r["running_mean_bn1"] < 1e-5, r
+    _check(r, config)
     torch.cuda.empty_cache()
 
 
 def test_headline_workload_grouped_call_vs_oracle_fixture(L, conv_mode):
     """config 2 the way bench.py runs it: forward_pair(img_a, img_b) as ONE grouped launch sequence."""
     r = pc.run_config_against_fixture(2, pair_call=True)
-    assert r["desc_a"] < TOL and r["desc_b"] < TOL and r["loss"] < TOL and r["terms"] < TOL, r
-    assert r["hard_diff"] <= r["hard_tie_band"] + 2, r
-    assert r["grad_l2_ratio"] <= GRAD_L2_YARDSTICKS and r["grad_sample_ratio"] <= GRAD_SAMPLE_YARDSTICKS, r
-    assert r["running_mean_bn1"] < 1e-5, r
+    _check(r, 2)

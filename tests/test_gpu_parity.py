@@ -137,7 +137,7 @@ def test_conv_kernels_vs_torch_cpu(L, case):
     wg = w.detach().permute(0, 2, 3, 1).contiguous().cuda()
     out = torch.full((n, hout, wout, cout), float("nan"), device="cuda")
     mt = lib.dcn_conv_num_mtiles(ctypes.byref(d))
-    part = torch.full((mt, 2, cout), float("nan"), device="cuda")
+    part = torch.full((mt, 3, cout), float("nan"), device="cuda")
     st = L.stream_ptr()
     ws_f = torch.empty(max(lib.dcn_conv_gemm_workspace(ctypes.byref(d), 0), 4) // 4, device="cuda")
     ws_d = torch.empty(max(lib.dcn_conv_gemm_workspace(ctypes.byref(d), 1), 4) // 4, device="cuda")
@@ -186,7 +186,7 @@ def test_conv_f16x3_kernels_vs_torch_cpu(L, case):
     wh = torch.empty(cout, lib.dcn_f16_kpad(K), dtype=torch.float16, device="cuda"); wl = torch.empty_like(wh)
     assert lib.dcn_split_rows_f16(L.ptr(wg), L.ptr(wh), L.ptr(wl), cout, K, 64.0, st) == 0
     out = torch.full((n, hout, wout, cout), float("nan"), device="cuda")
-    part = torch.full((lib.dcn_conv_num_mtiles_f16(ctypes.byref(d)), 2, cout), float("nan"), device="cuda")
+    part = torch.full((lib.dcn_conv_num_mtiles_f16(ctypes.byref(d)), 3, cout), float("nan"), device="cuda")
     ws_f = torch.empty(max(lib.dcn_conv_gemm_workspace_f16(ctypes.byref(d), 0), 4) // 4, device="cuda")
     ws_d = torch.empty(max(lib.dcn_conv_gemm_workspace_f16(ctypes.byref(d), 1), 4) // 4, device="cuda")
     assert lib.dcn_conv_forward_f16(ctypes.byref(d), L.ptr(xg), None, L.ptr(wh), L.ptr(wl), 64.0, None, L.ptr(out),
@@ -285,18 +285,21 @@ def test_config1_full_size_vs_live_oracle(L, conv_mode):
     loss.backward()
     assert rel_err(ya.detach().cpu(), da_o) < TOL and rel_err(yb.detach().cpu(), db_o) < TOL
     assert abs(loss.item() - loss_o.item()) <= TOL * abs(loss_o.item())
-    # Gradients are NOT compared float32-against-float32 here: both sides carry their own ill-conditioning noise (the float32
-    # oracle is up to 3.6e-2 of max|g| away from its float64 self at this size).  tests/test_gpu_configs.py judges every
-    # gradient tensor against the FLOAT64 oracle with the float32 oracle's error as the yard-stick (<= 1.5 of them).
-    # Here: the two float32 results must at least be within the sum of two such yard-sticks of each other.
+    # Gradients are NOT judged float32-against-float32 tensor by tensor: both sides carry their own ill-conditioning noise
+    # (the float32 oracle is up to 3.6e-2 of max|g| away from its float64 self at this size).  tests/test_gpu_configs.py
+    # judges them against the FLOAT64 oracle.  Here only: the two float32 results are within the sum of two such errors of
+    # each other, in the r.m.s. over the tensors (yard-sticks from the committed fixture of the same configuration).
     z = np.load(os.path.join(GOLDEN_DIR, "config1_oracle.npz"))
-    yard = {str(k): (float(e), float(n)) for k, e, n in zip(z["grad_names"], z["grad_err32_l2"], z["grad_norms64"])}
+    yard = {str(k): float(e) / float(n) for k, e, n in zip(z["grad_names"], z["grad_err32_l2"], z["grad_norms64"])}
+    rel, ref = [], []
     for (k, p), (_, po) in zip(dcn.fcn.named_parameters(), o.named_parameters()):
         if k.endswith("fc.bias"):
             continue
-        e32, n64 = yard[k]
-        l2 = float((p.grad.cpu() - po.grad).norm())
-        assert l2 <= 2.5 * e32 + 4e-4 * n64, (k, l2 / n64, e32 / n64)
+        rel.append(float((p.grad.cpu() - po.grad).norm() / po.grad.norm()))
+        ref.append(yard[k])
+    rms = lambda v: float(np.sqrt(np.mean(np.square(v))))
+    assert rms(rel) <= 2.5 * rms(ref), (rms(rel), rms(ref))
+    assert max(rel) <= 3.0 * max(ref), (max(rel), max(ref))
 
 
 def test_batched_step_small_images_vs_oracle(L, conv_mode):
@@ -342,9 +345,9 @@ def test_resnet50_8s_forward_backward_vs_oracle(L, conv_mode):
     yo, y64 = o(x), o64(x.double())
     assert rel_err(y.detach().cpu(), y64) < 3 * rel_err(yo, y64) + 1e-5
     (y * gy.cuda()).sum().backward(); (yo * gy).sum().backward(); (y64 * gy.double()).sum().backward()
-    for (k, p), (_, po), (_, p6) in zip(dcn.fcn.named_parameters(), o.named_parameters(), o64.named_parameters()):
-        l2 = lambda g: float((g.double().cpu() - p6.grad).norm() / p6.grad.norm().clamp_min(1e-30))
-        assert l2(p.grad) < 2 * l2(po.grad) + 1e-3, (k, l2(p.grad), l2(po.grad))
+    import parity_common as pc
+    pc.assert_as_accurate_as_float32(pc.grad_error_stats(dcn.fcn.named_parameters(), o.parameters(), o64.parameters(), ()),
+                                     factor=2.0, floor=5e-4)   # (small case: 2 images, few hundred pixels per BN channel)
 
 
 def test_config2_full_size_properties(L, conv_mode):
@@ -420,13 +423,11 @@ def test_normalized_descriptor_training_step(L, conv_mode):
     r64 = o64(x.double())
     y64 = r64 / torch.norm(r64, 2, 1, keepdim=True)
     (y * gy.cuda()).sum().backward(); (yo * gy).sum().backward(); (y64 * gy.double()).sum().backward()
-    # against the float64 oracle, in units of the float32 oracle's own error (unit vectors of near-zero raw descriptors make
-    # this ill-conditioned: the float32 oracle itself is per cent off on some tensors)
-    for (k, p), (_, po), (_, p6) in zip(dcn.fcn.named_parameters(), o.named_parameters(), o64.named_parameters()):
-        n6 = float(p6.grad.norm().clamp_min(1e-300))
-        e_gpu = float((p.grad.double().cpu() - p6.grad).norm()) / n6
-        e_o32 = float((po.grad.double() - p6.grad).norm()) / n6
-        assert e_gpu < 2 * e_o32 + 1e-3, (k, e_gpu, e_o32)
+    # against the float64 oracle, with the float32 oracle's own error as the yard-stick (unit vectors of near-zero raw
+    # descriptors make this ill-conditioned: the float32 oracle itself is per cent off on some tensors)
+    import parity_common as pc
+    pc.assert_as_accurate_as_float32(pc.grad_error_stats(dcn.fcn.named_parameters(), o.parameters(), o64.parameters(), ()),
+                                     factor=2.0, floor=1e-3)
 
 
 def test_forward_pair_equals_two_forward_calls_full_size(L, conv_mode):

@@ -61,14 +61,10 @@ def test_activation_range_forward_backward(L, conv_mode, scale):
     assert rel_err(y.detach().cpu(), y64) < 3 * rel_err(yo, y64) + 2e-5, (rel_err(y.detach().cpu(), y64), rel_err(yo, y64))
     assert rel_err(y.detach().cpu(), yo.detach()) < TOL
     (y * gy.cuda()).sum().backward(); (yo * gy).sum().backward(); (y64 * gy.double()).sum().backward()
-    worst = 0.0
-    for (k, p), (_, po), (_, p6) in zip(dcn.fcn.named_parameters(), o.named_parameters(), o64.named_parameters()):
-        n6 = float(p6.grad.norm().clamp_min(1e-300))
-        e_gpu = float((p.grad.double().cpu() - p6.grad).norm()) / n6
-        e_o32 = float((po.grad.double() - p6.grad).norm()) / n6
-        worst = max(worst, (e_gpu - 5e-4) / max(e_o32, 1e-12))
-        assert e_gpu < 3 * e_o32 + 5e-4, (k, e_gpu, e_o32)
-    print("activation range %g (%s): worst gradient error %.2f float32-oracle yard-sticks" % (scale, conv_mode, worst))
+    st = pc.grad_error_stats(dcn.fcn.named_parameters(), o.parameters(), o64.parameters(), ())
+    print("activation range %g (%s): gradient error vs float64, r.m.s. over tensors %.2e (float32 oracle %.2e), worst tensor "
+          "%.2e (%.2e)" % (scale, conv_mode, st["rms_gpu"], st["rms_o32"], st["max_gpu"], st["max_o32"]))
+    pc.assert_as_accurate_as_float32(st, factor=2.0, floor=5e-4)
 
 
 def test_non_finite_activation_raises_status(L):
@@ -253,7 +249,7 @@ def test_batch_norm_kernels_vs_torch_cpu(L, rows, C, residual):
     eye = torch.eye(C).reshape(C, 1, 1, C).contiguous().cuda()
     xc = torch.empty(rows, C, device="cuda")
     mt = lib.dcn_conv_num_mtiles(ctypes.byref(d))
-    part = torch.empty(mt, 2, C, device="cuda")
+    part = torch.empty(mt, 3, C, device="cuda")
     assert lib.dcn_conv_forward(ctypes.byref(d), L.ptr(xg), L.ptr(eye), None, L.ptr(xc), L.ptr(part), None, st) == 0
     assert torch.equal(xc, xg)
     rm, rv = torch.zeros(C, device="cuda"), torch.ones(C, device="cuda")
@@ -267,15 +263,27 @@ def test_batch_norm_kernels_vs_torch_cpu(L, rows, C, residual):
     assert rel_err(rm.cpu(), bn.running_mean) < 1e-5 and rel_err(rv.cpu(), bn.running_var) < 1e-5
     bits = (y.reshape(-1, 4) > 0).to(torch.uint8)
     assert torch.equal(mask, bits[:, 0] | (bits[:, 1] << 1) | (bits[:, 2] << 2) | (bits[:, 3] << 3))
+    # An element whose pre-activation is within round-off of zero may land on the other side of the ReLU than on the CPU
+    # (x*scale + shift vs (x - mean)*invstd*gamma + beta): at most a handful among millions, and the backward pass is then
+    # checked against the batch-norm backward formula evaluated in float64 WITH THE DEVICE'S OWN MASK.
+    flips = int(((y.cpu() > 0) != (y_ref > 0)).sum())
+    assert flips <= 4, flips
+    m64 = (y.cpu() > 0).double()
+    x64, dy64 = x.double(), dy.double() * m64
+    mean, var = x64.mean(0), x64.var(0, unbiased=False)
+    xhat = (x64 - mean) / torch.sqrt(var + 1e-5)
+    ref_dgamma, ref_dbeta = (dy64 * xhat).sum(0), dy64.sum(0)
+    ref_dx = gamma.double() / torch.sqrt(var + 1e-5) * (dy64 - ref_dbeta / rows - xhat * ref_dgamma / rows)
     ws = torch.empty(lib.dcn_bn_backward_workspace(rows, C), dtype=torch.uint8, device="cuda")
     dgamma, dbeta = torch.empty(C, device="cuda"), torch.empty(C, device="cuda")
     dx, gout = torch.empty(rows, C, device="cuda"), torch.empty(rows, C, device="cuda")
     assert lib.dcn_bn_backward(L.ptr(dy.cuda()), L.ptr(mask), L.ptr(xc), L.ptr(stats), L.ptr(gamma.cuda()), C, rows, L.ptr(dgamma),
                                L.ptr(dbeta), L.ptr(dx), L.ptr(gout), L.ptr(ws), st) == 0
-    assert rel_err(dgamma.cpu(), bn.weight.grad) < 2e-5 and rel_err(dbeta.cpu(), bn.bias.grad) < 2e-5
-    assert rel_err(dx.cpu(), xr.grad) < 2e-5
-    if residual:
-        assert rel_err(gout.cpu(), rr.grad) < 1e-6
+    assert rel_err(dgamma.cpu(), ref_dgamma) < 2e-5 and rel_err(dbeta.cpu(), ref_dbeta) < 2e-5
+    assert rel_err(dx.cpu(), ref_dx) < 2e-5
+    assert rel_err(gout.cpu(), dy64) < 1e-6          # the masked upstream gradient (the residual branch's share)
+    if flips == 0:                                   # and against autograd itself when no element sat on the kink
+        assert rel_err(dgamma.cpu(), bn.weight.grad) < 2e-5 and rel_err(dx.cpu(), xr.grad) < 2e-5
     # eval mode: running statistics
     bn.eval()
     ye = F.relu(bn(x.t().reshape(1, C, rows, 1))).reshape(C, rows).t()

@@ -61,7 +61,7 @@ def main():
         dy = torch.randn(n, hout, wout, cout, device=dev)
         dx = torch.empty_like(x)
         dw = torch.empty_like(w)
-        part = torch.empty(lib.dcn_conv_num_mtiles(ctypes.byref(d)), 2, cout, device=dev)
+        part = torch.empty(lib.dcn_conv_num_mtiles(ctypes.byref(d)), 3, cout, device=dev)
         slab = torch.empty(max(lib.dcn_conv_wgrad_workspace(ctypes.byref(d)), 4) // 4, device=dev)
         flops = 2.0 * n * hout * wout * cout * k * k * (3 if cin == 4 else cin)
         wsf = torch.empty(max(lib.dcn_conv_gemm_workspace(ctypes.byref(d), 0), 4) // 4, device=dev)
@@ -76,7 +76,7 @@ def main():
             amax = dy.abs().max().reshape(1)
             wsf = torch.empty(max(lib.dcn_conv_gemm_workspace_f16(ctypes.byref(d), 0), 4) // 4, device=dev)
             wsd = torch.empty(max(lib.dcn_conv_gemm_workspace_f16(ctypes.byref(d), 1), 4) // 4, device=dev)
-            part = torch.empty(lib.dcn_conv_num_mtiles_f16(ctypes.byref(d)), 2, cout, device=dev)
+            part = torch.empty(lib.dcn_conv_num_mtiles_f16(ctypes.byref(d)), 3, cout, device=dev)
         calls = {
             "fwd": lambda: lib.dcn_conv_forward(ctypes.byref(d), _lib.ptr(x), _lib.ptr(w), None, _lib.ptr(y), _lib.ptr(part), _lib.ptr(wsf), st),
             "dgrad": lambda: lib.dcn_conv_dgrad(ctypes.byref(d), _lib.ptr(dy), _lib.ptr(wt), None, _lib.ptr(dx), _lib.ptr(wsd), st),
@@ -108,7 +108,7 @@ def main():
             calls["wgrad"] = wgrad_f16
             if a.check:   # f16x3 vs the fp32 MFMA kernels on the same operands
                 y2, dx2, dw2 = torch.empty_like(y), torch.empty_like(dx), torch.empty_like(dw)
-                part2 = torch.empty(lib.dcn_conv_num_mtiles(ctypes.byref(d)), 2, cout, device=dev)
+                part2 = torch.empty(lib.dcn_conv_num_mtiles(ctypes.byref(d)), 3, cout, device=dev)
                 w2 = torch.empty(max(lib.dcn_conv_gemm_workspace(ctypes.byref(d), 0), lib.dcn_conv_gemm_workspace(ctypes.byref(d), 1),
                                      lib.dcn_conv_wgrad_workspace(ctypes.byref(d)), 4) // 4, device=dev)
                 assert lib.dcn_conv_forward(ctypes.byref(d), _lib.ptr(x), _lib.ptr(w), None, _lib.ptr(y2), _lib.ptr(part2), _lib.ptr(w2), st) == 0

@@ -62,7 +62,11 @@ __global__ void split_hl32_kernel(const float* __restrict__ x, _Float16* __restr
 
 // ---------------------------------------------------------------------------------------------- GEMM core
 // 8 wavefronts as WR (rows) x WC (cols); wavefront tile (32 TM) x (32 TN); workgroup tile BM = 32 TM WR, BN = 32 TN WC.
-template <int TM, int TN, int WR, int WC>
+// PIPE 0: issue next stage, compute this stage (both k-steps), barrier.   PIPE 1: software-pipelined like the shipped
+// gather-GEMM -- fragments of k-step 1 are read before the MFMAs of k-step 0, the barrier sits between the two MFMA groups, the
+// LDS-DMA of stage kt + 2 and the fragment reads of stage kt + 1 are issued behind it, in the shadow of k-step 1's MFMAs.
+// PIPE 2: PIPE 1 + sched_group_barrier interleave (1 MFMA, then a few DS / VMEM / SALU instructions).
+template <int TM, int TN, int WR, int WC, int PIPE>
 __global__ void __launch_bounds__(512, 1)
 gemm_hl_kernel(const _Float16* __restrict__ A, const _Float16* __restrict__ B, float* __restrict__ C, int M, int N, int K,
                float inv_scale) {
@@ -120,35 +124,68 @@ gemm_hl_kernel(const _Float16* __restrict__ A, const _Float16* __restrict__ B, f
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    issue(0, 0);
-    __syncthreads();   // (the compiler drains vmcnt before the barrier while an LDS-DMA is in flight)
-    for (int kt = 0; kt < nk; ++kt) {
-        const int buf = kt & 1;
-        if (kt + 1 < nk) issue(kt + 1, buf ^ 1);
+    h8 ah[2][TM], al[2][TM], bh[2][TN], bl[2][TN];
+    auto read_frags = [&](int buf, int ks, int set) {
         const unsigned char* st = lds + buf * kStageBytes;
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            h8 ah[TM], al[TM], bh[TN], bl[TN];
-#pragma unroll
-            for (int t = 0; t < TM; ++t) {
-                ah[t] = *reinterpret_cast<const h8*>(st + a_row + t * 4096 + foff[0][ks]);
-                al[t] = *reinterpret_cast<const h8*>(st + a_row + t * 4096 + foff[1][ks]);
-            }
-#pragma unroll
-            for (int t = 0; t < TN; ++t) {
-                bh[t] = *reinterpret_cast<const h8*>(st + b_row + t * 4096 + foff[0][ks]);
-                bl[t] = *reinterpret_cast<const h8*>(st + b_row + t * 4096 + foff[1][ks]);
-            }
-#pragma unroll
-            for (int pt = 0; pt < 3; ++pt)
-#pragma unroll
-                for (int tm = 0; tm < TM; ++tm)
-#pragma unroll
-                    for (int tn = 0; tn < TN; ++tn)
-                        acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(pt == 0 ? al[tm] : ah[tm], pt == 1 ? bl[tn] : bh[tn],
-                                                                             acc[tm][tn], 0, 0, 0);
+        for (int t = 0; t < TM; ++t) {
+            ah[set][t] = *reinterpret_cast<const h8*>(st + a_row + t * 4096 + foff[0][ks]);
+            al[set][t] = *reinterpret_cast<const h8*>(st + a_row + t * 4096 + foff[1][ks]);
         }
+#pragma unroll
+        for (int t = 0; t < TN; ++t) {
+            bh[set][t] = *reinterpret_cast<const h8*>(st + b_row + t * 4096 + foff[0][ks]);
+            bl[set][t] = *reinterpret_cast<const h8*>(st + b_row + t * 4096 + foff[1][ks]);
+        }
+    };
+    auto mfmas = [&](int set) {
+#pragma unroll
+        for (int pt = 0; pt < 3; ++pt)
+#pragma unroll
+            for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+                for (int tn = 0; tn < TN; ++tn)
+                    acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(pt == 0 ? al[set][tm] : ah[set][tm],
+                                                                         pt == 1 ? bl[set][tn] : bh[set][tn], acc[tm][tn], 0, 0, 0);
+    };
+    constexpr int kMfma = 3 * TM * TN;
+    auto interleave = [&]() {
+        if (PIPE < 2) return;
+#pragma unroll
+        for (int i = 0; i < kMfma; ++i) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                    // 1 MFMA
+            __builtin_amdgcn_sched_group_barrier(0x126, (2 * (TM + TN) + IA + IB) / kMfma + 1, 0);   // VALU | SALU | VMEM read | DS read
+        }
+    };
+    if (PIPE == 0) {
+        issue(0, 0);
+        __syncthreads();   // (the compiler drains vmcnt before the barrier while an LDS-DMA is in flight)
+        for (int kt = 0; kt < nk; ++kt) {
+            const int buf = kt & 1;
+            if (kt + 1 < nk) issue(kt + 1, buf ^ 1);
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                read_frags(buf, ks, 0);
+                mfmas(0);
+            }
+            __syncthreads();
+        }
+    } else {
+        issue(0, 0);
+        if (nk > 1) issue(1, 1);
         __syncthreads();
+        read_frags(0, 0, 0);
+        for (int kt = 0; kt < nk; ++kt) {
+            const int cur = kt & 1;
+            read_frags(cur, 1, 1);
+            mfmas(0);
+            interleave();
+            __syncthreads();                       // stage kt + 1 has landed everywhere; buffer `cur` is free
+            if (kt + 2 < nk) issue(kt + 2, cur);
+            if (kt + 1 < nk) read_frags(cur ^ 1, 0, 0);
+            mfmas(1);
+            interleave();
+        }
     }
 #pragma unroll
     for (int tm = 0; tm < TM; ++tm)
@@ -162,19 +199,19 @@ gemm_hl_kernel(const _Float16* __restrict__ A, const _Float16* __restrict__ B, f
             }
 }
 
-template <int TM, int TN, int WR, int WC>
+template <int TM, int TN, int WR, int WC, int PIPE>
 double run_gemm(const _Float16* A, const _Float16* B, float* C, int M, int N, int K, float inv, int reps) {
     constexpr int BM = 32 * TM * WR, BN = 32 * TN * WC;
     const size_t lds = 2 * (size_t)(BM + BN) * 128;
-    CHECK(hipFuncSetAttribute((const void*)gemm_hl_kernel<TM, TN, WR, WC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    CHECK(hipFuncSetAttribute((const void*)gemm_hl_kernel<TM, TN, WR, WC, PIPE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     const dim3 grid(((M + BM - 1) / BM) * (N / BN)), block(512);
     hipEvent_t e0, e1;
     CHECK(hipEventCreate(&e0));
     CHECK(hipEventCreate(&e1));
-    for (int i = 0; i < 2; ++i) hipLaunchKernelGGL((gemm_hl_kernel<TM, TN, WR, WC>), grid, block, lds, 0, A, B, C, M, N, K, inv);
+    for (int i = 0; i < 2; ++i) hipLaunchKernelGGL((gemm_hl_kernel<TM, TN, WR, WC, PIPE>), grid, block, lds, 0, A, B, C, M, N, K, inv);
     CHECK(hipDeviceSynchronize());
     CHECK(hipEventRecord(e0));
-    for (int i = 0; i < reps; ++i) hipLaunchKernelGGL((gemm_hl_kernel<TM, TN, WR, WC>), grid, block, lds, 0, A, B, C, M, N, K, inv);
+    for (int i = 0; i < reps; ++i) hipLaunchKernelGGL((gemm_hl_kernel<TM, TN, WR, WC, PIPE>), grid, block, lds, 0, A, B, C, M, N, K, inv);
     CHECK(hipEventRecord(e1));
     CHECK(hipEventSynchronize(e1));
     float ms = 0;
@@ -245,18 +282,25 @@ int main(int argc, char** argv) {
     hipLaunchKernelGGL(split_hl32_kernel, dim3((unsigned)((b.size() + 255) / 256)), dim3(256), 0, 0, db, hb, (long)N, K, 64.0f);
     CHECK(hipDeviceSynchronize());
     const double flop = 2.0 * M * N * (double)K;
-    struct { const char* name; double ms; double err; } res[3];
-    res[0].name = "256x256 (2x4 wavefronts of 128x64)";
-    res[0].ms = run_gemm<4, 2, 2, 4>(ha, hb, dc, M, N, K, 1.0f / 64.0f, 10);
-    res[0].err = check(a, b, dc, M, N, K);
-    res[1].name = "256x256 (4x2 wavefronts of 64x128)";
-    CHECK(hipMemset(dc, 0, (size_t)M * N * 4));
-    res[1].ms = run_gemm<2, 4, 4, 2>(ha, hb, dc, M, N, K, 1.0f / 64.0f, 10);
-    res[1].err = check(a, b, dc, M, N, K);
-    res[2].name = "256x128 (4x2 wavefronts of 64x64)";
-    CHECK(hipMemset(dc, 0, (size_t)M * N * 4));
-    res[2].ms = run_gemm<2, 2, 4, 2>(ha, hb, dc, M, N, K, 1.0f / 64.0f, 10);
-    res[2].err = check(a, b, dc, M, N, K);
+    struct R { const char* name; double ms; double err; };
+    std::vector<R> res;
+    auto run = [&](const char* name, auto fn) {
+        CHECK(hipMemset(dc, 0, (size_t)M * N * 4));
+        R r;
+        r.name = name;
+        r.ms = fn();
+        r.err = check(a, b, dc, M, N, K);
+        res.push_back(r);
+    };
+    const float inv = 1.0f / 64.0f;
+    run("256x256 (2x4 waves of 128x64), plain loop", [&] { return run_gemm<4, 2, 2, 4, 0>(ha, hb, dc, M, N, K, inv, 10); });
+    run("256x256 (2x4 waves of 128x64), pipelined", [&] { return run_gemm<4, 2, 2, 4, 1>(ha, hb, dc, M, N, K, inv, 10); });
+    run("256x256 (2x4 waves of 128x64), pipelined + interleave", [&] { return run_gemm<4, 2, 2, 4, 2>(ha, hb, dc, M, N, K, inv, 10); });
+    run("256x256 (4x2 waves of 64x128), plain loop", [&] { return run_gemm<2, 4, 4, 2, 0>(ha, hb, dc, M, N, K, inv, 10); });
+    run("256x256 (4x2 waves of 64x128), pipelined", [&] { return run_gemm<2, 4, 4, 2, 1>(ha, hb, dc, M, N, K, inv, 10); });
+    run("256x256 (4x2 waves of 64x128), pipelined + interleave", [&] { return run_gemm<2, 4, 4, 2, 2>(ha, hb, dc, M, N, K, inv, 10); });
+    run("256x128 (4x2 waves of 64x64), plain loop", [&] { return run_gemm<2, 2, 4, 2, 0>(ha, hb, dc, M, N, K, inv, 10); });
+    run("256x128 (4x2 waves of 64x64), pipelined", [&] { return run_gemm<2, 2, 4, 2, 1>(ha, hb, dc, M, N, K, inv, 10); });
     for (auto& r : res)
         printf("hl32 LDS-DMA GEMM %d x %d x %d, tile %s: %.1f us, %.1f TFLOP/s algorithmic (x3 MFMA products: %.0f TF fp16), "
                "max rel err vs float64 %.2e\n", M, N, K, r.name, r.ms * 1e3, flop / (r.ms * 1e-3) / 1e12,
