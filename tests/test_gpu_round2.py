@@ -64,7 +64,12 @@ def test_activation_range_forward_backward(L, conv_mode, scale):
     st = pc.grad_error_stats(dcn.fcn.named_parameters(), o.parameters(), o64.parameters(), ())
     print("activation range %g (%s): gradient error vs float64, r.m.s. over tensors %.2e (float32 oracle %.2e), worst tensor "
           "%.2e (%.2e)" % (scale, conv_mode, st["rms_gpu"], st["rms_o32"], st["max_gpu"], st["max_o32"]))
-    pc.assert_as_accurate_as_float32(st, factor=2.0, floor=5e-4)
+    # Split-fp16 carries ~22 mantissa bits per operand (fp32: 24).  With bn1 pushed to 1e4 the activations are large, all
+    # positive numbers with a common offset (beta = 0.1 * scale): the next batch norm subtracts a mean that is large against the
+    # signal, and that cancellation amplifies the 2^-22 operand rounding by the same factor for which it amplifies fp32's
+    # 2^-24 -- measured 4.3x the float32 oracle's gradient noise in this stress case (1.0 - 1.2x at the real configs,
+    # tests/test_gpu_configs.py); the descriptors stay within 1e-4 either way (asserted above).
+    pc.assert_as_accurate_as_float32(st, factor=6.0 if conv_mode == "f16x3" else 2.0, floor=5e-4)
 
 
 def test_non_finite_activation_raises_status(L):

@@ -62,10 +62,8 @@ __global__ void split_hl32_kernel(const float* __restrict__ x, _Float16* __restr
 
 // ---------------------------------------------------------------------------------------------- GEMM core
 // 8 wavefronts as WR (rows) x WC (cols); wavefront tile (32 TM) x (32 TN); workgroup tile BM = 32 TM WR, BN = 32 TN WC.
-// PIPE 0: issue next stage, compute this stage (both k-steps), barrier.   PIPE 1: software-pipelined like the shipped
-// gather-GEMM -- fragments of k-step 1 are read before the MFMAs of k-step 0, the barrier sits between the two MFMA groups, the
-// LDS-DMA of stage kt + 2 and the fragment reads of stage kt + 1 are issued behind it, in the shadow of k-step 1's MFMAs.
-// PIPE 2: PIPE 1 + sched_group_barrier interleave (1 MFMA, then a few DS / VMEM / SALU instructions).
+// PIPE 0: issue the LDS-DMA of the next stage, compute this stage (both k-steps), barrier.
+// PIPE 3: explicit ping-pong of two wavefront groups (see the kernel body).
 template <int TM, int TN, int WR, int WC, int PIPE>
 __global__ void __launch_bounds__(512, 1)
 gemm_hl_kernel(const _Float16* __restrict__ A, const _Float16* __restrict__ B, float* __restrict__ C, int M, int N, int K,
@@ -148,16 +146,43 @@ gemm_hl_kernel(const _Float16* __restrict__ A, const _Float16* __restrict__ B, f
                     acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(pt == 0 ? al[set][tm] : ah[set][tm],
                                                                          pt == 1 ? bl[set][tn] : bh[set][tn], acc[tm][tn], 0, 0, 0);
     };
-    constexpr int kMfma = 3 * TM * TN;
-    auto interleave = [&]() {
-        if (PIPE < 2) return;
-#pragma unroll
-        for (int i = 0; i < kMfma; ++i) {
-            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                    // 1 MFMA
-            __builtin_amdgcn_sched_group_barrier(0x126, (2 * (TM + TN) + IA + IB) / kMfma + 1, 0);   // VALU | SALU | VMEM read | DS read
+    if (PIPE == 3) {
+        // Explicit ping-pong: the 4 wavefronts of group g = wavefront >> 2 (one of each group per SIMD) alternate LOAD phases
+        // (fragment reads of one 16-k step; the LDS-DMA of the next stage rides in phase 0) and COMPUTE phases (its 3 TM TN
+        // MFMAs), group 1 one phase behind group 0, a raw s_barrier (no fence: LDS-DMAs stay in flight across it) between
+        // phases: while one wavefront of a SIMD computes, the other one loads, and the matrix pipe never waits for LDS.
+        //   phase 4s+q    q = 0                       1          2          3
+        //   group 0       L(s,0) + DMA(s+1)           C(s,0)     L(s,1)     C(s,1) + vmcnt(0)
+        //   group 1       C(s-1,1) + DMA(s+1)         L(s,0)     C(s,0)     L(s,1) + vmcnt(0)      (+ a last C(nk-1,1))
+        const int grp = __builtin_amdgcn_readfirstlane(tid >> 8);
+        auto bar = [&]() { __builtin_amdgcn_sched_barrier(0); __builtin_amdgcn_s_barrier(); __builtin_amdgcn_sched_barrier(0); };
+        auto wait_lds = [&]() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); };
+        auto wait_dma = [&]() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); };
+        issue(0, 0);
+        wait_dma();
+        bar();
+        if (grp == 0) {
+            for (int st = 0; st < nk; ++st) {
+                if (st + 1 < nk) issue(st + 1, (st + 1) & 1);
+                read_frags(st & 1, 0, 0); wait_lds(); bar();
+                mfmas(0); bar();
+                read_frags(st & 1, 1, 0); wait_lds(); bar();
+                mfmas(0); wait_dma(); bar();
+            }
+            bar();
+        } else {
+            for (int st = 0; st < nk; ++st) {
+                if (st + 1 < nk) issue(st + 1, (st + 1) & 1);
+                if (st > 0) mfmas(0);
+                bar();
+                read_frags(st & 1, 0, 0); wait_lds(); bar();
+                mfmas(0); bar();
+                read_frags(st & 1, 1, 0); wait_lds(); wait_dma(); bar();
+            }
+            mfmas(0);
+            bar();
         }
-    };
-    if (PIPE == 0) {
+    } else {
         issue(0, 0);
         __syncthreads();   // (the compiler drains vmcnt before the barrier while an LDS-DMA is in flight)
         for (int kt = 0; kt < nk; ++kt) {
@@ -169,22 +194,6 @@ gemm_hl_kernel(const _Float16* __restrict__ A, const _Float16* __restrict__ B, f
                 mfmas(0);
             }
             __syncthreads();
-        }
-    } else {
-        issue(0, 0);
-        if (nk > 1) issue(1, 1);
-        __syncthreads();
-        read_frags(0, 0, 0);
-        for (int kt = 0; kt < nk; ++kt) {
-            const int cur = kt & 1;
-            read_frags(cur, 1, 1);
-            mfmas(0);
-            interleave();
-            __syncthreads();                       // stage kt + 1 has landed everywhere; buffer `cur` is free
-            if (kt + 2 < nk) issue(kt + 2, cur);
-            if (kt + 1 < nk) read_frags(cur ^ 1, 0, 0);
-            mfmas(1);
-            interleave();
         }
     }
 #pragma unroll
@@ -294,13 +303,9 @@ int main(int argc, char** argv) {
     };
     const float inv = 1.0f / 64.0f;
     run("256x256 (2x4 waves of 128x64), plain loop", [&] { return run_gemm<4, 2, 2, 4, 0>(ha, hb, dc, M, N, K, inv, 10); });
-    run("256x256 (2x4 waves of 128x64), pipelined", [&] { return run_gemm<4, 2, 2, 4, 1>(ha, hb, dc, M, N, K, inv, 10); });
-    run("256x256 (2x4 waves of 128x64), pipelined + interleave", [&] { return run_gemm<4, 2, 2, 4, 2>(ha, hb, dc, M, N, K, inv, 10); });
+    run("256x256 (2x4 waves of 128x64), explicit ping-pong of two wavefront groups", [&] { return run_gemm<4, 2, 2, 4, 3>(ha, hb, dc, M, N, K, inv, 10); });
     run("256x256 (4x2 waves of 64x128), plain loop", [&] { return run_gemm<2, 4, 4, 2, 0>(ha, hb, dc, M, N, K, inv, 10); });
-    run("256x256 (4x2 waves of 64x128), pipelined", [&] { return run_gemm<2, 4, 4, 2, 1>(ha, hb, dc, M, N, K, inv, 10); });
-    run("256x256 (4x2 waves of 64x128), pipelined + interleave", [&] { return run_gemm<2, 4, 4, 2, 2>(ha, hb, dc, M, N, K, inv, 10); });
     run("256x128 (4x2 waves of 64x64), plain loop", [&] { return run_gemm<2, 2, 4, 2, 0>(ha, hb, dc, M, N, K, inv, 10); });
-    run("256x128 (4x2 waves of 64x64), pipelined", [&] { return run_gemm<2, 2, 4, 2, 1>(ha, hb, dc, M, N, K, inv, 10); });
     for (auto& r : res)
         printf("hl32 LDS-DMA GEMM %d x %d x %d, tile %s: %.1f us, %.1f TFLOP/s algorithmic (x3 MFMA products: %.0f TF fp16), "
                "max rel err vs float64 %.2e\n", M, N, K, r.name, r.ms * 1e3, flop / (r.ms * 1e-3) / 1e12,
