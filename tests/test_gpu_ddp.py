@@ -77,7 +77,8 @@ def _worker(rank, world, port, q):
     res["stats"] = (st0["bucketed_steps"], st0["monolithic_steps"], st1["bucketed_steps"], st1["monolithic_steps"])
     mono2, _ = grads_of(False, True, False)            # two forward calls -> two backward calls -> buckets reduced twice
     buck2, st2 = grads_of(None, True, False)
-    res["bitwise_two_calls"] = bool(torch.equal(mono2, buck2))
+    # (two backward calls: (ga + gb)/2 summed over the ranks vs gb/2 summed + ga/2 summed -- another association, not the same bits)
+    res["two_calls_rel"] = float((mono2 - buck2).abs().max() / mono2.abs().max())
     res["two_calls_buckets"] = st2["bucketed_steps"]
     # ranks agree, and the average really is the average of the two ranks' own gradients
     gathered = [torch.zeros_like(buck) for _ in range(world)]
@@ -125,7 +126,7 @@ def test_two_ranks_bucketed_overlap_on_device():
     for rank, r in res:
         assert r["stats"] == (0, 1, 1, 0), (rank, r)
         assert r["bitwise_pair"], (rank, r)            # world 2: a + b is commutative, so the slicing cannot change a bit
-        assert r["bitwise_two_calls"] and r["two_calls_buckets"] == 2, (rank, r)
+        assert r["two_calls_rel"] < 1e-6 and r["two_calls_buckets"] == 2, (rank, r)
         assert r["ranks_agree"] and r["replicas_in_sync"], (rank, r)
         # two Adam steps on real (atomics-ordered) gradients: first steps are lr * sign(g), so a flipped near-zero gradient moves
         # a parameter by up to 2 * lr per step
