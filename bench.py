@@ -532,11 +532,50 @@ def main():
         npairs = pair_lists.total
         pair_bytes = (16 * D + 16) * npairs              # 2 descriptor reads + 2 int64 indices + 2 gradient accumulations
         fill_bytes = 2 * B * H * W * D * 4               # zero-fill of the two dense gradient maps
-        loss_roof = {"bound": "hbm", "kernel": "loss_fwd_kernel + loss_finalize_kernel + loss_bwd_kernel (+ memset)",
+        loss_roof = {"bound": "hbm", "kernel": "loss_fwd_kernel + loss_finalize_kernel + loss_bwd_kernel (+ zero-fill of the two gradient maps)",
                      "achieved": (pair_bytes + fill_bytes) / (ms * 1e-3) / 1e9, "peak": 8000.0, "unit": "GB/s",
                      "frac": (pair_bytes + fill_bytes) / (ms * 1e-3) / 1e9 / 8000.0, "us_per_call": 1e3 * ms,
                      "pixel_pairs": npairs, "algorithmic_bytes": {"pairs": pair_bytes, "zero_fill": fill_bytes},
                      "note": "latency-bound at this size: %d random %d-byte gathers per call" % (2 * npairs, 4 * D)}
+
+    # ---- the same loss measurement at BASELINE configs[2]'s list sizes (B = 32 pairs, D = 16, 10 000 + 50 000 + 50 000
+    # pixel pairs each: the only config where the gather moves enough bytes to talk about HBM bandwidth), on
+    # random descriptor maps resident in HBM
+    if loss_roof is not None and world == 1 and not args.no_variants and args.workload != "config3":
+        from dcn_hip.loss import PairLists
+        c3 = WORKLOADS["config3"]
+        B3, D3, HW3 = c3["B"], c3["D"], c3["H"] * c3["W"]
+        gen = torch.Generator().manual_seed(3)
+        lists3 = []
+        for _ in range(B3):
+            t8 = []
+            for n in (c3["Pm"], c3["Pk"], c3["Pg"]):
+                t8 += [torch.randint(0, HW3, (n,), generator=gen, dtype=torch.int64) for _ in range(2)]
+            t8 += [torch.tensor([-1], dtype=torch.int64)] * 2
+            lists3.append(tuple(t8))
+        pl3 = PairLists.from_lists(lists3, dev, hw=HW3)
+        gg = torch.Generator(device=dev).manual_seed(4)
+        da3 = ((torch.rand(B3, HW3, D3, device=dev, generator=gg) * 2 - 1) * 0.12).requires_grad_(True)
+        db3 = ((torch.rand(B3, HW3, D3, device=dev, generator=gg) * 2 - 1) * 0.12).requires_grad_(True)
+        pcl3 = type(pcl)(image_shape=[c3["H"], c3["W"]], config=LOSS_CONFIG)
+        for _ in range(2):
+            loss_composer.get_loss_batched(pcl3, match_type, da3, db3, pl3)[0].backward()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        reps3 = 5
+        e0.record()
+        for _ in range(reps3):
+            loss_composer.get_loss_batched(pcl3, match_type, da3, db3, pl3)[0].backward()
+        e1.record()
+        torch.cuda.synchronize()
+        ms3 = e0.elapsed_time(e1) / reps3
+        pb3, fb3 = (16 * D3 + 16) * pl3.total, 2 * B3 * HW3 * D3 * 4
+        loss_roof["at_config3_list_sizes"] = {
+            "pixel_pairs": pl3.total, "descriptor_dim": D3, "us_per_call": 1e3 * ms3,
+            "algorithmic_bytes": {"pairs": pb3, "zero_fill": fb3},
+            "achieved": (pb3 + fb3) / (ms3 * 1e-3) / 1e9, "frac": (pb3 + fb3) / (ms3 * 1e-3) / 1e9 / 8000.0,
+            "achieved_pairs_only": pb3 / (ms3 * 1e-3) / 1e9, "frac_pairs_only": pb3 / (ms3 * 1e-3) / 1e9 / 8000.0}
+        del da3, db3, pl3
+        torch.cuda.empty_cache()
 
     # ---- measurements that ride on the same line (driver-timed): the same-precision fp32-MFMA arithmetic, BASELINE
     # configs[3]'s per-GPU share on ONE GPU (the 1-GPU point of the weak-scaling curve the multi-GPU runs trace), and for

@@ -19,6 +19,10 @@ for s in $steps; do
     prof)      (cd /tmp && timeout 900 env DCN_BACKWARD_OVERLAP=0 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/${tag}_prof -- python $GRAFT_REPO_ROOT/bench.py --steps 10 --warmup 3 --cpu-baseline-steps 0 --no-variants --profile-steps 0 > $GRAFT_REPO_ROOT/gpurun_out/${tag}_prof_bench.log 2>&1); python tools/stats_summary.py gpurun_out/${tag}_prof > gpurun_out/${tag}_kernel_stats.txt 2>&1; head -45 gpurun_out/${tag}_kernel_stats.txt ;;
     pmc)       for ctr in FETCH_SIZE WRITE_SIZE; do (cd /tmp && timeout 900 rocprofv3 --kernel-trace --pmc $ctr --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/${tag}_pmc_$ctr -- python $GRAFT_REPO_ROOT/bench.py --steps 4 --warmup 2 --cpu-baseline-steps 0 --no-variants --profile-steps 0 > $GRAFT_REPO_ROOT/gpurun_out/${tag}_pmc_$ctr.log 2>&1); done; python tools/pmc_summary.py gpurun_out/${tag}_pmc_FETCH_SIZE gpurun_out/${tag}_pmc_WRITE_SIZE gpurun_out/${tag}_hbm_counters.txt gpurun_out/${tag}_hbm_counters.json 2>&1 | tail -3; head -40 gpurun_out/${tag}_hbm_counters.txt ;;
     pmc3)      for ctr in FETCH_SIZE WRITE_SIZE; do (cd /tmp && timeout 900 rocprofv3 --kernel-trace --pmc $ctr --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/${tag}_pmc3_$ctr -- python $GRAFT_REPO_ROOT/bench.py --workload config3 --steps 2 --warmup 1 --cpu-baseline-steps 0 --no-variants --profile-steps 0 > $GRAFT_REPO_ROOT/gpurun_out/${tag}_pmc3_$ctr.log 2>&1); done; DCN_PMC_WORKLOAD=config3 python tools/pmc_summary.py gpurun_out/${tag}_pmc3_FETCH_SIZE gpurun_out/${tag}_pmc3_WRITE_SIZE gpurun_out/${tag}_hbm_counters_config3.txt gpurun_out/${tag}_hbm_counters_config3.json 2>&1 | tail -3; grep -i "loss\|upsample\|fill" gpurun_out/${tag}_hbm_counters_config3.txt ;;
+    newtests)  timeout 900 python -m pytest tests/test_gpu_ddp.py tests/test_gpu_round2.py -m gpu -q -p no:cacheprovider > gpurun_out/${tag}_pytest_new.log 2>&1; tail -15 gpurun_out/${tag}_pytest_new.log | cut -c1-300 ;;
+    convbench) timeout 600 python tools/conv_bench.py --mode f16 --n 16 --x-direct --json gpurun_out/${tag}_conv_per_layer.json > gpurun_out/${tag}_conv_per_layer.txt 2>&1; cat gpurun_out/${tag}_conv_per_layer.txt | cut -c1-170
+               timeout 600 env DCN_GEMM_SK=0 python tools/conv_bench.py --mode f16 --n 16 --kinds fwd,dgrad --json gpurun_out/${tag}_conv_per_layer_nosk.json > gpurun_out/${tag}_conv_per_layer_nosk.txt 2>&1; cat gpurun_out/${tag}_conv_per_layer_nosk.txt | cut -c1-120 ;;
+    prof3)     (cd /tmp && timeout 900 env DCN_BACKWARD_OVERLAP=0 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/${tag}_prof3 -- python $GRAFT_REPO_ROOT/bench.py --workload config3 --steps 3 --warmup 1 --cpu-baseline-steps 0 --no-variants --profile-steps 0 > $GRAFT_REPO_ROOT/gpurun_out/${tag}_prof3_bench.log 2>&1); python tools/stats_summary.py gpurun_out/${tag}_prof3 > gpurun_out/${tag}_kernel_stats_config3.txt 2>&1; grep -i "loss\|fill\|upsample\|total" gpurun_out/${tag}_kernel_stats_config3.txt ;;
     *) echo "unknown step $s" ;;
   esac
 done
