@@ -150,65 +150,70 @@ __device__ __forceinline__ PairScales pair_scales(const dcn_loss_config& cfg, co
     return s;
 }
 
-// One workgroup.  Adds the partials in a fixed order in fp64, composes the 5-tuple per pair and the mean loss.
+// One workgroup PER IMAGE PAIR: adds that pair's partials in a fixed order in fp64 and composes its 5-tuple; the per-pair
+// losses go to pair_loss[] and a second, tiny kernel averages them in pair order (deterministic; a single workgroup walking
+// all pairs took 200 us at 32 pairs x 110 000 pixel pairs).
 __global__ void __launch_bounds__(kThreads)
-loss_finalize_kernel(const double* __restrict__ part_sum, const int* __restrict__ part_cnt, int chunks, int num_pairs,
+loss_finalize_kernel(const double* __restrict__ part_sum, const int* __restrict__ part_cnt, int chunks,
                      const int64_t* __restrict__ offsets, dcn_loss_config cfg, float* __restrict__ terms,
-                     float* __restrict__ sums, int* __restrict__ hard_neg, float* __restrict__ loss) {
+                     float* __restrict__ sums, int* __restrict__ hard_neg, double* __restrict__ pair_loss) {
     __shared__ double s_sum[kThreads / dcn::kWave];
     __shared__ int s_cnt[kThreads / dcn::kWave];
     __shared__ double s_S[4];
     __shared__ int s_h[4];
-    double total = 0.0;
-    for (int p = 0; p < num_pairs; ++p) {
-        for (int t = 0; t < 4; ++t) {
-            double a = 0.0;
-            int c = 0;
-            const int64_t base = (int64_t)(4 * p + t) * chunks;
-            for (int i = threadIdx.x; i < chunks; i += kThreads) { a += part_sum[base + i]; c += part_cnt[base + i]; }
-            a = dcn::block_sum<kThreads>(a, s_sum);
-            c = dcn::block_sum<kThreads>(c, s_cnt);
-            if (threadIdx.x == 0) { s_S[t] = a; s_h[t] = c; }
-        }
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            int64_t len[4];
-            int h[4];
-            for (int t = 0; t < 4; ++t) { len[t] = offsets[4 * p + t + 1] - offsets[4 * p + t]; h[t] = s_h[t]; }
-            h[0] = (int)len[0];
-            const PairScales sc = pair_scales(cfg, h, len);
-            float out[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
-            if (cfg.compose == DCN_COMPOSE_WITHIN_SCENE) {
-                const float match_loss = len[0] > 0 ? (float)(s_S[0] / (double)len[0]) : 0.f;
-                const float Sk = (float)s_S[1], Sg = (float)s_S[2], Sb = (float)s_S[3];
-                int64_t dk, dg, db;
-                if (cfg.scale_by_hard_negatives) {
-                    dk = h[1] > 1 ? h[1] : 1; dg = h[2] > 1 ? h[2] : 1;
-                    db = len[3] > 0 ? (h[3] > 1 ? h[3] : 1) : 1;
-                } else {
-                    dk = len[1] > 1 ? len[1] : 1; dg = len[2] > 1 ? len[2] : 1; db = len[3] > 1 ? len[3] : 1;
-                }
-                out[1] = match_loss;
-                out[2] = Sk / (float)dk;
-                out[3] = Sg / (float)dg;
-                out[4] = Sb / (float)db;
-                out[0] = cfg.match_loss_weight * match_loss + sc.nonmatch_coef * (Sk + Sg);
-            } else if (cfg.compose == DCN_COMPOSE_RAW_SUMS) {
-                out[1] = (float)s_S[0]; out[2] = (float)s_S[1]; out[3] = (float)s_S[2]; out[4] = (float)s_S[3];
-                out[0] = sc.match_coef * out[1] + sc.nonmatch_coef * (out[2] + out[3] + out[4]);
-            } else {
-                const float Sb = (float)s_S[3];
-                out[0] = sc.blind_coef * Sb;
-                // different_object returns the scaled blind loss, across_scene the raw sum, as 5th element
-                out[4] = cfg.compose == DCN_COMPOSE_DIFFERENT_OBJECT ? out[0] : Sb;
-            }
-            for (int k = 0; k < 5; ++k) terms[5 * p + k] = out[k];
-            for (int t = 0; t < 4; ++t) { sums[4 * p + t] = (float)s_S[t]; hard_neg[4 * p + t] = h[t]; }
-            total += (double)out[0];
-        }
-        __syncthreads();
+    const int p = blockIdx.x;
+    for (int t = 0; t < 4; ++t) {
+        double a = 0.0;
+        int c = 0;
+        const int64_t base = (int64_t)(4 * p + t) * chunks;
+        for (int i = threadIdx.x; i < chunks; i += kThreads) { a += part_sum[base + i]; c += part_cnt[base + i]; }
+        a = dcn::block_sum<kThreads>(a, s_sum);
+        c = dcn::block_sum<kThreads>(c, s_cnt);
+        if (threadIdx.x == 0) { s_S[t] = a; s_h[t] = c; }
     }
-    if (threadIdx.x == 0) loss[0] = (float)(total / (double)num_pairs);
+    __syncthreads();
+    if (threadIdx.x != 0) return;
+    int64_t len[4];
+    int h[4];
+    for (int t = 0; t < 4; ++t) { len[t] = offsets[4 * p + t + 1] - offsets[4 * p + t]; h[t] = s_h[t]; }
+    h[0] = (int)len[0];
+    const PairScales sc = pair_scales(cfg, h, len);
+    float out[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
+    if (cfg.compose == DCN_COMPOSE_WITHIN_SCENE) {
+        const float match_loss = len[0] > 0 ? (float)(s_S[0] / (double)len[0]) : 0.f;
+        const float Sk = (float)s_S[1], Sg = (float)s_S[2], Sb = (float)s_S[3];
+        int64_t dk, dg, db;
+        if (cfg.scale_by_hard_negatives) {
+            dk = h[1] > 1 ? h[1] : 1; dg = h[2] > 1 ? h[2] : 1;
+            db = len[3] > 0 ? (h[3] > 1 ? h[3] : 1) : 1;
+        } else {
+            dk = len[1] > 1 ? len[1] : 1; dg = len[2] > 1 ? len[2] : 1; db = len[3] > 1 ? len[3] : 1;
+        }
+        out[1] = match_loss;
+        out[2] = Sk / (float)dk;
+        out[3] = Sg / (float)dg;
+        out[4] = Sb / (float)db;
+        out[0] = cfg.match_loss_weight * match_loss + sc.nonmatch_coef * (Sk + Sg);
+    } else if (cfg.compose == DCN_COMPOSE_RAW_SUMS) {
+        out[1] = (float)s_S[0]; out[2] = (float)s_S[1]; out[3] = (float)s_S[2]; out[4] = (float)s_S[3];
+        out[0] = sc.match_coef * out[1] + sc.nonmatch_coef * (out[2] + out[3] + out[4]);
+    } else {
+        const float Sb = (float)s_S[3];
+        out[0] = sc.blind_coef * Sb;
+        // different_object returns the scaled blind loss, across_scene the raw sum, as 5th element
+        out[4] = cfg.compose == DCN_COMPOSE_DIFFERENT_OBJECT ? out[0] : Sb;
+    }
+    for (int k = 0; k < 5; ++k) terms[5 * p + k] = out[k];
+    for (int t = 0; t < 4; ++t) { sums[4 * p + t] = (float)s_S[t]; hard_neg[4 * p + t] = h[t]; }
+    pair_loss[p] = (double)out[0];
+}
+
+__global__ void __launch_bounds__(64)
+loss_mean_kernel(const double* __restrict__ pair_loss, int num_pairs, float* __restrict__ loss) {
+    if (threadIdx.x != 0) return;
+    double total = 0.0;
+    for (int p = 0; p < num_pairs; ++p) total += pair_loss[p];   // pair order: the sum the single-workgroup version formed
+    loss[0] = (float)(total / (double)num_pairs);
 }
 
 // grid = (chunks, 4*num_pairs).  Scatter-adds d loss / d descriptor with hardware fp32 atomics (lane mapping above).
@@ -413,7 +418,7 @@ namespace {
 
 extern "C" size_t dcn_loss_workspace_bytes(int num_pairs, int64_t max_list_len) {
     const size_t n = (size_t)4 * (size_t)num_pairs * (size_t)chunks_for(max_list_len, 0);
-    return n * sizeof(double) + n * sizeof(int) + 64;
+    return n * sizeof(double) + (size_t)num_pairs * sizeof(double) + n * sizeof(int) + 64;
 }
 
 extern "C" int dcn_contrastive_loss_forward(const float* desc_a, const float* desc_b, int num_pairs, int64_t hw, int d,
@@ -431,7 +436,8 @@ extern "C" int dcn_contrastive_loss_forward(const float* desc_a, const float* de
     const int chunks = chunks_for(max_len(offsets_host, num_pairs), d);
     const size_t n = (size_t)4 * num_pairs * chunks;
     double* part_sum = (double*)workspace;
-    int* part_cnt = (int*)(part_sum + n);
+    double* pair_loss = part_sum + n;
+    int* part_cnt = (int*)(pair_loss + num_pairs);
     if (dcn::fill_bytes_async(status, 0, sizeof(int32_t), st) != DCN_OK) return DCN_E_LAUNCH;
     const dim3 grid(chunks, 4 * num_pairs), block(kThreads);
 #define DCN_LAUNCH_FWD(LP, SINGLE)                                                                                       \
@@ -447,8 +453,9 @@ extern "C" int dcn_contrastive_loss_forward(const float* desc_a, const float* de
             break;
     }
 #undef DCN_LAUNCH_FWD
-    hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), block, 0, st, part_sum, part_cnt, chunks, num_pairs, offsets_dev,
-                       *cfg, terms, sums, (int*)hard_neg, loss);
+    hipLaunchKernelGGL(loss_finalize_kernel, dim3(num_pairs), block, 0, st, part_sum, part_cnt, chunks, offsets_dev, *cfg,
+                       terms, sums, (int*)hard_neg, pair_loss);
+    hipLaunchKernelGGL(loss_mean_kernel, dim3(1), dim3(64), 0, st, (const double*)pair_loss, num_pairs, loss);
     return dcn::check_launch();
 }
 
