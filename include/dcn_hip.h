@@ -83,7 +83,8 @@ enum {
 
 typedef struct dcn_loss_config {
     float margin[DCN_NUM_LISTS];       /* hinge margin per list type (match entry unused) */
-    int32_t invert[DCN_NUM_LISTS];     /* 1: max(0, d - M)^2 instead of max(0, M - d)^2 (pcl.py:205-208) */
+    int32_t invert[DCN_NUM_LISTS];     /* 0: max(0, M - d)^2;  1: max(0, d - M)^2 (pcl.py:205-208);  2: max(0, M - d^2), the legacy
+                                          hinge on the squared distance of get_loss_original (pcl.py:399-404) */
     int32_t pixel_weight[DCN_NUM_LISTS]; /* 1: weight each term by min(|uv(gt) - uv(b)|, M_pixel)/M_pixel (pcl.py:307-334);
                                             the list must hold (len/len_match) consecutive entries per match */
     float m_pixel;

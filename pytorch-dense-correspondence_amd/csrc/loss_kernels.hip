@@ -94,9 +94,13 @@ loss_fwd_kernel(const float* __restrict__ A, const float* __restrict__ B, int64_
                     term = d2;
                     acc += sub == 0 ? term : 0.f;
                 } else {
-                    const float dist = sqrtf(d2);
-                    const float h = fmaxf(cfg.invert[t] ? dist - M : M - dist, 0.f);
-                    term = h * h;
+                    if (cfg.invert[t] == 2) {   // legacy hinge on the SQUARED distance, not squared again (pcl.py:399-404)
+                        term = fmaxf(M - d2, 0.f);
+                    } else {
+                        const float dist = sqrtf(d2);
+                        const float h = fmaxf(cfg.invert[t] ? dist - M : M - dist, 0.f);
+                        term = h * h;
+                    }
                     cnt += (sub == 0 && term != 0.f) ? 1 : 0;
                     float w = 1.f;
                     if (per > 0) {
@@ -272,6 +276,9 @@ loss_bwd_kernel(const float* __restrict__ A, const float* __restrict__ B, int64_
         const float cj = pair_grad ? pair_grad[beg + j] : coef;
         if (t == DCN_LIST_MATCH) {
             g = 2.f * cj;
+        } else if (cfg.invert[t] == 2) {        // legacy: d max(0, M - d2) / d diff = -2 diff where the hinge is active
+            if (!(M - d2 > 0.f)) continue;
+            g = -2.f * cj;
         } else {
             const float dist = sqrtf(d2);
             const float hinge = cfg.invert[t] ? dist - M : M - dist;

@@ -78,7 +78,7 @@ def make_config(margins, image_width, match_loss_weight=1.0, non_match_loss_weig
     cfg = _lib.LossConfig()
     for i in range(4):
         cfg.margin[i] = float(margins[i])
-        cfg.invert[i] = int(bool(invert[i]))
+        cfg.invert[i] = int(invert[i])   # 0 / 1 (inverted hinge) / 2 (legacy hinge on the squared distance)
         cfg.pixel_weight[i] = int(bool(pixel_weight[i]))
     cfg.m_pixel = float(m_pixel)
     cfg.image_width = int(image_width)

@@ -165,16 +165,14 @@ class PixelwiseContrastiveLoss(object):
 
     def get_loss_original(self, image_a_pred, image_b_pred, matches_a, matches_b, non_matches_a, non_matches_b,
                           M_margin=0.5, non_match_loss_weight=1.0):
-        """pcl.py:357-411 (legacy loss pegged to an old sha; hinge on the SQUARED distance, not squared after).
-        Legacy / unused by training.py; plain tensor ops."""
-        num_matches = matches_a.size()[0]
-        num_non_matches = non_matches_a.size()[0]
-        ma = torch.index_select(image_a_pred, 1, matches_a)
-        mb = torch.index_select(image_b_pred, 1, matches_b)
-        match_loss = 1.0 / num_matches * (ma - mb).pow(2).sum()
-        na = torch.index_select(image_a_pred, 1, non_matches_a)
-        nb = torch.index_select(image_b_pred, 1, non_matches_b)
-        pixel_wise_loss = torch.add(torch.neg((na - nb).pow(2).sum(dim=2)), M_margin)
-        non_match_loss = non_match_loss_weight * 1.0 / num_non_matches * \
-            torch.max(torch.zeros_like(pixel_wise_loss), pixel_wise_loss).sum()
-        return match_loss + non_match_loss, match_loss, non_match_loss
+        """pcl.py:357-411, the legacy loss (no caller in the reference): ``1/P_m sum ||a - b||^2`` +
+        ``w/P sum max(0, M - ||a - b||^2)`` -- the hinge acts on the SQUARED distance and is not squared again.  One fused
+        kernel pass (hinge mode 2 of dcn_loss_config.invert, raw-sum composition); -> (loss, match_loss, non_match_loss)."""
+        lists = _k.PairLists.from_lists([(matches_a, matches_b, non_matches_a, non_matches_b, None, None, None, None)],
+                                        image_a_pred.device, hw=int(image_a_pred.shape[1]))
+        pm, pn = max(lists.length(0, _k.LIST_MATCH), 1), max(lists.length(0, _k.LIST_MASKED), 1)
+        cfg = _k.make_config([0.0, M_margin, 0.0, 0.0], self.image_width, match_loss_weight=1.0 / pm,
+                             non_match_loss_weight=float(non_match_loss_weight) / pn, compose=_k.COMPOSE_RAW_SUMS,
+                             invert=(0, 2, 0, 0))
+        loss, terms, _sums, _hard, _status, _ = _k.contrastive_loss(image_a_pred, image_b_pred, lists, cfg)
+        return loss, terms[0, 1] / pm, terms[0, 2] * (float(non_match_loss_weight) / pn)

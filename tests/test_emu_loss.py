@@ -74,6 +74,14 @@ def test_building_blocks_match_reference_goldens():
         PCL.get_triplet_loss(A3, B3, ma, mb, tna[:-1], kb[:-1], cfg["alpha_triplet"])
     orig = pcl.get_loss_original(A, B, ma, mb, ka, kb)
     np.testing.assert_allclose([o.item() for o in orig], z["original_loss"], rtol=1e-6)
+    # ... and its gradient (hinge on the squared distance: kernel hinge mode 2) against the oracle's autograd
+    A5 = torch.tensor(z["A"], requires_grad=True); B5 = torch.tensor(z["B"], requires_grad=True)
+    A6 = torch.tensor(z["A"], requires_grad=True); B6 = torch.tensor(z["B"], requires_grad=True)
+    pcl.get_loss_original(A5, B5, ma, mb, ka, kb, M_margin=0.3, non_match_loss_weight=0.7)[0].backward()
+    opcl = loss_oracle.PixelwiseContrastiveLoss([int(z["H"]), int(z["W"])], cfg)
+    lo = opcl.get_loss_original(A6, B6, ma, mb, ka, kb, M_margin=0.3, non_match_loss_weight=0.7)
+    lo[0].backward()
+    assert float(lo[2]) > 0 and rel_err(A5.grad, A6.grad) < 1e-5 and rel_err(B5.grad, B6.grad) < 1e-5
 
 
 @pytest.mark.parametrize("D", [2, 3, 5, 8, 16, 32, 40])   # lane groups of 4 / 8 / 16 / 32 per pair; 40: two components per lane

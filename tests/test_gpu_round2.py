@@ -150,6 +150,20 @@ def test_within_scene_wrapper_and_legacy_loss_on_gpu(L):
     np.testing.assert_allclose(float(ml), z["f6_match_loss"], rtol=5e-6)
     np.testing.assert_allclose(float(nml), z["f7_vec"].sum(), rtol=2e-5)
     assert int(hn) == int(z["f7_hard"])
+    # get_loss_original (pcl.py:357-411; hinge on the squared distance = kernel hinge mode 2): the reference's golden value,
+    # gradients against the oracle's autograd
+    from oracle import loss_oracle
+    orig = pcl.get_loss_original(A, B, t("matches_a"), t("matches_b"), t("masked_a"), t("masked_b"))
+    np.testing.assert_allclose([float(o) for o in orig], z["original_loss"], rtol=5e-6)
+    Ag, Bg = A.clone().requires_grad_(True), B.clone().requires_grad_(True)
+    Ao, Bo = torch.tensor(z["A"], requires_grad=True), torch.tensor(z["B"], requires_grad=True)
+    pcl.get_loss_original(Ag, Bg, t("matches_a"), t("matches_b"), t("masked_a"), t("masked_b"), M_margin=0.3,
+                          non_match_loss_weight=0.7)[0].backward()
+    c = lambda k: torch.tensor(z[k])
+    opcl = loss_oracle.PixelwiseContrastiveLoss([int(z["H"]), int(z["W"])], cfg)
+    opcl.get_loss_original(Ao, Bo, c("matches_a"), c("matches_b"), c("masked_a"), c("masked_b"), M_margin=0.3,
+                           non_match_loss_weight=0.7)[0].backward()
+    assert rel_err(Ag.grad.cpu(), Ao.grad) < 1e-5 and rel_err(Bg.grad.cpu(), Bo.grad) < 1e-5
 
 
 # ------------------------------------------------------------------------------------------------ checkpoints (f3)
