@@ -194,6 +194,10 @@ int dcn_plan_param_info(const dcn_plan* plan, int i, char* name, int name_cap, i
 /* name prefix ("layer1.0.bn1") and channel count of batch-norm j. */
 int dcn_plan_bn_info(const dcn_plan* plan, int j, char* name, int name_cap, int64_t* channels);
 
+/* number of batch norms of the last dcn_backbone_backward call whose backward reduction ran in the epilogue of the dgrad
+ * that produced their upstream gradient (split-fp16 mode; DCN_BN_BWD_FUSED=0 disables) */
+int dcn_plan_fused_bn_backward(const dcn_plan* plan);
+
 /* Inside the `saved` buffer of a forward call, at byte offset dcn_plan_activation_absmax_offset: one float per
  * activation tensor that feeds a convolution (dcn_plan_num_activation_slots of them; slot 0 = the input image) with its
  * abs-max as the split-fp16 kernels used it (all zero in fp32 mode), followed by one int32 STATUS word: bit 0 = some
@@ -288,6 +292,17 @@ int dcn_conv_forward_f16(const dcn_conv_desc* c, const float* in, const float* i
 /* dout_absmax: device scalar >= max|dout| (picks the power-of-two pre-scale of the gradient tensor) or NULL */
 int dcn_conv_dgrad_f16(const dcn_conv_desc* c, const float* dout, const void* wt_hi, const void* wt_lo, float w_scale,
                        const float* dout_absmax, const float* add, float* din, void* workspace, void* stream);
+/* dcn_conv_dgrad_f16 whose result din is the upstream gradient of a train-mode batch norm (the one that produced this
+ * convolution's input, training.py:345 through the backbone's BasicBlock): the batch norm's backward REDUCTION runs in the
+ * GEMM epilogue.  din receives the gradient masked by relu_mask (the bytes dcn_bn_forward wrote for that batch norm's
+ * output; NULL: no ReLU) and bn_partial[dcn_conv_dgrad_bn_num_mtiles_f16(c)][cin][4] the per-tile sums that
+ * dcn_bn_backward_from_partial consumes.  bn_x: the batch norm's input [n, hin, win, cin]; bn_stats: its statistics
+ * [4][cin] (per group when c->group_rows is set: M tiles then never straddle a group). */
+int dcn_conv_dgrad_bn_num_mtiles_f16(const dcn_conv_desc* c);
+int dcn_conv_dgrad_bn_f16(const dcn_conv_desc* c, const float* dout, const void* wt_hi, const void* wt_lo, float w_scale,
+                          const float* dout_absmax, const float* add, float* din, const float* bn_x,
+                          const unsigned char* relu_mask, const float* bn_stats, float* bn_partial, void* workspace,
+                          void* stream);
 
 /* All weight tensors of a network in one launch: w[i] = [cout[i]][taps[i]][cin[i]] (device), hi[i] / lo[i] (device) receive
  * the forward image [cout][kpad(taps*cin)] or, transposed != 0, the dgrad image [cin][kpad(taps*ldn[i])] of
@@ -334,6 +349,11 @@ size_t dcn_bn_backward_workspace(int64_t rows, int c);
 int dcn_bn_backward(const float* dy, const unsigned char* relu_mask, const float* x, const float* stats, const float* gamma,
                     int c, int64_t rows, float* dgamma, float* dbeta, float* dx, float* g_out, void* workspace,
                     void* stream);
+/* dcn_bn_backward with the reduction already done by dcn_conv_dgrad_bn_f16 (dy masked, bn_partial [mtiles][c][4]);
+ * workspace: 3 * c floats */
+int dcn_bn_backward_from_partial(const float* dy, const float* bn_partial, int mtiles, const float* x, const float* stats,
+                                 const float* gamma, int c, int64_t rows, float* dgamma, float* dbeta, float* dx,
+                                 void* workspace, void* stream);
 /* 3x3 / stride 2 / pad 1 max pool (kernel K2) of in [n,hin,win,c] -> out [n,(hin+1)/2,(win+1)/2,c]; argmax (nullable in
  * forward): one byte per output element (window position 0..8); backward gathers with it (deterministic). */
 int dcn_maxpool_forward(const float* in, int n, int hin, int win, int c, float* out, unsigned char* argmax, void* stream);

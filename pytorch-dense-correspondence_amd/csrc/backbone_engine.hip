@@ -105,6 +105,7 @@ struct dcn_plan {
     std::vector<hipEvent_t> ev_bucket;
     hipEvent_t ev_bucket_side = nullptr;
     int bucket_state = 0;   // 0: events not created yet, 1: ready, -1: unavailable
+    int fused_bn_bwd = 0;   // batch norms of the last backward call whose reduction ran in a dgrad epilogue
 };
 
 namespace {
@@ -326,6 +327,8 @@ int build_plan(dcn_plan& p) {
         }
         const size_t pf = (size_t)std::max(c.mtiles[0], c.mtiles[1]) * 3 * c.d.cout;
         if (pf > max_part) max_part = pf;
+        const size_t pb = (size_t)std::max(dcn_conv_dgrad_bn_num_mtiles_f16(&c.d), 0) * 4 * c.d.cin;   // fused BN-backward sums
+        if (pb > max_part) max_part = pb;
         if (c.d.cout > max_c) max_c = c.d.cout;
     }
     for (const BnL& b : p.bns) {
@@ -587,6 +590,7 @@ extern "C" int dcn_plan_stream_wait_grad_bucket(dcn_plan* plan, int k, void* str
     if (plan->bucket_state != 1) return DCN_E_UNSUPPORTED;   // no backward pass has run yet (or events unavailable)
     return hipStreamWaitEvent((hipStream_t)stream, plan->ev_bucket[k], 0) == hipSuccess ? DCN_OK : DCN_E_LAUNCH;
 }
+extern "C" int dcn_plan_fused_bn_backward(const dcn_plan* plan) { return plan ? plan->fused_bn_bwd : DCN_E_INVALID; }
 extern "C" int dcn_plan_num_activation_slots(const dcn_plan* plan) { return plan ? plan->n_act : DCN_E_INVALID; }
 extern "C" size_t dcn_plan_activation_absmax_offset(const dcn_plan* plan) { return plan ? plan->s_actmax * sizeof(float) : 0; }
 extern "C" size_t dcn_plan_saved_bytes(const dcn_plan* plan) { return plan ? plan->saved_floats * sizeof(float) : 0; }
@@ -746,6 +750,13 @@ extern "C" int dcn_backbone_backward(dcn_plan* plan, const float* grad_descripto
     float* const dqbuf[2] = {R.Wk(p.w_dq), R.Wk(p.w_dq2)};
     const float* dq_of = nullptr;       // gradient tensor whose pixel-blocked split copy is in dqbuf[cur]
     // BN backward of conv c's batch norm: dy (+ optional relu mask from relu_out) -> dx; g_out optional
+    // Fused reduction (split-fp16 mode): the dgrad that produces a batch norm's upstream gradient dy also masks it with the
+    // ReLU bits and leaves the per-tile sums of the BN backward reduction in `part` (GemmConv::bnb_*): bn_bwd then only
+    // runs finalize + apply.  red_dy / red_tiles: the tensor that currently has its sums in `part`, and how many rows per group.
+    const bool fuse_red = f16 && dcn::tuning().bn_bwd_fused != 0;
+    p.fused_bn_bwd = 0;
+    const float* red_dy = nullptr;
+    int red_tiles = 0;
     auto bn_bwd = [&](const ConvL& c, const float* dy, const float* relu_out, float* dx, float* g_out) {
         const BnL& b = p.bns[c.bn];
         const float* s = R.S(b.stats);
@@ -753,8 +764,12 @@ extern "C" int dcn_backbone_backward(dcn_plan* plan, const float* grad_descripto
         const unsigned char* mask = relu_out ? R.M((size_t)(relu_out - R.saved)) : nullptr;
         cur = overlap ? (n_bn & 1) : 0;
         if (overlap && wg_pending[cur]) RT(hipStreamWaitEvent(st, p.ev_wg[cur], 0));   // the wgrad that read this buffer two layers ago
+        const int tiles = (red_dy == dy && dy) ? red_tiles : 0;
+        red_dy = nullptr;
+        if (tiles > 0) { relu_out = nullptr; mask = nullptr; g_out = nullptr; ++p.fused_bn_bwd; }   // dy is already the masked gradient
         dcn::launch_bn_bwd(dy, relu_out, mask, R.S(c.x), s, R.P(b.g), b.C, b.rows, p.groups, part, grads[b.g],
-                           grads[b.b], k123, dx, g_out, f16 ? amax + c.idx : nullptr, f16 ? (void*)dqbuf[cur] : nullptr, st);
+                           grads[b.b], k123, dx, g_out, f16 ? amax + c.idx : nullptr, f16 ? (void*)dqbuf[cur] : nullptr, st,
+                           tiles);
         if (overlap) RT(hipEventRecord(p.ev_dq[cur], st));
         ++n_bn;
         dq_of = f16 ? dx : nullptr;   // the pixel-blocked split copy of this dx now sits in dqbuf[cur]
@@ -780,10 +795,26 @@ extern "C" int dcn_backbone_backward(dcn_plan* plan, const float* grad_descripto
             return dcn_conv_wgrad_f16(&c.d, in, 1, R.A(c.in_act), dqbuf[cur], amax + c.idx, dw, slab, st);
         });
     };
-    auto dgrad = [&](const ConvL& c, const float* dx, const float* add, float* din) -> int {
+    // bn_of: the convolution whose batch norm's backward consumes din as its upstream gradient (din = gradient w.r.t. that
+    // batch norm's ReLU'd output `relu_out`), or null
+    auto dgrad = [&](const ConvL& c, const float* dx, const float* add, float* din, const ConvL* bn_of = nullptr,
+                     const float* relu_out = nullptr) -> int {
         if (!f16) {
             DCN_TRY(dcn_transpose_weight(R.P(c.w), wt, c.d.cout, c.d.kh * c.d.kw, c.d.cin, c.d.ldc, st));
             return R.timed(0, c.flops, [&] { return dcn_conv_dgrad(&c.d, dx, wt, add, din, R.Wk(p.w_sk), st); });
+        }
+        if (fuse_red && bn_of) {
+            const BnL& b = p.bns[bn_of->bn];
+            const int tiles = dcn_conv_dgrad_bn_num_mtiles_f16(&c.d);
+            if (tiles > 0 && tiles % p.groups == 0 && b.C == c.d.cin && b.rows == (int64_t)c.d.n * c.d.hin * c.d.win) {
+                const unsigned char* mask = relu_out ? R.M((size_t)(relu_out - R.saved)) : nullptr;
+                red_dy = din;
+                red_tiles = tiles / p.groups;
+                return R.timed(0, c.flops, [&] {
+                    return dcn_conv_dgrad_bn_f16(&c.d, dx, R.wimg(p.w_wh, c), R.wimg(p.w_wl, c), kWeightScale, amax + c.idx, add,
+                                                 din, R.S(bn_of->x), mask, R.S(b.stats), part, R.Wk(p.w_sk), st);
+                });
+            }
         }
         return R.timed(0, c.flops, [&] {   // (transposed weight images: split_all_weights(true) below)
             return dcn_conv_dgrad_f16(&c.d, dx, R.wimg(p.w_wh, c), R.wimg(p.w_wl, c), kWeightScale, amax + c.idx, add, din,
@@ -813,35 +844,43 @@ extern "C" int dcn_backbone_backward(dcn_plan* plan, const float* grad_descripto
     float* dxa = R.Wk(p.w_buf[3]);
     float* dxb = R.Wk(p.w_buf[4]);
     float* dpart = R.Wk(p.w_buf[5]);
-    DCN_TRY(dgrad(fc, glow, nullptr, dout));
+    {
+        const BlockL& lb = p.blocks.back();
+        DCN_TRY(dgrad(fc, glow, nullptr, dout, &p.convs[lb.conv[lb.nconv - 1]], R.S(lb.out)));
+    }
 
     for (int bi = (int)p.blocks.size() - 1; bi >= 0; --bi) {
         const BlockL& blk = p.blocks[bi];
         const float* in = R.S(blk.in);
         // last conv's BN: relu mask from the block output, emits g for the identity branch
         const ConvL& last = p.convs[blk.conv[blk.nconv - 1]];
+        // (with the fused reduction dout already IS the relu-masked gradient: it serves as the residual branch's gradient)
+        const float* gres = (red_dy == dout) ? dout : gbuf;
         bn_bwd(last, dout, R.S(blk.out), dxa, gbuf);
         float* dx = dxa;
         float* dy = dxb;
+        // the gradient w.r.t. this block's input is the upstream gradient of the previous block's last batch norm
+        const ConvL* up_bn = bi > 0 ? &p.convs[p.blocks[bi - 1].conv[p.blocks[bi - 1].nconv - 1]] : nullptr;
+        const float* up_relu = bi > 0 ? R.S(p.blocks[bi - 1].out) : nullptr;
         for (int i = blk.nconv - 1; i >= 0; --i) {
             const ConvL& c = p.convs[blk.conv[i]];
             const float* cin = i == 0 ? in : R.S(blk.mid[i - 1]);
             DCN_TRY(wgrad(c, cin, dx, grads[c.w]));
             if (i > 0) {
-                DCN_TRY(dgrad(c, dx, nullptr, dy));  // dy = grad w.r.t. mid[i-1]
                 const ConvL& prev = p.convs[blk.conv[i - 1]];
+                DCN_TRY(dgrad(c, dx, nullptr, dy, &prev, R.S(blk.mid[i - 1])));  // dy = grad w.r.t. mid[i-1]
                 bn_bwd(prev, dy, R.S(blk.mid[i - 1]), dx, nullptr);  // dx reused: grad w.r.t. prev conv output
             } else if (blk.down >= 0) {
                 DCN_TRY(dgrad(c, dx, nullptr, dpart));
             } else {
-                DCN_TRY(dgrad(c, dx, gbuf, dnext));  // + identity gradient
+                DCN_TRY(dgrad(c, dx, gres, dnext, up_bn, up_relu));  // + identity gradient
             }
         }
         if (blk.down >= 0) {
             const ConvL& dc = p.convs[blk.down];
-            bn_bwd(dc, gbuf, nullptr, dxa, nullptr);
+            bn_bwd(dc, gres, nullptr, dxa, nullptr);
             DCN_TRY(wgrad(dc, in, dxa, grads[dc.w]));
-            DCN_TRY(dgrad(dc, dxa, dpart, dnext));
+            DCN_TRY(dgrad(dc, dxa, dpart, dnext, up_bn, up_relu));
         }
         float* t = dout; dout = dnext; dnext = t;
         // gradient bucket complete?  (every launch that writes one of its gradients has been enqueued: the side stream's

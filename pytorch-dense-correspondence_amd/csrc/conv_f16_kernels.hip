@@ -14,6 +14,9 @@
 // MFMA work per K drops 5.3x (3 x 32 cycles per 16 K vs 8 x 64 cycles), so the kernels are designed around the
 // operand path: 128x128 tiles, 32-K stages, fp32->(hi,lo) conversion once per element at staging time (v_cvt_pk_f16_f32),
 // conflict-free 80-byte-pitch fp16 LDS images, one ds_read_b128 per 32x16 fragment.
+#include <algorithm>
+#include <atomic>
+
 #include "conv_shared.h"
 #include "dcn_tuning.h"
 #include "f16_split.h"
@@ -131,6 +134,23 @@ template <int TM, int TN, int WR = 2> struct F16Geo {
                          kStageHalves = 2 * (BM + BN) * LDH;   // A hi, A lo, B hi, B lo
     static_assert(BN % RB == 0, "WR = 4 needs TN = 2");
 };
+
+// Stream-K tiles completed INSIDE the GEMM launch: every workgroup that parks a partial accumulator of a tile then counts
+// itself into the tile's arrival word; the one that finds itself last (all the others' partials are then visible: release
+// fence before the arrival, acquire fence after it, both device-wide -- the XCDs have separate L2s) sums the parked
+// partials in the fixed order of the contributing workgroups and runs the epilogue -- bit-identical to the separate fix-up
+// kernel, without its launch, and overlapped with the tiles still being computed.  The arrival word is
+// (launch id << 32) | arrivals: a word left behind by any other launch (or never initialised) counts as zero, so the
+// workspace needs no clearing; the last arriver resets it to 0 so that a replay of the same captured launch starts clean.
+__device__ __forceinline__ bool sk_arrive_is_last(unsigned long long* cnt, unsigned id, int contributors) {
+    unsigned long long old = __atomic_load_n(cnt, __ATOMIC_RELAXED);
+    for (;;) {
+        const unsigned long long nv = (unsigned)(old >> 32) == id ? old + 1ull : (((unsigned long long)id << 32) | 1ull);
+        const unsigned long long seen = atomicCAS(cnt, old, nv);
+        if (seen == old) return (int)(unsigned)(nv & 0xffffffffull) == contributors;
+        old = seen;
+    }
+}
 
 constexpr int kOob = (int)0x80000000;   // voffset that fails the bounds check of any buffer <= 2 GiB: the load returns 0
 
@@ -449,6 +469,44 @@ __device__ __forceinline__ void gemm_segment_f16(const GemmConv& p, _Float16* ld
                 for (int q = 0; q < 4; ++q)
                     o[((tm * TN + tn) * 4 + q) * 64] = make_float4(acc[tm][tn][4 * q], acc[tm][tn][4 * q + 1],
                                                                    acc[tm][tn][4 * q + 2], acc[tm][tn][4 * q + 3]);
+        // (the 128 x 128 / 4-wavefront shape sits exactly at its 256-register budget: it keeps the separate fix-up kernel)
+        if constexpr (!(WR == 2 && TM == 2 && TN == 2)) if (p.sk_count) {
+            __shared__ int s_last;
+            const int rel = tile - p.sk_dp;                    // (index among the stream-K'd tiles)
+            const int ua = rel * nk, ub = ua + nk - 1;         // its unit range relative to the start of the stream-K pass
+            const int ga = ua / p.sk_units, gb = ub / p.sk_units;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            __syncthreads();
+            if (tid == 0) s_last = sk_arrive_is_last(p.sk_count + rel, p.sk_id, gb - ga + 1) ? 1 : 0;
+            __syncthreads();
+            if (s_last) {
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+#pragma unroll
+                for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+                    for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) acc[tm][tn][r] = 0.f;
+                for (int g = ga; g <= gb; ++g) {               // fixed order, own partial included: deterministic
+                    const int first_tile = (g * p.sk_units) / nk;
+                    const float4* q4 = reinterpret_cast<const float4*>(
+                                           p.sk_partial + (int64_t)(2 * g + (first_tile == rel ? 0 : 1)) * (BM * BN) +
+                                           wv * (TM * TN * 16 * 64)) + lane;
+#pragma unroll
+                    for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+                        for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) {
+                                const float4 v = q4[((tm * TN + tn) * 4 + q) * 64];
+                                acc[tm][tn][4 * q] += v.x; acc[tm][tn][4 * q + 1] += v.y;
+                                acc[tm][tn][4 * q + 2] += v.z; acc[tm][tn][4 * q + 3] += v.w;
+                            }
+                }
+                gemm_epilogue<WR, TM, TN, 16, 2>(p, acc, mt, nt, reinterpret_cast<float*>(lds));
+                if (tid == 0) atomicExch(p.sk_count + rel, 0ull);
+            }
+        }
     }
 }
 
@@ -491,7 +549,7 @@ template <int TM, int TN, int WR = 2>
 __global__ void __launch_bounds__(64 * WR)
 conv_gemm_f16_fixup_kernel(GemmConv p) {
     using G = F16Geo<TM, TN, WR>;
-    __shared__ float red[3 * WR * G::BN / 2];            // 3 WR x (BN / 2)
+    __shared__ float red[4 * WR * G::BN / 2];            // 4 WR x (BN / 2)
     const int nk = (p.K + HBK - 1) / HBK;
     const int rel = blockIdx.x >> 1, half = blockIdx.x & 1;
     const int tile = p.sk_dp + rel;                      // only the leftover tiles were stream-K'd
@@ -529,7 +587,7 @@ conv_gemm_f16_fixup_kernel(GemmConv p) {
 struct F16Shape {
     int tm, tn, wr, mtiles, ntiles, nk, sk_wgs, sk_units, sk_dp;   // tile = (32 tm wr) x (64 tn), 128 wr work-items
     bool sk;
-    size_t ws_bytes;
+    size_t ws_bytes, sk_count_off;
 };
 // align: 0, or the M tile must divide it (rows per batch-norm group)
 F16Shape f16_shape(int M, int cd, int K, int align = 0) {
@@ -570,7 +628,7 @@ F16Shape f16_shape(int M, int cd, int K, int align = 0) {
         if (v == 0) g.sk = false;
         if (v > 1) { g.sk = g.nk >= 2; wgs = v; }
     }
-    g.sk_wgs = 0; g.sk_units = 0; g.sk_dp = 0; g.ws_bytes = 0;
+    g.sk_wgs = 0; g.sk_units = 0; g.sk_dp = 0; g.ws_bytes = 0; g.sk_count_off = 0;
     if (g.sk) {
         if ((int64_t)tiles * g.nk >= ((int64_t)1 << 30)) { g.sk = false; return g; }
         g.sk_dp = tiles / wgs * wgs;                       // whole rounds stay data-parallel
@@ -580,6 +638,8 @@ F16Shape f16_shape(int M, int cd, int K, int align = 0) {
         g.sk_units = (int)((total + wgs - 1) / wgs);
         g.sk_wgs = g.sk_dp > 0 ? wgs : (int)((total + g.sk_units - 1) / g.sk_units);
         g.ws_bytes = (size_t)2 * g.sk_wgs * bm * (64 * g.tn) * sizeof(float);
+        g.sk_count_off = g.ws_bytes;                                   // arrival words of the stream-K'd tiles
+        g.ws_bytes += (size_t)(tiles - g.sk_dp) * sizeof(unsigned long long);
     }
     return g;
 }
@@ -603,6 +663,12 @@ int launch_gemm_f16(GemmConv& p, void* workspace, hipStream_t st, int align = 0)
     p.sk_units = sk ? g.sk_units : 0;
     p.sk_dp = sk ? g.sk_dp : 0;
     p.sk_partial = sk ? (float*)workspace : nullptr;
+    const bool sk_inline = sk && dcn::tuning().gemm_sk_inline != 0 && !(g.wr == 2 && g.tm == 2 && g.tn == 2);
+    p.sk_count = sk_inline ? (unsigned long long*)((char*)workspace + g.sk_count_off) : nullptr;
+    if (sk_inline) {
+        static std::atomic<unsigned> next_id{1u};
+        do { p.sk_id = next_id.fetch_add(1u, std::memory_order_relaxed); } while (p.sk_id == 0u);
+    }
     // uniform-tap fast path: whole 32-K stages inside one filter tap, tensors addressable through 2 GiB buffer resources
     const int64_t src_bytes = (int64_t)p.M / (p.hd * p.wd) * p.hs * p.ws * p.cs * 4, w_bytes = (int64_t)p.cd * p.kp * 2;
     bool uni = (p.cs % HBK) == 0 && src_bytes <= ((int64_t)1 << 31) && w_bytes <= ((int64_t)1 << 31);
@@ -620,7 +686,7 @@ int launch_gemm_f16(GemmConv& p, void* workspace, hipStream_t st, int align = 0)
         if (sk) {                                                                                  \
             if (p.transposed) DCN_GEMM16_K(TM, TN, WR, true, true);                                \
             else DCN_GEMM16_K(TM, TN, WR, false, true);                                            \
-            hipLaunchKernelGGL((conv_gemm_f16_fixup_kernel<TM, TN, WR>), fgrid, fblock, 0, st, p);  \
+            if (!sk_inline) hipLaunchKernelGGL((conv_gemm_f16_fixup_kernel<TM, TN, WR>), fgrid, fblock, 0, st, p);  \
         } else {                                                                                   \
             if (p.transposed) DCN_GEMM16_K(TM, TN, WR, true, false);                               \
             else DCN_GEMM16_K(TM, TN, WR, false, false);                                           \
@@ -946,6 +1012,13 @@ bool valid_desc16(const dcn_conv_desc* c) {
            c->cout > 0 && c->kh > 0 && c->kw > 0 && c->stride > 0 && c->dil > 0 && c->pad >= 0 && c->ldc >= c->cout;
 }
 
+// rows of the dgrad result per batch-norm statistics group (the descriptor's group_rows counts rows of the conv OUTPUT)
+int dgrad_group_rows(const dcn_conv_desc* c) {
+    if (c->group_rows <= 0) return 0;
+    const int groups = c->n * c->hout * c->wout / c->group_rows;
+    return groups > 1 ? c->n / groups * c->hin * c->win : 0;
+}
+
 }  // namespace
 
 extern "C" int dcn_f16_kpad(int k) { return (k + 7) / 8 * 8; }
@@ -1010,7 +1083,9 @@ extern "C" int dcn_conv_num_mtiles_f16(const dcn_conv_desc* c) {
 
 extern "C" size_t dcn_conv_gemm_workspace_f16(const dcn_conv_desc* c, int dgrad) {
     if (!valid_desc16(c)) return 0;
-    if (dgrad) return f16_shape(c->n * c->hin * c->win, c->cin, c->kh * c->kw * c->ldc).ws_bytes;
+    if (dgrad)   // (either tiling: plain, or aligned to the statistics groups for dcn_conv_dgrad_bn_f16)
+        return std::max(f16_shape(c->n * c->hin * c->win, c->cin, c->kh * c->kw * c->ldc).ws_bytes,
+                        f16_shape(c->n * c->hin * c->win, c->cin, c->kh * c->kw * c->ldc, dgrad_group_rows(c)).ws_bytes);
     return f16_shape(c->n * c->hout * c->wout, c->cout, c->kh * c->kw * c->cin, c->group_rows).ws_bytes;
 }
 
@@ -1058,6 +1133,35 @@ extern "C" int dcn_conv_dgrad_f16(const dcn_conv_desc* c, const float* dout, con
     p.kh = c->kh; p.kw = c->kw; p.stride = c->stride; p.pad = c->pad; p.dil = c->dil; p.ldc = c->cin;
     p.M = c->n * c->hin * c->win; p.K = c->kh * c->kw * c->ldc; p.kp = dcn_f16_kpad(p.K); p.transposed = 1; p.relu = 0;
     return launch_gemm_f16(p, workspace, (hipStream_t)stream);
+}
+
+extern "C" int dcn_conv_dgrad_bn_num_mtiles_f16(const dcn_conv_desc* c) {
+    if (!valid_desc16(c)) return DCN_E_INVALID;
+    return f16_shape(c->n * c->hin * c->win, c->cin, c->kh * c->kw * c->ldc, dgrad_group_rows(c)).mtiles;
+}
+
+// dcn_conv_dgrad_f16 whose result din is the upstream gradient of a batch norm (the one that produced this convolution's
+// input): din receives the ReLU-masked gradient (relu_mask: the bytes dcn_bn_apply wrote for that batch norm's output, or
+// NULL: no ReLU) and bn_partial[dcn_conv_dgrad_bn_num_mtiles_f16(c)][cin][4] the per-tile sums of the backward reduction
+// (consumed by dcn_bn_backward_from_partial).  bn_x: that batch norm's input [n, hin, win, cin]; bn_stats: its
+// [groups][4][cin] statistics block (scale, shift, mean, invstd).
+extern "C" int dcn_conv_dgrad_bn_f16(const dcn_conv_desc* c, const float* dout, const void* wt_hi, const void* wt_lo,
+                                     float w_scale, const float* dout_absmax, const float* add, float* din,
+                                     const float* bn_x, const unsigned char* relu_mask, const float* bn_stats,
+                                     float* bn_partial, void* workspace, void* stream) {
+    if (!valid_desc16(c) || !dout || !wt_hi || !wt_lo || !din || (c->ldc % 4) != 0 || !(w_scale > 0.f) || !bn_x || !bn_stats ||
+        !bn_partial || (c->cin % 4) != 0)
+        return DCN_E_INVALID;
+    GemmConv p;
+    p.src = dout; p.wm = nullptr; p.bias = nullptr; p.add = add; p.dst = din; p.bn_partial = nullptr; p.out_absmax = nullptr;
+    p.wh = (const _Float16*)wt_hi; p.wl = (const _Float16*)wt_lo; p.a_absmax = dout_absmax; p.b_inv_scale = 1.f / w_scale;
+    p.hs = c->hout; p.ws = c->wout; p.cs = c->ldc;
+    p.hd = c->hin; p.wd = c->win; p.cd = c->cin;
+    p.kh = c->kh; p.kw = c->kw; p.stride = c->stride; p.pad = c->pad; p.dil = c->dil; p.ldc = c->cin;
+    p.M = c->n * c->hin * c->win; p.K = c->kh * c->kw * c->ldc; p.kp = dcn_f16_kpad(p.K); p.transposed = 1; p.relu = 0;
+    p.bnb_x = bn_x; p.bnb_mask = relu_mask; p.bnb_mean = bn_stats + 2 * c->cin; p.bnb_invstd = bn_stats + 3 * c->cin;
+    p.bnb_partial = bn_partial; p.bnb_gstride = 4 * c->cin; p.bnb_group_rows = dgrad_group_rows(c);
+    return launch_gemm_f16(p, workspace, (hipStream_t)stream, p.bnb_group_rows);
 }
 
 extern "C" int dcn_split_act_f16(const float* src, void* dst, int64_t n, void* stream) {

@@ -37,6 +37,20 @@ struct GemmConv {
     float* dst;         // [M][ldc]
     float* bn_partial;  // [mtiles][3][cd] (sum, sum of squares, max |x| per channel of the M tile) or null
     float* sk_partial;  // stream-K: [2 * workgroups][BM*BN] parked accumulators (fragment order)
+    unsigned long long* sk_count = nullptr;   // split-fp16 kernel, optional: arrival word per stream-K tile -- (launch id << 32) | arrivals;
+                                    // the last contributor of a tile completes it inside the launch (no fix-up kernel)
+    unsigned sk_id = 0;             // id of this launch (never 0)
+    // Optional (dgrad whose result is the upstream gradient dy of a batch norm): the backward REDUCTION of that batch norm in
+    // this epilogue -- dst receives the ReLU-masked gradient g (mask bit of the BN's output taken from bnb_mask, one byte
+    // per float4, when given) and bnb_partial[mtile][cd][4] = (sum g, sum g xhat, max |g|, max |xhat|) over the tile's
+    // rows, xhat = (bnb_x - mean) * invstd: what bn_bwd_reduce_kernel computes per row chunk, without its pass over dy.
+    // M tiles must not straddle a statistics group (rows >= bnb_group_rows use the second group's mean / invstd).
+    const float* bnb_x = nullptr;
+    const unsigned char* bnb_mask = nullptr;
+    const float* bnb_mean = nullptr;
+    const float* bnb_invstd = nullptr;
+    float* bnb_partial = nullptr;
+    int bnb_gstride = 0, bnb_group_rows = 0;
     float* out_absmax;  // null, or device scalar raised to max |dst| (fused inference path: the next layer's operand pre-scale)
     // split-fp16 path only: pre-split weights [cd][kp] (hi, lo), device scalar with max|src| (or null), 1 / weight scale
     const _Float16* wh;
@@ -65,8 +79,8 @@ template <int WM, int TM, int TN, int BK> struct GemmGeo {
 };
 
 // Epilogue: C/D fragments -> NHWC rows (32 consecutive channels per half-wave = 128 B segments), + bias, + residual
-// gradient, + per-M-tile batch-norm partial statistics (sum, sum of squares, max |x|; fixed order).  `red` = at least
-// 3*WM*BN floats of LDS, free to use.
+// gradient, + per-M-tile batch-norm partial statistics (sum, sum of squares, max |x|; fixed order), or the backward
+// reduction of the batch norm that consumes dst (GemmConv::bnb_*).  `red` = at least 4*WM*BN floats of LDS, free to use.
 // WN: wavefronts along N (WM * WN wavefronts per workgroup; 4 for every kernel but the 8-wavefront f16x3 tile).
 template <int WM, int TM, int TN, int BK, int WN = 4 / WM>
 __device__ __forceinline__ void gemm_epilogue(const GemmConv& p, f32x16 (&acc)[TM][TN], int mt, int nt, float* red) {
@@ -77,6 +91,64 @@ __device__ __forceinline__ void gemm_epilogue(const GemmConv& p, f32x16 (&acc)[T
     const int m0 = mt * G::BM, n0 = nt * G::BN;
     float csum[TN], csq[TN], cmax[TN];
     float vmax = 0.f;
+    if (p.bnb_partial) {   // (never together with bn_partial / relu / out_absmax)
+        const int goff = (p.bnb_group_rows > 0 && m0 >= p.bnb_group_rows) ? p.bnb_gstride : 0;
+        float cgx[TN], cxm[TN];
+#pragma unroll
+        for (int tn = 0; tn < TN; ++tn) {
+            csum[tn] = 0.f; cgx[tn] = 0.f; cmax[tn] = 0.f; cxm[tn] = 0.f;
+            const int col = n0 + wn_ * 32 * TN + tn * 32 + fi;
+            const bool cok = col < p.cd;
+            const float bv = (p.bias && cok) ? p.bias[col] : 0.f;
+            const float mu = cok ? p.bnb_mean[goff + col] : 0.f, is = cok ? p.bnb_invstd[goff + col] : 0.f;
+#pragma unroll
+            for (int tm = 0; tm < TM; ++tm) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = m0 + wm_ * 32 * TM + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh;
+                    if (cok && row < p.M) {
+                        const int64_t o = (int64_t)row * p.ldc + col;
+                        float v = acc[tm][tn][r] + bv;
+                        if (p.add) v += p.add[o];
+                        if (p.bnb_mask) v = ((p.bnb_mask[o >> 2] >> (col & 3)) & 1) ? v : 0.f;
+                        p.dst[o] = v;
+                        const float xh = (p.bnb_x[o] - mu) * is;
+                        csum[tn] += v;
+                        cgx[tn] = fmaf(v, xh, cgx[tn]);
+                        cmax[tn] = fmaxf(cmax[tn], fabsf(v));
+                        cxm[tn] = fmaxf(cxm[tn], fabsf(xh));
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int tn = 0; tn < TN; ++tn) {
+            csum[tn] += __shfl_xor(csum[tn], 32, 64);
+            cgx[tn] += __shfl_xor(cgx[tn], 32, 64);
+            cmax[tn] = fmaxf(cmax[tn], __shfl_xor(cmax[tn], 32, 64));
+            cxm[tn] = fmaxf(cxm[tn], __shfl_xor(cxm[tn], 32, 64));
+            if (fh == 0) {
+                const int cl = wn_ * 32 * TN + tn * 32 + fi;
+                red[(wm_ * 4 + 0) * G::BN + cl] = csum[tn];
+                red[(wm_ * 4 + 1) * G::BN + cl] = cgx[tn];
+                red[(wm_ * 4 + 2) * G::BN + cl] = cmax[tn];
+                red[(wm_ * 4 + 3) * G::BN + cl] = cxm[tn];
+            }
+        }
+        __syncthreads();
+        if (tid < G::BN && n0 + tid < p.cd) {
+            float a = red[0 * G::BN + tid], b = red[1 * G::BN + tid], mg = red[2 * G::BN + tid], mx = red[3 * G::BN + tid];
+#pragma unroll
+            for (int w = 1; w < WM; ++w) {   // fixed order
+                a += red[(w * 4 + 0) * G::BN + tid];
+                b += red[(w * 4 + 1) * G::BN + tid];
+                mg = fmaxf(mg, red[(w * 4 + 2) * G::BN + tid]);
+                mx = fmaxf(mx, red[(w * 4 + 3) * G::BN + tid]);
+            }
+            reinterpret_cast<float4*>(p.bnb_partial)[(int64_t)mt * p.cd + n0 + tid] = make_float4(a, b, mg, mx);
+        }
+        return;
+    }
 #pragma unroll
     for (int tn = 0; tn < TN; ++tn) {
         csum[tn] = 0.f; csq[tn] = 0.f; cmax[tn] = 0.f;

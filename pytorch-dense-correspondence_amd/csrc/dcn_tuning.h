@@ -6,6 +6,10 @@
 //   DCN_GEMM_SK             0: no stream-K, 1: as decided, N > 1: force N workgroups
 //   DCN_GEMM_SK_MIN_GAIN    stage times stream-K must save to be chosen (split-fp16 kernel)
 //   DCN_GEMM_UNI            0: disable the uniform-tap fast path
+//   DCN_GEMM_SK_FIXUP       kernel: stream-K tiles are completed by the separate fix-up kernel instead of by the last
+//                           contributing workgroup of the GEMM launch itself (split-fp16 kernel)
+//   DCN_BN_BWD_FUSED         0: the batch-norm backward reduction stays a separate pass (1: in the epilogue of the dgrad that
+//                           produces its upstream gradient; split-fp16 mode)
 //   DCN_WGRAD_SPLITS        force the pixel-range split count of the split-fp16 wgrad kernel
 #pragma once
 
@@ -19,6 +23,8 @@ struct Tuning {
     int gemm_sk = -1;            // -1: unset
     double gemm_sk_min_gain = 20.0;
     int gemm_uni = 1;
+    int gemm_sk_inline = 1;      // stream-K tiles completed inside the GEMM launch (0: separate fix-up kernel)
+    int bn_bwd_fused = 1;
     int wgrad_splits = 0;        // 0: unset
 };
 

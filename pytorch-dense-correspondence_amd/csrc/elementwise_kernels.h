@@ -30,8 +30,11 @@ int bn_bwd_chunks(int64_t rows_per_group);
 void launch_bn_bwd(const float* dy, const float* relu_out, const unsigned char* relu_mask, const float* x, const float* stats,
                    const float* gamma, int C,
                    int64_t rows, int groups, float* partial, float* dgamma, float* dbeta, float* k123, float* dx,
-                   float* g_out, float* absmax, void* dq, hipStream_t st);   // dq (optional, with absmax): dx also as the
-                                                                             // pixel-blocked split-fp16 tensor (f16_split.h)
+                   float* g_out, float* absmax, void* dq, hipStream_t st,    // dq (optional, with absmax): dx also as the
+                   int reduced_tiles_per_group = 0);                         // pixel-blocked split-fp16 tensor (f16_split.h)
+// reduced_tiles_per_group > 0: `partial` already holds that many rows per group of per-tile sums, written by the epilogue
+// of the dgrad that produced dy (GemmConv::bnb_partial) -- the reduce pass is skipped; dy is then already ReLU-masked
+// (pass relu_out = relu_mask = nullptr)
 void launch_add(const float* a, const float* b, float* out, int64_t n, hipStream_t st);
 
 void launch_maxpool_fwd(const float* in, float* out, unsigned char* argmax, int n, int hin, int win, int hout,

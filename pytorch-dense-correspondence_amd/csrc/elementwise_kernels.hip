@@ -682,14 +682,17 @@ int bn_bwd_chunks(int64_t rows_per_group) {
 void launch_bn_bwd(const float* dy, const float* relu_out, const unsigned char* relu_mask, const float* x, const float* stats,
                    const float* gamma, int C,
                    int64_t rows, int groups, float* partial, float* dgamma, float* dbeta, float* k123, float* dx,
-                   float* g_out, float* absmax, void* dq, hipStream_t st) {
+                   float* g_out, float* absmax, void* dq, hipStream_t st, int reduced_tiles_per_group) {
     const int64_t rpg = rows / groups;
-    const int chunks = bn_bwd_chunks(rpg);   // per group
-    const int rpc = (int)ceil_div64(rpg, chunks);
     const float* mean = stats + 2 * C;
     const float* invstd = stats + 3 * C;
-    hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(ceil_div(C, 64), chunks * groups), dim3(256), 0, st, dy, relu_out,
-                       relu_mask, x, mean, invstd, C, rpg, chunks, 4 * C, rpc, partial);
+    int chunks = reduced_tiles_per_group;
+    if (chunks <= 0) {
+        chunks = bn_bwd_chunks(rpg);   // per group
+        const int rpc = (int)ceil_div64(rpg, chunks);
+        hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(ceil_div(C, 64), chunks * groups), dim3(256), 0, st, dy, relu_out,
+                           relu_mask, x, mean, invstd, C, rpg, chunks, 4 * C, rpc, partial);
+    }
     hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(ceil_div(C, 4)), dim3(256), 0, st, (const float*)partial, chunks,
                        groups, C, (double)rpg, gamma, invstd, 4 * C, dgamma, dbeta, k123, absmax);
     const int64_t total4 = rows * (C / 4);
@@ -792,6 +795,19 @@ extern "C" int dcn_bn_backward(const float* dy, const unsigned char* relu_mask, 
     float* k123 = partial + (size_t)dcn::bn_bwd_chunks(rows) * 4 * c;
     dcn::launch_bn_bwd(dy, nullptr, relu_mask, x, stats, gamma, c, rows, 1, partial, dgamma, dbeta, k123, dx, g_out, nullptr,
                        nullptr, (hipStream_t)stream);
+    return dcn::check_launch();
+}
+
+// the same with the reduction already done by the epilogue of the convolution that produced dy (dcn_conv_dgrad_bn_f16:
+// dy is ReLU-masked, bn_partial holds `mtiles` rows of per-tile sums); workspace: 3 * c floats
+extern "C" int dcn_bn_backward_from_partial(const float* dy, const float* bn_partial, int mtiles, const float* x,
+                                            const float* stats, const float* gamma, int c, int64_t rows, float* dgamma,
+                                            float* dbeta, float* dx, void* workspace, void* stream) {
+    if (!dy || !bn_partial || mtiles < 1 || !x || !stats || !gamma || !dgamma || !dbeta || !dx || !workspace || c < 4 ||
+        (c % 4) != 0 || rows < 1)
+        return DCN_E_INVALID;
+    dcn::launch_bn_bwd(dy, nullptr, nullptr, x, stats, gamma, c, rows, 1, const_cast<float*>(bn_partial), dgamma, dbeta,
+                       (float*)workspace, dx, nullptr, nullptr, nullptr, (hipStream_t)stream, mtiles);
     return dcn::check_launch();
 }
 

@@ -34,6 +34,7 @@ SYMBOLS = {
     "dcn_version": (c_char_p, []),
     "dcn_reload_env": (None, []),
     "dcn_plan_num_activation_slots": (c_int, [c_void_p]),
+    "dcn_plan_fused_bn_backward": (c_int, [c_void_p]),
     "dcn_plan_activation_absmax_offset": (c_size_t, [c_void_p]),
     "dcn_plan_num_grad_buckets": (c_int, [c_void_p]),
     "dcn_plan_grad_bucket_first_param": (c_int, [c_void_p, c_int]),
@@ -83,6 +84,11 @@ SYMBOLS = {
                                      c_void_p, c_void_p, c_void_p, c_void_p]),
     "dcn_conv_dgrad_f16": (c_int, [ctypes.POINTER(ConvDesc), c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_void_p,
                                    c_void_p, c_void_p, c_void_p]),
+    "dcn_conv_dgrad_bn_num_mtiles_f16": (c_int, [ctypes.POINTER(ConvDesc)]),
+    "dcn_conv_dgrad_bn_f16": (c_int, [ctypes.POINTER(ConvDesc), c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_void_p,
+                                      c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "dcn_bn_backward_from_partial": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int64,
+                                             c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "dcn_triplet_loss_workspace_bytes": (c_size_t, [c_int64]),
     "dcn_triplet_loss_forward": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_void_p, c_void_p, c_void_p, c_int64, c_int64,
                                          c_float, c_void_p, c_void_p, c_void_p, c_void_p]),

@@ -65,6 +65,10 @@ class Plan(object):
         """Make the stream wait until every gradient of bucket k of the LAST backward pass has been computed."""
         _lib.check(_lib.get().dcn_plan_stream_wait_grad_bucket(self.handle, k, stream_ptr), "dcn_plan_stream_wait_grad_bucket")
 
+    def fused_bn_backward(self):
+        """Batch norms of the last backward call whose reduction ran in a dgrad epilogue (0 in fp32 mode / DCN_BN_BWD_FUSED=0)."""
+        return int(_lib.get().dcn_plan_fused_bn_backward(self.handle))
+
     def activation_range(self, saved):
         """(abs-max per activation slot [n] fp32, status int) of the forward call that filled ``saved`` (device tensors are
         sliced, not synchronised: call .item() / .cpu() to look).  Status bit 0: a convolution input was not finite."""

@@ -183,7 +183,7 @@ template <class F> inline void launch(dim3 grid, dim3 block, F&& f) {
     ::hipemu::launch((grid), (block), [=]() { kernel(__VA_ARGS__); })
 
 static inline void __syncthreads() { ::hipemu::block_barrier(); }
-static inline void __threadfence() {}
+static inline void __threadfence() { __atomic_thread_fence(__ATOMIC_SEQ_CST); }
 static inline void __threadfence_block() {}
 
 template <class T> static inline T __shfl_xor(T v, int mask, int width = 64) {
@@ -250,6 +250,14 @@ static inline unsigned atomicMax(unsigned* p, unsigned v) {
     while (v > old && !__atomic_compare_exchange_n(p, &old, v, false, __ATOMIC_RELAXED, __ATOMIC_RELAXED)) {}
     return old;
 }
+static inline unsigned long long atomicCAS(unsigned long long* p, unsigned long long expected, unsigned long long desired) {
+    __atomic_compare_exchange_n(p, &expected, desired, false, __ATOMIC_SEQ_CST, __ATOMIC_SEQ_CST);
+    return expected;   // (the value found, like the device function)
+}
+static inline unsigned long long atomicExch(unsigned long long* p, unsigned long long v) {
+    return __atomic_exchange_n(p, v, __ATOMIC_SEQ_CST);
+}
+#define __builtin_amdgcn_fence(order, scope) __atomic_thread_fence(__ATOMIC_SEQ_CST)
 static inline unsigned __float_as_uint(float f) { unsigned u; memcpy(&u, &f, 4); return u; }
 static inline float __uint_as_float(unsigned u) { float f; memcpy(&f, &u, 4); return f; }
 #define unsafeAtomicAdd atomicAdd

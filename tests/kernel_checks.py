@@ -1,0 +1,145 @@
+"""Kernel-level checks shared by the CPU (host-emulated) and the -m gpu suites (not a test module): the same C-ABI calls
+against torch CPU ops, on `device` ("cpu" with the emulation library loaded, "cuda" with libdcn_hip.so)."""
+import ctypes
+
+import torch
+import torch.nn.functional as F
+
+from helpers import rel_err
+
+
+def _split_rows(L, lib, w2d, dev):
+    rows, K = w2d.shape
+    kp = lib.dcn_f16_kpad(K)
+    hi = torch.empty(rows, kp, dtype=torch.float16, device=dev)
+    lo = torch.empty(rows, kp, dtype=torch.float16, device=dev)
+    assert lib.dcn_split_rows_f16(L.ptr(w2d), L.ptr(hi), L.ptr(lo), rows, K, 64.0, None) == 0
+    return hi, lo
+
+
+def garbage(nbytes, dev, seed=0):
+    g = torch.Generator().manual_seed(seed)
+    t = torch.randint(-2 ** 31, 2 ** 31 - 1, (max(nbytes, 8) // 4 + 2,), generator=g, dtype=torch.int32)
+    return t.to(dev)
+
+
+def check_dgrad_with_bn_backward(L, dev, n, h, w, cin, cout, k, dil, groups=1, with_add=True, relu=True, seed=0):
+    """conv (stride 1, `same` padding) behind a train-mode batch norm + ReLU:  x -> BN -> ReLU -> y -> conv -> out.
+    dcn_conv_dgrad_bn_f16 must deliver the ReLU-masked gradient w.r.t. y and the per-tile sums from which
+    dcn_bn_backward_from_partial produces dx / dgamma / dbeta -- against torch autograd on the CPU (float64)."""
+    lib = L.get()
+    g = torch.Generator().manual_seed(seed)
+    pad = dil * (k - 1) // 2
+    x = torch.randn(n, h, w, cin, generator=g) * 1.5 + 0.3            # NHWC: the batch norm's input (a conv output)
+    gamma = torch.rand(cin, generator=g) + 0.5
+    beta = torch.randn(cin, generator=g) * 0.2
+    wt_ = torch.randn(cout, cin, k, k, generator=g) * 0.1
+    dout = torch.randn(n, h, w, cout, generator=g) * 1e-3
+    add = torch.randn(n, h, w, cin, generator=g) * 1e-3 if with_add else None
+    rows = n * h * w
+    rpg = rows // groups
+    # ---- reference (float64, per statistics group)
+    xd = x.double().requires_grad_(True)
+    gd = gamma.double().requires_grad_(True)
+    bd = beta.double().requires_grad_(True)
+    ys = []
+    for gi in range(groups):
+        xg = xd.reshape(groups, rpg, cin)[gi]
+        ys.append(F.batch_norm(xg, None, None, gd, bd, True, 0.1, 1e-5))
+    y = torch.stack(ys).reshape(n, h, w, cin)
+    if relu:
+        y = torch.relu(y)
+    y.retain_grad()
+    out = F.conv2d(y.permute(0, 3, 1, 2), wt_.double(), None, 1, pad, dil)
+    loss = (out * dout.double().permute(0, 3, 1, 2)).sum()
+    if add is not None:
+        loss = loss + (y * add.double()).sum()
+    loss.backward()
+    g_ref = y.grad * ((y > 0) if relu else 1.0)                         # masked gradient w.r.t. the BN output
+    # ---- device: forward statistics through dcn_bn_forward (partial sums of ONE tile per group = the group's column sums)
+    t = lambda a: a.to(dev).contiguous()
+    xdev = t(x)
+    stats = torch.empty(groups, 4, cin, device=dev)
+    ydev = torch.empty(n, h, w, cin, device=dev)
+    mask = torch.zeros(rows * cin // 4, dtype=torch.uint8, device=dev)
+    for gi in range(groups):
+        xg = x.reshape(groups, rpg, cin)[gi]
+        part = t(torch.stack([xg.double().sum(0), (xg.double() ** 2).sum(0), xg.abs().amax(0).double()]).float().reshape(1, 3, cin))
+        xs = xdev.reshape(groups, rpg, cin)[gi]
+        rc = lib.dcn_bn_forward(L.ptr(xs), L.ptr(part), 1, cin, rpg, L.ptr(t(gamma)), L.ptr(t(beta)), None, None, 0.1, 1e-5, 1,
+                                None, 1 if relu else 0, L.ptr(ydev.reshape(groups, rpg, cin)[gi]),
+                                L.ptr(mask.reshape(groups, rpg * cin // 4)[gi]) if relu else None, L.ptr(stats[gi]), None)
+        assert rc == 0
+    assert rel_err(ydev.cpu(), y.detach()) < 1e-5
+    d = L.ConvDesc(n, h, w, cin, h, w, cout, k, k, 1, pad, dil, cout, rpg if groups > 1 else 0)
+    w_k = wt_.permute(0, 2, 3, 1).contiguous()                           # [cout][kh][kw][cin]
+    wtr = t(w_k.reshape(cout, k * k, cin).permute(2, 1, 0).contiguous().reshape(cin, k * k * cout))
+    wth, wtl = _split_rows(L, lib, wtr, dev)
+    amax = t(dout.abs().max().reshape(1))
+    mt = lib.dcn_conv_dgrad_bn_num_mtiles_f16(ctypes.byref(d))
+    assert mt >= groups and mt % groups == 0
+    bn_part = torch.full((mt, cin, 4), float("nan"), device=dev)
+    ws = garbage(lib.dcn_conv_gemm_workspace_f16(ctypes.byref(d), 1), dev, seed + 1)
+    din = torch.full((n, h, w, cin), float("nan"), device=dev)
+    rc = lib.dcn_conv_dgrad_bn_f16(ctypes.byref(d), L.ptr(t(dout)), L.ptr(wth), L.ptr(wtl), 64.0, L.ptr(amax),
+                                   L.ptr(t(add)) if add is not None else None, L.ptr(din), L.ptr(xdev),
+                                   L.ptr(mask) if relu else None, L.ptr(stats), L.ptr(bn_part), L.ptr(ws), None)
+    assert rc == 0
+    e_g = rel_err(din.cpu(), g_ref)
+    assert e_g < 1e-5, e_g
+    # per-tile sums: column 0 totals = dbeta, column 1 totals = dgamma (per group; the parameters are shared)
+    bp = bn_part.cpu().double()
+    assert bool(torch.isfinite(bp).all())
+    assert rel_err(bp[:, :, 0].sum(0), bd.grad) < 2e-5
+    assert rel_err(bp[:, :, 1].sum(0), gd.grad) < 2e-5
+    assert rel_err(bp[:, :, 2].amax(0), g_ref.abs().amax((0, 1, 2))) < 1e-5
+    out = {"masked_grad": e_g, "mtiles": mt}
+    if groups == 1:
+        dgam = torch.empty(cin, device=dev)
+        dbet = torch.empty(cin, device=dev)
+        dx = torch.full((n, h, w, cin), float("nan"), device=dev)
+        ws3 = torch.empty(3 * cin, device=dev)
+        rc = lib.dcn_bn_backward_from_partial(L.ptr(din), L.ptr(bn_part), mt, L.ptr(xdev), L.ptr(stats), L.ptr(t(gamma)), cin,
+                                              rows, L.ptr(dgam), L.ptr(dbet), L.ptr(dx), L.ptr(ws3), None)
+        assert rc == 0
+        out.update(dx=rel_err(dx.cpu(), xd.grad), dgamma=rel_err(dgam.cpu(), gd.grad), dbeta=rel_err(dbet.cpu(), bd.grad))
+        assert out["dx"] < 2e-5 and out["dgamma"] < 2e-5 and out["dbeta"] < 2e-5, out
+    return out
+
+
+def check_stream_k_inline(L, dev, set_env, n, h, w, cin, cout, k, dil, sk, tile_m=None, repeats=3, seed=0):
+    """Stream-K tiles completed inside the GEMM launch (default) vs by the separate fix-up kernel
+    (DCN_GEMM_SK_FIXUP=kernel): bit-identical outputs and batch-norm partial sums, on a garbage-filled workspace, again
+    and again on the workspace the previous launches left behind."""
+    lib = L.get()
+    g = torch.Generator().manual_seed(seed)
+    pad = dil * (k - 1) // 2
+    t = lambda a: a.to(dev).contiguous()
+    x = t(torch.randn(n, h, w, cin, generator=g))
+    wt_ = torch.randn(cout, k, k, cin, generator=g) * 0.1
+    wh, wl = _split_rows(L, lib, t(wt_.reshape(cout, k * k * cin)), dev)
+    d = L.ConvDesc(n, h, w, cin, h, w, cout, k, k, 1, pad, dil, cout, 0)
+    env = {"DCN_GEMM_SK": sk}
+    if tile_m:
+        env["DCN_GEMM_TILE_M"] = tile_m
+    res = {}
+    for mode in ("kernel", "inline"):
+        set_env(DCN_GEMM_SK_FIXUP=mode, **env)
+        mt = lib.dcn_conv_num_mtiles_f16(ctypes.byref(d))
+        nbytes = lib.dcn_conv_gemm_workspace_f16(ctypes.byref(d), 0)
+        assert nbytes > 8, "stream-K is not exercised by this shape"
+        ws = garbage(nbytes, dev, seed + 7)
+        runs = []
+        for _ in range(repeats if mode == "inline" else 1):
+            out = torch.full((n, h, w, cout), float("nan"), device=dev)
+            part = torch.full((mt, 3, cout), float("nan"), device=dev)
+            assert lib.dcn_conv_forward_f16(ctypes.byref(d), L.ptr(x), None, L.ptr(wh), L.ptr(wl), 64.0, None, L.ptr(out),
+                                            L.ptr(part), L.ptr(ws), None) == 0
+            runs.append((out.cpu(), part.cpu()))
+        res[mode] = runs
+    ref = F.conv2d(x.cpu().permute(0, 3, 1, 2), wt_.permute(0, 3, 1, 2), None, 1, pad, dil).permute(0, 2, 3, 1)
+    o_k, p_k = res["kernel"][0]
+    assert rel_err(o_k, ref) < 5e-6
+    for o_i, p_i in res["inline"]:
+        assert torch.equal(o_i, o_k) and torch.equal(p_i, p_k)
+    return True

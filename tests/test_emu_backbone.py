@@ -127,6 +127,46 @@ def test_forward_backward_with_stream_k_forced(dcn_env):
     assert max(rel_err(p.grad, po.grad) for p, po in zip(m.parameters(), o.parameters())) < 1e-4
 
 
+@pytest.mark.parametrize("arch,groups", [("Resnet18_8s", 1), ("Resnet50_8s", 1), ("Resnet18_8s", 2)])
+def test_bn_backward_reduction_fused_into_dgrad(arch, groups, conv_mode, dcn_env):
+    """Split-fp16 mode: the dgrad that produces a batch norm's upstream gradient masks it with the ReLU bits and leaves the
+    per-tile sums of the BN backward reduction behind (GemmConv::bnb_*), for every batch norm but the stem's (fed by the
+    max-pool backward) and the downsample branches' (fed by the residual gradient).  Same gradients as the separate
+    reduce pass (DCN_BN_BWD_FUSED=0) up to summation order; stream-K tiles (inline completion and fix-up kernel) included."""
+    from dcn_hip import backbone
+    grads = {}
+    for fused, sk, fix in ((0, None, None), (1, None, None), (1, 3, "inline"), (1, 3, "kernel")):
+        env = {"DCN_BN_BWD_FUSED": fused}
+        if sk:
+            env.update(DCN_GEMM_SK=sk, DCN_GEMM_SK_FIXUP=fix)
+        dcn_env(**env)
+        m, _ = _pair(arch, 3, 8)
+        g = torch.Generator().manual_seed(5)
+        H, W = (64, 64) if groups == 2 else (32, 40)
+        xa = torch.randn(2, 3, H, W, generator=g)
+        xb = torch.randn(2, 3, H, W, generator=g)
+        gy = torch.randn(2, 3, H, W, generator=g)
+        m.train()
+        if groups == 2:
+            ya, yb = m.forward_pair(xa, xb)
+            ((ya * gy).sum() + (yb * gy).sum()).backward()
+        else:
+            (m(xa) * gy).sum().backward()
+        plan = m._last_plan
+        assert plan.groups == groups
+        n_bn = len(plan.bn_names)
+        n_down = sum(1 for k in plan.bn_names if "downsample" in k)
+        want = (n_bn - n_down - 1) if (fused and conv_mode == "f16x3") else 0
+        assert plan.fused_bn_backward() == want, (plan.fused_bn_backward(), want)
+        grads[(fused, sk, fix)] = [p.grad.clone() for p in m.parameters()]
+    ref = grads[(0, None, None)]
+    # (summation order differs: per-tile sums instead of 128-row chunks, K split by stream-K -- and these narrow, tiny-batch
+    # networks amplify round-off through their batch norms, cf. the float64 yard-stick of test_forward_backward_vs_oracle)
+    for key, gl in grads.items():
+        assert max(rel_err(a, b) for a, b in zip(gl, ref)) < (1e-2 if key[1] else 1e-3), key
+    assert all(torch.equal(a, b) for a, b in zip(grads[(1, 3, "inline")], grads[(1, 3, "kernel")]))
+
+
 def test_normalized_descriptors_forward_backward():
     """DenseCorrespondenceNetwork(normalize=True): res / ||res||_2 over D (network.py:256-259), fused into the upsample
     kernel; backward through it."""

@@ -241,6 +241,27 @@ def test_conv_f16x3_forward_dgrad(L, case, tile_m, sk, dcn_env):
     assert lib.dcn_conv_dgrad_f16(ctypes.byref(d), L.ptr(dout), L.ptr(wth), L.ptr(wtl), 64.0, L.ptr(amax), L.ptr(add),
                                   L.ptr(din), L.ptr(ws_d), None) == 0
     assert rel_err(din, x.grad.permute(0, 2, 3, 1) + add) < 5e-6
+    if sk != "0":
+        # stream-K tiles are completed inside the launch by their last contributor (arrival words behind the parked
+        # partials, tagged with a launch id: no clearing needed -- the workspace is filled with garbage here);
+        # DCN_GEMM_SK_FIXUP=kernel keeps the separate fix-up kernel: the two must agree bit for bit
+        ws_f.view(torch.int32).random_(-2 ** 31, 2 ** 31 - 1)
+        ws_d.view(torch.int32).random_(-2 ** 31, 2 ** 31 - 1)
+        dcn_env(DCN_GEMM_TILE_M=tile_m, DCN_GEMM_SK=sk, DCN_GEMM_SK_FIXUP="kernel")
+        out_k = torch.full_like(out, float("nan"))
+        part_k = torch.full_like(part, float("nan"))
+        din_k = torch.full_like(din, float("nan"))
+        assert lib.dcn_conv_forward_f16(ctypes.byref(d), L.ptr(x_nhwc), None, L.ptr(wh), L.ptr(wl), 64.0, None, L.ptr(out_k),
+                                        L.ptr(part_k), L.ptr(ws_f), None) == 0
+        assert lib.dcn_conv_dgrad_f16(ctypes.byref(d), L.ptr(dout), L.ptr(wth), L.ptr(wtl), 64.0, L.ptr(amax), L.ptr(add),
+                                      L.ptr(din_k), L.ptr(ws_d), None) == 0
+        assert torch.equal(out_k, out) and torch.equal(part_k, part) and torch.equal(din_k, din)
+        dcn_env(DCN_GEMM_TILE_M=tile_m, DCN_GEMM_SK=sk, DCN_GEMM_SK_FIXUP="inline")
+        for _ in range(2):   # (and again on the workspace the previous launches left behind)
+            out_i = torch.full_like(out, float("nan"))
+            assert lib.dcn_conv_forward_f16(ctypes.byref(d), L.ptr(x_nhwc), None, L.ptr(wh), L.ptr(wl), 64.0, None,
+                                            L.ptr(out_i), None, L.ptr(ws_f), None) == 0
+            assert torch.equal(out_i, out)
     # wgrad: pixels are the reduction index, dy again 1e-7-scaled; fixed split order -> deterministic
     dw = torch.full((cout, k, k, cin), float("nan"))
     slabs = torch.empty(max(lib.dcn_conv_wgrad_workspace_f16(ctypes.byref(d)), 4) // 4)
@@ -353,3 +374,25 @@ def test_match_statistics_wide_descriptors_and_degenerate_masks(L):
             assert tuple(s["uv_b_pred_masked"][q].tolist()) == (9, 7)
             assert abs(int(s["num_pixels_closer_than_ground_truth"][q]) - o["num_pixels_closer_than_ground_truth"]) <= 1
             assert int(s["num_pixels_closer_than_ground_truth_masked"][q]) in (0, 1)
+
+
+@pytest.mark.parametrize("case", [
+    # n, h, w, cin, cout, k, dil, groups, add, relu
+    (1, 12, 16, 32, 24, 3, 1, 1, True, True),      # UNI path (cs = ldc % 32 != 0 here: generic path), one M tile
+    (2, 16, 16, 64, 32, 3, 2, 1, True, True),      # dilation 2, several M tiles, uniform-tap path (ldc = 32)
+    (2, 8, 16, 8, 64, 1, 1, 1, False, True),       # 1x1 (bottleneck conv3 -> bn2), no residual gradient
+    (2, 16, 16, 16, 32, 3, 1, 2, True, True),      # two statistics groups: tiles must not straddle them
+    (1, 10, 12, 12, 8, 3, 1, 1, True, False),      # no ReLU behind the batch norm (mask NULL), ragged tile
+])
+@pytest.mark.parametrize("sk", ["0", "3"])
+def test_dgrad_with_fused_bn_backward_reduction(L, case, sk, dcn_env):
+    import kernel_checks
+    dcn_env(DCN_GEMM_SK=sk, DCN_GEMM_TILE_M="64")
+    n, h, w, cin, cout, k, dil, groups, add, relu = case
+    kernel_checks.check_dgrad_with_bn_backward(L, "cpu", n, h, w, cin, cout, k, dil, groups, add, relu)
+
+
+def test_stream_k_inline_completion(L, dcn_env):
+    import kernel_checks
+    kernel_checks.check_stream_k_inline(L, "cpu", dcn_env, 1, 12, 12, 32, 136, 3, 2, sk="5", tile_m="256")
+    kernel_checks.check_stream_k_inline(L, "cpu", dcn_env, 2, 9, 9, 32, 40, 3, 1, sk="7", tile_m="64")
