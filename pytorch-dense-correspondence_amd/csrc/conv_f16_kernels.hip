@@ -136,8 +136,8 @@ template <int TM, int TN, int WR = 2> struct F16Geo {
 };
 
 // Stream-K tiles completed INSIDE the GEMM launch: every workgroup that parks a partial accumulator of a tile then counts
-// itself into the tile's arrival word; the one that finds itself last (all the others' partials are then visible: release
-// fence before the arrival, acquire fence after it, both device-wide -- the XCDs have separate L2s) sums the parked
+// itself into the tile's arrival word; the one that finds itself last (all the others' partials are then visible: they
+// are written through and read past the per-XCD L2s with device-coherent accesses, see gemm_segment_f16) sums the parked
 // partials in the fixed order of the contributing workgroups and runs the epilogue -- bit-identical to the separate fix-up
 // kernel, without its launch, and overlapped with the tiles still being computed.  The arrival word is
 // (launch id << 32) | arrivals: a word left behind by any other launch (or never initialised) counts as zero, so the
@@ -460,27 +460,52 @@ __device__ __forceinline__ void gemm_segment_f16(const GemmConv& p, _Float16* ld
         gemm_epilogue<WR, TM, TN, 16, 2>(p, acc, mt, nt, reinterpret_cast<float*>(lds));
     } else {
         // slot layout [wavefront][tm][tn][r / 4][lane][r % 4]: one 16-byte store per lane, 1 KB per wave-instruction
-        float4* o = reinterpret_cast<float4*>(slot + wv * (TM * TN * 16 * 64)) + lane;
-#pragma unroll
-        for (int tm = 0; tm < TM; ++tm)
-#pragma unroll
-            for (int tn = 0; tn < TN; ++tn)
-#pragma unroll
-                for (int q = 0; q < 4; ++q)
-                    o[((tm * TN + tn) * 4 + q) * 64] = make_float4(acc[tm][tn][4 * q], acc[tm][tn][4 * q + 1],
-                                                                   acc[tm][tn][4 * q + 2], acc[tm][tn][4 * q + 3]);
+        bool inl = false;
         // (the 128 x 128 / 4-wavefront shape sits exactly at its 256-register budget: it keeps the separate fix-up kernel)
-        if constexpr (!(WR == 2 && TM == 2 && TN == 2)) if (p.sk_count) {
+        if constexpr (!(WR == 2 && TM == 2 && TN == 2)) inl = p.sk_count != nullptr;
+        if (!inl) {
+            float4* o = reinterpret_cast<float4*>(slot + wv * (TM * TN * 16 * 64)) + lane;
+#pragma unroll
+            for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+                for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+                        o[((tm * TN + tn) * 4 + q) * 64] = make_float4(acc[tm][tn][4 * q], acc[tm][tn][4 * q + 1],
+                                                                       acc[tm][tn][4 * q + 2], acc[tm][tn][4 * q + 3]);
+        }
+        if constexpr (!(WR == 2 && TM == 2 && TN == 2)) if (inl) {
+            // Completed inside the launch.  The parked partials travel between workgroups on different XCDs (separate
+            // L2s), so they are written and read with device-coherent accesses (sc1: write-through / L2-bypassing) and ordered
+            // against the arrival word by counter waits only -- NO device-scope fence: a release / acquire fence writes back
+            // and invalidates the whole L2 of the XCD under the 31 other CUs that are in the middle of their K loops
+            // (measured: +50 us per launch, profiles/r2b_ab.txt).
             __shared__ int s_last;
+            const __amdgpu_buffer_rsrc_t rs_p = __builtin_amdgcn_make_buffer_rsrc(p.sk_partial, 0, (int)p.sk_bytes, 0x00020000);
+            constexpr int kSc1 = 16;                           // cache-policy bit of buffer loads / stores: device scope
+            const int lane_off = (wv * (TM * TN * 16 * 64) + lane * 4) * 4;
+            {
+                const int so = (int)((slot - p.sk_partial) * 4);
+#pragma unroll
+                for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+                    for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            const float4 v = make_float4(acc[tm][tn][4 * q], acc[tm][tn][4 * q + 1], acc[tm][tn][4 * q + 2],
+                                                         acc[tm][tn][4 * q + 3]);
+                            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rs_p,
+                                                                   lane_off + ((tm * TN + tn) * 4 + q) * 1024, so, kSc1);
+                        }
+            }
             const int rel = tile - p.sk_dp;                    // (index among the stream-K'd tiles)
             const int ua = rel * nk, ub = ua + nk - 1;         // its unit range relative to the start of the stream-K pass
             const int ga = ua / p.sk_units, gb = ub / p.sk_units;
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            __builtin_amdgcn_s_waitcnt(0x0F70);                // vmcnt(0): this work-item's partial has been written through
             __syncthreads();
             if (tid == 0) s_last = sk_arrive_is_last(p.sk_count + rel, p.sk_id, gb - ga + 1) ? 1 : 0;
             __syncthreads();
             if (s_last) {
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
 #pragma unroll
                 for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
@@ -489,16 +514,15 @@ __device__ __forceinline__ void gemm_segment_f16(const GemmConv& p, _Float16* ld
                         for (int r = 0; r < 16; ++r) acc[tm][tn][r] = 0.f;
                 for (int g = ga; g <= gb; ++g) {               // fixed order, own partial included: deterministic
                     const int first_tile = (g * p.sk_units) / nk;
-                    const float4* q4 = reinterpret_cast<const float4*>(
-                                           p.sk_partial + (int64_t)(2 * g + (first_tile == rel ? 0 : 1)) * (BM * BN) +
-                                           wv * (TM * TN * 16 * 64)) + lane;
+                    const int so = (2 * g + (first_tile == rel ? 0 : 1)) * (BM * BN * 4);
 #pragma unroll
                     for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
                         for (int tn = 0; tn < TN; ++tn)
 #pragma unroll
                             for (int q = 0; q < 4; ++q) {
-                                const float4 v = q4[((tm * TN + tn) * 4 + q) * 64];
+                                const float4 v = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(
+                                                     rs_p, lane_off + ((tm * TN + tn) * 4 + q) * 1024, so, kSc1));
                                 acc[tm][tn][4 * q] += v.x; acc[tm][tn][4 * q + 1] += v.y;
                                 acc[tm][tn][4 * q + 2] += v.z; acc[tm][tn][4 * q + 3] += v.w;
                             }
@@ -665,6 +689,7 @@ int launch_gemm_f16(GemmConv& p, void* workspace, hipStream_t st, int align = 0)
     p.sk_partial = sk ? (float*)workspace : nullptr;
     const bool sk_inline = sk && dcn::tuning().gemm_sk_inline != 0 && !(g.wr == 2 && g.tm == 2 && g.tn == 2);
     p.sk_count = sk_inline ? (unsigned long long*)((char*)workspace + g.sk_count_off) : nullptr;
+    p.sk_bytes = sk_inline ? (unsigned)g.sk_count_off : 0u;
     if (sk_inline) {
         static std::atomic<unsigned> next_id{1u};
         do { p.sk_id = next_id.fetch_add(1u, std::memory_order_relaxed); } while (p.sk_id == 0u);

@@ -8,8 +8,10 @@
 //   DCN_GEMM_UNI            0: disable the uniform-tap fast path
 //   DCN_GEMM_SK_FIXUP       kernel: stream-K tiles are completed by the separate fix-up kernel instead of by the last
 //                           contributing workgroup of the GEMM launch itself (split-fp16 kernel)
-//   DCN_BN_BWD_FUSED         0: the batch-norm backward reduction stays a separate pass (1: in the epilogue of the dgrad that
-//                           produces its upstream gradient; split-fp16 mode)
+//   DCN_BN_BWD_FUSED        1: the batch-norm backward reduction runs in the epilogue of the dgrad that produces its upstream
+//                           gradient (split-fp16 mode) instead of as a separate pass.  Default 0: measured SLOWER on the
+//                           MI355X (+1.3 ms per config-2 step, profiles/r2b_ab.txt: the one-workgroup-per-CU GEMM exposes the
+//                           epilogue's extra loads, the separate pass streams at HBM speed)
 //   DCN_WGRAD_SPLITS        force the pixel-range split count of the split-fp16 wgrad kernel
 #pragma once
 
@@ -24,7 +26,7 @@ struct Tuning {
     double gemm_sk_min_gain = 20.0;
     int gemm_uni = 1;
     int gemm_sk_inline = 1;      // stream-K tiles completed inside the GEMM launch (0: separate fix-up kernel)
-    int bn_bwd_fused = 1;
+    int bn_bwd_fused = 0;
     int wgrad_splits = 0;        // 0: unset
 };
 

@@ -359,6 +359,12 @@ static inline hipemu_u32x2 hipemu_raw_buffer_load_b64(hipemu_buffer_rsrc r, int 
             { unsigned w; memcpy(&w, r.base + (long long)(unsigned)voffset + (unsigned)soffset + 4 * i, 4); v[i] = w; }
     return v;
 }
+static inline void hipemu_raw_buffer_store_b128(hipemu_u32x4 v, hipemu_buffer_rsrc r, int voffset, int soffset, int) {
+    if ((unsigned long long)(unsigned)voffset + 16ull <= r.num_records)
+        memcpy(const_cast<char*>(r.base) + (long long)(unsigned)voffset + (unsigned)soffset, &v, 16);
+}
+#define __builtin_amdgcn_raw_buffer_store_b128 hipemu_raw_buffer_store_b128
+#define __builtin_amdgcn_s_waitcnt(x) __atomic_thread_fence(__ATOMIC_SEQ_CST)
 #define __amdgpu_buffer_rsrc_t hipemu_buffer_rsrc
 #define __builtin_amdgcn_make_buffer_rsrc(p, stride, n, flags) hipemu_make_buffer_rsrc((const void*)(p), stride, n, flags)
 #define __builtin_amdgcn_raw_buffer_load_b128 hipemu_raw_buffer_load_b128

@@ -59,14 +59,18 @@ def check_dgrad_with_bn_backward(L, dev, n, h, w, cin, cout, k, dil, groups=1, w
     # ---- device: forward statistics through dcn_bn_forward (partial sums of ONE tile per group = the group's column sums)
     t = lambda a: a.to(dev).contiguous()
     xdev = t(x)
+    gam_d, bet_d, dout_d = t(gamma), t(beta), t(dout)   # (kept alive: the launches are asynchronous on the GPU)
+    add_d = t(add) if add is not None else None
+    keep = []
     stats = torch.empty(groups, 4, cin, device=dev)
     ydev = torch.empty(n, h, w, cin, device=dev)
     mask = torch.zeros(rows * cin // 4, dtype=torch.uint8, device=dev)
     for gi in range(groups):
         xg = x.reshape(groups, rpg, cin)[gi]
         part = t(torch.stack([xg.double().sum(0), (xg.double() ** 2).sum(0), xg.abs().amax(0).double()]).float().reshape(1, 3, cin))
+        keep.append(part)
         xs = xdev.reshape(groups, rpg, cin)[gi]
-        rc = lib.dcn_bn_forward(L.ptr(xs), L.ptr(part), 1, cin, rpg, L.ptr(t(gamma)), L.ptr(t(beta)), None, None, 0.1, 1e-5, 1,
+        rc = lib.dcn_bn_forward(L.ptr(xs), L.ptr(part), 1, cin, rpg, L.ptr(gam_d), L.ptr(bet_d), None, None, 0.1, 1e-5, 1,
                                 None, 1 if relu else 0, L.ptr(ydev.reshape(groups, rpg, cin)[gi]),
                                 L.ptr(mask.reshape(groups, rpg * cin // 4)[gi]) if relu else None, L.ptr(stats[gi]), None)
         assert rc == 0
@@ -81,8 +85,8 @@ def check_dgrad_with_bn_backward(L, dev, n, h, w, cin, cout, k, dil, groups=1, w
     bn_part = torch.full((mt, cin, 4), float("nan"), device=dev)
     ws = garbage(lib.dcn_conv_gemm_workspace_f16(ctypes.byref(d), 1), dev, seed + 1)
     din = torch.full((n, h, w, cin), float("nan"), device=dev)
-    rc = lib.dcn_conv_dgrad_bn_f16(ctypes.byref(d), L.ptr(t(dout)), L.ptr(wth), L.ptr(wtl), 64.0, L.ptr(amax),
-                                   L.ptr(t(add)) if add is not None else None, L.ptr(din), L.ptr(xdev),
+    rc = lib.dcn_conv_dgrad_bn_f16(ctypes.byref(d), L.ptr(dout_d), L.ptr(wth), L.ptr(wtl), 64.0, L.ptr(amax),
+                                   L.ptr(add_d), L.ptr(din), L.ptr(xdev),
                                    L.ptr(mask) if relu else None, L.ptr(stats), L.ptr(bn_part), L.ptr(ws), None)
     assert rc == 0
     e_g = rel_err(din.cpu(), g_ref)
@@ -99,7 +103,7 @@ def check_dgrad_with_bn_backward(L, dev, n, h, w, cin, cout, k, dil, groups=1, w
         dbet = torch.empty(cin, device=dev)
         dx = torch.full((n, h, w, cin), float("nan"), device=dev)
         ws3 = torch.empty(3 * cin, device=dev)
-        rc = lib.dcn_bn_backward_from_partial(L.ptr(din), L.ptr(bn_part), mt, L.ptr(xdev), L.ptr(stats), L.ptr(t(gamma)), cin,
+        rc = lib.dcn_bn_backward_from_partial(L.ptr(din), L.ptr(bn_part), mt, L.ptr(xdev), L.ptr(stats), L.ptr(gam_d), cin,
                                               rows, L.ptr(dgam), L.ptr(dbet), L.ptr(dx), L.ptr(ws3), None)
         assert rc == 0
         out.update(dx=rel_err(dx.cpu(), xd.grad), dgamma=rel_err(dgam.cpu(), gd.grad), dbeta=rel_err(dbet.cpu(), bd.grad))
@@ -117,7 +121,8 @@ def check_stream_k_inline(L, dev, set_env, n, h, w, cin, cout, k, dil, sk, tile_
     t = lambda a: a.to(dev).contiguous()
     x = t(torch.randn(n, h, w, cin, generator=g))
     wt_ = torch.randn(cout, k, k, cin, generator=g) * 0.1
-    wh, wl = _split_rows(L, lib, t(wt_.reshape(cout, k * k * cin)), dev)
+    w2d = t(wt_.reshape(cout, k * k * cin))
+    wh, wl = _split_rows(L, lib, w2d, dev)
     d = L.ConvDesc(n, h, w, cin, h, w, cout, k, k, 1, pad, dil, cout, 0)
     env = {"DCN_GEMM_SK": sk}
     if tile_m:

@@ -20,17 +20,17 @@ def L():
 
 
 @pytest.mark.parametrize("shape", [
-    # n, h, w, cin, cout, k, dil
-    (8, 60, 80, 256, 256, 3, 2),     # layer 3 of config 2: 300 tiles of 256 x 128 on 256 CUs -> 256 data-parallel + 44 stream-K
-    (8, 60, 80, 512, 512, 3, 4),     # layer 4: 600 tiles, 88 stream-K'd
-    (4, 60, 80, 128, 256, 1, 1),     # 1x1: few K stages per tile
+    # n, h, w, cin, cout, k, dil, DCN_GEMM_SK
+    (8, 60, 80, 256, 256, 3, 2, "1"),     # layer 3 of config 2: 300 tiles of 256 x 128 on 256 CUs -> 256 data-parallel + 44 stream-K
+    (8, 60, 80, 512, 512, 3, 4, "1"),     # layer 4: 600 tiles, 88 stream-K'd
+    (4, 60, 80, 128, 256, 1, 1, "100"),   # 1x1: 4 K stages per tile, forced over 100 workgroups
 ])
 def test_stream_k_inline_completion_at_layer_shapes(L, shape, dcn_env):
     """The last contributor of a stream-K tile sums the parked partials and runs the epilogue inside the GEMM launch:
     bit-identical to the separate fix-up kernel, on a garbage-filled workspace, 8 launches in a row (race screen: the
     arrival words, the device-wide release / acquire around them and the self-reset are what is being exercised)."""
-    n, h, w, cin, cout, k, dil = shape
-    kernel_checks.check_stream_k_inline(L, "cuda", dcn_env, n, h, w, cin, cout, k, dil, sk="1", repeats=8)
+    n, h, w, cin, cout, k, dil, sk = shape
+    kernel_checks.check_stream_k_inline(L, "cuda", dcn_env, n, h, w, cin, cout, k, dil, sk=sk, repeats=8)
 
 
 def test_stream_k_inline_forced_small_splits(L, dcn_env):
