@@ -54,7 +54,7 @@ def test_dgrad_with_fused_bn_backward_reduction(L, case, dcn_env):
     print("dgrad + BN backward reduction", case, r)
 
 
-@pytest.mark.parametrize("arch,H,W,D", [("Resnet34_8s", 240, 320, 3), ("Resnet50_8s", 128, 160, 8)])
+@pytest.mark.parametrize("arch,H,W,D", [("Resnet34_8s", 256, 320, 3), ("Resnet50_8s", 128, 160, 8)])
 def test_network_step_fused_vs_separate_bn_reduction(L, arch, H, W, D, dcn_env):
     """A training step of the real network with the fused reduction (default) and with the separate reduce pass
     (DCN_BN_BWD_FUSED=0): every batch norm but the stem's and the downsample branches' is fused; gradients agree to
@@ -75,6 +75,7 @@ def test_network_step_fused_vs_separate_bn_reduction(L, arch, H, W, D, dcn_env):
             ((ya * gy.cuda()).sum() + (yb * gy.cuda()).sum()).backward()
             torch.cuda.synchronize()
             plan = dcn.fcn._last_plan
+            assert plan.groups == 2   # (forward_pair as ONE grouped launch sequence: statistics per group in the fused sums)
             n_bn = len(plan.bn_names)
             n_down = sum(1 for k in plan.bn_names if "downsample" in k)
             assert plan.fused_bn_backward() == (n_bn - n_down - 1 if fused else 0)
