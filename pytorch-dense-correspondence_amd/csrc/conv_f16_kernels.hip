@@ -784,8 +784,11 @@ struct WgradF16 {
 // (image, y, x) position is carried from stage to stage with a few selects instead of being re-derived by division.
 // XPRE: the activation operand is the pre-split tensor xs; otherwise it is the fp32 tensor itself and is split on the fly
 // (same addresses, 4 bytes per element either way) -- cheaper when an element is only used by a few tiles (1x1 convs).
+// TM = 1, 2: 256 work-items, two workgroups per CU.  TM = 4: 256 output channels x 128 K columns on 8 wavefronts (4 x 2),
+// ONE workgroup per CU: the gradient operand -- stored pre-split, a pure copy -- is the doubled one, so per MFMA the
+// activation operand's loads, conversions, 4x4 transposes and LDS stores halve (wavefronts 0-3 stage it, all 8 stage dy).
 template <int TM, bool FAST, bool XPRE>   // 64*TM output channels x 128 K columns per workgroup
-__global__ void __launch_bounds__(NT, 2)
+__global__ void __launch_bounds__(TM == 4 ? 512 : NT, TM == 4 ? 1 : 2)
 conv_wgrad_f16_kernel(WgradF16 p) {
     constexpr int BM = 64 * TM, BN = 128, kStage = 2 * (BM + BN) * LDH;
     __shared__ __attribute__((aligned(16))) _Float16 lds[2 * kStage];
@@ -803,12 +806,13 @@ conv_wgrad_f16_kernel(WgradF16 p) {
     const __amdgpu_buffer_rsrc_t rs_d = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.dq), 0, (int)p.d_bytes, 0x00020000);
 
     // micro-tile of this work-item: pixels 4*pq .. 4*pq+3 of the stage, channel quad cq (dout: n0 + 4*cq, in: j0 + 4*cq)
-    const int pq = tid & 7, cq = tid >> 3;                    // 8 pixel quads x 32 channel quads
+    const int pq = tid & 7, cq = tid >> 3;                    // 8 pixel quads x 32 (TM = 4: 64) channel quads
     const bool dact = 4 * cq < BM;                            // (BM = 64: only half of the work-items stage dout)
+    const bool xact = TM != 4 || tid < 256;                   // (TM = 4: wavefronts 0-3 stage the activation operand; wave-uniform)
     const int ncol = n0 + cq * 4;
     const bool nval = dact & (ncol < p.ldo);
-    const int kcol = j0 + cq * 4;
-    const bool kval = kcol < p.K;
+    const int kcol = j0 + (cq & 31) * 4;
+    const bool kval = xact & (kcol < p.K);
     const int kc0 = kval ? kcol : 0;
     const int tap = fdiv(kc0, p.div_cin), cc = kc0 - tap * p.cin;
     const int tr = fdiv(tap, p.div_kw), ts = tap - tr * p.kw;
@@ -871,8 +875,9 @@ conv_wgrad_f16_kernel(WgradF16 p) {
     auto issue_loads = [&]() {
 #pragma unroll
         for (int h = 0; h < 4; ++h) rd[h] = __builtin_amdgcn_raw_buffer_load_b128(rs_d, doff, h * d_sub, 0);
+        if (xact)
 #pragma unroll
-        for (int i = 0; i < 4; ++i) rx[i] = __builtin_amdgcn_raw_buffer_load_b128(rs_x, xoff[i], 0, 0);
+            for (int i = 0; i < 4; ++i) rx[i] = __builtin_amdgcn_raw_buffer_load_b128(rs_x, xoff[i], 0, 0);
     };
     const float sx = (!XPRE && p.x_absmax) ? pow2_scale(*p.x_absmax) : 1.f;
     auto store_tile = [&](int stage) {
@@ -880,7 +885,7 @@ conv_wgrad_f16_kernel(WgradF16 p) {
         _Float16* dl = dh + BM * LDH;
         _Float16* xh = dl + BM * LDH;
         _Float16* xl = xh + BN * LDH;
-        if (!XPRE) {
+        if (!XPRE && xact) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 h4 a, b;
@@ -893,8 +898,9 @@ conv_wgrad_f16_kernel(WgradF16 p) {
         for (int pl = 0; pl < 2; ++pl) {
             _Float16* xd = pl ? xl : xh;
             // 4x4 transpose of halves: channel e of pixels 0..3 = {lo/hi half of dword e>>1 of each pixel}
+            if (xact)
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
+                for (int e = 0; e < 4; ++e) {
                 const int w = 2 * pl + (e >> 1);
                 u32x2 o;
                 if ((e & 1) == 0) {
@@ -904,7 +910,7 @@ conv_wgrad_f16_kernel(WgradF16 p) {
                     o[0] = (rx[0][w] >> 16) | (rx[1][w] & 0xffff0000u);
                     o[1] = (rx[2][w] >> 16) | (rx[3][w] & 0xffff0000u);
                 }
-                *reinterpret_cast<u32x2*>(xd + (4 * cq + e) * LDH + 4 * pq) = o;
+                *reinterpret_cast<u32x2*>(xd + (4 * (cq & 31) + e) * LDH + 4 * pq) = o;
             }
             if (dact) {
                 _Float16* dd = pl ? dl : dh;
@@ -919,8 +925,8 @@ conv_wgrad_f16_kernel(WgradF16 p) {
         }
     };
 
-    // wavefront tiling: TM == 2: 2x2 waves, each 64 channels x 64 columns; TM == 1: 1x4 waves, each 64 channels x 32 columns
-    constexpr int CT = TM == 2 ? 2 : 1;
+    // wavefront tiling: TM == 2 / 4: 2x2 / 4x2 waves, each 64 channels x 64 columns; TM == 1: 1x4 waves, each 64 channels x 32 columns
+    constexpr int CT = TM >= 2 ? 2 : 1;
     f32x16 acc[2][CT];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
@@ -929,7 +935,7 @@ conv_wgrad_f16_kernel(WgradF16 p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
     const int fi = lane & 31, fh = lane >> 5;
-    const int wrow0 = TM == 2 ? wm_ * 64 : 0, wcol0 = TM == 2 ? wn_ * 64 : wv * 32;
+    const int wrow0 = TM >= 2 ? wm_ * 64 : 0, wcol0 = TM >= 2 ? wn_ * 64 : wv * 32;
     const int a_off = (wrow0 + fi) * LDH + 8 * fh;
     const int b_off = 2 * BM * LDH + (wcol0 + fi) * LDH + 8 * fh;
     h8 fah[2][2], fal[2][2], fbh[2][CT], fbl[2][CT];
@@ -1001,11 +1007,17 @@ conv_wgrad_f16_kernel(WgradF16 p) {
 // Pixel-range splits: enough workgroups to fill the chip (2 resident per CU), chosen so that the LAST round of
 // workgroups is nearly full -- e.g. 144 tiles x 4 splits = 576 workgroups = 1.125 rounds of 512 wastes almost half of the
 // machine, 144 x 7 = 1.97 rounds does not.  Fewer splits win ties (less slab traffic for the reduce pass).
+// the 256-channel / 8-wavefront tile: layers whose output channels fill it (DCN_WGRAD_TILE=128 keeps the 128-channel tile)
+bool wgrad_wide_f16(const dcn_conv_desc* c) {
+    return c->cout >= 256 && (c->cout % 256) == 0 && dcn::tuning().wgrad_tile != 128;
+}
+
 int wgrad_splits_f16(const dcn_conv_desc* c, int* rows_per_split) {
     const int M = c->n * c->hout * c->wout, K = c->kh * c->kw * c->cin;
     const bool narrow = c->cout <= 64;
-    const int tiles = dcn::ceil_div(c->cout, narrow ? 64 : 128) * dcn::ceil_div(K, 128);
-    const int slots = 512;
+    const bool wide = wgrad_wide_f16(c);
+    const int tiles = dcn::ceil_div(c->cout, narrow ? 64 : (wide ? 256 : 128)) * dcn::ceil_div(K, 128);
+    const int slots = wide ? 256 : 512;   // workgroups the chip holds at once
     const int max_by_rows = (M / (8 * HBK)) > 1 ? (M / (8 * HBK)) : 1;
     int cap = narrow ? 256 : (tiles < 16 ? 128 : 64);   // (slab traffic grows with the split count; few-tile layers need more splits to fill the chip)
     if (cap > max_by_rows) cap = max_by_rows;
@@ -1229,13 +1241,13 @@ extern "C" int dcn_conv_wgrad_f16(const dcn_conv_desc* c, const void* xs, int xs
     p.kh = c->kh; p.kw = c->kw; p.stride = c->stride; p.pad = c->pad; p.dil = c->dil; p.ldo = c->ldc;
     p.M = c->n * c->hout * c->wout; p.K = c->kh * c->kw * c->cin;
     p.splits = wgrad_splits_f16(c, &p.rows_per_split);
-    const bool narrow = c->cout <= 64;
-    p.ntiles_n = dcn::ceil_div(c->cout, narrow ? 64 : 128); p.ntiles_k = dcn::ceil_div(p.K, 128);
+    const bool narrow = c->cout <= 64, wide = wgrad_wide_f16(c);
+    p.ntiles_n = dcn::ceil_div(c->cout, narrow ? 64 : (wide ? 256 : 128)); p.ntiles_k = dcn::ceil_div(p.K, 128);
     p.div_hw = make_fastdiv(c->hout * c->wout); p.div_w = make_fastdiv(c->wout);
     p.div_cin = make_fastdiv(c->cin); p.div_kw = make_fastdiv(c->kw);
     p.slab = p.splits == 1 ? dw : (float*)slabs;
     hipStream_t st = (hipStream_t)stream;
-    const dim3 grid(p.ntiles_n * p.ntiles_k * p.splits), block(NT);
+    const dim3 grid(p.ntiles_n * p.ntiles_k * p.splits), block(wide ? 512 : NT);
     const bool fast = (c->wout % 4) == 0 && c->wout >= HBK;
 #define DCN_WGRAD16(TM)                                                                                        \
     do {                                                                                                       \
@@ -1248,6 +1260,7 @@ extern "C" int dcn_conv_wgrad_f16(const dcn_conv_desc* c, const void* xs, int xs
         }                                                                                                      \
     } while (0)
     if (narrow) DCN_WGRAD16(1);
+    else if (wide) DCN_WGRAD16(4);
     else DCN_WGRAD16(2);
 #undef DCN_WGRAD16
     if (p.splits > 1) launch_wgrad_reduce((const float*)slabs, dw, (int64_t)c->cout * p.K / 4, p.splits, st);

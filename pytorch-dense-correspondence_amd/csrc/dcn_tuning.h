@@ -12,6 +12,7 @@
 //                           gradient (split-fp16 mode) instead of as a separate pass.  Default 0: measured SLOWER on the
 //                           MI355X (+1.3 ms per config-2 step, profiles/r2b_ab.txt: the one-workgroup-per-CU GEMM exposes the
 //                           epilogue's extra loads, the separate pass streams at HBM speed)
+//   DCN_WGRAD_TILE          128: keep the 128-channel / 4-wavefront tile of the split-fp16 wgrad kernel on wide layers
 //   DCN_WGRAD_SPLITS        force the pixel-range split count of the split-fp16 wgrad kernel
 #pragma once
 
@@ -28,6 +29,7 @@ struct Tuning {
     int gemm_sk_inline = 1;      // stream-K tiles completed inside the GEMM launch (0: separate fix-up kernel)
     int bn_bwd_fused = 0;
     int wgrad_splits = 0;        // 0: unset
+    int wgrad_tile = 0;          // 0: unset
 };
 
 const Tuning& tuning();

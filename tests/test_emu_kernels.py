@@ -178,6 +178,9 @@ F16_CASES = [
     (1, 3, 36, 8, 8, 3, 1, 1, 1),
     (1, 6, 72, 4, 12, 3, 2, 1, 1),       # stride 2
     (2, 2, 40, 8, 16, 1, 1, 0, 1),       # row and image wrap inside a split
+    # 256 output channels and more: wgrad's 256-channel / 8-wavefront tile
+    (1, 4, 36, 8, 256, 3, 1, 1, 1),      # carried-position path, 2 x 72 K columns -> one ragged K tile
+    (2, 5, 6, 32, 512, 1, 1, 0, 1),      # two channel tiles, division path, 60 pixels
 ]
 
 

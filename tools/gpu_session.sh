@@ -28,6 +28,11 @@ for s in $steps; do
                for rep in 1 2 3; do for v in ${AB_VARIANTS:-inline:0 kernel:0}; do
                  timeout 300 env DCN_GEMM_SK_FIXUP=${v%%:*} DCN_BN_BWD_FUSED=${v##*:} python bench.py --steps 20 --warmup 5 --cpu-baseline-steps 0 --no-variants --profile-steps 0 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('ab sk_fixup=${v%%:*} bn_fused=${v##*:} rep=$rep  %.1f images/s  %.3f ms/step' % (d['value'], d['ms_per_step']))" | tee -a gpurun_out/${tag}_ab.txt
                done; done ;;
+    wgab)      # wgrad tile A/B per layer (256-channel / 8-wavefront tile vs 128-channel), N = 8 (config 2) and 16, + numerical check
+               for n in 8 16; do for t in 0 128; do echo "--- wgrad tile ${t} (0 = default: 256 on wide layers), N = $n" | tee -a gpurun_out/${tag}_wgab.txt
+                 timeout 300 env DCN_WGRAD_TILE=$t python tools/conv_bench.py --mode f16 --n $n --x-direct --no-split --kinds wgrad --only layer --reps 20 $( [ $n = 8 ] && [ $t = 0 ] && echo --check ) 2>&1 | grep -v "^net\|Warn" | cut -c1-200 | tee -a gpurun_out/${tag}_wgab.txt
+               done; done ;;
+    parity)    timeout 900 python -m pytest tests/test_gpu_parity.py -m gpu -q -p no:cacheprovider -k "conv" > gpurun_out/${tag}_pytest_conv.log 2>&1; tail -5 gpurun_out/${tag}_pytest_conv.log | cut -c1-300 ;;
     *) echo "unknown step $s" ;;
   esac
 done
