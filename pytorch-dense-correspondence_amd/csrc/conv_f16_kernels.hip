@@ -1007,9 +1007,11 @@ conv_wgrad_f16_kernel(WgradF16 p) {
 // Pixel-range splits: enough workgroups to fill the chip (2 resident per CU), chosen so that the LAST round of
 // workgroups is nearly full -- e.g. 144 tiles x 4 splits = 576 workgroups = 1.125 rounds of 512 wastes almost half of the
 // machine, 144 x 7 = 1.97 rounds does not.  Fewer splits win ties (less slab traffic for the reduce pass).
-// the 256-channel / 8-wavefront tile: layers whose output channels fill it (DCN_WGRAD_TILE=128 keeps the 128-channel tile)
+// the 256-channel / 8-wavefront tile: layers whose output channels fill it (DCN_WGRAD_TILE=128 keeps the 128-channel tile).
+// Measured per layer at N = 8 / 16 (profiles/r2d_wgrad_tile_ab.txt): 256-channel layer-3 convolutions +13 % / +5 %, layer 4
+// +7-11 % / +1-7 %; only the 1x1 128 -> 256 downsample (a single K tile) loses 6 %: K >= 256 required.
 bool wgrad_wide_f16(const dcn_conv_desc* c) {
-    return c->cout >= 256 && (c->cout % 256) == 0 && dcn::tuning().wgrad_tile != 128;
+    return c->cout >= 256 && (c->cout % 256) == 0 && c->kh * c->kw * c->cin >= 256 && dcn::tuning().wgrad_tile != 128;
 }
 
 int wgrad_splits_f16(const dcn_conv_desc* c, int* rows_per_split) {
