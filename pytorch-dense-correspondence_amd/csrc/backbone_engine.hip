@@ -85,7 +85,7 @@ struct dcn_plan {
     size_t w_buf[6] = {0, 0, 0, 0, 0, 0}, w_wt = 0, w_slab = 0, w_part = 0, w_k123 = 0, w_wstem = 0, w_dwstem = 0,
            w_glow = 0, w_ups = 0, w_sk = 0, w_gnorm = 0, w_wh = 0, w_wl = 0, w_amax = 0, w_dq = 0, w_dq2 = 0, ws_floats = 0;
     int conv_mode = DCN_CONV_F16X3;
-    size_t max_act = 0;
+    size_t max_act = 0, sk_bytes = 0;   // sk_bytes: size of the stream-K scratch at w_sk
     double flops = 0;
     // optional launch-level timing (dcn_plan_profile_begin/end)
     bool prof_on = false;
@@ -325,9 +325,10 @@ int build_plan(dcn_plan& p) {
             const size_t sk = std::max(dcn_conv_gemm_workspace(&c.d, dg), dcn_conv_gemm_workspace_f16(&c.d, dg)) / sizeof(float);
             if (sk > max_sk) max_sk = sk;
         }
-        const size_t pf = (size_t)std::max(c.mtiles[0], c.mtiles[1]) * 3 * c.d.cout;
+        // (sized for the smallest M tile any tuning override can select -- 32 rows --, not for the tile chosen today)
+        const size_t pf = ((size_t)c.d.n * c.d.hout * c.d.wout / 32 + 2) * 3 * c.d.cout;
         if (pf > max_part) max_part = pf;
-        const size_t pb = (size_t)std::max(dcn_conv_dgrad_bn_num_mtiles_f16(&c.d), 0) * 4 * c.d.cin;   // fused BN-backward sums
+        const size_t pb = ((size_t)c.d.n * c.d.hin * c.d.win / 32 + 2) * 4 * c.d.cin;   // fused BN-backward sums (dgrad M tiles)
         if (pb > max_part) max_part = pb;
         if (c.d.cout > max_c) max_c = c.d.cout;
     }
@@ -338,6 +339,7 @@ int build_plan(dcn_plan& p) {
     p.w_wt = alloc(max_w);
     p.w_slab = alloc(max_slab);
     p.w_sk = alloc(max_sk);
+    p.sk_bytes = max_sk * sizeof(float);
     p.w_part = alloc(max_part);
     p.w_k123 = alloc((size_t)3 * max_c * p.groups);
     p.w_wstem = alloc((size_t)p.base * 49 * 4);
@@ -426,6 +428,12 @@ struct Run {
         return rc;
     }
 
+    // stream-K scratch for one gather-GEMM launch, or null (no stream-K) when the tile shape selected by the tuning table
+    // of the moment needs more than the plan reserved (the table may have changed since the plan was made)
+    void* SK(const ConvL& c, int dgrad) const {
+        const size_t need = p.conv_mode == DCN_CONV_FP32 ? dcn_conv_gemm_workspace(&c.d, dgrad) : dcn_conv_gemm_workspace_f16(&c.d, dgrad);
+        return need <= p.sk_bytes ? (void*)(ws + p.w_sk) : nullptr;
+    }
     float* S(size_t off) const { return saved + off; }
     // abs-max scalar of activation slot `a` (split-fp16 mode only: null otherwise, i.e. "no pre-scale")
     float* A(int a) const { return (p.conv_mode == DCN_CONV_F16X3 && a >= 0) ? saved + p.s_actmax + a : nullptr; }
@@ -441,11 +449,11 @@ struct Run {
     // forward convolution in the plan's conv mode (w: [cout][taps][d.cin] fp32)
     int conv_fwd(const ConvL& c, const float* in, const float* w, const float* bias, float* out, float* part) {
         if (p.conv_mode == DCN_CONV_FP32)
-            return timed(0, c.flops, [&] { return dcn_conv_forward(&c.d, in, w, bias, out, part, Wk(p.w_sk), st); });
+            return timed(0, c.flops, [&] { return dcn_conv_forward(&c.d, in, w, bias, out, part, SK(c, 0), st); });
         (void)w;   // split-fp16 mode: the image was produced by split_all_weights at the start of the call
         return timed(0, c.flops, [&] {
             return dcn_conv_forward_f16(&c.d, in, A(c.in_act), wimg(p.w_wh, c), wimg(p.w_wl, c), kWeightScale, bias, out, part,
-                                        Wk(p.w_sk), st);
+                                        SK(c, 0), st);
         });
     }
 
@@ -478,7 +486,7 @@ struct Run {
         const float* shift = S(p.bns[c.bn].stats) + p.bns[c.bn].C;
         return timed(0, c.flops, [&] {
             return dcn_conv_forward_fused_f16(&c.d, in, A(c.in_act), wimg(p.w_wh, c), wimg(p.w_wl, c), kWeightScale, shift, add,
-                                              relu, out, A(out_act), Wk(p.w_sk), st);
+                                              relu, out, A(out_act), SK(c, 0), st);
         });
     }
 
@@ -493,7 +501,9 @@ struct Run {
         float* rm = bn_running ? bn_running[2 * b.idx] : nullptr;
         float* rv = bn_running ? bn_running[2 * b.idx + 1] : nullptr;
         if (!training && (!rm || !rv)) return DCN_E_INVALID;
-        dcn::launch_bn_finalize(part, c.mtiles[p.conv_mode] / p.groups, p.groups, b.C, (double)(b.rows / p.groups), P(b.g),
+        // (M tiles of the launch just made: asked again, the tile shape follows the tuning table of the moment)
+        const int mtiles = p.conv_mode == DCN_CONV_FP32 ? dcn_conv_num_mtiles(&c.d) : dcn_conv_num_mtiles_f16(&c.d);
+        dcn::launch_bn_finalize(part, mtiles / p.groups, p.groups, b.C, (double)(b.rows / p.groups), P(b.g),
                                 P(b.b), rm, rv, momentum, eps, training, stats, training ? A(out_act) : nullptr,
                                 training ? A(res_act) : nullptr, st);
         return DCN_OK;
@@ -801,7 +811,7 @@ extern "C" int dcn_backbone_backward(dcn_plan* plan, const float* grad_descripto
                      const float* relu_out = nullptr) -> int {
         if (!f16) {
             DCN_TRY(dcn_transpose_weight(R.P(c.w), wt, c.d.cout, c.d.kh * c.d.kw, c.d.cin, c.d.ldc, st));
-            return R.timed(0, c.flops, [&] { return dcn_conv_dgrad(&c.d, dx, wt, add, din, R.Wk(p.w_sk), st); });
+            return R.timed(0, c.flops, [&] { return dcn_conv_dgrad(&c.d, dx, wt, add, din, R.SK(c, 1), st); });
         }
         if (fuse_red && bn_of) {
             const BnL& b = p.bns[bn_of->bn];
@@ -812,13 +822,13 @@ extern "C" int dcn_backbone_backward(dcn_plan* plan, const float* grad_descripto
                 red_tiles = tiles / p.groups;
                 return R.timed(0, c.flops, [&] {
                     return dcn_conv_dgrad_bn_f16(&c.d, dx, R.wimg(p.w_wh, c), R.wimg(p.w_wl, c), kWeightScale, amax + c.idx, add,
-                                                 din, R.S(bn_of->x), mask, R.S(b.stats), part, R.Wk(p.w_sk), st);
+                                                 din, R.S(bn_of->x), mask, R.S(b.stats), part, R.SK(c, 1), st);
                 });
             }
         }
         return R.timed(0, c.flops, [&] {   // (transposed weight images: split_all_weights(true) below)
             return dcn_conv_dgrad_f16(&c.d, dx, R.wimg(p.w_wh, c), R.wimg(p.w_wl, c), kWeightScale, amax + c.idx, add, din,
-                                      R.Wk(p.w_sk), st);
+                                      R.SK(c, 1), st);
         });
     };
     if (f16) DCN_TRY(R.split_all_weights(true, nullptr));

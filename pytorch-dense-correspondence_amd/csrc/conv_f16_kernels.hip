@@ -129,10 +129,13 @@ transpose_split_batched_kernel(SplitTable t) {
 // WR: wavefront rows of the workgroup (WR x 2 wavefronts, 128 WR work-items): 2 -> tiles of 64 TM x 64 TN, two workgroups
 // per CU; 4 -> 128 TM x 64 TN on 8 wavefronts, ONE workgroup per CU (same 8 wavefronts per CU, but a quarter fewer
 // operand bytes per MFMA through the vector-memory path and the LDS store path).
-template <int TM, int TN, int WR = 2> struct F16Geo {
-    static constexpr int NTH = 128 * WR, BM = 32 * TM * WR, BN = 64 * TN, RA = 16 * WR, RB = 32 * WR, PA = BM / RA, PB = BN / RB,
-                         kStageHalves = 2 * (BM + BN) * LDH;   // A hi, A lo, B hi, B lo
-    static_assert(BN % RB == 0, "WR = 4 needs TN = 2");
+// WC: wavefront columns (WR x WC wavefronts).  WR = 2, WC = 4: 128 x 256 tiles on 8 wavefronts -- the doubled operand is
+// the WEIGHT image (pre-split, a pure copy), so per MFMA the gathered operand's loads, fp32 -> (hi, lo) conversions and LDS
+// stores are half those of the 256 x 128 shape (which doubles the converting operand).
+template <int TM, int TN, int WR = 2, int WC = 2> struct F16Geo {
+    static constexpr int NTH = 64 * WR * WC, BM = 32 * TM * WR, BN = 32 * TN * WC, RA = NTH / 8, RB = NTH / 4, PA = BM / RA,
+                         PB = BN / RB, kStageHalves = 2 * (BM + BN) * LDH;   // A hi, A lo, B hi, B lo
+    static_assert(BM % RA == 0 && BN % RB == 0, "tile rows must be whole staging passes (WR = 4, WC = 2 needs TN = 2)");
 };
 
 // Stream-K tiles completed INSIDE the GEMM launch: every workgroup that parks a partial accumulator of a tile then counts
@@ -158,13 +161,13 @@ constexpr int kOob = (int)0x80000000;   // voffset that fails the bounds check o
 // gather is `buffer_load_dwordx4 voffset[row] + soffset(channel chunk)` with per-row byte offsets that only change when
 // the tap does; out-of-image taps, rows past M and weight rows past cd get an out-of-range voffset and come back as
 // zeros from the bounds check (no address clamps, no zero-fill selects in the K loop).
-template <int TM, int TN, bool TR, bool UNI, int WR = 2>
+template <int TM, int TN, bool TR, bool UNI, int WR = 2, int WC = 2>
 __device__ __forceinline__ void gemm_segment_f16(const GemmConv& p, _Float16* lds, int tile, int k0, int k1, int nk,
                                                  float* slot) {
-    using G = F16Geo<TM, TN, WR>;
+    using G = F16Geo<TM, TN, WR, WC>;
     constexpr int BM = G::BM, BN = G::BN, PA = G::PA, PB = G::PB, kStage = G::kStageHalves;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const int wm_ = wv >> 1, wn_ = wv & 1;
+    const int wm_ = wv / WC, wn_ = wv % WC;
     const int mt = fdiv(tile, p.div_nt), nt = tile - mt * p.ntiles;
     const int m0 = mt * BM, n0 = nt * BN;
 
@@ -457,12 +460,12 @@ __device__ __forceinline__ void gemm_segment_f16(const GemmConv& p, _Float16* ld
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[tm][tn][r] *= inv;
     if (k0 == 0 && k1 == nk) {
-        gemm_epilogue<WR, TM, TN, 16, 2>(p, acc, mt, nt, reinterpret_cast<float*>(lds));
+        gemm_epilogue<WR, TM, TN, 16, WC>(p, acc, mt, nt, reinterpret_cast<float*>(lds));
     } else {
         // slot layout [wavefront][tm][tn][r / 4][lane][r % 4]: one 16-byte store per lane, 1 KB per wave-instruction
         bool inl = false;
         // (the 128 x 128 / 4-wavefront shape sits exactly at its 256-register budget: it keeps the separate fix-up kernel)
-        if constexpr (!(WR == 2 && TM == 2 && TN == 2)) inl = p.sk_count != nullptr;
+        if constexpr (!(WR == 2 && WC == 2 && TM == 2 && TN == 2)) inl = p.sk_count != nullptr;
         if (!inl) {
             float4* o = reinterpret_cast<float4*>(slot + wv * (TM * TN * 16 * 64)) + lane;
 #pragma unroll
@@ -474,7 +477,7 @@ __device__ __forceinline__ void gemm_segment_f16(const GemmConv& p, _Float16* ld
                         o[((tm * TN + tn) * 4 + q) * 64] = make_float4(acc[tm][tn][4 * q], acc[tm][tn][4 * q + 1],
                                                                        acc[tm][tn][4 * q + 2], acc[tm][tn][4 * q + 3]);
         }
-        if constexpr (!(WR == 2 && TM == 2 && TN == 2)) if (inl) {
+        if constexpr (!(WR == 2 && WC == 2 && TM == 2 && TN == 2)) if (inl) {
             // Completed inside the launch.  The parked partials travel between workgroups on different XCDs (separate
             // L2s), so they are written and read with device-coherent accesses (sc1: write-through / L2-bypassing) and ordered
             // against the arrival word by counter waits only -- NO device-scope fence: a release / acquire fence writes back
@@ -527,27 +530,27 @@ __device__ __forceinline__ void gemm_segment_f16(const GemmConv& p, _Float16* ld
                                 acc[tm][tn][4 * q + 2] += v.z; acc[tm][tn][4 * q + 3] += v.w;
                             }
                 }
-                gemm_epilogue<WR, TM, TN, 16, 2>(p, acc, mt, nt, reinterpret_cast<float*>(lds));
+                gemm_epilogue<WR, TM, TN, 16, WC>(p, acc, mt, nt, reinterpret_cast<float*>(lds));
                 if (tid == 0) atomicExch(p.sk_count + rel, 0ull);
             }
         }
     }
 }
 
-template <int TM, int TN, bool TR, bool SK, bool UNI, int WR = 2>
-__global__ void __launch_bounds__(128 * WR, WR == 4 ? 1 : 2)
+template <int TM, int TN, bool TR, bool SK, bool UNI, int WR = 2, int WC = 2>
+__global__ void __launch_bounds__(64 * WR * WC, WR * WC == 8 ? 1 : 2)
 conv_gemm_f16_kernel(GemmConv p) {
-    using G = F16Geo<TM, TN, WR>;
+    using G = F16Geo<TM, TN, WR, WC>;
     __shared__ __attribute__((aligned(16))) _Float16 lds[2 * G::kStageHalves];
     const int nk = (p.K + HBK - 1) / HBK;
     if (!SK) {
-        gemm_segment_f16<TM, TN, TR, UNI, WR>(p, lds, xcd_remap(blockIdx.x, p.mtiles * p.ntiles), 0, nk, nk, nullptr);
+        gemm_segment_f16<TM, TN, TR, UNI, WR, WC>(p, lds, xcd_remap(blockIdx.x, p.mtiles * p.ntiles), 0, nk, nk, nullptr);
     } else {
         // hybrid schedule: whole rounds of tiles data-parallel (all workgroups of an XCD walk K in step and share their
         // operands through L2), then ONE stream-K pass that splits the K stages of the leftover tiles evenly
         const int g = xcd_remap(blockIdx.x, gridDim.x);
         for (int tile = g; tile < p.sk_dp; tile += gridDim.x) {
-            gemm_segment_f16<TM, TN, TR, UNI, WR>(p, lds, tile, 0, nk, nk, nullptr);
+            gemm_segment_f16<TM, TN, TR, UNI, WR, WC>(p, lds, tile, 0, nk, nk, nullptr);
             __syncthreads();
         }
         int u = p.sk_dp * nk + g * p.sk_units;
@@ -557,7 +560,7 @@ conv_gemm_f16_kernel(GemmConv p) {
         while (u < u_end) {
             const int tile = fdiv(u, p.div_nk), k0 = u - tile * nk;
             const int k1 = min(nk, k0 + (u_end - u));
-            gemm_segment_f16<TM, TN, TR, UNI, WR>(p, lds, tile, k0, k1, nk,
+            gemm_segment_f16<TM, TN, TR, UNI, WR, WC>(p, lds, tile, k0, k1, nk,
                                          p.sk_partial + (int64_t)(2 * g + (first ? 0 : 1)) * (G::BM * G::BN));
             u += k1 - k0;
             first = false;
@@ -566,21 +569,21 @@ conv_gemm_f16_kernel(GemmConv p) {
     }
 }
 
-// completes stream-K tiles (32-K stages).  TWO workgroups per tile, one per wavefront column (the WR wavefronts that own
-// one half of the tile's columns): batch-norm partial sums are per column, so the halves are independent, and the pass
-// -- a few dozen leftover tiles -- spreads over twice as many CUs.
-template <int TM, int TN, int WR = 2>
+// completes stream-K tiles (32-K stages).  WC workgroups per tile, one per wavefront column (the WR wavefronts that own
+// one slice of the tile's columns): batch-norm partial sums are per column, so the slices are independent, and the pass
+// -- a few dozen leftover tiles -- spreads over more CUs.
+template <int TM, int TN, int WR = 2, int WC = 2>
 __global__ void __launch_bounds__(64 * WR)
 conv_gemm_f16_fixup_kernel(GemmConv p) {
-    using G = F16Geo<TM, TN, WR>;
-    __shared__ float red[4 * WR * G::BN / 2];            // 4 WR x (BN / 2)
+    using G = F16Geo<TM, TN, WR, WC>;
+    __shared__ float red[4 * WR * G::BN / WC];           // 4 WR x (BN / WC)
     const int nk = (p.K + HBK - 1) / HBK;
-    const int rel = blockIdx.x >> 1, half = blockIdx.x & 1;
+    const int rel = blockIdx.x / WC, part = blockIdx.x % WC;
     const int tile = p.sk_dp + rel;                      // only the leftover tiles were stream-K'd
     const int ua = rel * nk, ub = ua + nk - 1;           // unit range relative to the start of the stream-K pass
     const int ga = ua / p.sk_units, gb = ub / p.sk_units;
     if (ga == gb) return;
-    const int lane = threadIdx.x & 63, wv = 2 * (threadIdx.x >> 6) + half;   // wavefront index inside the GEMM workgroup
+    const int lane = threadIdx.x & 63, wv = WC * (threadIdx.x >> 6) + part;   // wavefront index inside the GEMM workgroup
     f32x16 acc[TM][TN];
 #pragma unroll
     for (int i = 0; i < TM; ++i)
@@ -605,11 +608,11 @@ conv_gemm_f16_fixup_kernel(GemmConv p) {
                 }
     }
     const int mt = tile / p.ntiles, nt = tile - mt * p.ntiles;
-    gemm_epilogue<WR, TM, TN, 16, 1>(p, acc, mt, 2 * nt + half, red);   // a (32 TM WR) x (32 TN) "tile" of one wavefront column
+    gemm_epilogue<WR, TM, TN, 16, 1>(p, acc, mt, WC * nt + part, red);   // a (32 TM WR) x (32 TN) "tile" of one wavefront column
 }
 
 struct F16Shape {
-    int tm, tn, wr, mtiles, ntiles, nk, sk_wgs, sk_units, sk_dp;   // tile = (32 tm wr) x (64 tn), 128 wr work-items
+    int tm, tn, wr, wc, mtiles, ntiles, nk, sk_wgs, sk_units, sk_dp;   // tile = (32 tm wr) x (32 tn wc), 64 wr wc work-items
     bool sk;
     size_t ws_bytes, sk_count_off;
 };
@@ -621,22 +624,26 @@ F16Shape f16_shape(int M, int cd, int K, int align = 0) {
     g.tm = dcn::ceil_div(M, 128) * ntiles128 < 2 * 256 ? 1 : 2;
     // 256 x 128 on 8 wavefronts wherever the channel count fills a 128-wide tile: measured +4-5 % on every such layer of
     // configs 1-3 against the best 64 / 128-row choice (a quarter fewer operand bytes per MFMA at the same 8 wavefronts per CU)
-    g.wr = 2;
+    g.wr = 2; g.wc = 2;
     if (g.tn == 2 && M >= 4096) { g.tm = 2; g.wr = 4; }
     const dcn::Tuning& tune = dcn::tuning();
+    // 128 x 256 on 8 wavefronts (2 x 4) where the destination has whole 256-channel tiles: the doubled operand is the
+    // pre-split weight image instead of the gathered, converted one (DCN_GEMM_TILE_N=128 keeps 256 x 128)
+    if (g.wr == 4 && cd >= 256 && (cd % 256) == 0 && tune.gemm_tile_n != 128) { g.wr = 2; g.wc = 4; }
     if (tune.gemm_tile_m) {
         const int v = tune.gemm_tile_m;
-        if (v == 64) { g.tm = 1; g.wr = 2; }
-        if (v == 128) { g.tm = 2; g.wr = 2; }
-        if (v == 256 && g.tn == 2) { g.tm = 2; g.wr = 4; }
+        if (v == 64) { g.tm = 1; g.wr = 2; g.wc = 2; }
+        if (v == 128 && g.wc == 2) { g.tm = 2; g.wr = 2; }
+        if (v == 256 && g.tn == 2) { g.tm = 2; g.wr = 4; g.wc = 2; }
     }
-    if (align > 0 && (align % (32 * g.tm * g.wr)) != 0) { g.wr = 2; if ((align % (64 * g.tm)) != 0) g.tm = 1; }
-    const int bm = 32 * g.tm * g.wr;
+    if (tune.gemm_tile_n == 256 && g.tn == 2) { g.tm = 2; g.wr = 2; g.wc = 4; }   // (test override: any M, ragged N)
+    if (align > 0 && (align % (32 * g.tm * g.wr)) != 0) { g.wr = 2; g.wc = 2; if ((align % (64 * g.tm)) != 0) g.tm = 1; }
+    const int bm = 32 * g.tm * g.wr, bn = 32 * g.tn * g.wc;
     g.mtiles = dcn::ceil_div(M, bm);
-    g.ntiles = dcn::ceil_div(cd, 64 * g.tn);
+    g.ntiles = dcn::ceil_div(cd, bn);
     g.nk = dcn::ceil_div(K, HBK);
     const int tiles = g.mtiles * g.ntiles;
-    const int resident = g.wr == 4 ? 256 : 512;   // workgroups the chip holds at once
+    const int resident = g.wr * g.wc == 8 ? 256 : 512;   // workgroups the chip holds at once
     const double rounds = tiles / 256.0;
     const double waste = 1.0 - rounds / (double)(int)(rounds + 0.999999);
     // Stream-K removes the idle part of the last round -- (ceil(rounds) - rounds) * nk stage times -- and costs the
@@ -661,7 +668,7 @@ F16Shape f16_shape(int M, int cd, int K, int align = 0) {
         if (g.sk_dp == 0 && wgs > total / 2) wgs = (int)(total / 2) > 0 ? (int)(total / 2) : 1;
         g.sk_units = (int)((total + wgs - 1) / wgs);
         g.sk_wgs = g.sk_dp > 0 ? wgs : (int)((total + g.sk_units - 1) / g.sk_units);
-        g.ws_bytes = (size_t)2 * g.sk_wgs * bm * (64 * g.tn) * sizeof(float);
+        g.ws_bytes = (size_t)2 * g.sk_wgs * bm * bn * sizeof(float);
         g.sk_count_off = g.ws_bytes;                                   // arrival words of the stream-K'd tiles
         g.ws_bytes += (size_t)(tiles - g.sk_dp) * sizeof(unsigned long long);
     }
@@ -687,7 +694,7 @@ int launch_gemm_f16(GemmConv& p, void* workspace, hipStream_t st, int align = 0)
     p.sk_units = sk ? g.sk_units : 0;
     p.sk_dp = sk ? g.sk_dp : 0;
     p.sk_partial = sk ? (float*)workspace : nullptr;
-    const bool sk_inline = sk && dcn::tuning().gemm_sk_inline != 0 && !(g.wr == 2 && g.tm == 2 && g.tn == 2);
+    const bool sk_inline = sk && dcn::tuning().gemm_sk_inline != 0 && !(g.wr == 2 && g.wc == 2 && g.tm == 2 && g.tn == 2);
     p.sk_count = sk_inline ? (unsigned long long*)((char*)workspace + g.sk_count_off) : nullptr;
     p.sk_bytes = sk_inline ? (unsigned)g.sk_count_off : 0u;
     if (sk_inline) {
@@ -700,26 +707,28 @@ int launch_gemm_f16(GemmConv& p, void* workspace, hipStream_t st, int align = 0)
     uni = uni && dcn::tuning().gemm_uni != 0;
     p.src_bytes = uni ? (unsigned)src_bytes : 0u;
     p.w_bytes = uni ? (unsigned)w_bytes : 0u;
-    const dim3 grid(sk ? g.sk_wgs : g.mtiles * g.ntiles), fgrid(2 * (g.mtiles * g.ntiles - g.sk_dp)), block(128 * g.wr), fblock(64 * g.wr);
-#define DCN_GEMM16_K(TM, TN, WR, TR, SK)                                                                        \
-    do {                                                                                                        \
-        if (uni) hipLaunchKernelGGL((conv_gemm_f16_kernel<TM, TN, TR, SK, true, WR>), grid, block, 0, st, p);   \
-        else hipLaunchKernelGGL((conv_gemm_f16_kernel<TM, TN, TR, SK, false, WR>), grid, block, 0, st, p);      \
+    const dim3 grid(sk ? g.sk_wgs : g.mtiles * g.ntiles), fgrid(g.wc * (g.mtiles * g.ntiles - g.sk_dp)), block(64 * g.wr * g.wc),
+               fblock(64 * g.wr);
+#define DCN_GEMM16_K(TM, TN, WR, WC, TR, SK)                                                                        \
+    do {                                                                                                            \
+        if (uni) hipLaunchKernelGGL((conv_gemm_f16_kernel<TM, TN, TR, SK, true, WR, WC>), grid, block, 0, st, p);   \
+        else hipLaunchKernelGGL((conv_gemm_f16_kernel<TM, TN, TR, SK, false, WR, WC>), grid, block, 0, st, p);      \
     } while (0)
-#define DCN_GEMM16(TM, TN, WR)                                                                     \
-    do {                                                                                           \
-        if (sk) {                                                                                  \
-            if (p.transposed) DCN_GEMM16_K(TM, TN, WR, true, true);                                \
-            else DCN_GEMM16_K(TM, TN, WR, false, true);                                            \
-            if (!sk_inline) hipLaunchKernelGGL((conv_gemm_f16_fixup_kernel<TM, TN, WR>), fgrid, fblock, 0, st, p);  \
-        } else {                                                                                   \
-            if (p.transposed) DCN_GEMM16_K(TM, TN, WR, true, false);                               \
-            else DCN_GEMM16_K(TM, TN, WR, false, false);                                           \
-        }                                                                                          \
+#define DCN_GEMM16(TM, TN, WR, WC)                                                                     \
+    do {                                                                                               \
+        if (sk) {                                                                                      \
+            if (p.transposed) DCN_GEMM16_K(TM, TN, WR, WC, true, true);                                \
+            else DCN_GEMM16_K(TM, TN, WR, WC, false, true);                                            \
+            if (!sk_inline) hipLaunchKernelGGL((conv_gemm_f16_fixup_kernel<TM, TN, WR, WC>), fgrid, fblock, 0, st, p);  \
+        } else {                                                                                       \
+            if (p.transposed) DCN_GEMM16_K(TM, TN, WR, WC, true, false);                               \
+            else DCN_GEMM16_K(TM, TN, WR, WC, false, false);                                           \
+        }                                                                                              \
     } while (0)
-    if (g.wr == 4) DCN_GEMM16(2, 2, 4);
-    else if (g.tm == 1) { if (g.tn == 1) DCN_GEMM16(1, 1, 2); else DCN_GEMM16(1, 2, 2); }
-    else { if (g.tn == 1) DCN_GEMM16(2, 1, 2); else DCN_GEMM16(2, 2, 2); }
+    if (g.wc == 4) DCN_GEMM16(2, 2, 2, 4);
+    else if (g.wr == 4) DCN_GEMM16(2, 2, 4, 2);
+    else if (g.tm == 1) { if (g.tn == 1) DCN_GEMM16(1, 1, 2, 2); else DCN_GEMM16(1, 2, 2, 2); }
+    else { if (g.tn == 1) DCN_GEMM16(2, 1, 2, 2); else DCN_GEMM16(2, 2, 2, 2); }
 #undef DCN_GEMM16_K
 #undef DCN_GEMM16
     return dcn::check_launch();
@@ -1014,10 +1023,9 @@ bool wgrad_wide_f16(const dcn_conv_desc* c) {
     return c->cout >= 256 && (c->cout % 256) == 0 && c->kh * c->kw * c->cin >= 256 && dcn::tuning().wgrad_tile != 128;
 }
 
-int wgrad_splits_f16(const dcn_conv_desc* c, int* rows_per_split) {
+int wgrad_splits_f16(const dcn_conv_desc* c, int* rows_per_split, bool wide) {
     const int M = c->n * c->hout * c->wout, K = c->kh * c->kw * c->cin;
     const bool narrow = c->cout <= 64;
-    const bool wide = wgrad_wide_f16(c);
     const int tiles = dcn::ceil_div(c->cout, narrow ? 64 : (wide ? 256 : 128)) * dcn::ceil_div(K, 128);
     const int slots = wide ? 256 : 512;   // workgroups the chip holds at once
     const int max_by_rows = (M / (8 * HBK)) > 1 ? (M / (8 * HBK)) : 1;
@@ -1225,8 +1233,8 @@ extern "C" int dcn_split_grad_blocked_f16(const float* dy, int m, int ld, const 
 // slab bytes only; the split operands are the caller's (dcn_split_act_f16 / dcn_split_grad_blocked_f16)
 extern "C" size_t dcn_conv_wgrad_workspace_f16(const dcn_conv_desc* c) {
     if (!valid_desc16(c)) return 0;
-    int rps;
-    const int splits = wgrad_splits_f16(c, &rps);
+    int rps;   // (either tile: the tuning table may change between sizing and launch)
+    const int splits = std::max(wgrad_splits_f16(c, &rps, false), wgrad_splits_f16(c, &rps, c->cout >= 256 && (c->cout % 256) == 0));
     return (size_t)splits * c->cout * c->kh * c->kw * c->cin * sizeof(float);
 }
 
@@ -1242,8 +1250,8 @@ extern "C" int dcn_conv_wgrad_f16(const dcn_conv_desc* c, const void* xs, int xs
     p.hin = c->hin; p.win = c->win; p.cin = c->cin; p.hout = c->hout; p.wout = c->wout; p.cout = c->cout;
     p.kh = c->kh; p.kw = c->kw; p.stride = c->stride; p.pad = c->pad; p.dil = c->dil; p.ldo = c->ldc;
     p.M = c->n * c->hout * c->wout; p.K = c->kh * c->kw * c->cin;
-    p.splits = wgrad_splits_f16(c, &p.rows_per_split);
     const bool narrow = c->cout <= 64, wide = wgrad_wide_f16(c);
+    p.splits = wgrad_splits_f16(c, &p.rows_per_split, wide);
     p.ntiles_n = dcn::ceil_div(c->cout, narrow ? 64 : (wide ? 256 : 128)); p.ntiles_k = dcn::ceil_div(p.K, 128);
     p.div_hw = make_fastdiv(c->hout * c->wout); p.div_w = make_fastdiv(c->wout);
     p.div_cin = make_fastdiv(c->cin); p.div_kw = make_fastdiv(c->kw);

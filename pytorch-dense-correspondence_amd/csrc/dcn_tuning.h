@@ -3,6 +3,7 @@
 //   DCN_CONV_MODE           fp32 | f16x3    default arithmetic of new plans
 //   DCN_BACKWARD_OVERLAP    0: weight-gradient GEMMs stay on the caller's stream
 //   DCN_GEMM_TILE_M         32 | 64 | 128 | 256   workgroup-tile height of the gather-GEMM kernels
+//   DCN_GEMM_TILE_N         128: keep the 256 x 128 tile where the split-fp16 gather-GEMM would pick 128 x 256
 //   DCN_GEMM_SK             0: no stream-K, 1: as decided, N > 1: force N workgroups
 //   DCN_GEMM_SK_MIN_GAIN    stage times stream-K must save to be chosen (split-fp16 kernel)
 //   DCN_GEMM_UNI            0: disable the uniform-tap fast path
@@ -23,6 +24,7 @@ struct Tuning {
     int conv_mode_invalid = 0;   // DCN_CONV_MODE holds something else than fp32 / f16x3
     int backward_overlap = 1;
     int gemm_tile_m = 0;         // 0: unset
+    int gemm_tile_n = 0;         // 0: unset
     int gemm_sk = -1;            // -1: unset
     double gemm_sk_min_gain = 20.0;
     int gemm_uni = 1;
