@@ -3,7 +3,8 @@
 //   DCN_CONV_MODE           fp32 | f16x3    default arithmetic of new plans
 //   DCN_BACKWARD_OVERLAP    0: weight-gradient GEMMs stay on the caller's stream
 //   DCN_GEMM_TILE_M         32 | 64 | 128 | 256   workgroup-tile height of the gather-GEMM kernels
-//   DCN_GEMM_TILE_N         128: keep the 256 x 128 tile where the split-fp16 gather-GEMM would pick 128 x 256
+//   DCN_GEMM_TILE_N         256: 128 x 256 tiles (2 x 4 wavefronts) instead of 256 x 128 in the split-fp16 gather-GEMM
+//                           (measured: no gain, profiles/r2f_gemm_tile_n_ab.txt)
 //   DCN_GEMM_SK             0: no stream-K, 1: as decided, N > 1: force N workgroups
 //   DCN_GEMM_SK_MIN_GAIN    stage times stream-K must save to be chosen (split-fp16 kernel)
 //   DCN_GEMM_UNI            0: disable the uniform-tap fast path

@@ -31,6 +31,13 @@ for s in $steps; do
                for rep in 1 2 3; do for t in 0 128; do
                  timeout 300 env DCN_GEMM_TILE_N=$t python bench.py --steps 20 --warmup 5 --cpu-baseline-steps 0 --no-variants --profile-steps 0 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('abn gemm_tile_n=$t rep=$rep  %.1f images/s  %.3f ms/step' % (d['value'], d['ms_per_step']))" | tee -a gpurun_out/${tag}_gnab.txt
                done; done ;;
+    skab)      # stream-K threshold A/B (stage times stream-K must save to be chosen), per layer at N = 8 and on the step
+               for g in 20 10 5; do echo "--- DCN_GEMM_SK_MIN_GAIN=$g, N = 8" | tee -a gpurun_out/${tag}_skab.txt
+                 timeout 300 env DCN_GEMM_SK_MIN_GAIN=$g python tools/conv_bench.py --mode f16 --n 8 --kinds fwd,dgrad --only layer --reps 20 2>&1 | grep -v "Warn\|amdgpu.ids" | cut -c1-150 | tee -a gpurun_out/${tag}_skab.txt
+               done
+               for rep in 1 2; do for g in 20 10 5; do
+                 timeout 300 env DCN_GEMM_SK_MIN_GAIN=$g python bench.py --steps 20 --warmup 5 --cpu-baseline-steps 0 --no-variants --profile-steps 0 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('absk sk_min_gain=$g rep=$rep  %.1f images/s  %.3f ms/step' % (d['value'], d['ms_per_step']))" | tee -a gpurun_out/${tag}_skab.txt
+               done; done ;;
     abw)       # same-box A/B of the wgrad tile on the whole step
                for rep in 1 2 3; do for t in 0 128; do
                  timeout 300 env DCN_WGRAD_TILE=$t python bench.py --steps 20 --warmup 5 --cpu-baseline-steps 0 --no-variants --profile-steps 0 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('abw wgrad_tile=$t rep=$rep  %.1f images/s  %.3f ms/step' % (d['value'], d['ms_per_step']))" | tee -a gpurun_out/${tag}_abw.txt
