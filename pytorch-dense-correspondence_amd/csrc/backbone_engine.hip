@@ -767,7 +767,9 @@ extern "C" int dcn_backbone_backward(dcn_plan* plan, const float* grad_descripto
     p.fused_bn_bwd = 0;
     const float* red_dy = nullptr;
     int red_tiles = 0;
-    auto bn_bwd = [&](const ConvL& c, const float* dy, const float* relu_out, float* dx, float* g_out) {
+    // dy2 (optional): the upstream gradient is dy + dy2 -- the residual branch's share, added in the batch norm's streaming
+    // passes instead of in the epilogue of the dgrad that produced dy
+    auto bn_bwd = [&](const ConvL& c, const float* dy, const float* relu_out, float* dx, float* g_out, const float* dy2 = nullptr) {
         const BnL& b = p.bns[c.bn];
         const float* s = R.S(b.stats);
         // (the mask bytes the forward wrote next to that activation; relu_out itself is then not read)
@@ -779,7 +781,7 @@ extern "C" int dcn_backbone_backward(dcn_plan* plan, const float* grad_descripto
         if (tiles > 0) { relu_out = nullptr; mask = nullptr; g_out = nullptr; ++p.fused_bn_bwd; }   // dy is already the masked gradient
         dcn::launch_bn_bwd(dy, relu_out, mask, R.S(c.x), s, R.P(b.g), b.C, b.rows, p.groups, part, grads[b.g],
                            grads[b.b], k123, dx, g_out, f16 ? amax + c.idx : nullptr, f16 ? (void*)dqbuf[cur] : nullptr, st,
-                           tiles);
+                           tiles, dy2);
         if (overlap) RT(hipEventRecord(p.ev_dq[cur], st));
         ++n_bn;
         dq_of = f16 ? dx : nullptr;   // the pixel-blocked split copy of this dx now sits in dqbuf[cur]
@@ -859,6 +861,14 @@ extern "C" int dcn_backbone_backward(dcn_plan* plan, const float* grad_descripto
         DCN_TRY(dgrad(fc, glow, nullptr, dout, &p.convs[lb.conv[lb.nconv - 1]], R.S(lb.out)));
     }
 
+    // The gradient w.r.t. a block's input is  dgrad(conv1) + (identity gradient | dgrad(downsample) + ...): the second
+    // summand is NOT added in the GEMM epilogue (scalar loads on the critical path of a one-workgroup-per-CU kernel:
+    // measured +22 % / +43 % / +58 % on such a dgrad of layer 4 / 3 / 2) but handed to the previous block's batch-norm
+    // backward, whose streaming passes read dy + dy2 (DCN_DEFER_RESIDUAL_ADD=0 restores the epilogue add; the first block's
+    // input gradient feeds the max-pool backward and keeps it)
+    const bool defer_add = dcn::tuning().defer_residual_add != 0 && !fuse_red;
+    const float* dout_add = nullptr;   // second summand of dout (the current block's output gradient), or null
+    const float* next_add = nullptr;
     for (int bi = (int)p.blocks.size() - 1; bi >= 0; --bi) {
         const BlockL& blk = p.blocks[bi];
         const float* in = R.S(blk.in);
@@ -866,7 +876,8 @@ extern "C" int dcn_backbone_backward(dcn_plan* plan, const float* grad_descripto
         const ConvL& last = p.convs[blk.conv[blk.nconv - 1]];
         // (with the fused reduction dout already IS the relu-masked gradient: it serves as the residual branch's gradient)
         const float* gres = (red_dy == dout) ? dout : gbuf;
-        bn_bwd(last, dout, R.S(blk.out), dxa, gbuf);
+        bn_bwd(last, dout, R.S(blk.out), dxa, gbuf, dout_add);
+        dout_add = nullptr;
         float* dx = dxa;
         float* dy = dxb;
         // the gradient w.r.t. this block's input is the upstream gradient of the previous block's last batch norm
@@ -882,6 +893,9 @@ extern "C" int dcn_backbone_backward(dcn_plan* plan, const float* grad_descripto
                 bn_bwd(prev, dy, R.S(blk.mid[i - 1]), dx, nullptr);  // dx reused: grad w.r.t. prev conv output
             } else if (blk.down >= 0) {
                 DCN_TRY(dgrad(c, dx, nullptr, dpart));
+            } else if (defer_add && bi > 0) {
+                DCN_TRY(dgrad(c, dx, nullptr, dnext));   // the identity gradient joins in the previous block's BN backward
+                next_add = gres;
             } else {
                 DCN_TRY(dgrad(c, dx, gres, dnext, up_bn, up_relu));  // + identity gradient
             }
@@ -890,8 +904,15 @@ extern "C" int dcn_backbone_backward(dcn_plan* plan, const float* grad_descripto
             const ConvL& dc = p.convs[blk.down];
             bn_bwd(dc, gres, nullptr, dxa, nullptr);
             DCN_TRY(wgrad(dc, in, dxa, grads[dc.w]));
-            DCN_TRY(dgrad(dc, dxa, dpart, dnext, up_bn, up_relu));
+            if (defer_add && bi > 0) {
+                DCN_TRY(dgrad(dc, dxa, nullptr, dnext));
+                next_add = dpart;
+            } else {
+                DCN_TRY(dgrad(dc, dxa, dpart, dnext, up_bn, up_relu));
+            }
         }
+        dout_add = next_add;
+        next_add = nullptr;
         float* t = dout; dout = dnext; dnext = t;
         // gradient bucket complete?  (every launch that writes one of its gradients has been enqueued: the side stream's
         // weight-gradient GEMMs are joined into the caller's stream first)

@@ -14,6 +14,7 @@
 //                           gradient (split-fp16 mode) instead of as a separate pass.  Default 0: measured SLOWER on the
 //                           MI355X (+1.3 ms per config-2 step, profiles/r2b_ab.txt: the one-workgroup-per-CU GEMM exposes the
 //                           epilogue's extra loads, the separate pass streams at HBM speed)
+//   DCN_DEFER_RESIDUAL_ADD  0: the residual branch's gradient is added in the dgrad epilogue (1: in the BN backward passes)
 //   DCN_WGRAD_TILE          128: keep the 128-channel / 4-wavefront tile of the split-fp16 wgrad kernel on wide layers
 //   DCN_WGRAD_SPLITS        force the pixel-range split count of the split-fp16 wgrad kernel
 #pragma once
@@ -31,6 +32,7 @@ struct Tuning {
     int gemm_uni = 1;
     int gemm_sk_inline = 1;      // stream-K tiles completed inside the GEMM launch (0: separate fix-up kernel)
     int bn_bwd_fused = 0;
+    int defer_residual_add = 1;
     int wgrad_splits = 0;        // 0: unset
     int wgrad_tile = 0;          // 0: unset
 };

@@ -31,7 +31,8 @@ void launch_bn_bwd(const float* dy, const float* relu_out, const unsigned char* 
                    const float* gamma, int C,
                    int64_t rows, int groups, float* partial, float* dgamma, float* dbeta, float* k123, float* dx,
                    float* g_out, float* absmax, void* dq, hipStream_t st,    // dq (optional, with absmax): dx also as the
-                   int reduced_tiles_per_group = 0);                         // pixel-blocked split-fp16 tensor (f16_split.h)
+                   int reduced_tiles_per_group = 0,                          // pixel-blocked split-fp16 tensor (f16_split.h)
+                   const float* dy2 = nullptr);   // dy2 (optional): the upstream gradient is dy + dy2 (residual branch's share)
 // reduced_tiles_per_group > 0: `partial` already holds that many rows per group of per-tile sums, written by the epilogue
 // of the dgrad that produced dy (GemmConv::bnb_partial) -- the reduce pass is skipped; dy is then already ReLU-masked
 // (pass relu_out = relu_mask = nullptr)

@@ -217,13 +217,26 @@ __device__ __forceinline__ float4 relu_masked(float4 g, const float* relu_out, c
     return g;
 }
 
+// upstream gradient given as the sum of two tensors (dy2 nullable): the residual branch's gradient is added HERE, in the
+// streaming passes, instead of in the epilogue of the dgrad that produced dy (measured: the one-workgroup-per-CU GEMM
+// exposes the epilogue's scalar loads -- +22 % on a layer-4 dgrad, +43 % on layer 3, profiles/r2h_kernel_stats_before_add_move.txt)
+// (dy2 may be the very buffer the apply pass writes g_out to -- same index, read before written: no __restrict__ on it)
+__device__ __forceinline__ float4 load_dy(const float* __restrict__ dy, const float* dy2, int64_t i4) {
+    float4 g = reinterpret_cast<const float4*>(dy)[i4];
+    if (dy2) {
+        const float4 h = reinterpret_cast<const float4*>(dy2)[i4];
+        g.x += h.x; g.y += h.y; g.z += h.z; g.w += h.w;
+    }
+    return g;
+}
+
 // Backward reduction.  g = relu_out ? (relu_out > 0 ? dy : 0) : dy.
 // partial[chunk][C][4] = ( sum g , sum g * xhat , max |g| , max |xhat| ) over the chunk's rows, xhat = (x - mean) * invstd
 // (the four statistics of a channel are one float4: the finalize kernel reads them with a single load).
 // (The two maxima bound |dx| per channel without another pass or any atomics in the big kernels: bn_bwd_finalize.)
 // work-item (c4 = tid & 15, rl = tid >> 4): 16 channel quads x 16 row lanes; grid = (C/64 groups, chunks).
 __global__ void __launch_bounds__(256)
-bn_bwd_reduce_kernel(const float* __restrict__ dy, const float* __restrict__ relu_out,
+bn_bwd_reduce_kernel(const float* __restrict__ dy, const float* dy2, const float* __restrict__ relu_out,
                      const unsigned char* __restrict__ relu_mask, const float* __restrict__ x,
                      const float* __restrict__ mean, const float* __restrict__ invstd, int C, int64_t rows_per_group,
                      int chunks_per_group, int gstride, int rows_per_chunk, float* __restrict__ partial) {
@@ -244,7 +257,7 @@ bn_bwd_reduce_kernel(const float* __restrict__ dy, const float* __restrict__ rel
 #pragma unroll 4   // (8 loads in flight per work-item instead of 2: 27 -> 23 us per launch)
         for (int64_t r = r0 + rl; r < r1; r += 16) {
             const int64_t o = r * C + c;
-            const float4 g = relu_masked(*reinterpret_cast<const float4*>(dy + o), relu_out, relu_mask, o >> 2);
+            const float4 g = relu_masked(load_dy(dy, dy2, o >> 2), relu_out, relu_mask, o >> 2);
             const float4 v = *reinterpret_cast<const float4*>(x + o);
             const float4 xh = make_float4((v.x - mu.x) * is.x, (v.y - mu.y) * is.y, (v.z - mu.z) * is.z, (v.w - mu.w) * is.w);
             ag.x += g.x; ag.y += g.y; ag.z += g.z; ag.w += g.w;
@@ -350,16 +363,16 @@ bn_bwd_finalize_kernel(const float* __restrict__ partial, int chunks, int groups
 // dx = k1*(g - k2 - (x-mean)*invstd*k3); optionally also writes g (the relu-masked upstream gradient) for the
 // residual branch.
 __global__ void __launch_bounds__(256)
-bn_bwd_apply_kernel(const float* __restrict__ dy, const float* __restrict__ relu_out,
+bn_bwd_apply_kernel(const float* __restrict__ dy, const float* dy2, const float* __restrict__ relu_out,
                     const unsigned char* __restrict__ relu_mask, const float* __restrict__ x,
                     const float* __restrict__ mean, const float* __restrict__ invstd, const float* __restrict__ k1,
                     const float* __restrict__ k2, const float* __restrict__ k3, float* __restrict__ dx,
-                    float* __restrict__ g_out, int c4n, int64_t total4, int64_t group4, int gstride, int kstride) {
+                    float* g_out, int c4n, int64_t total4, int64_t group4, int gstride, int kstride) {
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total4; i += (int64_t)gridDim.x * 256) {
         const int c0 = (int)(i % c4n) * 4;
         const bool second = i >= group4;                          // (at most two groups)
         const int c = c0 + (second ? gstride : 0), ck = c0 + (second ? kstride : 0);
-        const float4 g = relu_masked(reinterpret_cast<const float4*>(dy)[i], relu_out, relu_mask, i);
+        const float4 g = relu_masked(load_dy(dy, dy2, i), relu_out, relu_mask, i);
         const float4 v = reinterpret_cast<const float4*>(x)[i];
         const float4 mu = *reinterpret_cast<const float4*>(mean + c);
         const float4 is = *reinterpret_cast<const float4*>(invstd + c);
@@ -380,11 +393,11 @@ bn_bwd_apply_kernel(const float* __restrict__ dy, const float* __restrict__ relu
 // dx as the pixel-blocked split tensor wgrad consumes (f16_split.h), scaled by the power of two chosen from the bound the
 // finalize kernel has just stored in *absmax -- no separate split pass over dx.  rows_per_group % 4 == 0 when grouped.
 __global__ void __launch_bounds__(256)
-bn_bwd_apply_blocked_kernel(const float* __restrict__ dy, const float* __restrict__ relu_out,
+bn_bwd_apply_blocked_kernel(const float* __restrict__ dy, const float* dy2, const float* __restrict__ relu_out,
                             const unsigned char* __restrict__ relu_mask, const float* __restrict__ x,
                             const float* __restrict__ mean, const float* __restrict__ invstd, const float* __restrict__ k1,
                             const float* __restrict__ k2, const float* __restrict__ k3, float* __restrict__ dx,
-                            float* __restrict__ g_out, dcnsplit::u32x4* __restrict__ dq, const float* __restrict__ absmax,
+                            float* g_out, dcnsplit::u32x4* __restrict__ dq, const float* __restrict__ absmax,
                             int c4n, int64_t rows, int64_t rows_per_group, int gstride, int kstride) {
     const float s = dcnsplit::pow2_scale(*absmax);
     const int64_t total = ((rows + 3) >> 2) * c4n;
@@ -404,7 +417,7 @@ bn_bwd_apply_blocked_kernel(const float* __restrict__ dy, const float* __restric
             const int64_t m = q * 4 + r;
             if (m < rows) {
                 const int64_t e = m * c4n + cq;
-                const float4 g = relu_masked(reinterpret_cast<const float4*>(dy)[e], relu_out, relu_mask, e);
+                const float4 g = relu_masked(load_dy(dy, dy2, e), relu_out, relu_mask, e);
                 const float4 v = reinterpret_cast<const float4*>(x)[e];
                 o[r][0] = a.x * (g.x - b.x - (v.x - mu.x) * is.x * d.x);
                 o[r][1] = a.y * (g.y - b.y - (v.y - mu.y) * is.y * d.y);
@@ -682,7 +695,7 @@ int bn_bwd_chunks(int64_t rows_per_group) {
 void launch_bn_bwd(const float* dy, const float* relu_out, const unsigned char* relu_mask, const float* x, const float* stats,
                    const float* gamma, int C,
                    int64_t rows, int groups, float* partial, float* dgamma, float* dbeta, float* k123, float* dx,
-                   float* g_out, float* absmax, void* dq, hipStream_t st, int reduced_tiles_per_group) {
+                   float* g_out, float* absmax, void* dq, hipStream_t st, int reduced_tiles_per_group, const float* dy2) {
     const int64_t rpg = rows / groups;
     const float* mean = stats + 2 * C;
     const float* invstd = stats + 3 * C;
@@ -690,7 +703,7 @@ void launch_bn_bwd(const float* dy, const float* relu_out, const unsigned char* 
     if (chunks <= 0) {
         chunks = bn_bwd_chunks(rpg);   // per group
         const int rpc = (int)ceil_div64(rpg, chunks);
-        hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(ceil_div(C, 64), chunks * groups), dim3(256), 0, st, dy, relu_out,
+        hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(ceil_div(C, 64), chunks * groups), dim3(256), 0, st, dy, dy2, relu_out,
                            relu_mask, x, mean, invstd, C, rpg, chunks, 4 * C, rpc, partial);
     }
     hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(ceil_div(C, 4)), dim3(256), 0, st, (const float*)partial, chunks,
@@ -698,12 +711,12 @@ void launch_bn_bwd(const float* dy, const float* relu_out, const unsigned char* 
     const int64_t total4 = rows * (C / 4);
     if (dq && absmax) {
         hipLaunchKernelGGL(bn_bwd_apply_blocked_kernel, dim3(blocks_for(((rows + 3) / 4) * (C / 4), kGridCap)), dim3(256), 0, st,
-                           dy, relu_out, relu_mask, x, mean, invstd, (const float*)k123, (const float*)(k123 + C),
+                           dy, dy2, relu_out, relu_mask, x, mean, invstd, (const float*)k123, (const float*)(k123 + C),
                            (const float*)(k123 + 2 * C), dx, g_out, (dcnsplit::u32x4*)dq, (const float*)absmax, C / 4, rows,
                            rpg, 4 * C, 3 * C);
         return;
     }
-    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(blocks_for(total4, kGridCap)), dim3(256), 0, st, dy, relu_out, relu_mask,
+    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(blocks_for(total4, kGridCap)), dim3(256), 0, st, dy, dy2, relu_out, relu_mask,
                        x, mean, invstd, (const float*)k123, (const float*)(k123 + C), (const float*)(k123 + 2 * C), dx, g_out,
                        C / 4, total4, total4 / groups, 4 * C, 3 * C);
 }

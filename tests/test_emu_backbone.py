@@ -167,6 +167,24 @@ def test_bn_backward_reduction_fused_into_dgrad(arch, groups, conv_mode, dcn_env
     assert all(torch.equal(a, b) for a, b in zip(grads[(1, 3, "inline")], grads[(1, 3, "kernel")]))
 
 
+@pytest.mark.parametrize("arch", ["Resnet18_8s", "Resnet50_8s"])
+def test_residual_gradient_added_in_bn_backward(arch, dcn_env):
+    """The second summand of a block's input gradient (identity gradient, or the downsample branch's dgrad partner) is
+    handed to the previous block's batch-norm backward (dy + dy2 in its streaming passes) instead of being added in the
+    dgrad epilogue: the same two floats are added either way -- bit-identical gradients (DCN_DEFER_RESIDUAL_ADD=0 / 1)."""
+    grads = []
+    for defer in (0, 1):
+        dcn_env(DCN_DEFER_RESIDUAL_ADD=defer)
+        m, _ = _pair(arch, 3, 8)
+        g = torch.Generator().manual_seed(9)
+        x = torch.randn(2, 3, 32, 40, generator=g)
+        gy = torch.randn(2, 3, 32, 40, generator=g)
+        m.train()
+        (m(x) * gy).sum().backward()
+        grads.append([p.grad.clone() for p in m.parameters()])
+    assert all(torch.equal(a, b) for a, b in zip(*grads))
+
+
 def test_normalized_descriptors_forward_backward():
     """DenseCorrespondenceNetwork(normalize=True): res / ||res||_2 over D (network.py:256-259), fused into the upsample
     kernel; backward through it."""

@@ -38,6 +38,11 @@ for s in $steps; do
                for rep in 1 2; do for g in 20 10 5; do
                  timeout 300 env DCN_GEMM_SK_MIN_GAIN=$g python bench.py --steps 20 --warmup 5 --cpu-baseline-steps 0 --no-variants --profile-steps 0 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('absk sk_min_gain=$g rep=$rep  %.1f images/s  %.3f ms/step' % (d['value'], d['ms_per_step']))" | tee -a gpurun_out/${tag}_skab.txt
                done; done ;;
+    abenv)     # same-box A/B of one environment switch on the whole step: AB_ENV="NAME a b" (default: residual add deferred 1 | in the epilogue 0)
+               set -- ${AB_ENV:-DCN_DEFER_RESIDUAL_ADD 1 0}; name=$1; shift
+               for rep in 1 2 3; do for v in "$@"; do
+                 timeout 300 env $name=$v python bench.py --steps 20 --warmup 5 --cpu-baseline-steps 0 --no-variants --profile-steps 0 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('abenv $name=$v rep=$rep  %.1f images/s  %.3f ms/step' % (d['value'], d['ms_per_step']))" | tee -a gpurun_out/${tag}_abenv.txt
+               done; done ;;
     abw)       # same-box A/B of the wgrad tile on the whole step
                for rep in 1 2 3; do for t in 0 128; do
                  timeout 300 env DCN_WGRAD_TILE=$t python bench.py --steps 20 --warmup 5 --cpu-baseline-steps 0 --no-variants --profile-steps 0 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('abw wgrad_tile=$t rep=$rep  %.1f images/s  %.3f ms/step' % (d['value'], d['ms_per_step']))" | tee -a gpurun_out/${tag}_abw.txt
