@@ -864,8 +864,8 @@ extern "C" int dcn_backbone_backward(dcn_plan* plan, const float* grad_descripto
     // The gradient w.r.t. a block's input is  dgrad(conv1) + (identity gradient | dgrad(downsample) + ...): the second
     // summand is NOT added in the GEMM epilogue (scalar loads on the critical path of a one-workgroup-per-CU kernel:
     // measured +22 % / +43 % / +58 % on such a dgrad of layer 4 / 3 / 2) but handed to the previous block's batch-norm
-    // backward, whose streaming passes read dy + dy2 (DCN_DEFER_RESIDUAL_ADD=0 restores the epilogue add; the first block's
-    // input gradient feeds the max-pool backward and keeps it)
+    // backward, whose streaming passes read dy + dy2 (the first block's: to the max-pool backward); DCN_DEFER_RESIDUAL_ADD=0
+    // restores the epilogue add
     const bool defer_add = dcn::tuning().defer_residual_add != 0 && !fuse_red;
     const float* dout_add = nullptr;   // second summand of dout (the current block's output gradient), or null
     const float* next_add = nullptr;
@@ -893,7 +893,7 @@ extern "C" int dcn_backbone_backward(dcn_plan* plan, const float* grad_descripto
                 bn_bwd(prev, dy, R.S(blk.mid[i - 1]), dx, nullptr);  // dx reused: grad w.r.t. prev conv output
             } else if (blk.down >= 0) {
                 DCN_TRY(dgrad(c, dx, nullptr, dpart));
-            } else if (defer_add && bi > 0) {
+            } else if (defer_add) {
                 DCN_TRY(dgrad(c, dx, nullptr, dnext));   // the identity gradient joins in the previous block's BN backward
                 next_add = gres;
             } else {
@@ -904,7 +904,7 @@ extern "C" int dcn_backbone_backward(dcn_plan* plan, const float* grad_descripto
             const ConvL& dc = p.convs[blk.down];
             bn_bwd(dc, gres, nullptr, dxa, nullptr);
             DCN_TRY(wgrad(dc, in, dxa, grads[dc.w]));
-            if (defer_add && bi > 0) {
+            if (defer_add) {
                 DCN_TRY(dgrad(dc, dxa, nullptr, dnext));
                 next_add = dpart;
             } else {
@@ -930,7 +930,7 @@ extern "C" int dcn_backbone_backward(dcn_plan* plan, const float* grad_descripto
     const BnL& sb = p.bns[stem.bn];
     const int hp = (stem.d.hout + 2 - 3) / 2 + 1, wp = (stem.d.wout + 2 - 3) / 2 + 1;
     dcn::launch_maxpool_bwd(dout, (const unsigned char*)R.S(p.s_argmax), dnext, N, stem.d.hout, stem.d.wout, hp, wp, sb.C,
-                            st);
+                            st, dout_add);   // (the first block's deferred identity gradient joins here)
     bn_bwd(stem, dnext, R.S(p.s_stem_y), dxa, nullptr);
     DCN_TRY(wgrad(stem, R.S(p.s_in4), dxa, R.Wk(p.w_dwstem)));
     if (overlap) {   // join: everything the side stream produced is ordered before whatever follows on the caller's stream

@@ -41,7 +41,7 @@ void launch_add(const float* a, const float* b, float* out, int64_t n, hipStream
 void launch_maxpool_fwd(const float* in, float* out, unsigned char* argmax, int n, int hin, int win, int hout,
                         int wout, int C, hipStream_t st);
 void launch_maxpool_bwd(const float* gout, const unsigned char* argmax, float* gin, int n, int hin, int win, int hout,
-                        int wout, int C, hipStream_t st);
+                        int wout, int C, hipStream_t st, const float* gout2 = nullptr);   // gout2 (optional): gradient = gout + gout2
 
 void launch_upsample_fwd(const float* low, int n, int hl, int wl, int ldl, int d, int h, int w, int normalize,
                          float* out, hipStream_t st);

@@ -487,8 +487,8 @@ maxpool_fwd_kernel(const float* __restrict__ in, float* __restrict__ out, unsign
 
 // gather form: every input element collects from the (<= 4) windows that contain it
 __global__ void __launch_bounds__(256)
-maxpool_bwd_kernel(const float* __restrict__ gout, const unsigned char* __restrict__ argmax, float* __restrict__ gin,
-                   int hin, int win, int hout, int wout, int c4n, int64_t total4) {
+maxpool_bwd_kernel(const float* __restrict__ gout, const float* __restrict__ gout2, const unsigned char* __restrict__ argmax,
+                   float* __restrict__ gin, int hin, int win, int hout, int wout, int c4n, int64_t total4) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;  // over n*hin*win*c4n
     if (i >= total4) return;
     const int c4 = (int)(i % c4n);
@@ -507,7 +507,11 @@ maxpool_bwd_kernel(const float* __restrict__ gout, const unsigned char* __restri
             if (s < 0 || s > 2) continue;
             const int t = r * 3 + s;
             const int64_t o = ((n * hout + oy) * wout + ox) * c4n + c4;
-            const float4 g = reinterpret_cast<const float4*>(gout)[o];
+            float4 g = reinterpret_cast<const float4*>(gout)[o];
+            if (gout2) {   // the pooled tensor's gradient arrives as a sum of two (first block's dgrad + its identity gradient)
+                const float4 h = reinterpret_cast<const float4*>(gout2)[o];
+                g.x += h.x; g.y += h.y; g.z += h.z; g.w += h.w;
+            }
             const unsigned char* a = argmax + o * 4;
             if (a[0] == t) acc.x += g.x;
             if (a[1] == t) acc.y += g.y;
@@ -730,9 +734,9 @@ void launch_maxpool_fwd(const float* in, float* out, unsigned char* argmax, int 
                        wout, C / 4, total4);
 }
 void launch_maxpool_bwd(const float* gout, const unsigned char* argmax, float* gin, int n, int hin, int win, int hout,
-                        int wout, int C, hipStream_t st) {
+                        int wout, int C, hipStream_t st, const float* gout2) {
     const int64_t total4 = (int64_t)n * hin * win * (C / 4);
-    hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(blocks_for(total4)), dim3(256), 0, st, gout, argmax, gin, hin, win,
+    hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(blocks_for(total4)), dim3(256), 0, st, gout, gout2, argmax, gin, hin, win,
                        hout, wout, C / 4, total4);
 }
 static inline float ac_scale(int in, int out) { return out > 1 ? (float)(in - 1) / (float)(out - 1) : 0.f; }
