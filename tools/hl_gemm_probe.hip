@@ -182,6 +182,22 @@ gemm_hl_kernel(const _Float16* __restrict__ A, const _Float16* __restrict__ B, f
             mfmas(0);
             bar();
         }
+    } else if (PIPE == 1) {
+        // PIPE 1: as PIPE 0, but the fragments are double-buffered in registers: the LDS reads of k-step s + 1 are issued
+        // before the MFMAs of k-step s (the first k-step of the NEXT stage right behind the barrier that publishes it), so
+        // that a wavefront never waits for LDS in front of its matrix burst.
+        issue(0, 0);
+        __syncthreads();
+        read_frags(0, 0, 0);
+        for (int kt = 0; kt < nk; ++kt) {
+            const int buf = kt & 1;
+            if (kt + 1 < nk) issue(kt + 1, buf ^ 1);
+            read_frags(buf, 1, 1);
+            mfmas(0);
+            __syncthreads();          // (drains the LDS-DMA of stage kt + 1: it had the MFMAs of k-step 0 to land)
+            if (kt + 1 < nk) read_frags(buf ^ 1, 0, 0);
+            mfmas(1);
+        }
     } else {
         issue(0, 0);
         __syncthreads();   // (the compiler drains vmcnt before the barrier while an LDS-DMA is in flight)
@@ -304,6 +320,9 @@ int main(int argc, char** argv) {
     const float inv = 1.0f / 64.0f;
     run("256x256 (2x4 waves of 128x64), plain loop", [&] { return run_gemm<4, 2, 2, 4, 0>(ha, hb, dc, M, N, K, inv, 10); });
     run("256x256 (2x4 waves of 128x64), explicit ping-pong of two wavefront groups", [&] { return run_gemm<4, 2, 2, 4, 3>(ha, hb, dc, M, N, K, inv, 10); });
+    run("256x256 (2x4 waves of 128x64), double-buffered fragments", [&] { return run_gemm<4, 2, 2, 4, 1>(ha, hb, dc, M, N, K, inv, 10); });
+    run("256x256 (4x2 waves of 64x128), double-buffered fragments", [&] { return run_gemm<2, 4, 4, 2, 1>(ha, hb, dc, M, N, K, inv, 10); });
+    run("256x128 (4x2 waves of 64x64), double-buffered fragments", [&] { return run_gemm<2, 2, 4, 2, 1>(ha, hb, dc, M, N, K, inv, 10); });
     run("256x256 (4x2 waves of 64x128), plain loop", [&] { return run_gemm<2, 4, 4, 2, 0>(ha, hb, dc, M, N, K, inv, 10); });
     run("256x128 (4x2 waves of 64x64), plain loop", [&] { return run_gemm<2, 2, 4, 2, 0>(ha, hb, dc, M, N, K, inv, 10); });
     for (auto& r : res)
