@@ -43,6 +43,12 @@ for s in $steps; do
                for rep in 1 2 3; do for v in "$@"; do
                  timeout 300 env $name=$v python bench.py --steps 20 --warmup 5 --cpu-baseline-steps 0 --no-variants --profile-steps 0 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('abenv $name=$v rep=$rep  %.1f images/s  %.3f ms/step' % (d['value'], d['ms_per_step']))" | tee -a gpurun_out/${tag}_abenv.txt
                done; done ;;
+    sqw)       # SQ counters of the wgrad kernel on the layer-4 3x3 convolution, N = 8: 256-channel / 8-wavefront tile vs 128-channel
+               for t in 0 128; do i=0; for pass in "SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES GRBM_GUI_ACTIVE SQ_WAIT_INST_ANY SQ_WAIT_ANY" "SQ_WAVE_CYCLES SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS"; do i=$((i+1))
+                 (cd /tmp && timeout 300 env DCN_WGRAD_TILE=$t rocprofv3 --kernel-trace --pmc $pass --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/${tag}_sqw_${t}_$i -- python $GRAFT_REPO_ROOT/tools/conv_bench.py --mode f16 --n 8 --kinds wgrad --x-direct --no-split --only "layer4 3x3" --reps 5 > $GRAFT_REPO_ROOT/gpurun_out/${tag}_sqw_${t}_$i.log 2>&1)
+               done
+               python tools/sq_summary.py gpurun_out/${tag}_wgrad_sq_counters_tile$t.txt "rocprofv3 --kernel-trace --pmc <two passes> -- DCN_WGRAD_TILE=$t python tools/conv_bench.py --mode f16 --n 8 --kinds wgrad --x-direct --no-split --only 'layer4 3x3' --reps 5  (0 = default: 256-channel tile on 8 wavefronts; 128 = the 128-channel / 4-wavefront tile)" gpurun_out/${tag}_sqw_${t}_1 gpurun_out/${tag}_sqw_${t}_2; cat gpurun_out/${tag}_wgrad_sq_counters_tile$t.txt
+               done ;;
     abw)       # same-box A/B of the wgrad tile on the whole step
                for rep in 1 2 3; do for t in 0 128; do
                  timeout 300 env DCN_WGRAD_TILE=$t python bench.py --steps 20 --warmup 5 --cpu-baseline-steps 0 --no-variants --profile-steps 0 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('abw wgrad_tile=$t rep=$rep  %.1f images/s  %.3f ms/step' % (d['value'], d['ms_per_step']))" | tee -a gpurun_out/${tag}_abw.txt
