@@ -798,7 +798,7 @@ struct WgradF16 {
 // TM = 1, 2: 256 work-items, two workgroups per CU.  TM = 4: 256 output channels x 128 K columns on 8 wavefronts (4 x 2),
 // ONE workgroup per CU: the gradient operand -- stored pre-split, a pure copy -- is the doubled one, so per MFMA the
 // activation operand's loads, conversions, 4x4 transposes and LDS stores halve (wavefronts 0-3 stage it, all 8 stage dy).
-template <int TM, bool FAST, bool XPRE>   // 64*TM output channels x 128 K columns per workgroup
+template <int TM, bool FAST, bool XPRE, bool DEEP = false>   // 64*TM output channels x 128 K columns per workgroup
 __global__ void __launch_bounds__(TM == 4 ? 512 : NT, TM == 4 ? 1 : 2)
 conv_wgrad_f16_kernel(WgradF16 p) {
     constexpr int BM = 64 * TM, BN = 128, kStage = 2 * (BM + BN) * LDH;
@@ -828,8 +828,13 @@ conv_wgrad_f16_kernel(WgradF16 p) {
     const int tap = fdiv(kc0, p.div_cin), cc = kc0 - tap * p.cin;
     const int tr = fdiv(tap, p.div_kw), ts = tap - tr * p.kw;
     const int oy = tr * p.dil - p.pad, ox = ts * p.dil - p.pad;
-    u32x4 rd[4];       // sub-planes: hi (ch 0,1), hi (ch 2,3), lo (ch 0,1), lo (ch 2,3), each x 4 pixels
-    u32x4 rx[4];       // per pixel: hi x4 | lo x4
+    // DEEP: two register sets, so that the global loads of a stage are issued 1.5 iterations before the stage is stored to
+    // LDS instead of half an iteration (SQ counters of the single-set loop on the layer-4 convolution: matrix pipe busy 36 %
+    // of the cycles at 2.0 GHz -- not power-limited --, wavefronts parked at s_waitcnt / the barrier 48 % of theirs,
+    // profiles/r2l_wgrad_sq_counters_*.txt).  Where the register budget allows it.
+    constexpr int NSET = DEEP ? 2 : 1;
+    u32x4 rd[NSET][4];       // sub-planes: hi (ch 0,1), hi (ch 2,3), lo (ch 0,1), lo (ch 2,3), each x 4 pixels
+    u32x4 rx[NSET][4];       // per pixel: hi x4 | lo x4
     const int d_sub = (p.ldo >> 2) * 16;   // bytes between sub-planes of one pixel quad
 
     // Addresses of a stage are prepared ahead (prep: VALU only, placed before the barrier) so that the loads of the next
@@ -883,15 +888,16 @@ conv_wgrad_f16_kernel(WgradF16 p) {
             }
         }
     };
-    auto issue_loads = [&]() {
+    auto issue_loads = [&](int set) {
 #pragma unroll
-        for (int h = 0; h < 4; ++h) rd[h] = __builtin_amdgcn_raw_buffer_load_b128(rs_d, doff, h * d_sub, 0);
-        if (xact)
+        for (int h = 0; h < 4; ++h) rd[set][h] = __builtin_amdgcn_raw_buffer_load_b128(rs_d, doff, h * d_sub, 0);
+        // (wavefronts that do not stage the activation operand carry out-of-range offsets: their loads touch no memory; no
+        // branch here, so that the compiler's vmcnt bookkeeping knows exactly how many loads a stage has in flight)
 #pragma unroll
-            for (int i = 0; i < 4; ++i) rx[i] = __builtin_amdgcn_raw_buffer_load_b128(rs_x, xoff[i], 0, 0);
+        for (int i = 0; i < 4; ++i) rx[set][i] = __builtin_amdgcn_raw_buffer_load_b128(rs_x, xoff[i], 0, 0);
     };
     const float sx = (!XPRE && p.x_absmax) ? pow2_scale(*p.x_absmax) : 1.f;
-    auto store_tile = [&](int stage) {
+    auto store_tile = [&](int stage, int set) {
         _Float16* dh = lds + stage * kStage;
         _Float16* dl = dh + BM * LDH;
         _Float16* xh = dl + BM * LDH;
@@ -900,9 +906,9 @@ conv_wgrad_f16_kernel(WgradF16 p) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 h4 a, b;
-                split4(__builtin_bit_cast(float4, rx[i]), sx, a, b);
+                split4(__builtin_bit_cast(float4, rx[set][i]), sx, a, b);
                 const u32x2 ua = __builtin_bit_cast(u32x2, a), ub = __builtin_bit_cast(u32x2, b);
-                rx[i] = u32x4{ua[0], ua[1], ub[0], ub[1]};
+                rx[set][i] = u32x4{ua[0], ua[1], ub[0], ub[1]};
             }
         }
 #pragma unroll
@@ -915,11 +921,11 @@ conv_wgrad_f16_kernel(WgradF16 p) {
                 const int w = 2 * pl + (e >> 1);
                 u32x2 o;
                 if ((e & 1) == 0) {
-                    o[0] = (rx[0][w] & 0xffffu) | (rx[1][w] << 16);
-                    o[1] = (rx[2][w] & 0xffffu) | (rx[3][w] << 16);
+                    o[0] = (rx[set][0][w] & 0xffffu) | (rx[set][1][w] << 16);
+                    o[1] = (rx[set][2][w] & 0xffffu) | (rx[set][3][w] << 16);
                 } else {
-                    o[0] = (rx[0][w] >> 16) | (rx[1][w] & 0xffff0000u);
-                    o[1] = (rx[2][w] >> 16) | (rx[3][w] & 0xffff0000u);
+                    o[0] = (rx[set][0][w] >> 16) | (rx[set][1][w] & 0xffff0000u);
+                    o[1] = (rx[set][2][w] >> 16) | (rx[set][3][w] & 0xffff0000u);
                 }
                 *reinterpret_cast<u32x2*>(xd + (4 * (cq & 31) + e) * LDH + 4 * pq) = o;
             }
@@ -928,8 +934,8 @@ conv_wgrad_f16_kernel(WgradF16 p) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     u32x2 o;
-                    o[0] = rd[2 * pl + (e >> 1)][2 * (e & 1)];
-                    o[1] = rd[2 * pl + (e >> 1)][2 * (e & 1) + 1];
+                    o[0] = rd[set][2 * pl + (e >> 1)][2 * (e & 1)];
+                    o[1] = rd[set][2 * pl + (e >> 1)][2 * (e & 1) + 1];
                     *reinterpret_cast<u32x2*>(dd + (4 * cq + e) * LDH + 4 * pq) = o;
                 }
             }
@@ -979,24 +985,58 @@ conv_wgrad_f16_kernel(WgradF16 p) {
     const int nsteps = (m_end - m_begin + HBK - 1) / HBK;
     if (nsteps > 0) {
         // (stages past the end of the split prepare out-of-range addresses: their loads return zeros and are never used)
-        prep(m_begin);
-        issue_loads();
-        prep(m_begin + HBK);
-        store_tile(0);
-        issue_loads();
-        prep(m_begin + 2 * HBK);
-        __syncthreads();
-        read_frags(0, 0, 0);
-        for (int st = 0; st < nsteps; ++st) {
-            const int cur = st & 1;
-            read_frags(cur, 1, 1);
-            store_tile(cur ^ 1);
-            mfma_steps(0);
+        if constexpr (!DEEP) {
+            prep(m_begin);
+            issue_loads(0);
+            prep(m_begin + HBK);
+            store_tile(0, 0);
+            issue_loads(0);
+            prep(m_begin + 2 * HBK);
             __syncthreads();
-            issue_loads();                                   // stage st + 2
-            read_frags(cur ^ 1, 0, 0);
-            mfma_steps(1);
-            prep(m_begin + (st + 3) * HBK);
+            read_frags(0, 0, 0);
+            for (int st = 0; st < nsteps; ++st) {
+                const int cur = st & 1;
+                read_frags(cur, 1, 1);
+                store_tile(cur ^ 1, 0);
+                mfma_steps(0);
+                __syncthreads();
+                issue_loads(0);                                  // stage st + 2
+                read_frags(cur ^ 1, 0, 0);
+                mfma_steps(1);
+                prep(m_begin + (st + 3) * HBK);
+            }
+        } else {
+            // stage k travels in register set k & 1; its loads are issued in iteration k - 3 (behind the barrier) and it
+            // is stored to LDS at the top of iteration k - 1.  Unrolled by two: set and LDS-stage indices are literals.
+            prep(m_begin);
+            issue_loads(0);
+            __builtin_amdgcn_sched_barrier(0);   // (issue order = stage order: the compiler's vmcnt waits count in it)
+            prep(m_begin + HBK);
+            issue_loads(1);
+            __builtin_amdgcn_sched_barrier(0);
+            prep(m_begin + 2 * HBK);
+            store_tile(0, 0);
+            issue_loads(0);
+            __builtin_amdgcn_sched_barrier(0);
+            prep(m_begin + 3 * HBK);
+            __syncthreads();
+            read_frags(0, 0, 0);
+            auto iter = [&](int st, int cur, int set1) {
+                read_frags(cur, 1, 1);
+                store_tile(cur ^ 1, set1);                       // stage st + 1
+                mfma_steps(0);
+                __syncthreads();
+                issue_loads(set1);                               // stage st + 3
+                read_frags(cur ^ 1, 0, 0);
+                mfma_steps(1);
+                prep(m_begin + (st + 4) * HBK);
+            };
+            int st = 0;
+            for (; st + 1 < nsteps; st += 2) {
+                iter(st, 0, 1);
+                iter(st + 1, 1, 0);
+            }
+            if (st < nsteps) iter(st, 0, 1);
         }
     }
     // C fragment: row (r) <-> output channel, column (lane & 31) <-> K column: 128-byte coalesced rows
@@ -1261,19 +1301,27 @@ extern "C" int dcn_conv_wgrad_f16(const dcn_conv_desc* c, const void* xs, int xs
     hipStream_t st = (hipStream_t)stream;
     const dim3 grid(p.ntiles_n * p.ntiles_k * p.splits), block(wide ? 512 : NT);
     const bool fast = (c->wout % 4) == 0 && c->wout >= HBK;
-#define DCN_WGRAD16(TM)                                                                                        \
-    do {                                                                                                       \
-        if (fast) {                                                                                            \
-            if (xs_is_fp32) hipLaunchKernelGGL((conv_wgrad_f16_kernel<TM, true, false>), grid, block, 0, st, p); \
-            else hipLaunchKernelGGL((conv_wgrad_f16_kernel<TM, true, true>), grid, block, 0, st, p);            \
-        } else {                                                                                               \
-            if (xs_is_fp32) hipLaunchKernelGGL((conv_wgrad_f16_kernel<TM, false, false>), grid, block, 0, st, p); \
-            else hipLaunchKernelGGL((conv_wgrad_f16_kernel<TM, false, true>), grid, block, 0, st, p);           \
-        }                                                                                                      \
+    // deep prefetch (two register sets): DCN_WGRAD_DEEP is a mask over the tile variants (1: 64-channel, 2: 128, 4: 256)
+    const int deep_mask = dcn::tuning().wgrad_deep;
+#define DCN_WGRAD16_D(TM, DEEP)                                                                                        \
+    do {                                                                                                               \
+        if (fast) {                                                                                                    \
+            if (xs_is_fp32) hipLaunchKernelGGL((conv_wgrad_f16_kernel<TM, true, false, DEEP>), grid, block, 0, st, p); \
+            else hipLaunchKernelGGL((conv_wgrad_f16_kernel<TM, true, true, DEEP>), grid, block, 0, st, p);            \
+        } else {                                                                                                       \
+            if (xs_is_fp32) hipLaunchKernelGGL((conv_wgrad_f16_kernel<TM, false, false, DEEP>), grid, block, 0, st, p); \
+            else hipLaunchKernelGGL((conv_wgrad_f16_kernel<TM, false, true, DEEP>), grid, block, 0, st, p);           \
+        }                                                                                                              \
+    } while (0)
+#define DCN_WGRAD16(TM)                                      \
+    do {                                                     \
+        if (deep_mask & (TM)) DCN_WGRAD16_D(TM, true);       \
+        else DCN_WGRAD16_D(TM, false);                       \
     } while (0)
     if (narrow) DCN_WGRAD16(1);
     else if (wide) DCN_WGRAD16(4);
     else DCN_WGRAD16(2);
+#undef DCN_WGRAD16_D
 #undef DCN_WGRAD16
     if (p.splits > 1) launch_wgrad_reduce((const float*)slabs, dw, (int64_t)c->cout * p.K / 4, p.splits, st);
     return dcn::check_launch();

@@ -16,6 +16,8 @@
 //                           epilogue's extra loads, the separate pass streams at HBM speed)
 //   DCN_DEFER_RESIDUAL_ADD  0: the residual branch's gradient is added in the dgrad epilogue (1: in the BN backward passes)
 //   DCN_WGRAD_TILE          128: keep the 128-channel / 4-wavefront tile of the split-fp16 wgrad kernel on wide layers
+//   DCN_WGRAD_DEEP          mask of the wgrad tile variants that prefetch through two register sets (1: 64-channel tile,
+//                           2: 128, 4: 256; default 4)
 //   DCN_WGRAD_SPLITS        force the pixel-range split count of the split-fp16 wgrad kernel
 #pragma once
 
@@ -35,6 +37,7 @@ struct Tuning {
     int defer_residual_add = 1;
     int wgrad_splits = 0;        // 0: unset
     int wgrad_tile = 0;          // 0: unset
+    int wgrad_deep = 4;
 };
 
 const Tuning& tuning();

@@ -408,3 +408,42 @@ def test_stream_k_inline_completion(L, dcn_env):
     import kernel_checks
     kernel_checks.check_stream_k_inline(L, "cpu", dcn_env, 1, 12, 12, 32, 136, 3, 2, sk="5", tile_m="256")
     kernel_checks.check_stream_k_inline(L, "cpu", dcn_env, 2, 9, 9, 32, 40, 3, 1, sk="7", tile_m="64")
+
+
+@pytest.mark.parametrize("case", [
+    (1, 8, 36, 8, 16, 3, 1, 1, 1),       # 64-channel tile, carried-position path, several stages
+    (2, 9, 7, 4, 12, 7, 2, 3, 1),        # stem-like, division path
+    (1, 6, 40, 16, 136, 3, 1, 2, 2),     # 128-channel tile, two channel tiles
+    (1, 4, 36, 8, 256, 3, 1, 1, 1),      # 256-channel / 8-wavefront tile
+    (2, 5, 6, 32, 512, 1, 1, 0, 1),
+    (1, 1, 32, 8, 256, 3, 1, 1, 1),      # a single 32-pixel stage per split: prologue loads run past the end
+], ids=str)
+def test_wgrad_f16_deep_prefetch_is_bit_identical(L, case, dcn_env):
+    """DCN_WGRAD_DEEP: the global loads of a stage travel through two register sets (issued 1.5 iterations ahead) instead of
+    one -- the same values reach the same MFMAs in the same order: identical bits, odd and even stage counts, stages past
+    the end of a split (out-of-range loads that are never stored)."""
+    lib = L.get()
+    n, hin, win, cin, cout, k, stride, pad, dil = case
+    hout = (hin + 2 * pad - dil * (k - 1) - 1) // stride + 1
+    wout = (win + 2 * pad - dil * (k - 1) - 1) // stride + 1
+    d = L.ConvDesc(n, hin, win, cin, hout, wout, cout, k, k, stride, pad, dil, cout)
+    g = torch.Generator().manual_seed(4)
+    x = torch.randn(n, hin, win, cin, generator=g)
+    dout = torch.randn(n, hout, wout, cout, generator=g)
+    M = n * hout * wout
+    amax = dout.abs().max().reshape(1).clone()
+    dq = torch.empty(lib.dcn_grad_blocked_bytes(M, cout) // 4)
+    assert lib.dcn_split_grad_blocked_f16(L.ptr(dout), M, cout, L.ptr(amax), L.ptr(dq), None) == 0
+    res = []
+    for deep in (0, 7):
+        dcn_env(DCN_WGRAD_DEEP=deep)
+        slabs = torch.empty(max(lib.dcn_conv_wgrad_workspace_f16(ctypes.byref(d)), 4) // 4)
+        dw = torch.full((cout, k, k, cin), float("nan"))
+        assert lib.dcn_conv_wgrad_f16(ctypes.byref(d), L.ptr(x), 1, None, L.ptr(dq), L.ptr(amax), L.ptr(dw), L.ptr(slabs), None) == 0
+        res.append(dw)
+    ref = F.conv2d(x.permute(0, 3, 1, 2).requires_grad_(False), torch.zeros(cout, cin, k, k), None, stride, pad, dil)  # shape check only
+    assert ref.shape[2:] == (hout, wout)
+    w = torch.zeros(cout, cin, k, k, requires_grad=True)
+    (F.conv2d(x.permute(0, 3, 1, 2), w, None, stride, pad, dil) * dout.permute(0, 3, 1, 2)).sum().backward()
+    assert rel_err(res[0], w.grad.permute(0, 2, 3, 1)) < 5e-6
+    assert torch.equal(res[0], res[1])

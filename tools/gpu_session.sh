@@ -49,6 +49,13 @@ for s in $steps; do
                done
                python tools/sq_summary.py gpurun_out/${tag}_wgrad_sq_counters_tile$t.txt "rocprofv3 --kernel-trace --pmc <two passes> -- DCN_WGRAD_TILE=$t python tools/conv_bench.py --mode f16 --n 8 --kinds wgrad --x-direct --no-split --only 'layer4 3x3' --reps 5  (0 = default: 256-channel tile on 8 wavefronts; 128 = the 128-channel / 4-wavefront tile)" gpurun_out/${tag}_sqw_${t}_1 gpurun_out/${tag}_sqw_${t}_2; cat gpurun_out/${tag}_wgrad_sq_counters_tile$t.txt
                done ;;
+    wdab)      # wgrad deep-prefetch A/B per layer (mask 0 | 4 | 7), N = 8, then on the whole step
+               for m in 0 4 7; do echo "--- DCN_WGRAD_DEEP=$m, N = 8" | tee -a gpurun_out/${tag}_wdab.txt
+                 timeout 300 env DCN_WGRAD_DEEP=$m python tools/conv_bench.py --mode f16 --n 8 --x-direct --no-split --kinds wgrad --reps 20 $( [ $m = 7 ] && echo --check ) 2>&1 | grep -v "^net\|Warn\|amdgpu.ids" | cut -c1-60,108-150 | tee -a gpurun_out/${tag}_wdab.txt
+               done
+               for rep in 1 2 3; do for m in 0 4 7; do
+                 timeout 300 env DCN_WGRAD_DEEP=$m python bench.py --steps 20 --warmup 5 --cpu-baseline-steps 0 --no-variants --profile-steps 0 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('abwd wgrad_deep=$m rep=$rep  %.1f images/s  %.3f ms/step' % (d['value'], d['ms_per_step']))" | tee -a gpurun_out/${tag}_wdab.txt
+               done; done ;;
     abw)       # same-box A/B of the wgrad tile on the whole step
                for rep in 1 2 3; do for t in 0 128; do
                  timeout 300 env DCN_WGRAD_TILE=$t python bench.py --steps 20 --warmup 5 --cpu-baseline-steps 0 --no-variants --profile-steps 0 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('abw wgrad_tile=$t rep=$rep  %.1f images/s  %.3f ms/step' % (d['value'], d['ms_per_step']))" | tee -a gpurun_out/${tag}_abw.txt
