@@ -483,7 +483,7 @@ def main():
         # MI355X_MICROARCH.md's HBM section), attached only when workload / arithmetic / call pattern match -- the
         # field name says so: it was not measured in this run
         traffic, traffic_src = None, None
-        for name in ("r2_hbm_counters.json", "r1g_hbm_counters.json"):
+        for name in ("r2m_hbm_counters.json", "r2_hbm_counters.json", "r1g_hbm_counters.json"):
             try:
                 rec = json.load(open(os.path.join(ROOT, "profiles", name)))
                 if (rec["workload"] == args.workload and rec["conv_mode"] == conv_mode and not args.batch and job_ is job and
