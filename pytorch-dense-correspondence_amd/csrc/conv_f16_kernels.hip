@@ -798,9 +798,13 @@ struct WgradF16 {
 // TM = 1, 2: 256 work-items, two workgroups per CU.  TM = 4: 256 output channels x 128 K columns on 8 wavefronts (4 x 2),
 // ONE workgroup per CU: the gradient operand -- stored pre-split, a pure copy -- is the doubled one, so per MFMA the
 // activation operand's loads, conversions, 4x4 transposes and LDS stores halve (wavefronts 0-3 stage it, all 8 stage dy).
-template <int TM, bool FAST, bool XPRE, bool DEEP = false>   // 64*TM output channels x 128 K columns per workgroup
+// ROLES (TM = 4): wavefronts 0-3 stage ONLY the activation operand (loads, conversions, transposes) and wavefronts 4-7 the
+// whole gradient tile (two micro-tiles each, pure copies) -- instead of the gradient copy being spread over all eight on top
+// of the activation work of the first four: the two halves then reach the stage barrier closer together.
+template <int TM, bool FAST, bool XPRE, bool DEEP = false, bool ROLES = false>   // 64*TM output channels x 128 K columns per workgroup
 __global__ void __launch_bounds__(TM == 4 ? 512 : NT, TM == 4 ? 1 : 2)
 conv_wgrad_f16_kernel(WgradF16 p) {
+    static_assert(!ROLES || TM == 4, "ROLES is a variant of the 8-wavefront tile");
     constexpr int BM = 64 * TM, BN = 128, kStage = 2 * (BM + BN) * LDH;
     __shared__ __attribute__((aligned(16))) _Float16 lds[2 * kStage];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -813,15 +817,22 @@ conv_wgrad_f16_kernel(WgradF16 p) {
     const int m_begin = split * p.rows_per_split;
     const int m_end = min(p.M, m_begin + p.rows_per_split);
 
-    const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.xs), 0, (int)p.x_bytes, 0x00020000);
+    // (ROLES: the second load slot of a work-item reads the activations in wavefronts 0-3 and the gradient's second micro-tile
+    // in wavefronts 4-7: one wave-uniform resource, selected from scalars)
+    const bool hiw = ROLES && __builtin_amdgcn_readfirstlane(tid >> 8) != 0;
+    const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(hiw ? p.dq : p.xs), 0,
+                                                                          (int)(hiw ? p.d_bytes : p.x_bytes), 0x00020000);
     const __amdgpu_buffer_rsrc_t rs_d = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.dq), 0, (int)p.d_bytes, 0x00020000);
 
     // micro-tile of this work-item: pixels 4*pq .. 4*pq+3 of the stage, channel quad cq (dout: n0 + 4*cq, in: j0 + 4*cq)
-    const int pq = tid & 7, cq = tid >> 3;                    // 8 pixel quads x 32 (TM = 4: 64) channel quads
-    const bool dact = 4 * cq < BM;                            // (BM = 64: only half of the work-items stage dout)
+    const int pq = tid & 7;
+    const int cq = ROLES ? ((tid >> 3) & 31) : (tid >> 3);    // 8 pixel quads x 32 (TM = 4 without ROLES: 64) channel quads
+    // (ROLES: wavefronts 4-7 own gradient channel quads cq and cq + 32, wavefronts 0-3 none)
+    const bool dact = ROLES ? hiw : 4 * cq < BM;              // (BM = 64: only half of the work-items stage dout)
     const bool xact = TM != 4 || tid < 256;                   // (TM = 4: wavefronts 0-3 stage the activation operand; wave-uniform)
     const int ncol = n0 + cq * 4;
     const bool nval = dact & (ncol < p.ldo);
+    const bool nval2 = ROLES && dact && (ncol + 128 < p.ldo);
     const int kcol = j0 + (cq & 31) * 4;
     const bool kval = xact & (kcol < p.K);
     const int kc0 = kval ? kcol : 0;
@@ -855,6 +866,13 @@ conv_wgrad_f16_kernel(WgradF16 p) {
         const int mq = (m_base >> 2) + pq;                    // (m_base is a multiple of 32)
         const bool dok = nval & (4 * mq < m_end);
         doff = dok ? (int)((unsigned)mq * 4u * (unsigned)d_sub + (unsigned)(ncol >> 2) * 16u) : kOob;
+        if (ROLES && hiw) {   // second gradient micro-tile (channel quad cq + 32) through the activation slot
+            const bool dok2 = nval2 & (4 * mq < m_end);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                xoff[i] = dok2 ? (int)((unsigned)mq * 4u * (unsigned)d_sub + (unsigned)i * (unsigned)d_sub + (unsigned)((ncol >> 2) + 32) * 16u) : kOob;
+            return;
+        }
         if (FAST) {
             const bool qval = kval & (m_base + 4 * pq < m_end);
             const int sy = py * p.stride + oy;
@@ -937,6 +955,11 @@ conv_wgrad_f16_kernel(WgradF16 p) {
                     o[0] = rd[set][2 * pl + (e >> 1)][2 * (e & 1)];
                     o[1] = rd[set][2 * pl + (e >> 1)][2 * (e & 1) + 1];
                     *reinterpret_cast<u32x2*>(dd + (4 * cq + e) * LDH + 4 * pq) = o;
+                    if (ROLES) {   // second micro-tile (channel quad cq + 32), loaded through the activation slot
+                        o[0] = rx[set][2 * pl + (e >> 1)][2 * (e & 1)];
+                        o[1] = rx[set][2 * pl + (e >> 1)][2 * (e & 1) + 1];
+                        *reinterpret_cast<u32x2*>(dd + (128 + 4 * cq + e) * LDH + 4 * pq) = o;
+                    }
                 }
             }
         }
@@ -1319,6 +1342,10 @@ extern "C" int dcn_conv_wgrad_f16(const dcn_conv_desc* c, const void* xs, int xs
         else DCN_WGRAD16_D(TM, false);                       \
     } while (0)
     if (narrow) DCN_WGRAD16(1);
+    else if (wide && dcn::tuning().wgrad_roles && fast && xs_is_fp32) {
+        if (deep_mask & 4) hipLaunchKernelGGL((conv_wgrad_f16_kernel<4, true, false, true, true>), grid, block, 0, st, p);
+        else hipLaunchKernelGGL((conv_wgrad_f16_kernel<4, true, false, false, true>), grid, block, 0, st, p);
+    }
     else if (wide) DCN_WGRAD16(4);
     else DCN_WGRAD16(2);
 #undef DCN_WGRAD16_D

@@ -18,6 +18,7 @@
 //   DCN_WGRAD_TILE          128: keep the 128-channel / 4-wavefront tile of the split-fp16 wgrad kernel on wide layers
 //   DCN_WGRAD_DEEP          mask of the wgrad tile variants that prefetch through two register sets (1: 64-channel tile,
 //                           2: 128, 4: 256; default 4)
+//   DCN_WGRAD_ROLES         0: the wide tile's gradient copy is spread over all 8 wavefronts (default 1: wavefronts 4-7 only)
 //   DCN_WGRAD_SPLITS        force the pixel-range split count of the split-fp16 wgrad kernel
 #pragma once
 
@@ -38,6 +39,7 @@ struct Tuning {
     int wgrad_splits = 0;        // 0: unset
     int wgrad_tile = 0;          // 0: unset
     int wgrad_deep = 4;
+    int wgrad_roles = 1;         // wide tile: wavefronts 0-3 stage the activations, 4-7 the gradient (0: copy spread over all 8)
 };
 
 const Tuning& tuning();

@@ -31,6 +31,7 @@ void read_env(Tuning& t) {
     if (const char* e = getenv("DCN_BN_BWD_FUSED")) t.bn_bwd_fused = atoi(e) != 0;
     if (const char* e = getenv("DCN_DEFER_RESIDUAL_ADD")) t.defer_residual_add = atoi(e) != 0;
     if (const char* e = getenv("DCN_WGRAD_DEEP")) t.wgrad_deep = atoi(e);
+    if (const char* e = getenv("DCN_WGRAD_ROLES")) t.wgrad_roles = atoi(e);
     if (const char* e = getenv("DCN_WGRAD_TILE")) t.wgrad_tile = atoi(e);
     if (const char* e = getenv("DCN_WGRAD_SPLITS")) t.wgrad_splits = atoi(e);
 }

@@ -417,6 +417,7 @@ def test_stream_k_inline_completion(L, dcn_env):
     (1, 4, 36, 8, 256, 3, 1, 1, 1),      # 256-channel / 8-wavefront tile
     (2, 5, 6, 32, 512, 1, 1, 0, 1),
     (1, 1, 32, 8, 256, 3, 1, 1, 1),      # a single 32-pixel stage per split: prologue loads run past the end
+    (2, 3, 64, 16, 512, 3, 1, 2, 2),     # two 256-channel tiles, dilation
 ], ids=str)
 def test_wgrad_f16_deep_prefetch_is_bit_identical(L, case, dcn_env):
     """DCN_WGRAD_DEEP: the global loads of a stage travel through two register sets (issued 1.5 iterations ahead) instead of
@@ -435,8 +436,9 @@ def test_wgrad_f16_deep_prefetch_is_bit_identical(L, case, dcn_env):
     dq = torch.empty(lib.dcn_grad_blocked_bytes(M, cout) // 4)
     assert lib.dcn_split_grad_blocked_f16(L.ptr(dout), M, cout, L.ptr(amax), L.ptr(dq), None) == 0
     res = []
-    for deep in (0, 7):
-        dcn_env(DCN_WGRAD_DEEP=deep)
+    # (DCN_WGRAD_ROLES: wide tile only -- wavefronts 0-3 stage the activations, 4-7 the whole gradient tile)
+    for deep, roles in ((0, 0), (7, 0), (4, 1), (0, 1)):
+        dcn_env(DCN_WGRAD_DEEP=deep, DCN_WGRAD_ROLES=roles)
         slabs = torch.empty(max(lib.dcn_conv_wgrad_workspace_f16(ctypes.byref(d)), 4) // 4)
         dw = torch.full((cout, k, k, cin), float("nan"))
         assert lib.dcn_conv_wgrad_f16(ctypes.byref(d), L.ptr(x), 1, None, L.ptr(dq), L.ptr(amax), L.ptr(dw), L.ptr(slabs), None) == 0
@@ -446,4 +448,4 @@ def test_wgrad_f16_deep_prefetch_is_bit_identical(L, case, dcn_env):
     w = torch.zeros(cout, cin, k, k, requires_grad=True)
     (F.conv2d(x.permute(0, 3, 1, 2), w, None, stride, pad, dil) * dout.permute(0, 3, 1, 2)).sum().backward()
     assert rel_err(res[0], w.grad.permute(0, 2, 3, 1)) < 5e-6
-    assert torch.equal(res[0], res[1])
+    assert all(torch.equal(res[0], r) for r in res[1:])
