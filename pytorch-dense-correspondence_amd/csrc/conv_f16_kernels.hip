@@ -515,20 +515,29 @@ __device__ __forceinline__ void gemm_segment_f16(const GemmConv& p, _Float16* ld
                     for (int tn = 0; tn < TN; ++tn)
 #pragma unroll
                         for (int r = 0; r < 16; ++r) acc[tm][tn][r] = 0.f;
+                // (each contributor's partial in batches of kBatch 16-byte loads issued back to back -- the staging registers
+                // of the K loop are free here -- and only then added: left to itself the compiler waits for every 4 loads,
+                // i.e. 16 device-coherent round trips per contributor on the critical path of the launch)
+                constexpr int kPieces = TM * TN * 4, kBatch = kPieces < 32 ? kPieces : 32;
                 for (int g = ga; g <= gb; ++g) {               // fixed order, own partial included: deterministic
                     const int first_tile = (g * p.sk_units) / nk;
                     const int so = (2 * g + (first_tile == rel ? 0 : 1)) * (BM * BN * 4);
 #pragma unroll
-                    for (int tm = 0; tm < TM; ++tm)
+                    for (int b0 = 0; b0 < kPieces; b0 += kBatch) {
+                        u32x4 t[kBatch];
 #pragma unroll
-                        for (int tn = 0; tn < TN; ++tn)
+                        for (int j = 0; j < kBatch; ++j)
+                            t[j] = __builtin_amdgcn_raw_buffer_load_b128(rs_p, lane_off + (b0 + j) * 1024, so, kSc1);
+                        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                            for (int q = 0; q < 4; ++q) {
-                                const float4 v = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(
-                                                     rs_p, lane_off + ((tm * TN + tn) * 4 + q) * 1024, so, kSc1));
-                                acc[tm][tn][4 * q] += v.x; acc[tm][tn][4 * q + 1] += v.y;
-                                acc[tm][tn][4 * q + 2] += v.z; acc[tm][tn][4 * q + 3] += v.w;
-                            }
+                        for (int j = 0; j < kBatch; ++j) {
+                            const int pc = b0 + j, blk = pc >> 2, q = pc & 3;   // piece -> (tm, tn) block, row quad
+                            const float4 v = __builtin_bit_cast(float4, t[j]);
+                            acc[blk / TN][blk % TN][4 * q] += v.x; acc[blk / TN][blk % TN][4 * q + 1] += v.y;
+                            acc[blk / TN][blk % TN][4 * q + 2] += v.z; acc[blk / TN][blk % TN][4 * q + 3] += v.w;
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
                 }
                 gemm_epilogue<WR, TM, TN, 16, WC>(p, acc, mt, nt, reinterpret_cast<float*>(lds));
                 if (tid == 0) atomicExch(p.sk_count + rel, 0ull);
