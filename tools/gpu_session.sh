@@ -1,6 +1,8 @@
 #!/bin/bash
 # One GPU-box session (run through gpurun from the repo root): parity report, GPU test-suite, smoke, bench lines, profile.
-# Usage: bash tools/gpu_session.sh <tag> [steps...]   steps: report tests smoke bench forcedist config3 prof pmc
+# Usage: bash tools/gpu_session.sh <tag> [steps...]   steps: report tests smoke bench forcedist config3 configs prof pmc pmc3 prof3 convbench
+#        A/B steps (same box, alternating): ab (stream-K completion x BN reduction), abenv (AB_ENV="NAME a b"), abw / wgab (wgrad tile),
+#        wdab (wgrad deep prefetch), gnab (gather-GEMM tile), skab (stream-K threshold), sqw (SQ counters of the wgrad tiles), tests2b, parity
 # Everything lands in gpurun_out/<tag>_*; nothing here reads /root/reference.
 tag=${1:-r2}; shift
 steps=${*:-report tests smoke bench forcedist config3 prof}
