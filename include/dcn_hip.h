@@ -304,6 +304,14 @@ int dcn_conv_dgrad_bn_f16(const dcn_conv_desc* c, const float* dout, const void*
                           const unsigned char* relu_mask, const float* bn_stats, float* bn_partial, void* workspace,
                           void* stream);
 
+/* The backbone's stem (7x7 / stride 2 / pad 3 on 3 + 1 zero input channels; K1 of SURVEY.md section 8a) as a uniform-tap
+ * convolution: a filter ROW is one 32-K chunk (8 pixels x 4 channels = 128 contiguous bytes of the NHWC4 image, the 8th
+ * pixel with zero weights), so the gather is the wide layers' per-row buffer load instead of a per-element tap decode.
+ * w4: [cout][7][7][4] fp32; hi / lo receive [cout][7][8][4] fp16.  Same result as dcn_conv_forward_f16. */
+int dcn_split_stem_weights_f16(const float* w4, void* hi, void* lo, int cout, float scale, void* stream);
+int dcn_conv_stem_forward_f16(const dcn_conv_desc* c, const float* in, const float* in_absmax, const void* w_hi, const void* w_lo,
+                              float w_scale, float* out, float* bn_partial, void* stream);
+
 /* All weight tensors of a network in one launch: w[i] = [cout[i]][taps[i]][cin[i]] (device), hi[i] / lo[i] (device) receive
  * the forward image [cout][kpad(taps*cin)] or, transposed != 0, the dgrad image [cin][kpad(taps*ldn[i])] of
  * dcn_transpose_weight + dcn_split_rows_f16.  The seven arrays themselves are HOST arrays of length n. */

@@ -83,7 +83,7 @@ struct dcn_plan {
     int n_act = 0;    // activation tensors that feed a convolution: s_actmax[n_act] abs-max scalars + one status word behind them
     // workspace offsets (floats)
     size_t w_buf[6] = {0, 0, 0, 0, 0, 0}, w_wt = 0, w_slab = 0, w_part = 0, w_k123 = 0, w_wstem = 0, w_dwstem = 0,
-           w_glow = 0, w_ups = 0, w_sk = 0, w_gnorm = 0, w_wh = 0, w_wl = 0, w_amax = 0, w_dq = 0, w_dq2 = 0, ws_floats = 0;
+           w_glow = 0, w_ups = 0, w_sk = 0, w_stem8 = 0, w_gnorm = 0, w_wh = 0, w_wl = 0, w_amax = 0, w_dq = 0, w_dq2 = 0, ws_floats = 0;
     int conv_mode = DCN_CONV_F16X3;
     size_t max_act = 0, sk_bytes = 0;   // sk_bytes: size of the stream-K scratch at w_sk
     double flops = 0;
@@ -344,6 +344,7 @@ int build_plan(dcn_plan& p) {
     p.w_k123 = alloc((size_t)3 * max_c * p.groups);
     p.w_wstem = alloc((size_t)p.base * 49 * 4);
     p.w_dwstem = alloc((size_t)p.base * 49 * 4);
+    p.w_stem8 = alloc((size_t)p.base * 224);   // stem weights as [cout][7][8][4] fp16 hi | lo (uniform-tap stem path): 2 planes x 224 halves per channel
     p.w_glow = alloc((size_t)N * p.hl * p.wl * p.Dp);
     p.w_gnorm = alloc((size_t)N * p.H * p.W * p.D);
     p.w_ups = alloc(dcn::upsample_bwd_tmp_bytes(N, p.hl, p.W, p.D) / sizeof(float));
@@ -408,6 +409,7 @@ struct Run {
     float* saved;
     float* ws;
     hipStream_t st;
+    bool stem8 = false;   // this call runs the stem through dcn_conv_stem_forward_f16
 
     // bracket one matrix-core launch with events when profiling is on
     template <class F> int timed(int cat, double flops, F&& launch) {
@@ -451,6 +453,12 @@ struct Run {
         if (p.conv_mode == DCN_CONV_FP32)
             return timed(0, c.flops, [&] { return dcn_conv_forward(&c.d, in, w, bias, out, part, SK(c, 0), st); });
         (void)w;   // split-fp16 mode: the image was produced by split_all_weights at the start of the call
+        if (c.idx == p.stem && stem8) {   // the 7x7 stem through the uniform-tap path (image prepared by dcn_backbone_forward)
+            _Float16* hi = (_Float16*)Wk(p.w_stem8);
+            return timed(0, c.flops, [&] {
+                return dcn_conv_stem_forward_f16(&c.d, in, A(c.in_act), hi, hi + (size_t)p.base * 224, kWeightScale, out, part, st);
+            });
+        }
         return timed(0, c.flops, [&] {
             return dcn_conv_forward_f16(&c.d, in, A(c.in_act), wimg(p.w_wh, c), wimg(p.w_wl, c), kWeightScale, bias, out, part,
                                         SK(c, 0), st);
@@ -659,6 +667,11 @@ extern "C" int dcn_backbone_forward(dcn_plan* plan, const float* image, const fl
         }
     } else {
     if (p.conv_mode == DCN_CONV_F16X3) DCN_TRY(R.split_all_weights(false, R.Wk(p.w_wstem)));
+    if (p.conv_mode == DCN_CONV_F16X3 && dcn::tuning().stem8 != 0 && stem.d.win >= 8 && stem.d.kh == 7 && stem.d.cin == 4) {
+        _Float16* hi = (_Float16*)R.Wk(p.w_stem8);
+        DCN_TRY(dcn_split_stem_weights_f16(R.Wk(p.w_wstem), hi, hi + (size_t)p.base * 224, p.base, kWeightScale, st));
+        R.stem8 = true;
+    }
     DCN_TRY(R.conv_bn(stem, R.S(p.s_in4), R.Wk(p.w_wstem), bn_running, momentum, eps, training, p.blocks[0].act_in));
     {
         const BnL& b = p.bns[stem.bn];

@@ -125,6 +125,21 @@ transpose_split_batched_kernel(SplitTable t) {
     }
 }
 
+// stem weights w4[cout][7][7][4] (3 real channels + a zero) -> hi / lo [cout][7][8][4]: filter rows of 8 x 4 = 32 K, the 8th
+// column zero (the layout of the uniform-tap stem path, gemm_segment_f16)
+__global__ void __launch_bounds__(256)
+split_stem8_kernel(const float* __restrict__ w4, _Float16* __restrict__ hi, _Float16* __restrict__ lo, int cout, float s) {
+    const int i = blockIdx.x * 256 + threadIdx.x;   // over cout * 7 * 8
+    if (i >= cout * 56) return;
+    const int kx = i & 7, t = i >> 3;               // t = n * 7 + ky
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (kx < 7) v = *reinterpret_cast<const float4*>(w4 + ((int64_t)t * 7 + kx) * 4);
+    h4 a, b;
+    split4(v, s, a, b);
+    *reinterpret_cast<h4*>(hi + (int64_t)i * 4) = a;
+    *reinterpret_cast<h4*>(lo + (int64_t)i * 4) = b;
+}
+
 // ----------------------------------------------------------------------------------------------- gather-GEMM, f16x3
 // WR: wavefront rows of the workgroup (WR x 2 wavefronts, 128 WR work-items): 2 -> tiles of 64 TM x 64 TN, two workgroups
 // per CU; 4 -> 128 TM x 64 TN on 8 wavefronts, ONE workgroup per CU (same 8 wavefronts per CU, but a quarter fewer
@@ -212,20 +227,26 @@ __device__ __forceinline__ void gemm_segment_f16(const GemmConv& p, _Float16* ld
     const __amdgpu_buffer_rsrc_t rs_a = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.src), 0, (int)p.src_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rs_h = __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16*>(p.wh), 0, (int)p.w_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rs_l = __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16*>(p.wl), 0, (int)p.w_bytes, 0x00020000);
-    const int cpt = p.cs / HBK;                                     // 32-K chunks per tap
+    // STEM (p.stem8, forward only): the 7x7 / stride-2 stem on 4 (3 + 1) input channels as a uniform-tap convolution -- a
+    // "tap" is a filter ROW and its 32-K chunk the 8 pixels x 4 channels = 128 contiguous bytes that start at the row's
+    // first column (8th pixel: zero weights, not loaded); a work-item's k quad kq is then a PIXEL offset, so the validity
+    // of a load depends on (row, kq) -- still one offset per register, no per-element tap decode (K = 7 x 32 = 224)
+    const bool st8 = UNI && !TR && p.stem8 != 0;
+    const int cpt = st8 ? 1 : p.cs / HBK;                           // 32-K chunks per tap
     const int cbs = (4 * p.cs) >> (TR ? p.sshift : 0);             // bytes per unit of (by, bx)
     // K traversal of the UNI path: channel-chunk groups outermost (kcg chunks = up to 128 channels), then the filter
     // taps, then the chunks of the group -- a tap change (new voff[]) only every kcg stages, and the SAME input pixels
     // come back for the next tap after kcg stages, while they are still in this XCD's L2 (tap-major order re-reads them
     // cs / 32 stages later: measured 48 % L2 hit rate on the 512-channel layers).
     const int kcg = (cpt & 3) == 0 ? 4 : ((cpt & 1) == 0 ? 2 : 1);
-    const int taps = p.kh * p.kw;
+    const int taps = st8 ? p.kh : p.kh * p.kw;
     int rowoff[PA], voff[PA], voffb[PB];
     int u_tap = 0, u_grp = 0, u_c = 0, u_kt = k0;
     auto set_tap = [&](int tap) {
-        const int r = fdiv(tap, p.div_kw), s = tap - r * p.kw;
+        const int r = st8 ? tap : fdiv(tap, p.div_kw), s = st8 ? 0 : tap - r * p.kw;
         const int dy = r * p.dil, dx = s * p.dil;
         const int delta = (dy * p.ws + dx) * cbs;
+        const int dxq = st8 ? kq : 0;                               // (stem: this work-item's column inside the 8-pixel chunk)
 #pragma unroll
         for (int j = 0; j < PA; ++j) {
             bool ok;
@@ -233,7 +254,7 @@ __device__ __forceinline__ void gemm_segment_f16(const GemmConv& p, _Float16* ld
                 const int ny = by[j] - dy, nx = bx[j] - dx;
                 ok = ((ny | nx) >= 0) & (((ny | nx) & smask) == 0) & ((ny >> p.sshift) < p.hs) & ((nx >> p.sshift) < p.ws);
             } else {
-                ok = ((unsigned)(by[j] + dy) < (unsigned)p.hs) & ((unsigned)(bx[j] + dx) < (unsigned)p.ws);
+                ok = ((unsigned)(by[j] + dy) < (unsigned)p.hs) & ((unsigned)(bx[j] + dx + dxq) < (unsigned)p.ws) & (dxq < 7);
             }
             voff[j] = ok ? (TR ? rowoff[j] - delta : rowoff[j] + delta) : kOob;
         }
@@ -258,7 +279,7 @@ __device__ __forceinline__ void gemm_segment_f16(const GemmConv& p, _Float16* ld
 #pragma unroll
         for (int j = 0; j < PA; ++j)
             ra[set][j] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rs_a, voff[j], soff, 0));
-        const int soffb = (u_tap * p.cs + chunk * HBK) * 2;
+        const int soffb = (u_tap * (st8 ? HBK : p.cs) + chunk * HBK) * 2;
 #pragma unroll
         for (int j = 0; j < PB; ++j) {
             rbh[set][j] = __builtin_bit_cast(h8, __builtin_amdgcn_raw_buffer_load_b128(rs_h, voffb[j], soffb, 0));
@@ -714,7 +735,8 @@ int launch_gemm_f16(GemmConv& p, void* workspace, hipStream_t st, int align = 0)
     }
     // uniform-tap fast path: whole 32-K stages inside one filter tap, tensors addressable through 2 GiB buffer resources
     const int64_t src_bytes = (int64_t)p.M / (p.hd * p.wd) * p.hs * p.ws * p.cs * 4, w_bytes = (int64_t)p.cd * p.kp * 2;
-    bool uni = (p.cs % HBK) == 0 && src_bytes <= ((int64_t)1 << 31) && w_bytes <= ((int64_t)1 << 31);
+    bool uni = ((p.cs % HBK) == 0 || p.stem8) && src_bytes <= ((int64_t)1 << 31) && w_bytes <= ((int64_t)1 << 31);
+    if (p.stem8 && !(uni && dcn::tuning().gemm_uni != 0)) return DCN_E_UNSUPPORTED;
     uni = uni && dcn::tuning().gemm_uni != 0;
     p.src_bytes = uni ? (unsigned)src_bytes : 0u;
     p.w_bytes = uni ? (unsigned)w_bytes : 0u;
@@ -1222,6 +1244,28 @@ extern "C" int dcn_conv_forward_f16(const dcn_conv_desc* c, const float* in, con
     p.kh = c->kh; p.kw = c->kw; p.stride = c->stride; p.pad = c->pad; p.dil = c->dil; p.ldc = c->ldc;
     p.M = c->n * c->hout * c->wout; p.K = c->kh * c->kw * c->cin; p.kp = dcn_f16_kpad(p.K); p.transposed = 0; p.relu = 0;
     return launch_gemm_f16(p, workspace, (hipStream_t)stream, c->group_rows);
+}
+
+// The 7x7 / stride-2 / pad-3 stem on 4-channel input (3 + a zero channel) through the uniform-tap path: w_hi / w_lo from
+// dcn_split_stem_weights_f16 ([cout][7][8][4]).  Same result as dcn_conv_forward_f16 on the same descriptor.
+extern "C" int dcn_split_stem_weights_f16(const float* w4, void* hi, void* lo, int cout, float scale, void* stream) {
+    if (!w4 || !hi || !lo || cout < 1 || !(scale > 0.f)) return DCN_E_INVALID;
+    hipLaunchKernelGGL(split_stem8_kernel, dim3((unsigned)dcn::ceil_div(cout * 56, 256)), dim3(256), 0, (hipStream_t)stream, w4,
+                       (_Float16*)hi, (_Float16*)lo, cout, scale);
+    return dcn::check_launch();
+}
+
+extern "C" int dcn_conv_stem_forward_f16(const dcn_conv_desc* c, const float* in, const float* in_absmax, const void* w_hi,
+                                         const void* w_lo, float w_scale, float* out, float* bn_partial, void* stream) {
+    if (!valid_desc16(c) || !in || !w_hi || !w_lo || !out || !(w_scale > 0.f)) return DCN_E_INVALID;
+    if (c->kh != 7 || c->kw != 7 || c->cin != 4 || c->stride != 2 || c->pad != 3 || c->dil != 1 || c->win < 8) return DCN_E_UNSUPPORTED;
+    GemmConv p;
+    p.src = in; p.wm = nullptr; p.bias = nullptr; p.add = nullptr; p.dst = out; p.bn_partial = bn_partial; p.out_absmax = nullptr;
+    p.wh = (const _Float16*)w_hi; p.wl = (const _Float16*)w_lo; p.a_absmax = in_absmax; p.b_inv_scale = 1.f / w_scale;
+    p.hs = c->hin; p.ws = c->win; p.cs = c->cin; p.hd = c->hout; p.wd = c->wout; p.cd = c->cout;
+    p.kh = c->kh; p.kw = c->kw; p.stride = c->stride; p.pad = c->pad; p.dil = c->dil; p.ldc = c->ldc;
+    p.M = c->n * c->hout * c->wout; p.K = 7 * HBK; p.kp = 7 * HBK; p.transposed = 0; p.relu = 0; p.stem8 = 1;
+    return launch_gemm_f16(p, nullptr, (hipStream_t)stream, c->group_rows);
 }
 
 // Inference form: out = [relu](conv(in, w) + bias [+ add]) in one pass (w / bias with the eval-mode batch norm folded in:

@@ -40,6 +40,7 @@ struct GemmConv {
     unsigned long long* sk_count = nullptr;   // split-fp16 kernel, optional: arrival word per stream-K tile -- (launch id << 32) | arrivals;
                                     // the last contributor of a tile completes it inside the launch (no fix-up kernel)
     unsigned sk_id = 0;             // id of this launch (never 0)
+    int stem8 = 0;                  // split-fp16 forward: the 7x7 stem as a uniform-tap convolution over filter rows (conv_f16_kernels.hip)
     unsigned sk_bytes = 0;          // extent of sk_partial (buffer-resource bound of the device-coherent partial accesses)
     // Optional (dgrad whose result is the upstream gradient dy of a batch norm): the backward REDUCTION of that batch norm in
     // this epilogue -- dst receives the ReLU-masked gradient g (mask bit of the BN's output taken from bnb_mask, one byte

@@ -5,6 +5,7 @@
 //   DCN_GEMM_TILE_M         32 | 64 | 128 | 256   workgroup-tile height of the gather-GEMM kernels
 //   DCN_GEMM_TILE_N         256: 128 x 256 tiles (2 x 4 wavefronts) instead of 256 x 128 in the split-fp16 gather-GEMM
 //                           (measured: no gain, profiles/r2f_gemm_tile_n_ab.txt)
+//   DCN_STEM8               0: the 7x7 stem runs the generic gather path (1: as a uniform-tap convolution over filter rows)
 //   DCN_GEMM_SK             0: no stream-K, 1: as decided, N > 1: force N workgroups
 //   DCN_GEMM_SK_MIN_GAIN    stage times stream-K must save to be chosen (split-fp16 kernel)
 //   DCN_GEMM_UNI            0: disable the uniform-tap fast path
@@ -33,6 +34,7 @@ struct Tuning {
     int gemm_sk = -1;            // -1: unset
     double gemm_sk_min_gain = 20.0;
     int gemm_uni = 1;
+    int stem8 = 1;
     int gemm_sk_inline = 1;      // stream-K tiles completed inside the GEMM launch (0: separate fix-up kernel)
     int bn_bwd_fused = 0;
     int defer_residual_add = 1;

@@ -26,6 +26,7 @@ void read_env(Tuning& t) {
     if (const char* e = getenv("DCN_GEMM_TILE_N")) t.gemm_tile_n = atoi(e);
     if (const char* e = getenv("DCN_GEMM_SK")) t.gemm_sk = atoi(e);
     if (const char* e = getenv("DCN_GEMM_SK_MIN_GAIN")) t.gemm_sk_min_gain = atof(e);
+    if (const char* e = getenv("DCN_STEM8")) t.stem8 = atoi(e) != 0;
     if (const char* e = getenv("DCN_GEMM_UNI")) t.gemm_uni = atoi(e) != 0;
     if (const char* e = getenv("DCN_GEMM_SK_FIXUP")) t.gemm_sk_inline = strcmp(e, "kernel") != 0;
     if (const char* e = getenv("DCN_BN_BWD_FUSED")) t.bn_bwd_fused = atoi(e) != 0;

@@ -84,6 +84,9 @@ SYMBOLS = {
                                      c_void_p, c_void_p, c_void_p, c_void_p]),
     "dcn_conv_dgrad_f16": (c_int, [ctypes.POINTER(ConvDesc), c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_void_p,
                                    c_void_p, c_void_p, c_void_p]),
+    "dcn_split_stem_weights_f16": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_float, c_void_p]),
+    "dcn_conv_stem_forward_f16": (c_int, [ctypes.POINTER(ConvDesc), c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_void_p,
+                                          c_void_p, c_void_p]),
     "dcn_conv_dgrad_bn_num_mtiles_f16": (c_int, [ctypes.POINTER(ConvDesc)]),
     "dcn_conv_dgrad_bn_f16": (c_int, [ctypes.POINTER(ConvDesc), c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_void_p,
                                       c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),

@@ -148,3 +148,52 @@ def check_stream_k_inline(L, dev, set_env, n, h, w, cin, cout, k, dil, sk, tile_
     for o_i, p_i in res["inline"]:
         assert torch.equal(o_i, o_k) and torch.equal(p_i, p_k)
     return True
+
+
+def check_stem_uniform_tap(L, dev, n, hin, win):
+    """dcn_conv_stem_forward_f16: the 7x7 / 2 stem with a filter row as one 32-K chunk (8 pixels x 4 channels, 8th pixel zero
+    weights, per-work-item column validity) == the generic gather path == F.conv2d, borders and odd sizes included; a NaN in
+    the 8th (unused) column of a window must not leak into the result."""
+    lib = L.get()
+    cout = 16
+    hout, wout = (hin + 6 - 7) // 2 + 1, (win + 6 - 7) // 2 + 1
+    d = L.ConvDesc(n, hin, win, 4, hout, wout, cout, 7, 7, 2, 3, 1, cout)
+    g = torch.Generator().manual_seed(2)
+    x = torch.randn(n, hin, win, 4, generator=g)
+    x[..., 3] = 0
+    xd = x.to(dev)
+    w4 = torch.randn(cout, 7, 7, 4, generator=g) * 0.1
+    w4[..., 3] = 0
+    w4d = w4.to(dev)
+    hi = torch.empty(cout, 224, dtype=torch.float16, device=dev)
+    lo = torch.empty(cout, 224, dtype=torch.float16, device=dev)
+    assert lib.dcn_split_stem_weights_f16(L.ptr(w4d), L.ptr(hi), L.ptr(lo), cout, 64.0, None) == 0
+    rec = ((hi.float() + lo.float()) / 64.0).reshape(cout, 7, 8, 4).cpu()
+    assert rel_err(rec[:, :, :7], w4) < 1e-6 and float(rec[:, :, 7].abs().max()) == 0
+    mt = lib.dcn_conv_num_mtiles_f16(ctypes.byref(d))
+    out = torch.full((n, hout, wout, cout), float("nan"), device=dev)
+    part = torch.full((mt, 3, cout), float("nan"), device=dev)
+    assert lib.dcn_conv_stem_forward_f16(ctypes.byref(d), L.ptr(xd), None, L.ptr(hi), L.ptr(lo), 64.0, L.ptr(out), L.ptr(part), None) == 0
+    ref = F.conv2d(x.permute(0, 3, 1, 2), w4.permute(0, 3, 1, 2), None, 2, 3, 1).permute(0, 2, 3, 1)
+    assert rel_err(out.cpu(), ref) < 3e-6
+    assert rel_err(part.cpu().sum(0)[0], ref.sum((0, 1, 2))) < 1e-5
+    # generic path on the same tensors
+    K = 196
+    wh = torch.empty(cout, lib.dcn_f16_kpad(K), dtype=torch.float16, device=dev)
+    wl = torch.empty_like(wh)
+    w2 = w4d.reshape(cout, K).contiguous()
+    assert lib.dcn_split_rows_f16(L.ptr(w2), L.ptr(wh), L.ptr(wl), cout, K, 64.0, None) == 0
+    out2 = torch.full_like(out, float("nan"))
+    assert lib.dcn_conv_forward_f16(ctypes.byref(d), L.ptr(xd), None, L.ptr(wh), L.ptr(wl), 64.0, None, L.ptr(out2), None, None, None) == 0
+    assert rel_err(out.cpu(), out2.cpu()) < 2e-6
+    if win >= 12:   # a NaN that only ever sits in the 8th column of some window: x = 2*ox - 3 + 7 for ox = 1 -> column 6... use
+        xb = x.clone()   # the last pixel of a row seen as column 7 by the window of ox = (win - 1 - 4) / 2 when that is integral
+        col = win - 1
+        if (col - 4) % 2 == 0:
+            ox7 = (col - 4) // 2          # window of ox7 starts at 2*ox7 - 3 = col - 7: col is its 8th pixel
+            xb[0, 5 if hin > 5 else 0, col, 0] = float("nan")
+            xbd = xb.to(dev)
+            out3 = torch.full_like(out, float("nan"))
+            assert lib.dcn_conv_stem_forward_f16(ctypes.byref(d), L.ptr(xbd), None, L.ptr(hi), L.ptr(lo), 64.0, L.ptr(out3), None, None) == 0
+            refb = F.conv2d(xb.permute(0, 3, 1, 2), w4.permute(0, 3, 1, 2), None, 2, 3, 1).permute(0, 2, 3, 1)
+            assert torch.equal(torch.isnan(out3.cpu()), torch.isnan(refb))   # NaN exactly where the true convolution has it

@@ -449,3 +449,9 @@ def test_wgrad_f16_deep_prefetch_is_bit_identical(L, case, dcn_env):
     (F.conv2d(x.permute(0, 3, 1, 2), w, None, stride, pad, dil) * dout.permute(0, 3, 1, 2)).sum().backward()
     assert rel_err(res[0], w.grad.permute(0, 2, 3, 1)) < 5e-6
     assert all(torch.equal(res[0], r) for r in res[1:])
+
+
+@pytest.mark.parametrize("shape", [(2, 18, 26), (1, 9, 8), (1, 32, 40)], ids=str)
+def test_stem_through_uniform_tap_path(L, shape):
+    import kernel_checks
+    kernel_checks.check_stem_uniform_tap(L, "cpu", *shape)

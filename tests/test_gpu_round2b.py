@@ -93,3 +93,10 @@ def test_network_step_fused_vs_separate_bn_reduction(L, arch, H, W, D, dcn_env):
             pc.assert_as_accurate_as_float32(st, factor=2.0, floor=5e-4)
     finally:
         backbone.set_conv_mode(None)
+
+
+@pytest.mark.parametrize("shape", [(8, 480, 640), (2, 96, 128), (1, 33, 47)], ids=str)
+def test_stem_through_uniform_tap_path(L, shape):
+    """The 7x7 / 2 stem as a uniform-tap convolution over filter rows (dcn_conv_stem_forward_f16) == the generic gather path ==
+    F.conv2d on the CPU, at the full 640x480 image too."""
+    kernel_checks.check_stem_uniform_tap(L, "cuda", *shape)
