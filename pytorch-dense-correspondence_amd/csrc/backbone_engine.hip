@@ -667,7 +667,8 @@ extern "C" int dcn_backbone_forward(dcn_plan* plan, const float* image, const fl
         }
     } else {
     if (p.conv_mode == DCN_CONV_F16X3) DCN_TRY(R.split_all_weights(false, R.Wk(p.w_wstem)));
-    if (p.conv_mode == DCN_CONV_F16X3 && dcn::tuning().stem8 != 0 && stem.d.win >= 8 && stem.d.kh == 7 && stem.d.cin == 4) {
+    if (p.conv_mode == DCN_CONV_F16X3 && dcn::tuning().stem8 != 0 && dcn::tuning().gemm_uni != 0 && stem.d.win >= 8 && stem.d.kh == 7 &&
+        stem.d.cin == 4 && (int64_t)stem.d.n * stem.d.hin * stem.d.win * 16 <= ((int64_t)1 << 31)) {
         _Float16* hi = (_Float16*)R.Wk(p.w_stem8);
         DCN_TRY(dcn_split_stem_weights_f16(R.Wk(p.w_wstem), hi, hi + (size_t)p.base * 224, p.base, kWeightScale, st));
         R.stem8 = true;
