@@ -160,7 +160,11 @@ class _BackboneFn(torch.autograd.Function):
                                       _lib.ptr(ws), _lib.stream_ptr())
         _lib.check(rc, "dcn_backbone_forward")
         ctx.plan = plan
-        plan.last_activation_range = plan.activation_range(saved)   # views into this call's arena (no sync)
+        # the n + 1 range scalars are COPIED out (a small device-to-device copy, no sync): views would keep the whole saved
+        # arena of this call alive on the long-lived plan -- two arenas per forward, and one pinned for ever after an
+        # eval / inference call
+        amax, status = plan.activation_range(saved)
+        plan.last_activation_range = (amax.clone(), status.clone())
         ctx.grad_sink = getattr(bn_running, "grad_sink", None)
         ctx.grad_owner = getattr(bn_running, "grad_owner", None)
         ctx.grad_probe = (params[0], params[-1])  # to verify at backward time that .grad still aliases the sink

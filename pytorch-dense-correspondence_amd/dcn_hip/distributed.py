@@ -68,11 +68,20 @@ class FlatGradients(object):
     def note_detached(self):
         self._detached = True
 
+    def _join_comm_stream(self):
+        """A bucketed backward that was never followed by ``all_reduce_mean`` (a step skipped on a non-finite loss, world 1
+        with ``bucketed=True``) still has its ``flat[lo:hi].add_`` / all-reduce pending on the communication stream: anything
+        that touches the flat buffer on the current stream must be ordered behind it."""
+        if self._comm_stream is not None and self.flat.is_cuda:
+            torch.cuda.current_stream(self.flat.device).wait_stream(self._comm_stream)
+
     def ensure_views(self):
         """``optimizer.zero_grad()`` (training.py:325) defaults to ``set_to_none=True`` in today's torch and drops the
         ``p.grad`` views; autograd then allocates fresh gradient tensors and the flat buffer would be stale.  Called
         before every collective: any ``p.grad`` that no longer aliases the buffer is copied in and re-installed
         (``None`` -> that slice is zeroed), so the collective always averages what the optimizer will read."""
+        if self._bucket_step:
+            self._join_comm_stream()
         fixed = 0
         for p, v in zip(self.params, self._views):
             g = p.grad
@@ -92,6 +101,7 @@ class FlatGradients(object):
     def zero_(self):
         """optimizer.zero_grad() equivalent that keeps the views alive (preferred over set_to_none=True: no
         re-installation copies, and the fused backbone keeps accumulating with one kernel)."""
+        self._join_comm_stream()
         self.ensure_views()
         self.flat.zero_()
         self._bucket_step = False

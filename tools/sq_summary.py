@@ -18,17 +18,17 @@ def main():
     for d in dirs:
         for f in sorted(glob.glob(d + "/**/*_counter_collection.csv", recursive=True)):
             for r in csv.DictReader(open(f)):
-                name = re.sub(r"\(.*$", "", r["Kernel_Name"].replace("(anonymous namespace)::", ""))
+                name = re.sub(r"\(.*$", "", r["Kernel_Name"].replace("(anonymous namespace)::", "").replace("void ", ""))
                 tot[name][r["Counter_Name"]] += float(r["Counter_Value"])
                 cnt[name][r["Counter_Name"]] += 1
         for f in sorted(glob.glob(d + "/**/*_kernel_trace.csv", recursive=True)):
             for r in csv.DictReader(open(f)):
-                name = re.sub(r"\(.*$", "", r["Kernel_Name"].replace("(anonymous namespace)::", ""))
+                name = re.sub(r"\(.*$", "", r["Kernel_Name"].replace("(anonymous namespace)::", "").replace("void ", ""))
                 dur[name].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
     with open(out, "w") as o:
         o.write("# " + header + "\n")
         for name in sorted(tot, key=lambda k: -sum(dur.get(k, [0]))):
-            if "wgrad_f16" not in name and "conv_gemm_f16" not in name:
+            if "wgrad_f16" not in name and "conv_gemm_f16" not in name and "gemm_hl" not in name:
                 continue
             d = dur.get(name, [])
             o.write("%s   (%d launches, %.1f us average while counting)\n" % (name, len(d), sum(d) / max(len(d), 1)))
