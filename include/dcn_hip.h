@@ -304,6 +304,26 @@ int dcn_conv_dgrad_bn_f16(const dcn_conv_desc* c, const float* dout, const void*
                           const unsigned char* relu_mask, const float* bn_stats, float* bn_partial, void* workspace,
                           void* stream);
 
+/* ---- pre-split ("hl32") operand path of the wide layers (csrc/conv_hl_kernels.hip): the forward convolution and dgrad of
+ * every stride-1 convolution with >= 256 destination channels and source channels % 32 == 0 (layers 3-4 of the backbone behind
+ * network.py:255 / training.py:345).  Operands are "hl32" tensors -- per 32-channel chunk one 128-byte line
+ * [hi x32 | lo x32] fp16, the byte size of the fp32 tensor -- so that the GEMM loop is LDS-DMA + MFMA only (256 x 256 tiles,
+ * two wavefront groups one phase apart).  Results equal dcn_conv_forward_f16 / dcn_conv_dgrad_f16 (same products, other
+ * summation order).  dcn_conv_hl_eligible: 1 when the descriptor qualifies (forward: dgrad = 0). */
+int dcn_conv_hl_eligible(const dcn_conv_desc* c, int dgrad);
+int dcn_conv_num_mtiles_hl(const dcn_conv_desc* c);
+size_t dcn_conv_gemm_workspace_hl(const dcn_conv_desc* c, int dgrad);
+/* fp32 [rows][channels] (channels % 32 == 0) -> hl32, scaled by the power of two chosen from *absmax (NULL: 1) */
+int dcn_split_act_hl32(const float* src, const float* absmax, void* dst, int64_t rows, int channels, void* stream);
+/* n weight tensors w[i] = [cout][taps][cin] -> out[i] = hl32 [cout][taps*cin/32][hi|lo], or (transposed) the dgrad image
+ * [cin][taps*ldn/32][hi|lo]; all arrays are HOST arrays */
+int dcn_split_weights_hl32(int n, const float* const* w, void* const* out, const int* cout, const int* taps, const int* cin,
+                           const int* ldn, int transposed, float scale, void* stream);
+int dcn_conv_forward_hl(const dcn_conv_desc* c, const void* in_hl, const float* in_absmax, const void* w_hl, float w_scale,
+                        const float* bias, float* out, float* bn_partial, void* workspace, void* stream);
+int dcn_conv_dgrad_hl(const dcn_conv_desc* c, const void* dout_hl, const void* wt_hl, float w_scale, const float* dout_absmax,
+                      const float* add, float* din, void* workspace, void* stream);
+
 /* The backbone's stem (7x7 / stride 2 / pad 3 on 3 + 1 zero input channels; K1 of SURVEY.md section 8a) as a uniform-tap
  * convolution: a filter ROW is one 32-K chunk (8 pixels x 4 channels = 128 contiguous bytes of the NHWC4 image, the 8th
  * pixel with zero weights), so the gather is the wide layers' per-row buffer load instead of a per-element tap decode.

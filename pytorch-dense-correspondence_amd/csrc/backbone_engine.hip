@@ -37,6 +37,8 @@ struct ConvL {
     int cin_true = 0;
     int mtiles[2] = {0, 0};   // BN partial-sum rows of the forward kernel, per conv mode
     size_t wsplit = 0;        // offset (halves) of this conv's fp16 weight image inside w_wh / w_wl (forward or dgrad image)
+    size_t whl = 0;           // offset (floats) of its hl32 weight image inside w_whl (conv_hl_kernels.hip), forward or dgrad image
+    bool hl_any = false;      // some launch of this convolution may take the hl32 path (an image slot is reserved)
     int idx = 0;
     int in_act = -1;          // abs-max slot of the activation tensor this convolution reads (split-fp16 operand pre-scale)
     std::string name;
@@ -83,7 +85,8 @@ struct dcn_plan {
     int n_act = 0;    // activation tensors that feed a convolution: s_actmax[n_act] abs-max scalars + one status word behind them
     // workspace offsets (floats)
     size_t w_buf[6] = {0, 0, 0, 0, 0, 0}, w_wt = 0, w_slab = 0, w_part = 0, w_k123 = 0, w_wstem = 0, w_dwstem = 0,
-           w_glow = 0, w_ups = 0, w_sk = 0, w_stem8 = 0, w_gnorm = 0, w_wh = 0, w_wl = 0, w_amax = 0, w_dq = 0, w_dq2 = 0, ws_floats = 0;
+           w_glow = 0, w_ups = 0, w_sk = 0, w_stem8 = 0, w_gnorm = 0, w_wh = 0, w_wl = 0, w_amax = 0, w_dq = 0, w_dq2 = 0, w_whl = 0,
+           w_hl = 0, w_hl2 = 0, ws_floats = 0;
     int conv_mode = DCN_CONV_F16X3;
     size_t max_act = 0, sk_bytes = 0;   // sk_bytes: size of the stream-K scratch at w_sk
     double flops = 0;
@@ -322,7 +325,8 @@ int build_plan(dcn_plan& p) {
         const size_t sl = std::max(dcn_conv_wgrad_workspace(&c.d), dcn_conv_wgrad_workspace_f16(&c.d)) / sizeof(float);
         if (sl > max_slab) max_slab = sl;
         for (int dg = 0; dg < 2; ++dg) {
-            const size_t sk = std::max(dcn_conv_gemm_workspace(&c.d, dg), dcn_conv_gemm_workspace_f16(&c.d, dg)) / sizeof(float);
+            const size_t sk = std::max(std::max(dcn_conv_gemm_workspace(&c.d, dg), dcn_conv_gemm_workspace_f16(&c.d, dg)),
+                                       dcn_conv_gemm_workspace_hl(&c.d, dg)) / sizeof(float);
             if (sk > max_sk) max_sk = sk;
         }
         // (sized for the smallest M tile any tuning override can select -- 32 rows --, not for the tile chosen today)
@@ -359,6 +363,19 @@ int build_plan(dcn_plan& p) {
         }
         p.w_wh = alloc((halves + 1) / 2);
         p.w_wl = alloc((halves + 1) / 2);
+    }
+    {   // hl32 weight images (conv_hl_kernels.hip) of the convolutions whose forward or dgrad may take that path (the image of
+        // the forward pass and the one of the backward pass share the slot), and ONE transient hl32 activation / gradient image
+        size_t fl = 0;
+        for (ConvL& c : p.convs) {
+            if (c.idx == p.stem || c.idx == p.fc || c.d.stride != 1 || ((c.d.cin % 32) != 0 && (c.d.ldc % 32) != 0)) continue;
+            c.hl_any = true;
+            c.whl = fl;
+            fl += align64((size_t)c.d.kh * c.d.kw * std::max((size_t)c.d.cout * c.d.cin, (size_t)c.d.cin * c.d.ldc));
+        }
+        p.w_whl = alloc(fl);
+        p.w_hl = alloc(p.max_act);    // image of a block's input / output (forward), of a batch-norm backward's dx (backward)
+        p.w_hl2 = alloc(p.max_act);   // image of a block's mid activation
     }
     p.w_amax = alloc(p.convs.size());   // abs-max of the gradient w.r.t. each convolution's output
     {   // pixel-blocked split (fp16 hi | lo) copy of one gradient tensor: wgrad's dy operand, written by the BN backward pass
@@ -410,6 +427,7 @@ struct Run {
     float* ws;
     hipStream_t st;
     bool stem8 = false;   // this call runs the stem through dcn_conv_stem_forward_f16
+    const float* hl_src[2] = {nullptr, nullptr};   // the fp32 tensors whose hl32 images currently sit in w_hl / w_hl2
 
     // bracket one matrix-core launch with events when profiling is on
     template <class F> int timed(int cat, double flops, F&& launch) {
@@ -459,6 +477,19 @@ struct Run {
                 return dcn_conv_stem_forward_f16(&c.d, in, A(c.in_act), hi, hi + (size_t)p.base * 224, kWeightScale, out, part, st);
             });
         }
+        if (use_hl(c, 0)) {
+            // (the operand image was written by the batch-norm apply pass that produced `in` -- hl_image_for --, or is made
+            // here by a stand-alone pass)
+            return timed(0, c.flops, [&] {
+                int k = hl_src[0] == in ? 0 : (hl_src[1] == in ? 1 : -1);
+                if (k < 0) {
+                    k = 0;
+                    DCN_TRY(dcn_split_act_hl32(in, A(c.in_act), hlbuf(0), (int64_t)c.d.n * c.d.hin * c.d.win, c.d.cin, st));
+                    hl_src[0] = in;
+                }
+                return dcn_conv_forward_hl(&c.d, hlbuf(k), A(c.in_act), whl(c), kWeightScale, bias, out, part, SKhl(c, 0), st);
+            });
+        }
         return timed(0, c.flops, [&] {
             return dcn_conv_forward_f16(&c.d, in, A(c.in_act), wimg(p.w_wh, c), wimg(p.w_wl, c), kWeightScale, bias, out, part,
                                         SK(c, 0), st);
@@ -466,6 +497,44 @@ struct Run {
     }
 
     void* wimg(size_t plane, const ConvL& c) const { return (void*)((_Float16*)Wk(plane) + c.wsplit); }
+
+    // ---- pre-split (hl32) path of the wide layers (conv_hl_kernels.hip)
+    bool use_hl(const ConvL& c, int dgrad) const {
+        return p.conv_mode == DCN_CONV_F16X3 && c.hl_any && dcn_conv_hl_eligible(&c.d, dgrad) != 0;
+    }
+    void* whl(const ConvL& c) const { return (void*)Wk(p.w_whl + c.whl); }
+    float* hlbuf(int k) const { return Wk(k == 0 ? p.w_hl : p.w_hl2); }
+    // buffer k will hold the hl32 image of the activation `y` (written by the bn_apply pass that is about to produce y), if a
+    // convolution that reads y takes the hl32 path; returns the buffer or null
+    void* hl_image_for(const float* y, int k, const ConvL* consumer_a, const ConvL* consumer_b = nullptr) {
+        if (dcn::tuning().hl_producers == 0) return nullptr;
+        const bool want = (consumer_a && use_hl(*consumer_a, 0)) || (consumer_b && use_hl(*consumer_b, 0));
+        if (!want) return nullptr;
+        hl_src[k] = y;
+        return hlbuf(k);
+    }
+    void* SKhl(const ConvL& c, int dgrad) const {
+        return dcn_conv_gemm_workspace_hl(&c.d, dgrad) <= p.sk_bytes ? (void*)(ws + p.w_sk) : nullptr;
+    }
+    // rows of the batch-norm partial sums the forward kernel of the moment writes
+    int fwd_mtiles(const ConvL& c) const {
+        if (p.conv_mode == DCN_CONV_FP32) return dcn_conv_num_mtiles(&c.d);
+        return use_hl(c, 0) ? dcn_conv_num_mtiles_hl(&c.d) : dcn_conv_num_mtiles_f16(&c.d);
+    }
+    int split_hl_weights(bool transposed) {
+        std::vector<const float*> w;
+        std::vector<void*> out;
+        std::vector<int> cout, taps, cin, ldn;
+        for (const ConvL& c : p.convs) {
+            if (!use_hl(c, transposed ? 1 : 0)) continue;
+            w.push_back(P(c.w));
+            out.push_back(whl(c));
+            cout.push_back(c.d.cout); taps.push_back(c.d.kh * c.d.kw); cin.push_back(c.d.cin); ldn.push_back(c.d.ldc);
+        }
+        if (w.empty()) return DCN_OK;
+        return dcn_split_weights_hl32((int)w.size(), w.data(), out.data(), cout.data(), taps.data(), cin.data(), ldn.data(),
+                                      transposed ? 1 : 0, kWeightScale, st);
+    }
 
     // fp16 hi / lo images of every convolution's weights in one launch: forward images, or the channel-transposed dgrad
     // images (the stem has no dgrad).  `stem_w`: the stem's weights padded to 4 input channels.
@@ -510,7 +579,7 @@ struct Run {
         float* rv = bn_running ? bn_running[2 * b.idx + 1] : nullptr;
         if (!training && (!rm || !rv)) return DCN_E_INVALID;
         // (M tiles of the launch just made: asked again, the tile shape follows the tuning table of the moment)
-        const int mtiles = p.conv_mode == DCN_CONV_FP32 ? dcn_conv_num_mtiles(&c.d) : dcn_conv_num_mtiles_f16(&c.d);
+        const int mtiles = fwd_mtiles(c);
         dcn::launch_bn_finalize(part, mtiles / p.groups, p.groups, b.C, (double)(b.rows / p.groups), P(b.g),
                                 P(b.b), rm, rv, momentum, eps, training, stats, training ? A(out_act) : nullptr,
                                 training ? A(res_act) : nullptr, st);
@@ -666,7 +735,10 @@ extern "C" int dcn_backbone_forward(dcn_plan* plan, const float* image, const fl
             DCN_TRY(R.conv_fused(last, cur, res, 1, R.S(blk.out), blk.act_out));
         }
     } else {
-    if (p.conv_mode == DCN_CONV_F16X3) DCN_TRY(R.split_all_weights(false, R.Wk(p.w_wstem)));
+    if (p.conv_mode == DCN_CONV_F16X3) {
+        DCN_TRY(R.split_all_weights(false, R.Wk(p.w_wstem)));
+        DCN_TRY(R.split_hl_weights(false));
+    }
     if (p.conv_mode == DCN_CONV_F16X3 && dcn::tuning().stem8 != 0 && dcn::tuning().gemm_uni != 0 && stem.d.win >= 8 && stem.d.kh == 7 &&
         stem.d.cin == 4 && (int64_t)stem.d.n * stem.d.hin * stem.d.win * 16 <= ((int64_t)1 << 31)) {
         _Float16* hi = (_Float16*)R.Wk(p.w_stem8);
@@ -695,7 +767,9 @@ extern "C" int dcn_backbone_forward(dcn_plan* plan, const float* image, const fl
                 DCN_TRY(R.conv_bn(c, cur, R.P(c.w), bn_running, momentum, eps, training, blk.act_mid[i]));
                 const BnL& b = p.bns[c.bn];
                 const float* s = R.S(b.stats);
-                dcn::launch_bn_apply(R.S(c.x), s, nullptr, nullptr, 1, R.S(blk.mid[i]), R.M(blk.mid[i]), b.C, b.rows, p.groups, st);
+                void* hl = training ? R.hl_image_for(R.S(blk.mid[i]), 1, &p.convs[blk.conv[i + 1]]) : nullptr;
+                dcn::launch_bn_apply(R.S(c.x), s, nullptr, nullptr, 1, R.S(blk.mid[i]), R.M(blk.mid[i]), b.C, b.rows, p.groups, st,
+                                     hl, R.A(blk.act_mid[i]));
                 cur = R.S(blk.mid[i]);
             } else {
                 DCN_TRY(R.conv_bn(c, cur, R.P(c.w), bn_running, momentum, eps, training, blk.act_out,
@@ -705,12 +779,18 @@ extern "C" int dcn_backbone_forward(dcn_plan* plan, const float* image, const fl
         const ConvL& last = p.convs[blk.conv[blk.nconv - 1]];
         const BnL& bl = p.bns[last.bn];
         const float* sl = R.S(bl.stats);
+        // the block's output feeds the next block's first convolution (and its downsample branch)
+        const BlockL* nb = (&blk != &p.blocks.back()) ? &blk + 1 : nullptr;
+        void* hl = (training && nb) ? R.hl_image_for(R.S(blk.out), 0, &p.convs[nb->conv[0]], nb->down >= 0 ? &p.convs[nb->down] : nullptr)
+                                    : nullptr;
         if (blk.down >= 0) {
             const ConvL& dc = p.convs[blk.down];
             const float* sd = R.S(p.bns[dc.bn].stats);
-            dcn::launch_bn_apply(R.S(last.x), sl, R.S(dc.x), sd, 1, R.S(blk.out), R.M(blk.out), bl.C, bl.rows, p.groups, st);
+            dcn::launch_bn_apply(R.S(last.x), sl, R.S(dc.x), sd, 1, R.S(blk.out), R.M(blk.out), bl.C, bl.rows, p.groups, st, hl,
+                                 R.A(blk.act_out));
         } else {
-            dcn::launch_bn_apply(R.S(last.x), sl, in, nullptr, 1, R.S(blk.out), R.M(blk.out), bl.C, bl.rows, p.groups, st);
+            dcn::launch_bn_apply(R.S(last.x), sl, in, nullptr, 1, R.S(blk.out), R.M(blk.out), bl.C, bl.rows, p.groups, st, hl,
+                                 R.A(blk.act_out));
         }
     }
     }   // !fused_eval
@@ -781,6 +861,7 @@ extern "C" int dcn_backbone_backward(dcn_plan* plan, const float* grad_descripto
     p.fused_bn_bwd = 0;
     const float* red_dy = nullptr;
     int red_tiles = 0;
+    const float* hl_dx_of = nullptr;    // gradient tensor whose hl32 image sits in w_hl (written by the BN backward apply pass)
     // dy2 (optional): the upstream gradient is dy + dy2 -- the residual branch's share, added in the batch norm's streaming
     // passes instead of in the epilogue of the dgrad that produced dy
     auto bn_bwd = [&](const ConvL& c, const float* dy, const float* relu_out, float* dx, float* g_out, const float* dy2 = nullptr) {
@@ -793,9 +874,13 @@ extern "C" int dcn_backbone_backward(dcn_plan* plan, const float* grad_descripto
         const int tiles = (red_dy == dy && dy) ? red_tiles : 0;
         red_dy = nullptr;
         if (tiles > 0) { relu_out = nullptr; mask = nullptr; g_out = nullptr; ++p.fused_bn_bwd; }   // dy is already the masked gradient
+        // the dgrad of this convolution on the hl32 path: the apply pass writes dx as the hl32 image INSTEAD of the fp32 tensor
+        // (wgrad reads the pixel-blocked image, nobody reads the fp32 one)
+        const bool hl_d = f16 && !fuse_red && dcn::tuning().hl_producers != 0 && R.use_hl(c, 1);
+        hl_dx_of = hl_d ? dx : nullptr;
         dcn::launch_bn_bwd(dy, relu_out, mask, R.S(c.x), s, R.P(b.g), b.C, b.rows, p.groups, part, grads[b.g],
                            grads[b.b], k123, dx, g_out, f16 ? amax + c.idx : nullptr, f16 ? (void*)dqbuf[cur] : nullptr, st,
-                           tiles, dy2);
+                           tiles, dy2, hl_d ? (void*)R.hlbuf(0) : nullptr, 0);
         if (overlap) RT(hipEventRecord(p.ev_dq[cur], st));
         ++n_bn;
         dq_of = f16 ? dx : nullptr;   // the pixel-blocked split copy of this dx now sits in dqbuf[cur]
@@ -842,12 +927,23 @@ extern "C" int dcn_backbone_backward(dcn_plan* plan, const float* grad_descripto
                 });
             }
         }
+        if (R.use_hl(c, 1)) {
+            return R.timed(0, c.flops, [&] {
+                if (hl_dx_of != dx)
+                    DCN_TRY(dcn_split_act_hl32(dx, amax + c.idx, R.hlbuf(0), (int64_t)c.d.n * c.d.hout * c.d.wout, c.d.ldc, st));
+                hl_dx_of = nullptr;
+                return dcn_conv_dgrad_hl(&c.d, R.hlbuf(0), R.whl(c), kWeightScale, amax + c.idx, add, din, R.SKhl(c, 1), st);
+            });
+        }
         return R.timed(0, c.flops, [&] {   // (transposed weight images: split_all_weights(true) below)
             return dcn_conv_dgrad_f16(&c.d, dx, R.wimg(p.w_wh, c), R.wimg(p.w_wl, c), kWeightScale, amax + c.idx, add, din,
                                       R.SK(c, 1), st);
         });
     };
-    if (f16) DCN_TRY(R.split_all_weights(true, nullptr));
+    if (f16) {
+        DCN_TRY(R.split_all_weights(true, nullptr));
+        DCN_TRY(R.split_hl_weights(true));
+    }
     // split-fp16 mode: every gradient tensor that feeds a convolution records its abs-max (pre-scale selection)
     if (f16 && dcn::fill_bytes_async(amax, 0, p.convs.size() * sizeof(float), st) != DCN_OK) return DCN_E_LAUNCH;
 

@@ -57,6 +57,7 @@ struct SplitEntry {
     int rows, K, kp;          // forward: rows = cout, K = taps * cin.   transposed: rows = cin, K = taps * ldn
     int cout, taps, cin, ldn;
     int first_block;          // prefix sum of workgroups
+    int hl;                   // 1: ONE "hl32" image at `hi` -- [rows][K / 32][hi x32 | lo x32] (K % 32 == 0; conv_hl_kernels.hip)
 };
 constexpr int kSplitBatch = 48;   // 48 x 64 bytes + header < 4 KB of kernel arguments
 struct SplitTable {
@@ -84,6 +85,12 @@ split_rows_batched_kernel(SplitTable t) {
     if (k < E.K) v = *reinterpret_cast<const float4*>(E.w + r * E.K + k);
     h4 a, b;
     split4(v, E.row_scale ? t.scale * E.row_scale[r] : t.scale, a, b);
+    if (E.hl) {   // (4 consecutive k never straddle a 32-k chunk)
+        _Float16* line = E.hi + r * 2 * E.kp + (k >> 5) * 64 + (k & 31);
+        *reinterpret_cast<h4*>(line) = a;
+        *reinterpret_cast<h4*>(line + 32) = b;
+        return;
+    }
     *reinterpret_cast<h4*>(E.hi + r * E.kp + k) = a;
     *reinterpret_cast<h4*>(E.lo + r * E.kp + k) = b;
 }
@@ -111,6 +118,13 @@ transpose_split_batched_kernel(SplitTable t) {
     if (cc >= E.cin || n >= E.ldn) return;                   // (ldn % 4 == 0)
     h4 a, bb;
     split4(make_float4(tile[4 * nq][cl], tile[4 * nq + 1][cl], tile[4 * nq + 2][cl], tile[4 * nq + 3][cl]), t.scale, a, bb);
+    if (E.hl) {   // (K = taps * ldn, % 32 == 0: no padding to zero)
+        const int k = tap * E.ldn + n;
+        _Float16* line = E.hi + (int64_t)cc * 2 * E.kp + (k >> 5) * 64 + (k & 31);
+        *reinterpret_cast<h4*>(line) = a;
+        *reinterpret_cast<h4*>(line + 32) = bb;
+        return;
+    }
     const int64_t o = (int64_t)cc * E.kp + (int64_t)tap * E.ldn + n;
     *reinterpret_cast<h4*>(E.hi + o) = a;
     *reinterpret_cast<h4*>(E.lo + o) = bb;
@@ -153,22 +167,6 @@ template <int TM, int TN, int WR = 2, int WC = 2> struct F16Geo {
     static_assert(BM % RA == 0 && BN % RB == 0, "tile rows must be whole staging passes (WR = 4, WC = 2 needs TN = 2)");
 };
 
-// Stream-K tiles completed INSIDE the GEMM launch: every workgroup that parks a partial accumulator of a tile then counts
-// itself into the tile's arrival word; the one that finds itself last (all the others' partials are then visible: they
-// are written through and read past the per-XCD L2s with device-coherent accesses, see gemm_segment_f16) sums the parked
-// partials in the fixed order of the contributing workgroups and runs the epilogue -- bit-identical to the separate fix-up
-// kernel, without its launch, and overlapped with the tiles still being computed.  The arrival word is
-// (launch id << 32) | arrivals: a word left behind by any other launch (or never initialised) counts as zero, so the
-// workspace needs no clearing; the last arriver resets it to 0 so that a replay of the same captured launch starts clean.
-__device__ __forceinline__ bool sk_arrive_is_last(unsigned long long* cnt, unsigned id, int contributors) {
-    unsigned long long old = __atomic_load_n(cnt, __ATOMIC_RELAXED);
-    for (;;) {
-        const unsigned long long nv = (unsigned)(old >> 32) == id ? old + 1ull : (((unsigned long long)id << 32) | 1ull);
-        const unsigned long long seen = atomicCAS(cnt, old, nv);
-        if (seen == old) return (int)(unsigned)(nv & 0xffffffffull) == contributors;
-        old = seen;
-    }
-}
 
 constexpr int kOob = (int)0x80000000;   // voffset that fails the bounds check of any buffer <= 2 GiB: the load returns 0
 
@@ -729,10 +727,7 @@ int launch_gemm_f16(GemmConv& p, void* workspace, hipStream_t st, int align = 0)
     const bool sk_inline = sk && dcn::tuning().gemm_sk_inline != 0 && !(g.wr == 2 && g.wc == 2 && g.tm == 2 && g.tn == 2);
     p.sk_count = sk_inline ? (unsigned long long*)((char*)workspace + g.sk_count_off) : nullptr;
     p.sk_bytes = sk_inline ? (unsigned)g.sk_count_off : 0u;
-    if (sk_inline) {
-        static std::atomic<unsigned> next_id{1u};
-        do { p.sk_id = next_id.fetch_add(1u, std::memory_order_relaxed); } while (p.sk_id == 0u);
-    }
+    if (sk_inline) p.sk_id = next_sk_launch_id();
     // uniform-tap fast path: whole 32-K stages inside one filter tap, tensors addressable through 2 GiB buffer resources
     const int64_t src_bytes = (int64_t)p.M / (p.hd * p.wd) * p.hs * p.ws * p.cs * 4, w_bytes = (int64_t)p.cd * p.kp * 2;
     bool uni = ((p.cs % HBK) == 0 || p.stem8) && src_bytes <= ((int64_t)1 << 31) && w_bytes <= ((int64_t)1 << 31);
@@ -1164,6 +1159,13 @@ int dgrad_group_rows(const dcn_conv_desc* c) {
 
 }  // namespace
 
+unsigned dcnconv::next_sk_launch_id() {
+    static std::atomic<unsigned> next_id{1u};
+    unsigned id;
+    do { id = next_id.fetch_add(1u, std::memory_order_relaxed); } while (id == 0u);
+    return id;
+}
+
 extern "C" int dcn_f16_kpad(int k) { return (k + 7) / 8 * 8; }
 
 extern "C" int dcn_split_rows_f16(const float* w, void* hi, void* lo, int64_t rows, int k, float scale, void* stream) {
@@ -1185,10 +1187,31 @@ extern "C" int dcn_split_weights_f16(int n, const float* const* w, void* const* 
 }
 
 // row_scale (optional, forward images only): row_scale[i] is NULL or a device vector of cout[i] per-output-channel factors
+namespace {
+int split_weights_impl(int n, const float* const* w, const float* const* row_scale, void* const* hi, void* const* lo,
+                       const int* cout, const int* taps, const int* cin, const int* ldn, int transposed, float scale,
+                       void* stream, bool hl);
+}
+
 extern "C" int dcn_split_weights_scaled_f16(int n, const float* const* w, const float* const* row_scale, void* const* hi,
                                             void* const* lo, const int* cout, const int* taps, const int* cin,
                                             const int* ldn, int transposed, float scale, void* stream) {
-    if (n < 1 || !w || !hi || !lo || !cout || !taps || !cin || (transposed && (!ldn || row_scale)) || !(scale > 0.f))
+    if (!lo) return DCN_E_INVALID;
+    return split_weights_impl(n, w, row_scale, hi, lo, cout, taps, cin, ldn, transposed, scale, stream, false);
+}
+
+// hl32 images (conv_hl_kernels.hip): out[i] receives [cout][taps * cin / 32][hi x32 | lo x32] or, transposed,
+// [cin][taps * ldn / 32][hi x32 | lo x32]; the K of every entry must be a multiple of 32.
+extern "C" int dcn_split_weights_hl32(int n, const float* const* w, void* const* out, const int* cout, const int* taps,
+                                      const int* cin, const int* ldn, int transposed, float scale, void* stream) {
+    return split_weights_impl(n, w, nullptr, out, nullptr, cout, taps, cin, ldn, transposed, scale, stream, true);
+}
+
+namespace {
+int split_weights_impl(int n, const float* const* w, const float* const* row_scale, void* const* hi, void* const* lo,
+                       const int* cout, const int* taps, const int* cin, const int* ldn, int transposed, float scale,
+                       void* stream, bool hl) {
+    if (n < 1 || !w || !hi || (!hl && !lo) || !cout || !taps || !cin || (transposed && (!ldn || row_scale)) || !(scale > 0.f))
         return DCN_E_INVALID;
     hipStream_t st = (hipStream_t)stream;
     for (int base = 0; base < n; base += kSplitBatch) {
@@ -1199,8 +1222,8 @@ extern "C" int dcn_split_weights_scaled_f16(int n, const float* const* w, const 
         for (int j = 0; j < t.n; ++j) {
             const int i = base + j;
             SplitEntry& E = t.e[j];
-            if (!w[i] || !hi[i] || !lo[i] || cout[i] < 1 || taps[i] < 1 || cin[i] < 4 || (cin[i] % 4)) return DCN_E_INVALID;
-            E.w = w[i]; E.hi = (_Float16*)hi[i]; E.lo = (_Float16*)lo[i];
+            if (!w[i] || !hi[i] || (!hl && !lo[i]) || cout[i] < 1 || taps[i] < 1 || cin[i] < 4 || (cin[i] % 4)) return DCN_E_INVALID;
+            E.w = w[i]; E.hi = (_Float16*)hi[i]; E.lo = hl ? nullptr : (_Float16*)lo[i]; E.hl = hl ? 1 : 0;
             E.row_scale = row_scale ? row_scale[i] : nullptr;
             E.cout = cout[i]; E.taps = taps[i]; E.cin = cin[i]; E.ldn = transposed ? ldn[i] : cout[i];
             E.first_block = blocks;
@@ -1212,12 +1235,14 @@ extern "C" int dcn_split_weights_scaled_f16(int n, const float* const* w, const 
                 E.rows = E.cout; E.K = E.taps * E.cin; E.kp = dcn_f16_kpad(E.K);
                 blocks += (int)dcn::ceil_div64((int64_t)E.rows * (E.kp / 4), 256);
             }
+            if (hl && (E.K % 32) != 0) return DCN_E_INVALID;
         }
         if (transposed) hipLaunchKernelGGL(transpose_split_batched_kernel, dim3(blocks), dim3(256), 0, st, t);
         else hipLaunchKernelGGL(split_rows_batched_kernel, dim3(blocks), dim3(256), 0, st, t);
     }
     return dcn::check_launch();
 }
+}  // namespace
 
 extern "C" int dcn_conv_num_mtiles_f16(const dcn_conv_desc* c) {
     if (!valid_desc16(c)) return DCN_E_INVALID;

@@ -1,0 +1,533 @@
+// Split-fp16 ("f16x3") gather-GEMM on PRE-SPLIT operands for the wide layers (destination >= 256 channels, source channels
+// % 32 == 0, stride 1): forward convolution and dgrad of layers 3-4 of the dilated ResNets -- 70 % of the network's FLOPs.
+//
+// Both operands arrive as "hl32" tensors: per 32-channel chunk one 128-byte line [hi x32 | lo x32] fp16 with
+// hi = fp16(s x), lo = fp16(s x - hi) -- the byte size of the fp32 tensor.  The activation / gradient image is written by
+// the kernel that PRODUCES the tensor (the batch-norm apply passes, elementwise_kernels.hip; dcn_split_act_hl32 as a
+// stand-alone pass), the weight images by one batched launch per call.  The GEMM loop then contains no conversion, no
+// VGPR staging and no LDS store: tiles are filled by LDS-DMA (`buffer_load_dwordx4 ... lds`, 64 lanes x 16 B land at
+// M0 + 16 lane; rows outside the image / past M carry an out-of-range offset and arrive as zeros) into a lane-linear image
+// whose 16-byte slots are XOR-swizzled on the SOURCE side (slot ^ ((row >> 1) & 7): conflict-free ds_read_b128 fragments).
+//
+// Tile 256 x 256 on 8 wavefronts (2 x 4; wavefront tile 128 x 64 = 8 accumulators of 32 x 32), 32-K stages of 64 KB, two
+// stage buffers.  Schedule (tools/hl_gemm_probe2.hip, profiles/r3a_hl_gemm_probe2.txt): the wavefronts of group 1 (waves
+// 4-7, one per SIMD) run ONE barrier behind group 0 (waves 0-3); a stage is four phases -- one 64 x 32 quadrant of the
+// wavefront tile x both 16-k steps x 3 products = 12 MFMAs = 384 matrix-pipe cycles -- and a phase is
+//     LOAD slot (fragment reads of the quadrant, 2 LDS-DMA pieces of the NEXT stage, counted vmcnt) | s_barrier |
+//     COMPUTE slot (12 MFMAs under s_setprio 1) | s_barrier
+// so that on every SIMD one wavefront computes while the other one loads.
+// Half-tiles (16 KB = 16 pieces of 8 rows, two per wavefront) in the order a stage's phases first need them:
+//     H0 = A_0, H1 = B_0, H2 = B_1, H3 = A_1;   A_i = tile rows {128 g + 64 i + [0, 64)}, B_j = columns {64 wn + 32 j + [0, 32)}
+// (quadrant (i, j) of wavefront (g, wn) reads A_i and B_j only; phase order (0,0) (0,1) (1,1) (1,0)).
+// LDS-DMA discipline (every wavefront, LOAD slot of phase p of stage s): issue H_p(s + 1) into the other buffer, then wait
+// until at most two half-tiles (4 pieces) are in flight; the barrier that closes the slot publishes what has landed:
+//     LOAD(s, 1) reads H2(s)  [landed by the end of LOAD(s, 0)],   LOAD(s, 2) reads H3(s)  [end of LOAD(s, 1)],
+//     LOAD(s + 1, 0) reads H0, H1 of s + 1  [end of LOAD(s, 3)];  group 1's slots are one barrier later than group 0's, so
+// the latest publication still precedes the earliest read.  WAR: H_p(s + 1) overwrites H_p(s - 1), last read in LOAD(s - 1, 3)
+// of group 1, two barriers before LOAD(s, 0) of group 0.  ALL shared memory of the kernel is ONE array (a second
+// __shared__ object makes hipcc drain vmcnt in front of every fragment read, cdna_hip_programming.md section 5).
+#include <algorithm>
+#include <atomic>
+#include <type_traits>
+
+#include "conv_shared.h"
+#include "dcn_tuning.h"
+#include "f16_split.h"
+
+namespace {
+
+using namespace dcnconv;
+using namespace dcnsplit;
+
+typedef __attribute__((address_space(3))) void* hl_lds_ptr;
+
+constexpr int kOob = (int)0x80000000;   // voffset that fails the bounds check of any buffer <= 2 GiB: LDS receives zeros
+constexpr int kHlStage = 65536;         // bytes per 32-K stage: [A rows 0..255][B rows 0..255] x 128 B
+constexpr int HLK = 32;
+
+// (a NON-template function: inside a template this builtin breaks the host-side kernel stub with this compiler)
+__device__ __forceinline__ void glds16(__amdgpu_buffer_rsrc_t rs, void* lds_dst, int voffset, int soffset) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (hl_lds_ptr)lds_dst, 16, voffset, soffset, 0, 0);
+}
+
+// fp32 [rows][C] (C % 32 == 0) -> hl32 [rows][C / 32][hi x32 | lo x32], scaled by pow2_scale(*absmax).
+// One work-item per 8 channels: 32 B in, 16 B of the hi half-line + 16 B of the lo half-line out.
+__global__ void __launch_bounds__(256)
+split_act_hl32_kernel(const float* __restrict__ src, const float* __restrict__ absmax, u32x4* __restrict__ dst, int64_t n8) {
+    const float s = absmax ? pow2_scale(*absmax) : 1.f;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n8; i += (int64_t)gridDim.x * 256) {
+        const float4 a = reinterpret_cast<const float4*>(src)[2 * i], b = reinterpret_cast<const float4*>(src)[2 * i + 1];
+        h4 ah, al, bh, bl;
+        split4(a, s, ah, al);
+        split4(b, s, bh, bl);
+        const u32x2 h0 = __builtin_bit_cast(u32x2, ah), h1 = __builtin_bit_cast(u32x2, bh);
+        const u32x2 l0 = __builtin_bit_cast(u32x2, al), l1 = __builtin_bit_cast(u32x2, bl);
+        u32x4* line = dst + (i >> 2) * 8 + (i & 3);
+        line[0] = u32x4{h0[0], h0[1], h1[0], h1[1]};
+        line[4] = u32x4{l0[0], l0[1], l1[0], l1[1]};
+    }
+}
+
+// One (tile, K-stage range) of the gather-GEMM.  TR: dgrad (the gather runs over the output gradient with mirrored taps).
+template <bool TR>
+__device__ __forceinline__ void gemm_segment_hl(const GemmConv& p, unsigned char* lds, int tile, int k0, int k1, int nk,
+                                                float* slot) {
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int grp = wv >> 2, wn = wv & 3;
+    const int mt = fdiv(tile, p.div_nt), nt = tile - mt * p.ntiles;
+    const int m0 = mt * 256, n0 = nt * 256;
+    const __amdgpu_buffer_rsrc_t rs_a = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.src), 0, (int)p.src_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_b = __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16*>(p.wh), 0, (int)p.w_bytes, 0x00020000);
+
+    // ---- LDS-DMA pieces of this lane: piece e (0, 1) of half-tile A_i covers tile rows 128 g + 64 i + 8 (2 wn + e) + [0, 8),
+    // of B_j rows 64 (wv >> 1) + 32 j + 8 (2 (wv & 1) + e) + [0, 8); lane l fetches row (l >> 3), PHYSICAL slot l & 7 =
+    // logical 16-byte slot (l & 7) ^ ((row >> 1) & 7) of the row's 128-byte line
+    const int l8 = lane >> 3, ls = lane & 7;
+    const int cs4 = p.cs * 4;              // bytes per pixel of the activation image
+    int by[2][2], bx[2][2], rowoff[2][2], voa[2][2], vob[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            const int row = grp * 128 + i * 64 + (2 * wn + e) * 8 + l8;
+            const int sl = ls ^ ((row >> 1) & 7);
+            const int m = m0 + row;
+            const bool ok = m < p.M;
+            const int mm = ok ? m : 0;
+            const int img = fdiv(mm, p.div_hw), rem = mm - img * p.div_hw.d;
+            const int y = fdiv(rem, p.div_w), x = rem - y * p.div_w.d;
+            by[i][e] = ok ? (TR ? y + p.pad : y - p.pad) : -(1 << 28);   // (stride 1; rows past M: never inside the image)
+            bx[i][e] = TR ? x + p.pad : x - p.pad;
+            rowoff[i][e] = ok ? (img * p.hs * p.ws + by[i][e] * p.ws + bx[i][e]) * cs4 + sl * 16 : 0;
+        }
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            const int row = (wv >> 1) * 64 + j * 32 + (2 * (wv & 1) + e) * 8 + l8;
+            const int sl = ls ^ ((row >> 1) & 7);
+            const int n = n0 + row;
+            vob[j][e] = n < p.cd ? n * (nk * 128) + sl * 16 : kOob;
+        }
+    // K traversal: channel-chunk groups outermost (kcg chunks = up to 128 channels), then the filter taps, then the chunks
+    // of the group: the same input pixels come back for the next tap after kcg stages, while they are still in this XCD's L2
+    const int cpt = p.cs / HLK;
+    const int kcg = (cpt & 3) == 0 ? 4 : ((cpt & 1) == 0 ? 2 : 1);
+    const int taps = p.kh * p.kw;
+    int u_grp, u_tap, u_c, u_kt = k0;      // the stage whose LDS-DMA is issued next
+    auto set_tap = [&](int tap) {
+        const int r = fdiv(tap, p.div_kw), s = tap - r * p.kw;
+        const int dy = r * p.dil, dx = s * p.dil;
+        const int delta = (dy * p.ws + dx) * cs4;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                bool ok;
+                if (TR) {
+                    const int ny = by[i][e] - dy, nx = bx[i][e] - dx;
+                    ok = ((ny | nx) >= 0) & (ny < p.hs) & (nx < p.ws);
+                } else {
+                    ok = ((unsigned)(by[i][e] + dy) < (unsigned)p.hs) & ((unsigned)(bx[i][e] + dx) < (unsigned)p.ws);
+                }
+                voa[i][e] = ok ? (TR ? rowoff[i][e] - delta : rowoff[i][e] + delta) : kOob;
+            }
+    };
+    {
+        const int per_grp = taps * kcg;
+        u_grp = k0 / per_grp;
+        const int rem = k0 - u_grp * per_grp;
+        u_tap = rem / kcg;
+        u_c = rem - u_tap * kcg;
+        set_tap(u_tap);
+    }
+    auto advance = [&]() {                 // steps to the next stage of the segment (stays on the last one)
+        if (u_kt + 1 < k1) {
+            ++u_kt;
+            if (++u_c == kcg) {
+                u_c = 0;
+                if (++u_tap == taps) { u_tap = 0; ++u_grp; }
+                set_tap(u_tap);
+            }
+        }
+    };
+    // half-tile h (0: A_0, 1: B_0, 2: B_1, 3: A_1) of the stage the traversal state points at, into stage buffer `buf`
+    auto issue_half = [&](int buf, int h) {
+        const int chunk = u_grp * kcg + u_c;
+        unsigned char* base = lds + buf * kHlStage;
+        if (h == 0 || h == 3) {
+            const int i = h == 0 ? 0 : 1;
+            unsigned char* d = base + (grp * 128 + i * 64 + 2 * wn * 8) * 128;
+            glds16(rs_a, d, voa[i][0], chunk * 128);
+            glds16(rs_a, d + 1024, voa[i][1], chunk * 128);
+        } else {
+            const int j = h == 1 ? 0 : 1;
+            unsigned char* d = base + 32768 + ((wv >> 1) * 64 + j * 32 + 2 * (wv & 1) * 8) * 128;
+            const int soff = (u_tap * cpt + chunk) * 128;
+            glds16(rs_b, d, vob[j][0], soff);
+            glds16(rs_b, d + 1024, vob[j][1], soff);
+        }
+    };
+
+    // ---- fragments: lane (fi = lane & 31, fh = lane >> 5) holds 8 consecutive k (k-octet 2 ks + fh) of row fi of a 32-row tile
+    const int fi = lane & 31, fh = lane >> 5, swz = (fi >> 1) & 7;
+    int foff[2][2];   // [plane][ks]: byte offset of the lane's slot inside its row (plane 0 = hi, 1 = lo)
+#pragma unroll
+    for (int pl = 0; pl < 2; ++pl)
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) foff[pl][ks] = ((pl * 4 + ks * 2 + fh) ^ swz) * 16;
+    const int a_row = (grp * 128 + fi) * 128, b_row = 32768 + (wn * 64 + fi) * 128;
+
+    f32x16 acc[4][2];   // [tm = 2 i + t][tn = j]: rows 128 g + 32 tm, columns 64 wn + 32 tn  (the common epilogue's map)
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    h8 fa[2][2][2], fb[2][2];   // A: [t][ks][plane], B: [ks][plane]
+    auto read_a = [&](int buf, int i) {
+        const unsigned char* st = lds + buf * kHlStage + a_row + i * 8192;
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                for (int pl = 0; pl < 2; ++pl) fa[t][ks][pl] = *reinterpret_cast<const h8*>(st + t * 4096 + foff[pl][ks]);
+    };
+    auto read_b = [&](int buf, int j) {
+        const unsigned char* st = lds + buf * kHlStage + b_row + j * 4096;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int pl = 0; pl < 2; ++pl) fb[ks][pl] = *reinterpret_cast<const h8*>(st + foff[pl][ks]);
+    };
+    // product-type outermost, the two accumulators of the quadrant alternating; the small cross terms before hi * hi
+    auto mfma_quadrant = [&](int i, int j) {
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int pt = 0; pt < 3; ++pt)
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                for (int t = 0; t < 2; ++t)
+                    acc[2 * i + t][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(pt == 0 ? fa[t][ks][1] : fa[t][ks][0],
+                                                                              pt == 1 ? fb[ks][1] : fb[ks][0], acc[2 * i + t][j], 0, 0, 0);
+        __builtin_amdgcn_s_setprio(0);
+    };
+    // raw s_barrier: no fence, LDS-DMA stays in flight across it
+    auto bar = [&]() { __builtin_amdgcn_sched_barrier(0); __builtin_amdgcn_s_barrier(); __builtin_amdgcn_sched_barrier(0); };
+    // one phase of stage s (LDS buffer s & 1).  MORE: stage s + 1 exists -- issue its half-tile p and leave two half-tiles
+    // in flight; otherwise drain what the next phases read.
+    auto phase = [&](auto more_tag, int buf, int ph) {
+        constexpr bool MORE = decltype(more_tag)::value;
+        const int qi = ph >> 1, qj = (ph == 1 || ph == 2) ? 1 : 0;
+        if (ph == 0) { read_b(buf, 0); __builtin_amdgcn_sched_barrier(0); read_a(buf, 0); }
+        else if (ph == 1) read_b(buf, 1);
+        else if (ph == 2) read_a(buf, 1);
+        else read_b(buf, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        if (MORE) {
+            issue_half(buf ^ 1, ph);
+            if (ph == 3) advance();   // (the traversal state now points at stage s + 2)
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (MORE) DCN_WAIT_VMCNT(4);
+        else if (ph == 0) DCN_WAIT_VMCNT(2);
+        else if (ph == 1) DCN_WAIT_VMCNT(0);
+        DCN_WAIT_LGKMCNT0();
+        bar();
+        mfma_quadrant(qi, qj);
+        bar();
+    };
+    using T = std::true_type;
+    using F = std::false_type;
+
+    issue_half(0, 0);
+    issue_half(0, 1);
+    issue_half(0, 2);
+    issue_half(0, 3);
+    advance();
+    __builtin_amdgcn_sched_barrier(0);
+    DCN_WAIT_VMCNT(4);
+    bar();
+    if (grp == 1) bar();
+    int buf = 0;
+    for (int s = k0; s + 1 < k1; ++s) {
+        phase(T{}, buf, 0);
+        phase(T{}, buf, 1);
+        phase(T{}, buf, 2);
+        phase(T{}, buf, 3);
+        buf ^= 1;
+    }
+    phase(F{}, buf, 0);
+    phase(F{}, buf, 1);
+    phase(F{}, buf, 2);
+    phase(F{}, buf, 3);
+    if (grp == 0) bar();
+    __syncthreads();
+
+    const float sa = p.a_absmax ? pow2_scale(*p.a_absmax) : 1.f;   // (the scale the producer of the hl32 image applied)
+    const float inv = p.b_inv_scale / sa;
+#pragma unroll
+    for (int tm = 0; tm < 4; ++tm)
+#pragma unroll
+        for (int tn = 0; tn < 2; ++tn)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[tm][tn][r] *= inv;
+    if (k0 == 0 && k1 == nk) {
+        gemm_epilogue<2, 4, 2, 16, 4>(p, acc, mt, nt, reinterpret_cast<float*>(lds));
+        return;
+    }
+    // ---- stream-K partial: parked device-coherently, completed by the last contributor inside the launch
+    // (conv_f16_kernels.hip, gemm_segment_f16: same protocol and slot layout [wavefront][tm][tn][r / 4][lane][r % 4])
+    constexpr int TM = 4, TN = 2;
+    const __amdgpu_buffer_rsrc_t rs_p = __builtin_amdgcn_make_buffer_rsrc(p.sk_partial, 0, (int)p.sk_bytes, 0x00020000);
+    constexpr int kSc1 = 16;
+    const int lane_off = (wv * (TM * TN * 16 * 64) + lane * 4) * 4;
+    {
+        const int so = (int)((slot - p.sk_partial) * 4);
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+            for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const float4 v = make_float4(acc[tm][tn][4 * q], acc[tm][tn][4 * q + 1], acc[tm][tn][4 * q + 2],
+                                                 acc[tm][tn][4 * q + 3]);
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rs_p,
+                                                           lane_off + ((tm * TN + tn) * 4 + q) * 1024, so, kSc1);
+                }
+    }
+    const int rel = tile - p.sk_dp;
+    const int ua = rel * nk, ub = ua + nk - 1;
+    const int ga = ua / p.sk_units, gb = ub / p.sk_units;
+    __builtin_amdgcn_s_waitcnt(0x0F70);                // vmcnt(0): this work-item's partial has been written through
+    __syncthreads();
+    int* s_last = reinterpret_cast<int*>(lds + 2 * kHlStage - 16);   // (inside the one LDS array: see the header)
+    if (tid == 0) *s_last = sk_arrive_is_last(p.sk_count + rel, p.sk_id, gb - ga + 1) ? 1 : 0;
+    __syncthreads();
+    if (*s_last) {
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+            for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[tm][tn][r] = 0.f;
+        // (each contributor's partial in batches of 16 loads of 16 B issued back to back, then added: left to itself the
+        // compiler waits for every 4 loads -- device-coherent round trips on the critical path of the launch)
+        constexpr int kPieces = TM * TN * 4, kBatch = 16;
+        for (int g = ga; g <= gb; ++g) {               // fixed order, own partial included: deterministic
+            const int first_tile = (g * p.sk_units) / nk;
+            const int so = (2 * g + (first_tile == rel ? 0 : 1)) * (256 * 256 * 4);
+#pragma unroll
+            for (int b0 = 0; b0 < kPieces; b0 += kBatch) {
+                u32x4 t[kBatch];
+#pragma unroll
+                for (int j = 0; j < kBatch; ++j) t[j] = __builtin_amdgcn_raw_buffer_load_b128(rs_p, lane_off + (b0 + j) * 1024, so, kSc1);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int j = 0; j < kBatch; ++j) {
+                    const int pc = b0 + j, blk = pc >> 2, q = pc & 3;
+                    const float4 v = __builtin_bit_cast(float4, t[j]);
+                    acc[blk / TN][blk % TN][4 * q] += v.x; acc[blk / TN][blk % TN][4 * q + 1] += v.y;
+                    acc[blk / TN][blk % TN][4 * q + 2] += v.z; acc[blk / TN][blk % TN][4 * q + 3] += v.w;
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        __syncthreads();                               // (s_last has been read by everyone: the epilogue reuses the array)
+        gemm_epilogue<2, 4, 2, 16, 4>(p, acc, mt, nt, reinterpret_cast<float*>(lds));
+        if (tid == 0) atomicExch(p.sk_count + rel, 0ull);
+    }
+}
+
+template <bool TR, bool SK>
+__global__ void __launch_bounds__(512, 1)
+conv_gemm_hl_kernel(GemmConv p) {
+    __shared__ __attribute__((aligned(16))) unsigned char lds[2 * kHlStage];
+    const int nk = p.K / HLK;
+    if (!SK) {
+        gemm_segment_hl<TR>(p, lds, xcd_remap(blockIdx.x, p.mtiles * p.ntiles), 0, nk, nk, nullptr);
+    } else {
+        // hybrid schedule (as conv_gemm_f16_kernel): whole rounds of tiles data-parallel, then ONE stream-K pass that splits
+        // the K stages of the leftover tiles evenly
+        const int g = xcd_remap(blockIdx.x, gridDim.x);
+        for (int tile = g; tile < p.sk_dp; tile += gridDim.x) {
+            gemm_segment_hl<TR>(p, lds, tile, 0, nk, nk, nullptr);
+            __syncthreads();
+        }
+        int u = p.sk_dp * nk + g * p.sk_units;
+        const int total = p.mtiles * p.ntiles * nk;
+        const int u_end = min(total, u + p.sk_units);
+        bool first = true;
+        while (u < u_end) {
+            const int tile = fdiv(u, p.div_nk), k0 = u - tile * nk;
+            const int k1 = min(nk, k0 + (u_end - u));
+            gemm_segment_hl<TR>(p, lds, tile, k0, k1, nk, p.sk_partial + (int64_t)(2 * g + (first ? 0 : 1)) * (256 * 256));
+            u += k1 - k0;
+            first = false;
+            __syncthreads();
+        }
+    }
+}
+
+struct HlShape {
+    int mtiles, ntiles, nk, sk_wgs, sk_units, sk_dp;
+    bool sk;
+    size_t ws_bytes, sk_count_off;
+};
+HlShape hl_shape(int M, int cd, int K) {
+    HlShape g;
+    g.mtiles = dcn::ceil_div(M, 256);
+    g.ntiles = dcn::ceil_div(cd, 256);
+    g.nk = K / HLK;
+    const int tiles = g.mtiles * g.ntiles;
+    const double rounds = tiles / 256.0;
+    const double waste = 1.0 - rounds / (double)(int)(rounds + 0.999999);
+    const double gain = ((double)(int)(rounds + 0.999999) - rounds) * g.nk;   // stage times stream-K can save
+    const dcn::Tuning& tune = dcn::tuning();
+    g.sk = tiles < 8 * 256 && waste > 0.08 && g.nk >= 8 && gain >= tune.gemm_sk_min_gain;
+    int wgs = 256;                                                              // one 512-work-item workgroup per CU
+    if (tune.gemm_sk >= 0) {
+        if (tune.gemm_sk == 0) g.sk = false;
+        if (tune.gemm_sk > 1) { g.sk = g.nk >= 2; wgs = tune.gemm_sk; }
+    }
+    g.sk_wgs = 0; g.sk_units = 0; g.sk_dp = 0; g.ws_bytes = 0; g.sk_count_off = 0;
+    if (g.sk) {
+        if ((int64_t)tiles * g.nk >= ((int64_t)1 << 30)) { g.sk = false; return g; }
+        g.sk_dp = tiles / wgs * wgs;
+        const int64_t total = (int64_t)(tiles - g.sk_dp) * g.nk;
+        if (total == 0) { g.sk = false; g.sk_dp = 0; return g; }
+        // Only the leftover tiles behind at least one whole data-parallel round are split: a 256 x 256 partial is 256 KB, and
+        // splitting EVERY tile of a sub-round launch parks more bytes than the launch reads (measured at N = 8 on the
+        // 256-channel layers, 150 tiles: 212 us with stream-K -- 172 MB of partials written and read back, matrix pipe 25 %
+        // busy -- against 154 us data-parallel on 150 CUs, profiles/r3d_hl_layer3_sk*.txt)
+        if (g.sk_dp == 0 && tune.gemm_sk <= 1) { g.sk = false; return g; }
+        if (g.sk_dp == 0 && wgs > total / 2) wgs = (int)(total / 2) > 0 ? (int)(total / 2) : 1;
+        g.sk_units = (int)((total + wgs - 1) / wgs);
+        g.sk_wgs = g.sk_dp > 0 ? wgs : (int)((total + g.sk_units - 1) / g.sk_units);
+        g.ws_bytes = (size_t)2 * g.sk_wgs * 256 * 256 * sizeof(float);
+        g.sk_count_off = g.ws_bytes;
+        g.ws_bytes += (size_t)(tiles - g.sk_dp) * sizeof(unsigned long long);
+        if (g.sk_count_off >= ((size_t)1 << 31)) { g.sk = false; g.sk_wgs = 0; g.sk_units = 0; g.sk_dp = 0; g.ws_bytes = 0; g.sk_count_off = 0; }
+    }
+    return g;
+}
+
+bool valid_desc_hl(const dcn_conv_desc* c) {
+    return c && c->n > 0 && c->hin > 0 && c->win > 0 && c->cin > 0 && c->hout > 0 && c->wout > 0 && c->cout > 0 && c->kh > 0 &&
+           c->kw > 0 && c->stride > 0 && c->dil > 0 && c->pad >= 0 && c->ldc >= c->cout;
+}
+
+int launch_gemm_hl(GemmConv& p, void* workspace, hipStream_t st) {
+    p.sshift = 0;
+    p.div_hw = make_fastdiv(p.hd * p.wd);
+    p.div_w = make_fastdiv(p.wd);
+    p.div_cs = make_fastdiv(p.cs);
+    p.div_kw = make_fastdiv(p.kw);
+    const HlShape g = hl_shape(p.M, p.cd, p.K);
+    const bool sk = g.sk && workspace != nullptr;
+    p.mtiles = g.mtiles;
+    p.ntiles = g.ntiles;
+    p.div_nt = make_fastdiv(g.ntiles);
+    p.div_nk = make_fastdiv(g.nk);
+    p.sk_units = sk ? g.sk_units : 0;
+    p.sk_dp = sk ? g.sk_dp : 0;
+    p.sk_partial = sk ? (float*)workspace : nullptr;
+    p.sk_count = sk ? (unsigned long long*)((char*)workspace + g.sk_count_off) : nullptr;
+    p.sk_bytes = sk ? (unsigned)g.sk_count_off : 0u;
+    if (sk) p.sk_id = next_sk_launch_id();
+    const dim3 grid(sk ? g.sk_wgs : g.mtiles * g.ntiles), block(512);
+    if (sk) {
+        if (p.transposed) hipLaunchKernelGGL((conv_gemm_hl_kernel<true, true>), grid, block, 0, st, p);
+        else hipLaunchKernelGGL((conv_gemm_hl_kernel<false, true>), grid, block, 0, st, p);
+    } else {
+        if (p.transposed) hipLaunchKernelGGL((conv_gemm_hl_kernel<true, false>), grid, block, 0, st, p);
+        else hipLaunchKernelGGL((conv_gemm_hl_kernel<false, false>), grid, block, 0, st, p);
+    }
+    return dcn::check_launch();
+}
+
+}  // namespace
+
+// What the kernel can compute at all: whole 32-channel source chunks, stride 1, tensors addressable through 2 GiB buffer
+// resources, statistics groups made of whole 256-row tiles.
+static bool hl_supported(const dcn_conv_desc* c, int dgrad) {
+    if (!valid_desc_hl(c)) return false;
+    if (c->stride != 1 || (c->ldc % 4) != 0) return false;
+    const int cs = dgrad ? c->ldc : c->cin, cd = dgrad ? c->cin : c->cout;
+    const int64_t M = (int64_t)c->n * (dgrad ? c->hin * c->win : c->hout * c->wout);
+    const int64_t K = (int64_t)c->kh * c->kw * cs;
+    if ((cs % HLK) != 0 || (dgrad && c->ldc != c->cout) || (cd % 4) != 0 || M >= ((int64_t)1 << 30)) return false;
+    if (dgrad && (c->hin != c->hout || c->win != c->wout)) return false;       // (stride-1 "same" convolutions)
+    if (!dgrad && c->group_rows > 0 && (c->group_rows % 256) != 0) return false;
+    const int64_t src_bytes = (int64_t)c->n * (dgrad ? c->hout * c->wout : c->hin * c->win) * cs * 4;
+    const int64_t w_bytes = (int64_t)cd * K * 4;
+    return src_bytes <= ((int64_t)1 << 31) - 1 && w_bytes <= ((int64_t)1 << 31) - 1;
+}
+
+// Which convolutions the engine sends down the hl32 path: supported, and wide / deep / tall enough for the 256 x 256 tile
+// and its software pipeline to pay (destination >= 256 channels, K >= 512, M >= 4096).
+extern "C" int dcn_conv_hl_eligible(const dcn_conv_desc* c, int dgrad) {
+    if (!hl_supported(c, dgrad) || dcn::tuning().gemm_hl == 0) return 0;
+    if (dcn::tuning().gemm_hl == 2) return 1;   // (tests: every supported convolution)
+    const int cs = dgrad ? c->ldc : c->cin, cd = dgrad ? c->cin : c->cout;
+    const int64_t M = (int64_t)c->n * (dgrad ? c->hin * c->win : c->hout * c->wout);
+    return (cd >= 256 && (int64_t)c->kh * c->kw * cs >= 512 && M >= 4096) ? 1 : 0;
+}
+
+extern "C" int dcn_conv_num_mtiles_hl(const dcn_conv_desc* c) {
+    if (!valid_desc_hl(c)) return DCN_E_INVALID;
+    return dcn::ceil_div(c->n * c->hout * c->wout, 256);
+}
+
+extern "C" size_t dcn_conv_gemm_workspace_hl(const dcn_conv_desc* c, int dgrad) {
+    if (!valid_desc_hl(c)) return 0;
+    if (dgrad) return hl_shape(c->n * c->hin * c->win, c->cin, c->kh * c->kw * c->ldc).ws_bytes;
+    return hl_shape(c->n * c->hout * c->wout, c->cout, c->kh * c->kw * c->cin).ws_bytes;
+}
+
+extern "C" int dcn_split_act_hl32(const float* src, const float* absmax, void* dst, int64_t rows, int channels, void* stream) {
+    if (!src || !dst || rows < 1 || channels < HLK || (channels % HLK) != 0) return DCN_E_INVALID;
+    const int64_t n8 = rows * (channels / 8);
+    const unsigned blocks = (unsigned)(dcn::ceil_div64(n8, 256) > 8192 ? 8192 : dcn::ceil_div64(n8, 256));
+    hipLaunchKernelGGL(split_act_hl32_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, src, absmax, (u32x4*)dst, n8);
+    return dcn::check_launch();
+}
+
+// in_hl: hl32 image of the input [n, hin, win, cin], scaled by pow2_scale(*in_absmax) (dcn_split_act_hl32 or a producer
+// kernel); w_hl: hl32 image [cout][taps * cin / 32][hi | lo] from dcn_split_weights_hl32 (scale w_scale).
+extern "C" int dcn_conv_forward_hl(const dcn_conv_desc* c, const void* in_hl, const float* in_absmax, const void* w_hl,
+                                   float w_scale, const float* bias, float* out, float* bn_partial, void* workspace,
+                                   void* stream) {
+    if (!in_hl || !w_hl || !out || !(w_scale > 0.f)) return DCN_E_INVALID;
+    if (!hl_supported(c, 0)) return DCN_E_UNSUPPORTED;
+    GemmConv p;
+    p.src = (const float*)in_hl; p.wm = nullptr; p.bias = bias; p.add = nullptr; p.dst = out; p.bn_partial = bn_partial;
+    p.out_absmax = nullptr; p.wh = (const _Float16*)w_hl; p.wl = nullptr; p.a_absmax = in_absmax; p.b_inv_scale = 1.f / w_scale;
+    p.hs = c->hin; p.ws = c->win; p.cs = c->cin; p.hd = c->hout; p.wd = c->wout; p.cd = c->cout;
+    p.kh = c->kh; p.kw = c->kw; p.stride = 1; p.pad = c->pad; p.dil = c->dil; p.ldc = c->ldc;
+    p.M = c->n * c->hout * c->wout; p.K = c->kh * c->kw * c->cin; p.kp = p.K; p.transposed = 0; p.relu = 0;
+    p.src_bytes = (unsigned)((int64_t)c->n * c->hin * c->win * c->cin * 4);
+    p.w_bytes = (unsigned)((int64_t)c->cout * p.K * 4);
+    return launch_gemm_hl(p, workspace, (hipStream_t)stream);
+}
+
+// dout_hl: hl32 image of the output gradient [n, hout, wout, ldc], scaled by pow2_scale(*dout_absmax); wt_hl: hl32 image of
+// the channel-transposed weights [cin][taps * ldc / 32][hi | lo] (dcn_split_weights_hl32, transposed).
+extern "C" int dcn_conv_dgrad_hl(const dcn_conv_desc* c, const void* dout_hl, const void* wt_hl, float w_scale,
+                                 const float* dout_absmax, const float* add, float* din, void* workspace, void* stream) {
+    if (!dout_hl || !wt_hl || !din || !(w_scale > 0.f)) return DCN_E_INVALID;
+    if (!hl_supported(c, 1)) return DCN_E_UNSUPPORTED;
+    GemmConv p;
+    p.src = (const float*)dout_hl; p.wm = nullptr; p.bias = nullptr; p.add = add; p.dst = din; p.bn_partial = nullptr;
+    p.out_absmax = nullptr; p.wh = (const _Float16*)wt_hl; p.wl = nullptr; p.a_absmax = dout_absmax; p.b_inv_scale = 1.f / w_scale;
+    p.hs = c->hout; p.ws = c->wout; p.cs = c->ldc; p.hd = c->hin; p.wd = c->win; p.cd = c->cin;
+    p.kh = c->kh; p.kw = c->kw; p.stride = 1; p.pad = c->pad; p.dil = c->dil; p.ldc = c->cin;
+    p.M = c->n * c->hin * c->win; p.K = c->kh * c->kw * c->ldc; p.kp = p.K; p.transposed = 1; p.relu = 0;
+    p.src_bytes = (unsigned)((int64_t)c->n * c->hout * c->wout * c->ldc * 4);
+    p.w_bytes = (unsigned)((int64_t)c->cin * p.K * 4);
+    return launch_gemm_hl(p, workspace, (hipStream_t)stream);
+}

@@ -71,6 +71,26 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
     return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + local;
 }
 
+// Stream-K tiles completed INSIDE the GEMM launch: every workgroup that parks a partial accumulator of a tile then counts
+// itself into the tile's arrival word; the one that finds itself last (all the others' partials are then visible: they
+// are written through and read past the per-XCD L2s with device-coherent accesses, see gemm_segment_f16) sums the parked
+// partials in the fixed order of the contributing workgroups and runs the epilogue -- bit-identical to the separate fix-up
+// kernel, without its launch, and overlapped with the tiles still being computed.  The arrival word is
+// (launch id << 32) | arrivals: a word left behind by any other launch (or never initialised) counts as zero, so the
+// workspace needs no clearing; the last arriver resets it to 0 so that a replay of the same captured launch starts clean.
+__device__ __forceinline__ bool sk_arrive_is_last(unsigned long long* cnt, unsigned id, int contributors) {
+    unsigned long long old = __atomic_load_n(cnt, __ATOMIC_RELAXED);
+    for (;;) {
+        const unsigned long long nv = (unsigned)(old >> 32) == id ? old + 1ull : (((unsigned long long)id << 32) | 1ull);
+        const unsigned long long seen = atomicCAS(cnt, old, nv);
+        if (seen == old) return (int)(unsigned)(nv & 0xffffffffull) == contributors;
+        old = seen;
+    }
+}
+
+// id of a stream-K launch with in-launch completion (process-wide, never 0; defined in conv_f16_kernels.hip)
+unsigned next_sk_launch_id();
+
 // ---- geometry shared by the gather-GEMM kernel and its stream-K fix-up kernel
 // WM: wavefronts along M (2 -> 2x2 wave grid, 1 -> 1x4).  TM / TN: 32x32 MFMA tiles per wavefront.
 // Workgroup tile = (32*TM*WM) x (32*TN*(4/WM)).  BK: K elements staged per barrier.

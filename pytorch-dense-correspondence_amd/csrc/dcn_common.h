@@ -5,6 +5,14 @@
 
 #include "dcn_hip.h"
 
+// Counted waits of the LDS-DMA pipelines (conv_hl_kernels.hip): inline asm, so that the counts stay exactly where they are
+// written (the compiler's own s_waitcnt insertion does not see them).  The test-only host emulation (tests/hostemu) defines
+// its own versions before this header is read.
+#ifndef DCN_WAIT_VMCNT
+#define DCN_WAIT_VMCNT(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
+#define DCN_WAIT_LGKMCNT0() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
+#endif
+
 namespace dcn {
 
 constexpr int kWave = 64;  // CDNA wavefront

@@ -21,8 +21,11 @@ void launch_bn_finalize(const float* partial, int tiles_per_group, int groups, i
                         int training, float* stats, float* out_bound, const float* res_bound, hipStream_t st);
 // y = [relu](x*scale1 + shift1 + (res ? (stats2 ? res*scale2 + shift2 : res) : 0))
 // relu_mask (optional, with relu): one byte per float4 of y, bit j = y[4i + j] > 0 (read back by launch_bn_bwd)
+// hl_out (optional, with hl_absmax; C % 32 == 0): y also as the hl32 image of conv_hl_kernels.hip, scaled by the power of two
+// chosen from *hl_absmax (the bound launch_bn_finalize stored for y)
 void launch_bn_apply(const float* x, const float* stats1, const float* res, const float* stats2, int relu, float* y,
-                     unsigned char* relu_mask, int C, int64_t rows, int groups, hipStream_t st);
+                     unsigned char* relu_mask, int C, int64_t rows, int groups, hipStream_t st, void* hl_out = nullptr,
+                     const float* hl_absmax = nullptr);
 int bn_bwd_chunks(int64_t rows_per_group);
 // partial: groups*bn_bwd_chunks(rows/groups)*4*C floats, k123: groups*3*C floats.  g_out (nullable) receives the
 // relu-masked dy.  absmax (optional): raised to an upper bound of max |dx|
@@ -32,7 +35,9 @@ void launch_bn_bwd(const float* dy, const float* relu_out, const unsigned char* 
                    int64_t rows, int groups, float* partial, float* dgamma, float* dbeta, float* k123, float* dx,
                    float* g_out, float* absmax, void* dq, hipStream_t st,    // dq (optional, with absmax): dx also as the
                    int reduced_tiles_per_group = 0,                          // pixel-blocked split-fp16 tensor (f16_split.h)
-                   const float* dy2 = nullptr);   // dy2 (optional): the upstream gradient is dy + dy2 (residual branch's share)
+                   const float* dy2 = nullptr,    // dy2 (optional): the upstream gradient is dy + dy2 (residual branch's share)
+                   void* hl_dx = nullptr,         // hl_dx (optional, with dq; C % 32 == 0): dx also as the hl32 image the pre-split
+                   int keep_dx = 0);              // dgrad reads; the fp32 dx is then NOT written unless keep_dx
 // reduced_tiles_per_group > 0: `partial` already holds that many rows per group of per-tile sums, written by the epilogue
 // of the dgrad that produced dy (GemmConv::bnb_partial) -- the reduce pass is skipped; dy is then already ReLU-masked
 // (pass relu_out = relu_mask = nullptr)

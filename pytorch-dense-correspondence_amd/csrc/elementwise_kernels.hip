@@ -179,7 +179,12 @@ __global__ void __launch_bounds__(256)
 bn_apply_kernel(const float* __restrict__ x, const float* __restrict__ s1, const float* __restrict__ b1,
                 const float* __restrict__ res, const float* __restrict__ s2, const float* __restrict__ b2, int relu,
                 float* __restrict__ y, unsigned char* __restrict__ relu_mask, int c4n, int64_t total4, int64_t group4,
-                int gstride) {
+                int gstride, dcnsplit::u32x2* __restrict__ hl, const float* __restrict__ hl_absmax) {
+    // hl (optional, c4n % 8 == 0): y also as the "hl32" image the pre-split convolution kernel reads (conv_hl_kernels.hip) --
+    // per 32-channel chunk one 128-byte line [hi x32 | lo x32] fp16 of s y, s = the power of two chosen from *hl_absmax (the
+    // bound of max |y| that bn_finalize_kernel stored before this pass): the consumer's operand split costs 4 B / element
+    // of extra stores here instead of a pass of its own
+    const float hs = hl ? dcnsplit::pow2_scale(*hl_absmax) : 1.f;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total4; i += (int64_t)gridDim.x * 256) {
         const int c = (int)(i % c4n) * 4 + (i >= group4 ? gstride : 0);   // (at most two groups: second group's statistics)
         const float4 v = reinterpret_cast<const float4*>(x)[i];
@@ -201,6 +206,13 @@ bn_apply_kernel(const float* __restrict__ x, const float* __restrict__ s1, const
         // of 16 to rebuild the ReLU mask
         if (relu_mask)
             relu_mask[i] = (unsigned char)((o.x > 0.f ? 1 : 0) | (o.y > 0.f ? 2 : 0) | (o.z > 0.f ? 4 : 0) | (o.w > 0.f ? 8 : 0));
+        if (hl) {   // float4 i = channel quad (i & 7) of 32-channel chunk (i >> 3): 8 bytes of the hi half-line, 8 of the lo one
+            dcnsplit::h4 a, b;
+            dcnsplit::split4(o, hs, a, b);
+            dcnsplit::u32x2* line = hl + (i >> 3) * 16 + (i & 7);
+            line[0] = __builtin_bit_cast(dcnsplit::u32x2, a);
+            line[8] = __builtin_bit_cast(dcnsplit::u32x2, b);
+        }
     }
 }
 
@@ -398,7 +410,10 @@ bn_bwd_apply_blocked_kernel(const float* __restrict__ dy, const float* dy2, cons
                             const float* __restrict__ mean, const float* __restrict__ invstd, const float* __restrict__ k1,
                             const float* __restrict__ k2, const float* __restrict__ k3, float* __restrict__ dx,
                             float* g_out, dcnsplit::u32x4* __restrict__ dq, const float* __restrict__ absmax,
-                            int c4n, int64_t rows, int64_t rows_per_group, int gstride, int kstride) {
+                            int c4n, int64_t rows, int64_t rows_per_group, int gstride, int kstride,
+                            dcnsplit::u32x2* __restrict__ hl) {
+    // hl (optional, c4n % 8 == 0): dx as the hl32 image the pre-split dgrad reads (same scale as dq); dx itself may then be
+    // null -- nobody else reads the fp32 tensor
     const float s = dcnsplit::pow2_scale(*absmax);
     const int64_t total = ((rows + 3) >> 2) * c4n;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
@@ -423,8 +438,15 @@ bn_bwd_apply_blocked_kernel(const float* __restrict__ dy, const float* dy2, cons
                 o[r][1] = a.y * (g.y - b.y - (v.y - mu.y) * is.y * d.y);
                 o[r][2] = a.z * (g.z - b.z - (v.z - mu.z) * is.z * d.z);
                 o[r][3] = a.w * (g.w - b.w - (v.w - mu.w) * is.w * d.w);
-                reinterpret_cast<float4*>(dx)[e] = make_float4(o[r][0], o[r][1], o[r][2], o[r][3]);
+                if (dx) reinterpret_cast<float4*>(dx)[e] = make_float4(o[r][0], o[r][1], o[r][2], o[r][3]);
                 if (g_out) reinterpret_cast<float4*>(g_out)[e] = g;
+                if (hl) {
+                    dcnsplit::h4 ha, hb;
+                    dcnsplit::split4(make_float4(o[r][0], o[r][1], o[r][2], o[r][3]), s, ha, hb);
+                    dcnsplit::u32x2* line = hl + (e >> 3) * 16 + (e & 7);
+                    line[0] = __builtin_bit_cast(dcnsplit::u32x2, ha);
+                    line[8] = __builtin_bit_cast(dcnsplit::u32x2, hb);
+                }
             } else {
                 o[r][0] = o[r][1] = o[r][2] = o[r][3] = 0.f;
             }
@@ -684,10 +706,13 @@ void launch_bn_finalize(const float* partial, int tiles_per_group, int groups, i
                        stats + 3 * C, 4 * C, out_bound, res_bound);
 }
 void launch_bn_apply(const float* x, const float* stats1, const float* res, const float* stats2, int relu, float* y,
-                     unsigned char* relu_mask, int C, int64_t rows, int groups, hipStream_t st) {
+                     unsigned char* relu_mask, int C, int64_t rows, int groups, hipStream_t st, void* hl_out,
+                     const float* hl_absmax) {
     const int64_t total4 = rows * (C / 4);
+    if ((C % 32) != 0 || !hl_absmax) hl_out = nullptr;
     hipLaunchKernelGGL(bn_apply_kernel, dim3(blocks_for(total4, kGridCap)), dim3(256), 0, st, x, stats1, stats1 + C, res,
-                       stats2, stats2 ? stats2 + C : nullptr, relu, y, relu_mask, C / 4, total4, total4 / groups, 4 * C);
+                       stats2, stats2 ? stats2 + C : nullptr, relu, y, relu_mask, C / 4, total4, total4 / groups, 4 * C,
+                       (dcnsplit::u32x2*)hl_out, hl_absmax);
 }
 int bn_bwd_chunks(int64_t rows_per_group) {
     // enough row chunks that even a 64-channel layer launches >= ~1000 workgroups (HBM-bound pass: fill all 256 CUs)
@@ -699,7 +724,8 @@ int bn_bwd_chunks(int64_t rows_per_group) {
 void launch_bn_bwd(const float* dy, const float* relu_out, const unsigned char* relu_mask, const float* x, const float* stats,
                    const float* gamma, int C,
                    int64_t rows, int groups, float* partial, float* dgamma, float* dbeta, float* k123, float* dx,
-                   float* g_out, float* absmax, void* dq, hipStream_t st, int reduced_tiles_per_group, const float* dy2) {
+                   float* g_out, float* absmax, void* dq, hipStream_t st, int reduced_tiles_per_group, const float* dy2,
+                   void* hl_dx, int keep_dx) {
     const int64_t rpg = rows / groups;
     const float* mean = stats + 2 * C;
     const float* invstd = stats + 3 * C;
@@ -716,8 +742,9 @@ void launch_bn_bwd(const float* dy, const float* relu_out, const unsigned char* 
     if (dq && absmax) {
         hipLaunchKernelGGL(bn_bwd_apply_blocked_kernel, dim3(blocks_for(((rows + 3) / 4) * (C / 4), kGridCap)), dim3(256), 0, st,
                            dy, dy2, relu_out, relu_mask, x, mean, invstd, (const float*)k123, (const float*)(k123 + C),
-                           (const float*)(k123 + 2 * C), dx, g_out, (dcnsplit::u32x4*)dq, (const float*)absmax, C / 4, rows,
-                           rpg, 4 * C, 3 * C);
+                           (const float*)(k123 + 2 * C), (hl_dx && (C % 32) == 0 && !keep_dx) ? nullptr : dx, g_out,
+                           (dcnsplit::u32x4*)dq, (const float*)absmax, C / 4, rows, rpg, 4 * C, 3 * C,
+                           (C % 32) == 0 ? (dcnsplit::u32x2*)hl_dx : nullptr);
         return;
     }
     hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(blocks_for(total4, kGridCap)), dim3(256), 0, st, dy, dy2, relu_out, relu_mask,

@@ -132,6 +132,16 @@ SYMBOLS = {
     "dcn_upsample_backward": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p,
                                       c_void_p]),
     "dcn_upsample_backward_tmp_bytes": (c_size_t, [c_int, c_int, c_int, c_int]),
+    "dcn_conv_hl_eligible": (c_int, [ctypes.POINTER(ConvDesc), c_int]),
+    "dcn_conv_num_mtiles_hl": (c_int, [ctypes.POINTER(ConvDesc)]),
+    "dcn_conv_gemm_workspace_hl": (c_size_t, [ctypes.POINTER(ConvDesc), c_int]),
+    "dcn_split_act_hl32": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_void_p]),
+    "dcn_split_weights_hl32": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_float,
+                                       c_void_p]),
+    "dcn_conv_forward_hl": (c_int, [ctypes.POINTER(ConvDesc), c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_void_p,
+                                    c_void_p, c_void_p, c_void_p]),
+    "dcn_conv_dgrad_hl": (c_int, [ctypes.POINTER(ConvDesc), c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_void_p,
+                                  c_void_p, c_void_p]),
 }
 
 ERRORS = {-1: "DCN_E_INVALID (bad argument)", -2: "DCN_E_LAUNCH (kernel launch failed)",

@@ -88,11 +88,18 @@ extern "C" void hipemu_switch(void** save_sp, void* new_sp);
 
 enum { RUNNABLE = 0, WAIT_BLOCK = 1, DONE = 2 };
 
+// LDS-DMA (`buffer_load ... lds`) in flight: 16 bytes captured at issue, written to LDS when the issuing work-item's
+// counted vmcnt wait retires it (the LATEST moment the hardware allows) -- or at issue (HIPEMU_LDS_DMA=early, the earliest)
+struct PendingDma {
+    void* dst;
+    unsigned char data[16];
+};
 struct Fiber {
     void* sp = nullptr;
     char* stack = nullptr;
     int state = DONE;
     unsigned tid = 0;
+    std::vector<PendingDma> dma;   // FIFO, oldest first
 };
 
 struct WaveState {
@@ -364,7 +371,7 @@ static inline void hipemu_raw_buffer_store_b128(hipemu_u32x4 v, hipemu_buffer_rs
         memcpy(const_cast<char*>(r.base) + (long long)(unsigned)voffset + (unsigned)soffset, &v, 16);
 }
 #define __builtin_amdgcn_raw_buffer_store_b128 hipemu_raw_buffer_store_b128
-#define __builtin_amdgcn_s_waitcnt(x) __atomic_thread_fence(__ATOMIC_SEQ_CST)
+#define __builtin_amdgcn_s_waitcnt(x) (hipemu_wait_vmcnt(((x) & 0xF) | (((x) >> 14) << 4)), __atomic_thread_fence(__ATOMIC_SEQ_CST))
 #define __amdgpu_buffer_rsrc_t hipemu_buffer_rsrc
 #define __builtin_amdgcn_make_buffer_rsrc(p, stride, n, flags) hipemu_make_buffer_rsrc((const void*)(p), stride, n, flags)
 #define __builtin_amdgcn_raw_buffer_load_b128 hipemu_raw_buffer_load_b128
@@ -372,6 +379,34 @@ static inline void hipemu_raw_buffer_store_b128(hipemu_u32x4 v, hipemu_buffer_rs
 #define __builtin_amdgcn_mfma_f32_32x32x16_f16 hipemu_mfma_32x32x16f16
 #define __builtin_amdgcn_mfma_f32_32x32x2f32 hipemu_mfma_32x32x2f32
 #define __builtin_amdgcn_mfma_f32_16x16x4f32 hipemu_mfma_16x16x4f32
+// ---- LDS-DMA + counted waits + raw barrier (conv_hl_kernels.hip)
+static inline bool hipemu_dma_early() {
+    static const int early = [] { const char* e = getenv("HIPEMU_LDS_DMA"); return (e && !strcmp(e, "early")) ? 1 : 0; }();
+    return early != 0;
+}
+static inline void hipemu_buffer_load_lds(hipemu_buffer_rsrc r, void* lds_base, int size, int voffset, int soffset) {
+    if (size != 16) { fprintf(stderr, "hipemu: LDS-DMA of %d bytes not modelled\n", size); abort(); }
+    ::hipemu::Worker* w = ::hipemu::t_worker;
+    ::hipemu::Fiber& f = w->fibers[w->cur];
+    ::hipemu::PendingDma d;
+    d.dst = (char*)lds_base + 16 * ::hipemu::lane_id();
+    const hipemu_u32x4 v = hipemu_raw_buffer_load_b128(r, voffset, soffset, 0);
+    memcpy(d.data, &v, 16);
+    if (hipemu_dma_early()) memcpy(d.dst, d.data, 16);
+    else f.dma.push_back(d);
+}
+static inline void hipemu_wait_vmcnt(int n) {   // retire the oldest LDS-DMA pieces until at most n are in flight
+    ::hipemu::Worker* w = ::hipemu::t_worker;
+    ::hipemu::Fiber& f = w->fibers[w->cur];
+    while ((int)f.dma.size() > n) {
+        memcpy(f.dma.front().dst, f.dma.front().data, 16);
+        f.dma.erase(f.dma.begin());
+    }
+}
+#define __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, lp, sz, vo, so, a, b) hipemu_buffer_load_lds(rs, (void*)(lp), sz, vo, so)
+#define DCN_WAIT_VMCNT(n) hipemu_wait_vmcnt(n)
+#define DCN_WAIT_LGKMCNT0() ((void)0)
+#define __builtin_amdgcn_s_barrier() ::hipemu::block_barrier()
 #define __builtin_amdgcn_s_setprio(x) ((void)0)
 #define __builtin_amdgcn_sched_barrier(x) ((void)0)
 #define __builtin_amdgcn_sched_group_barrier(a, b, c) ((void)0)

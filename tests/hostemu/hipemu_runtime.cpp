@@ -54,6 +54,7 @@ static void prepare_fiber(Fiber& f, unsigned tid) {
     f.sp = sp;
     f.state = RUNNABLE;
     f.tid = tid;
+    f.dma.clear();   // (LDS-DMA pieces a finished kernel never waited for)
 }
 
 static void run_block(Worker& w, dim3 block) {

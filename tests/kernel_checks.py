@@ -197,3 +197,103 @@ def check_stem_uniform_tap(L, dev, n, hin, win):
             assert lib.dcn_conv_stem_forward_f16(ctypes.byref(d), L.ptr(xbd), None, L.ptr(hi), L.ptr(lo), 64.0, L.ptr(out3), None, None) == 0
             refb = F.conv2d(xb.permute(0, 3, 1, 2), w4.permute(0, 3, 1, 2), None, 2, 3, 1).permute(0, 2, 3, 1)
             assert torch.equal(torch.isnan(out3.cpu()), torch.isnan(refb))   # NaN exactly where the true convolution has it
+
+
+def hl32_image(L, lib, x2d, absmax, dev):
+    """[rows][C] fp32 (device) -> its hl32 image (dcn_split_act_hl32) as a float32-typed byte buffer of the same size."""
+    rows, C = x2d.shape
+    out = torch.empty(rows * C, dtype=torch.float32, device=dev)
+    assert lib.dcn_split_act_hl32(L.ptr(x2d), L.ptr(absmax) if absmax is not None else None, L.ptr(out), rows, C, None) == 0
+    return out
+
+
+def hl32_decode(img, rows, C):
+    """hl32 byte buffer -> (hi, lo) float32 [rows][C] (host)."""
+    h = img.cpu().view(torch.float16).reshape(rows, C // 32, 2, 32).float()
+    return h[:, :, 0, :].reshape(rows, C), h[:, :, 1, :].reshape(rows, C)
+
+
+def check_conv_hl(L, dev, n, h, w, cin, cout, k, dil, set_env=None, sk=None, scale_x=1.0, seed=0):
+    """The pre-split (hl32) LDS-DMA gather-GEMM, forward and dgrad, against F.conv2d / its autograd in float64 and against
+    the fp32-operand split-fp16 kernel; the operand split, the weight images and the batch-norm partial sums on the way."""
+    lib = L.get()
+    g = torch.Generator().manual_seed(seed)
+    pad = dil * (k - 1) // 2
+    t = lambda a: a.to(dev).contiguous()
+    x = torch.randn(n, h, w, cin, generator=g) * scale_x
+    x = torch.relu(x) if seed % 2 else x
+    wt_ = torch.randn(cout, k, k, cin, generator=g) * 0.1
+    dout = torch.randn(n, h, w, cout, generator=g) * 1e-3 * scale_x
+    M = n * h * w
+    if sk is not None:
+        set_env(DCN_GEMM_SK=sk)
+    d = L.ConvDesc(n, h, w, cin, h, w, cout, k, k, 1, pad, dil, cout, 0)
+    xd, dd = t(x), t(dout)
+    ax, ad = t(x.abs().max().reshape(1)), t(dout.abs().max().reshape(1))
+    # ---- operand images
+    xi = hl32_image(L, lib, xd.reshape(M, cin), ax, dev)
+    hi, lo = hl32_decode(xi, M, cin)
+    s = 2.0 ** torch.floor(torch.log2(4096.0 / x.abs().max()))
+    assert rel_err((hi + lo) / s, x.reshape(M, cin)) < 3e-7 and float(hi.abs().max()) <= 4096.0
+    do_dgrad = cout % 32 == 0            # (the gathered operand of dgrad is the gradient: whole 32-channel chunks)
+    di = hl32_image(L, lib, dd.reshape(M, cout), ad, dev) if do_dgrad else None
+    K = k * k * cin
+    w2d = t(wt_.reshape(cout, K))
+    wtr = t(wt_.reshape(cout, k * k, cin).permute(2, 1, 0).contiguous().reshape(cin, k * k * cout))
+    w_hl = torch.empty(cout * K, dtype=torch.float32, device=dev)
+    wt_hl = torch.empty(cin * k * k * cout, dtype=torch.float32, device=dev)
+    P, I = ctypes.c_void_p, ctypes.c_int
+    arr = lambda ty, v: (ty * 1)(v)
+    assert lib.dcn_split_weights_hl32(1, arr(P, w2d.data_ptr()), arr(P, w_hl.data_ptr()), arr(I, cout), arr(I, k * k), arr(I, cin),
+                                      arr(I, cout), 0, 64.0, None) == 0
+    whi, wlo = hl32_decode(w_hl, cout, K)
+    assert rel_err((whi + wlo) / 64.0, wt_.reshape(cout, K)) < 3e-7
+    w4 = t(wt_)
+    if do_dgrad:
+        assert lib.dcn_split_weights_hl32(1, arr(P, w4.data_ptr()), arr(P, wt_hl.data_ptr()), arr(I, cout), arr(I, k * k),
+                                          arr(I, cin), arr(I, cout), 1, 64.0, None) == 0
+        thi, tlo = hl32_decode(wt_hl, cin, k * k * cout)
+        assert rel_err((thi + tlo) / 64.0, wtr.cpu()) < 3e-7
+    # ---- forward
+    mt = lib.dcn_conv_num_mtiles_hl(ctypes.byref(d))
+    assert mt == (M + 255) // 256
+    nws = max(lib.dcn_conv_gemm_workspace_hl(ctypes.byref(d), 0), lib.dcn_conv_gemm_workspace_hl(ctypes.byref(d), 1))
+    if sk is not None and str(sk) != "0":
+        assert nws > 8, "stream-K is not exercised by this shape"
+    ws = garbage(nws, dev, seed + 3)
+    out = torch.full((n, h, w, cout), float("nan"), device=dev)
+    part = torch.full((mt, 3, cout), float("nan"), device=dev)
+    assert lib.dcn_conv_forward_hl(ctypes.byref(d), L.ptr(xi), L.ptr(ax), L.ptr(w_hl), 64.0, None, L.ptr(out), L.ptr(part),
+                                   L.ptr(ws), None) == 0
+    xr = x.double().permute(0, 3, 1, 2).requires_grad_(True)
+    ref = F.conv2d(xr, wt_.double().permute(0, 3, 1, 2), None, 1, pad, dil)
+    refn = ref.detach().permute(0, 2, 3, 1)
+    res = {"fwd": rel_err(out.cpu(), refn)}
+    assert res["fwd"] < 5e-6, res
+    pc = part.cpu().double()
+    assert rel_err(pc[:, 0].sum(0), refn.sum((0, 1, 2))) < 2e-5
+    assert rel_err(pc[:, 1].sum(0), (refn ** 2).sum((0, 1, 2))) < 2e-5
+    assert rel_err(pc[:, 2].amax(0), refn.abs().amax((0, 1, 2))) < 5e-6
+    # same products as the fp32-operand kernel, other summation order
+    wh, wl = _split_rows(L, lib, w2d, dev)
+    out2 = torch.full_like(out, float("nan"))
+    ws2 = garbage(lib.dcn_conv_gemm_workspace_f16(ctypes.byref(d), 0), dev, seed + 4)
+    assert lib.dcn_conv_forward_f16(ctypes.byref(d), L.ptr(xd), L.ptr(ax), L.ptr(wh), L.ptr(wl), 64.0, None, L.ptr(out2), None,
+                                    L.ptr(ws2), None) == 0
+    res["fwd_vs_f16"] = rel_err(out.cpu(), out2.cpu())
+    assert res["fwd_vs_f16"] < 6e-6, res
+    # ---- dgrad (second launch on the workspace the forward left behind)
+    din = torch.full((n, h, w, cin), float("nan"), device=dev)
+    if not do_dgrad:
+        assert lib.dcn_conv_dgrad_hl(ctypes.byref(d), L.ptr(xi), L.ptr(wt_hl), 64.0, L.ptr(ad), None, L.ptr(din), L.ptr(ws), None) == -3
+        return res
+    assert lib.dcn_conv_dgrad_hl(ctypes.byref(d), L.ptr(di), L.ptr(wt_hl), 64.0, L.ptr(ad), None, L.ptr(din), L.ptr(ws), None) == 0
+    (ref * dout.double().permute(0, 3, 1, 2)).sum().backward()
+    res["dgrad"] = rel_err(din.cpu(), xr.grad.permute(0, 2, 3, 1))
+    assert res["dgrad"] < 5e-6, res
+    # bit-reproducible (stream-K completion order is fixed)
+    out3 = torch.full_like(out, float("nan"))
+    assert lib.dcn_conv_forward_hl(ctypes.byref(d), L.ptr(xi), L.ptr(ax), L.ptr(w_hl), 64.0, None, L.ptr(out3), None,
+                                   L.ptr(ws), None) == 0
+    assert torch.equal(out3.cpu(), out.cpu())
+    return res

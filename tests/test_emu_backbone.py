@@ -291,3 +291,51 @@ def test_grouped_pair_forward_equals_two_forward_calls(arch, bw, shape):
     xs = torch.randn(1, 3, 40, 24, generator=g)
     y1, y2 = m.forward_pair(xs, xs * 0.5)
     assert rel_err(y1, o(xs)) < 2e-5 and rel_err(y2, o(xs * 0.5)) < 2e-5
+
+
+@pytest.mark.parametrize("arch,bw,shape,groups,producers", [
+    ("Resnet18_8s", 32, (1, 32, 40), 1, 1), ("Resnet18_8s", 32, (1, 32, 40), 1, 0), ("Resnet50_8s", 32, (1, 32, 32), 1, 1),
+    ("Resnet18_8s", 32, (2, 128, 128), 2, 1)])
+def test_wide_layers_through_the_hl32_path(arch, bw, shape, groups, producers, dcn_env, conv_mode):
+    """DCN_GEMM_HL=2: every convolution the pre-split (hl32) LDS-DMA kernel supports takes it (forward and dgrad, engine
+    workspace, weight images per call).  Forward: against the engine's own fp32-operand kernels and the float64 oracle.
+    Backward: on the SAME forward pass (saved arena written with DCN_GEMM_HL=0, so that both backward passes see identical
+    ReLU masks -- a pre-activation within round-off of zero otherwise moves a whole channel's gradient by per cent in
+    whichever arithmetic it flips) the hl32 dgrads must reproduce the fp32-operand ones.  With two statistics groups
+    (forward_pair) only layers whose groups are whole 256-row tiles qualify.  producers: the hl32 activation / gradient
+    images are written by the batch-norm apply passes that produce the tensors (1) or by stand-alone split passes (0)."""
+    if conv_mode != "f16x3":
+        pytest.skip("the hl32 path belongs to the split-fp16 arithmetic")
+    N, H, W = shape
+    D = 3
+    m, o = _pair(arch, D, bw)
+    m2, m3 = copy.deepcopy(m), copy.deepcopy(m)
+    o64 = copy.deepcopy(o).double()
+    g = torch.Generator().manual_seed(7)
+    x = torch.randn(N, 3, H, W, generator=g)
+    gy = torch.randn(N, D, H, W, generator=g)
+    for net in (m, m2, m3, o, o64):
+        net.train()
+
+    def fwd(net):
+        if groups == 2:
+            return torch.cat(net.forward_pair(x[:N // 2], x[N // 2:]))
+        return net(x)
+    dcn_env(DCN_GEMM_HL=2, DCN_HL_PRODUCERS=producers)
+    y = fwd(m)
+    dcn_env(DCN_GEMM_HL=0)
+    y2, y3 = fwd(m2), fwd(m3)
+    if groups == 1:
+        yo, y64 = o(x), o64(x.double())
+        cond = rel_err(yo, y64)            # (how far float32 round-off moves this network's output)
+        assert rel_err(y, y64) < 3 * cond + 1e-5
+        assert rel_err(y, y2) < 3 * cond + 2e-5   # same products, other summation order, through the whole network
+    else:
+        assert rel_err(y, y2) < 1e-4
+    for (k, b), b2 in zip(m.named_buffers(), m2.buffers()):
+        assert rel_err(b.float(), b2.float()) < 1e-4 or float((b.float() - b2.float()).abs().max()) < 1e-5, k
+    (y2 * gy).sum().backward()             # fp32-operand dgrads
+    dcn_env(DCN_GEMM_HL=2, DCN_HL_PRODUCERS=producers)
+    (y3 * gy).sum().backward()             # hl32 dgrads on an identical saved arena
+    for (k, p2), p3 in zip(m2.named_parameters(), m3.parameters()):
+        assert rel_err(p3.grad, p2.grad) < 3e-5, (k, rel_err(p3.grad, p2.grad))

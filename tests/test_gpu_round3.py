@@ -1,0 +1,77 @@
+"""-m gpu tests of round 3: the pre-split (hl32) LDS-DMA gather-GEMM of the wide layers (conv_hl_kernels.hip) -- forward and
+dgrad against F.conv2d / autograd in float64 and against the fp32-operand split-fp16 kernel, at small ragged shapes and at
+the layer shapes of the BASELINE configs, plain launches and stream-K, repeated on one workspace (race screen)."""
+import pytest
+import torch
+
+from helpers import use_gfx950_library
+import kernel_checks
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def L():
+    lib = use_gfx950_library()
+    assert torch.cuda.is_available()
+    return lib
+
+
+HL_SMALL = [
+    # n, h, w, cin, cout, k, dil, DCN_GEMM_SK, x scale   (the CPU suite's cases: tests/test_emu_kernels.py)
+    (1, 12, 20, 32, 40, 3, 2, None, 1.0),
+    (2, 16, 24, 64, 288, 3, 1, None, 1.0),
+    (2, 16, 24, 64, 288, 3, 1, "5", 1e4),
+    (1, 20, 20, 128, 256, 1, 1, "3", 1.0),
+    (1, 9, 30, 96, 256, 3, 4, "3", 1e-6),
+]
+HL_LAYERS = [
+    (8, 60, 80, 256, 256, 3, 2, None, 1.0),     # layer 3 of config 2: 150 tiles on 256 CUs, less than a round: data-parallel
+    (8, 60, 80, 256, 256, 3, 2, "200", 1.0),    # ... and forced over 200 stream-K workgroups
+    (8, 60, 80, 512, 512, 3, 4, "1", 1.0),      # layer 4: 300 tiles -> 256 data-parallel + 44 stream-K
+    (8, 60, 80, 128, 256, 3, 1, None, 1.0),     # layer3.0.conv1 forward (dgrad: 128 destination channels, one ragged N tile)
+    (2, 60, 80, 256, 512, 3, 4, "0", 1.0),      # config 1 size, no stream-K: 38 tiles, ragged last M tile (9600 rows)
+    (3, 120, 160, 256, 1024, 1, 1, "1", 1.0),   # ResNet50-8s 1x1 expansion at 1280 x 960 (config 5): 225 x 4 tiles
+]
+
+
+@pytest.mark.parametrize("case", HL_SMALL + HL_LAYERS, ids=[str(c) for c in HL_SMALL + HL_LAYERS])
+def test_conv_hl32_lds_dma_gather_gemm(L, case, dcn_env):
+    n, h, w, cin, cout, k, dil, sk, sx = case
+    for rep in range(3):   # (again on the workspace the previous launches left behind; other seeds, other data)
+        res = kernel_checks.check_conv_hl(L, "cuda", n, h, w, cin, cout, k, dil, set_env=dcn_env, sk=sk, scale_x=sx,
+                                          seed=len(str(case)) + rep)
+    print(case, res)
+
+
+def test_conv_hl32_repeated_launches_are_bit_identical(L, dcn_env):
+    """Race screen of the LDS-DMA schedule: 20 launches of the layer-4 convolution on the same operands must agree bit for
+    bit (a fragment read that is not covered by counted wait + barrier shows up as a rare wrong tile)."""
+    import ctypes
+    lib = L.get()
+    n, h, w, cin, cout, k, dil = 8, 60, 80, 512, 512, 3, 4
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(n, h, w, cin, generator=g).cuda()
+    wt_ = (torch.randn(cout, k, k, cin, generator=g) * 0.1).cuda()
+    M, K = n * h * w, k * k * cin
+    ax = x.abs().max().reshape(1)
+    xi = kernel_checks.hl32_image(L, lib, x.reshape(M, cin), ax, "cuda")
+    w_hl = torch.empty(cout * K, device="cuda")
+    P, I = ctypes.c_void_p, ctypes.c_int
+    arr = lambda ty, v: (ty * 1)(v)
+    assert lib.dcn_split_weights_hl32(1, arr(P, wt_.data_ptr()), arr(P, w_hl.data_ptr()), arr(I, cout), arr(I, k * k), arr(I, cin),
+                                      arr(I, cout), 0, 64.0, None) == 0
+    d = L.ConvDesc(n, h, w, cin, h, w, cout, k, k, 1, dil, dil, cout, 0)
+    for sk in ("1", "0", "200"):
+        dcn_env(DCN_GEMM_SK=sk)
+        ws = kernel_checks.garbage(max(lib.dcn_conv_gemm_workspace_hl(ctypes.byref(d), 0), 8), "cuda", 1)
+        outs = []
+        for _ in range(20):
+            out = torch.full((n, h, w, cout), float("nan"), device="cuda")
+            assert lib.dcn_conv_forward_hl(ctypes.byref(d), L.ptr(xi), L.ptr(ax), L.ptr(w_hl), 64.0, None, L.ptr(out), None,
+                                           L.ptr(ws), L.stream_ptr()) == 0
+            outs.append(out)
+        torch.cuda.synchronize()
+        assert bool(torch.isfinite(outs[0]).all())
+        for o in outs[1:]:
+            assert torch.equal(o, outs[0]), "sk=%s" % sk

@@ -40,7 +40,10 @@ def main():
     ap.add_argument("--x-direct", action="store_true", help="f16 wgrad: fp32 activation operand split on the fly")
     ap.add_argument("--no-split", action="store_true", help="f16 wgrad: time the GEMM kernel alone (planes prepared once)")
     ap.add_argument("--check", action="store_true", help="with --mode f16: compare against the fp32 kernels")
-    ap.add_argument("--mode", default="fp32", choices=["fp32", "f16"], help="fp32 MFMA kernels or the split-fp16 (f16x3) ones")
+    ap.add_argument("--mode", default="fp32", choices=["fp32", "f16", "hl"],
+                    help="fp32 MFMA kernels, the split-fp16 (f16x3) ones, or f16 with the pre-split (hl32) LDS-DMA kernel where eligible")
+    ap.add_argument("--hl-split", action="store_true", help="hl mode: time the stand-alone operand split pass with the GEMM")
+    ap.add_argument("--relu-x", action="store_true", help="activations = relu(randn) (half zeros, one sign) instead of randn")
     a = ap.parse_args()
     lib = _lib.get()
     dev = torch.device("cuda")
@@ -55,6 +58,8 @@ def main():
         wout = (win + 2 * pad - dil * (k - 1) - 1) // stride + 1
         d = _lib.ConvDesc(n, hin, win, cin, hout, wout, cout, k, k, stride, pad, dil, cout)
         x = torch.randn(n, hin, win, cin, device=dev)
+        if a.relu_x:
+            x = torch.relu(x)
         w = torch.randn(cout, k, k, cin, device=dev) * 0.05
         wt = torch.randn(cin, k, k, cout, device=dev) * 0.05
         y = torch.empty(n, hout, wout, cout, device=dev)
@@ -66,7 +71,7 @@ def main():
         flops = 2.0 * n * hout * wout * cout * k * k * (3 if cin == 4 else cin)
         wsf = torch.empty(max(lib.dcn_conv_gemm_workspace(ctypes.byref(d), 0), 4) // 4, device=dev)
         wsd = torch.empty(max(lib.dcn_conv_gemm_workspace(ctypes.byref(d), 1), 4) // 4, device=dev)
-        if a.mode == "f16":
+        if a.mode in ("f16", "hl"):
             K, Kt = k * k * cin, k * k * cout
             kp, kpt = lib.dcn_f16_kpad(K), lib.dcn_f16_kpad(Kt)
             wh = torch.empty(cout, kp, dtype=torch.float16, device=dev); wl = torch.empty_like(wh)
@@ -82,7 +87,7 @@ def main():
             "dgrad": lambda: lib.dcn_conv_dgrad(ctypes.byref(d), _lib.ptr(dy), _lib.ptr(wt), None, _lib.ptr(dx), _lib.ptr(wsd), st),
             "wgrad": lambda: lib.dcn_conv_wgrad(ctypes.byref(d), _lib.ptr(x), _lib.ptr(dy), _lib.ptr(dw), _lib.ptr(slab), st),
         }
-        if a.mode == "f16":
+        if a.mode in ("f16", "hl"):
             calls["fwd"] = lambda: lib.dcn_conv_forward_f16(ctypes.byref(d), _lib.ptr(x), None, _lib.ptr(wh), _lib.ptr(wl), 64.0,
                                                             None, _lib.ptr(y), _lib.ptr(part), _lib.ptr(wsf), st)
             calls["dgrad"] = lambda: lib.dcn_conv_dgrad_f16(ctypes.byref(d), _lib.ptr(dy), _lib.ptr(wth), _lib.ptr(wtl), 64.0,
@@ -106,6 +111,36 @@ def main():
                                                    _lib.ptr(slab), st)
             assert wgrad_f16(True) == 0
             calls["wgrad"] = wgrad_f16
+            hl_f = a.mode == "hl" and lib.dcn_conv_hl_eligible(ctypes.byref(d), 0)
+            hl_d = a.mode == "hl" and lib.dcn_conv_hl_eligible(ctypes.byref(d), 1)
+            if hl_f or hl_d:
+                P, I = ctypes.c_void_p, ctypes.c_int
+                arr = lambda ty, v: (ty * 1)(v)
+                ws_hl = torch.empty(max(lib.dcn_conv_gemm_workspace_hl(ctypes.byref(d), 0), lib.dcn_conv_gemm_workspace_hl(ctypes.byref(d), 1), 4) // 4, device=dev)
+                ax = x.abs().max().reshape(1)
+            if hl_f:
+                x_hl = torch.empty(x.numel(), device=dev)
+                w_hl = torch.empty(cout * K, device=dev)
+                assert lib.dcn_split_weights_hl32(1, arr(P, w.data_ptr()), arr(P, w_hl.data_ptr()), arr(I, cout), arr(I, k * k), arr(I, cin), arr(I, cout), 0, 64.0, st) == 0
+                assert lib.dcn_split_act_hl32(_lib.ptr(x), _lib.ptr(ax), _lib.ptr(x_hl), n * hin * win, cin, st) == 0
+
+                def fwd_hl():
+                    rc = lib.dcn_split_act_hl32(_lib.ptr(x), _lib.ptr(ax), _lib.ptr(x_hl), n * hin * win, cin, st) if a.hl_split else 0
+                    return rc | lib.dcn_conv_forward_hl(ctypes.byref(d), _lib.ptr(x_hl), _lib.ptr(ax), _lib.ptr(w_hl), 64.0, None, _lib.ptr(y), _lib.ptr(part), _lib.ptr(ws_hl), st)
+                calls["fwd"] = fwd_hl
+                name = name + " [hl fwd]"
+            if hl_d:
+                dy_hl = torch.empty(dy.numel(), device=dev)
+                wt_hl = torch.empty(cin * Kt, device=dev)
+                w_nat = wt.reshape(cin, k * k, cout).permute(2, 1, 0).contiguous()   # [cout][taps][cin] whose transpose is wt
+                assert lib.dcn_split_weights_hl32(1, arr(P, w_nat.data_ptr()), arr(P, wt_hl.data_ptr()), arr(I, cout), arr(I, k * k), arr(I, cin), arr(I, cout), 1, 64.0, st) == 0
+                assert lib.dcn_split_act_hl32(_lib.ptr(dy), _lib.ptr(amax), _lib.ptr(dy_hl), n * hout * wout, cout, st) == 0
+
+                def dgrad_hl():
+                    rc = lib.dcn_split_act_hl32(_lib.ptr(dy), _lib.ptr(amax), _lib.ptr(dy_hl), n * hout * wout, cout, st) if a.hl_split else 0
+                    return rc | lib.dcn_conv_dgrad_hl(ctypes.byref(d), _lib.ptr(dy_hl), _lib.ptr(wt_hl), 64.0, _lib.ptr(amax), None, _lib.ptr(dx), _lib.ptr(ws_hl), st)
+                calls["dgrad"] = dgrad_hl
+                name = name + " [hl dgrad]"
             if a.check:   # f16x3 vs the fp32 MFMA kernels on the same operands
                 y2, dx2, dw2 = torch.empty_like(y), torch.empty_like(dx), torch.empty_like(dw)
                 part2 = torch.empty(lib.dcn_conv_num_mtiles(ctypes.byref(d)), 3, cout, device=dev)
