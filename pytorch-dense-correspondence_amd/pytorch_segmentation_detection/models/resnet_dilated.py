@@ -84,6 +84,40 @@ class _DilatedResnet8s(nn.Module):
                     o, c, kh, kw = p.shape
                     p.normal_(0, math.sqrt(2.0 / (kh * kw * o)))
 
+    def load_imagenet_trunk(self, source, strict=True):
+        """Start from an ImageNet-trained torchvision trunk, as the original backbone does (``pretrained=True`` behind
+        ``resnet_dilated.Resnet34_8s(num_classes=D)``, dense_correspondence_network.py:373-375; doc/model_zoo.md:6-18).
+        ``source``: the path of a stock ``torchvision.models.resnet{18,34,50,101}`` checkpoint (``.pth`` state dict) or the
+        state dict itself -- its keys (``conv1.weight``, ``layer1.0.bn1.running_mean`` ...) are this trunk's keys without
+        the ``resnetNN_8s.`` prefix, and dilation does not change a single shape.  The ImageNet classifier (``fc.*``,
+        1000 x C) is dropped and the scoring layer is re-initialised N(0, 0.01) / bias 0, like the original.
+        ``strict``: every trunk tensor must be present with the right shape (missing / unexpected keys raise).
+        Returns the names of the tensors that were loaded."""
+        sd = torch.load(source, map_location="cpu") if isinstance(source, (str, bytes)) or hasattr(source, "read") else source
+        if isinstance(sd, dict) and "state_dict" in sd and not any(k.endswith(".weight") for k in sd):
+            sd = sd["state_dict"]
+        sd = {(k[len("module."):] if k.startswith("module.") else k): v for k, v in sd.items()}
+        own = getattr(self, self.attr).state_dict()
+        wanted = [k for k in own if not k.startswith("fc.")]
+        missing = [k for k in wanted if k not in sd and not k.endswith("num_batches_tracked")]
+        unexpected = [k for k in sd if k not in own and not k.startswith("fc.")]
+        bad = [k for k in wanted if k in sd and tuple(sd[k].shape) != tuple(own[k].shape)]
+        if bad:
+            raise ValueError("load_imagenet_trunk: shape mismatch for %s (expected a torchvision %s checkpoint, base width %d)"
+                             % (bad[:4], self.arch.split("_")[0].lower(), self.base_width))
+        if strict and (missing or unexpected):
+            raise KeyError("load_imagenet_trunk: missing %s, unexpected %s" % (missing[:6], unexpected[:6]))
+        loaded = []
+        with torch.no_grad():
+            for k in wanted:
+                if k in sd:
+                    own[k].copy_(sd[k].to(own[k].dtype))   # (state_dict() tensors alias the parameters / buffers)
+                    loaded.append(k)
+            fcw, fcb = own["fc.weight"], own["fc.bias"]
+            fcw.normal_(0, 0.01)
+            fcb.zero_()
+        return loaded
+
     def _tables(self):
         trunk = getattr(self, self.attr)
         params = [trunk.get_parameter(n) for n in self._param_names]

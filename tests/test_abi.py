@@ -105,3 +105,26 @@ def test_synth_constants_consistent_with_bench():
         c = synth.CONFIGS[k]
         w = bench.WORKLOADS["config%d" % k]
         assert all(w[f] == c[f] for f in ("B", "H", "W", "D", "Pm", "Pk", "Pg", "backbone"))
+
+
+def test_import_time_shims_of_the_reference_training_script():
+    """training.py:20,28-36 and dense_correspondence_dataset_masked.py:19 import these names at module load; they must
+    resolve from this package, and say clearly what they are when used."""
+    import importlib
+    import tempfile
+    fcns = importlib.import_module("pytorch_segmentation_detection.models.fcn")
+    with pytest.raises(NotImplementedError):
+        fcns.FCN_8s
+    tr = importlib.import_module("pytorch_segmentation_detection.transforms")
+    for name in ("ComposeJoint", "RandomHorizontalFlipJoint", "RandomScaleJoint", "CropOrPad", "ResizeAspectRatioPreserve",
+                 "RandomCropJoint", "Split2D"):
+        cls = getattr(tr, name)
+        with pytest.raises(NotImplementedError):
+            cls()
+    tbl = importlib.import_module("tensorboard_logger")
+    with tempfile.TemporaryDirectory() as d:
+        lg = tbl.Logger(d)                                   # training.py:584
+        lg.log_value("train loss", 0.25, 7)                  # training.py:364-411
+        lg.log_value("learning rate", 1e-4, 7)
+        rows = open(os.path.join(d, "scalars.tsv")).read().strip().split("\n")
+        assert rows[0].split("\t") == ["7", "train loss", "0.25"] and len(rows) == 2

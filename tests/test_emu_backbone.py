@@ -339,3 +339,85 @@ def test_wide_layers_through_the_hl32_path(arch, bw, shape, groups, producers, d
     (y3 * gy).sum().backward()             # hl32 dgrads on an identical saved arena
     for (k, p2), p3 in zip(m2.named_parameters(), m3.parameters()):
         assert rel_err(p3.grad, p2.grad) < 3e-5, (k, rel_err(p3.grad, p2.grad))
+
+
+def _torchvision_like_state_dict(arch, bw, seed=3):
+    """A state dict with the keys and shapes of stock ``torchvision.models.resnetNN`` (no torchvision in this image: the
+    layout is rebuilt from the published architecture -- stem, four stages of BasicBlock / Bottleneck, 1000-way fc)."""
+    g = torch.Generator().manual_seed(seed)
+    layers, bott = {"Resnet18_8s": ([2, 2, 2, 2], False), "Resnet34_8s": ([3, 4, 6, 3], False),
+                    "Resnet50_8s": ([3, 4, 6, 3], True)}[arch]
+    sd = {}
+
+    def conv(name, o, c, k):
+        sd[name + ".weight"] = torch.randn(o, c, k, k, generator=g) * 0.05
+
+    def bn(name, c):
+        sd[name + ".weight"] = torch.rand(c, generator=g) + 0.5
+        sd[name + ".bias"] = torch.randn(c, generator=g) * 0.1
+        sd[name + ".running_mean"] = torch.randn(c, generator=g) * 0.1
+        sd[name + ".running_var"] = torch.rand(c, generator=g) + 0.5
+        sd[name + ".num_batches_tracked"] = torch.tensor(123)
+    conv("conv1", bw, 3, 7); bn("bn1", bw)
+    inpl, exp = bw, (4 if bott else 1)
+    for li, nb in enumerate(layers):
+        planes = bw << li
+        for bi in range(nb):
+            p = "layer%d.%d" % (li + 1, bi)
+            if bott:
+                conv(p + ".conv1", planes, inpl, 1); bn(p + ".bn1", planes)
+                conv(p + ".conv2", planes, planes, 3); bn(p + ".bn2", planes)
+                conv(p + ".conv3", planes * 4, planes, 1); bn(p + ".bn3", planes * 4)
+            else:
+                conv(p + ".conv1", planes, inpl, 3); bn(p + ".bn1", planes)
+                conv(p + ".conv2", planes, planes, 3); bn(p + ".bn2", planes)
+            if bi == 0 and (li > 0 or inpl != planes * exp):
+                conv(p + ".downsample.0", planes * exp, inpl, 1); bn(p + ".downsample.1", planes * exp)
+            inpl = planes * exp
+    sd["fc.weight"] = torch.randn(1000, inpl, generator=g) * 0.01
+    sd["fc.bias"] = torch.zeros(1000)
+    return sd
+
+
+@pytest.mark.parametrize("arch", ["Resnet34_8s", "Resnet50_8s"])
+def test_load_imagenet_trunk_from_a_torchvision_state_dict(arch, tmp_path, conv_mode):
+    """The original backbone starts from ImageNet weights (pretrained=True behind network.py:373-375,
+    doc/model_zoo.md:6-18): stock torchvision keys map one to one onto the trunk, the 1000-way classifier is dropped and the
+    scoring layer re-initialised."""
+    if conv_mode != "fp32":
+        pytest.skip("host-side loader: one arithmetic is enough")
+    from pytorch_segmentation_detection.models import resnet_dilated as prod
+    bw, D = 8, 3
+    m = getattr(prod, arch)(num_classes=D, base_width=bw)
+    sd = _torchvision_like_state_dict(arch, bw)
+    path = str(tmp_path / "resnet.pth")
+    torch.save(sd, path)
+    fc_before = m.state_dict()[m.attr + ".fc.weight"].clone()
+    loaded = m.load_imagenet_trunk(path)
+    own = m.state_dict()
+    assert len(loaded) == len([k for k in sd if not k.startswith("fc.")])
+    for k, v in sd.items():
+        if k.startswith("fc."):
+            continue
+        assert torch.equal(own[m.attr + "." + k].float(), v.float()), k
+    fcw = own[m.attr + ".fc.weight"]
+    assert tuple(fcw.shape) == (D, fc_before.shape[1], 1, 1) and not torch.equal(fcw, fc_before) and float(fcw.std()) < 0.05
+    assert float(own[m.attr + ".fc.bias"].abs().max()) == 0.0
+    # the network runs from the loaded trunk (train mode: batch statistics; the running statistics moved from the loaded ones)
+    m.train()
+    y = m(torch.randn(1, 3, 32, 40))
+    assert bool(torch.isfinite(y).all())
+    assert int(own[m.attr + ".bn1.num_batches_tracked"]) == 124
+    # strictness: a missing tensor, an extra tensor, a wrong shape
+    bad = dict(sd); bad.pop("layer2.0.conv1.weight")
+    with pytest.raises(KeyError):
+        m.load_imagenet_trunk(bad)
+    assert len(m.load_imagenet_trunk(bad, strict=False)) == len(loaded) - 1
+    bad = dict(sd); bad["layer9.weight"] = torch.zeros(1)
+    with pytest.raises(KeyError):
+        m.load_imagenet_trunk(bad)
+    bad = dict(sd); bad["conv1.weight"] = torch.zeros(bw, 3, 3, 3)
+    with pytest.raises(ValueError):
+        m.load_imagenet_trunk(bad)
+    # DataParallel-style "module." prefixes are accepted
+    m.load_imagenet_trunk({"module." + k: v for k, v in sd.items()})
