@@ -20,8 +20,9 @@ the picture: the fp32-MFMA arithmetic and configs[3]'s per-GPU share on ONE GPU 
 strong-scaling point (N > 1), and `allreduce_ms` / `communication` (collective alone, exposed per step, RCCL rank count).
 
 Prints ONE JSON line on rank 0 (contract in the task description) with `roofline` (dominant kernel = the gather-GEMM
-convolution, conv_gemm_f16_kernel in the default split-fp16 arithmetic / conv_gemm_kernel with --conv-mode fp32;
-algorithmic FLOPs and per-launch durations from HIP events recorded by the engine on the launch stream) and
+convolution, forward + dgrad: conv_gemm_hl_kernel on the wide layers and conv_gemm_f16_kernel on the others in the default
+split-fp16 arithmetic / conv_gemm_kernel with --conv-mode fp32; algorithmic FLOPs and per-launch durations from HIP events
+recorded by the engine on the launch stream; `roofline.hl_kernel` is the wide-layer kernel alone) and
 `cpu_baseline` (the oracle's step on this box's host cores, bounded sample).  `--workload pairgen` measures the device
 pair generator instead.
 """
@@ -41,7 +42,7 @@ import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
 # synthetic-input constants.  Kept here so the measured path never imports `oracle`;
-# tests/test_synth_consistency.py checks they equal oracle/synth.py.
+# tests/test_abi.py (test_synth_constants_consistent_with_bench) checks they equal oracle/synth.py.
 DEFAULT_IMAGE_MEAN = [0.5573105812072754, 0.37420374155044556, 0.37020164728164673]
 DEFAULT_IMAGE_STD_DEV = [0.24336038529872894, 0.2987397611141205, 0.31875079870224]
 LOSS_CONFIG = {"M_masked": 0.5, "M_background": 0.5, "M_pixel": 50, "match_loss_weight": 1.0,
@@ -466,6 +467,7 @@ def main():
         prof = plan.profile_end()
         ms, n, fl = prof["conv_gemm"]
         wms, wn, wfl = prof["conv_wgrad"]
+        hms, hn, hfl = prof["conv_gemm_hl"]
         if not (n > 0 and ms > 0):
             return None
         achieved = fl / (ms * 1e-3) / 1e12
@@ -475,7 +477,9 @@ def main():
         else:
             # one fp32-accurate multiply-add = 3 fp16 MFMA products (hi*hi + hi*lo + lo*hi): the ceiling for
             # ALGORITHMIC flops is a third of the fp16 pipe's dense peak
-            peak, kern = F16X3_PEAK_TFLOPS, "conv_gemm_f16_kernel (3x v_mfma_f32_32x32x16_f16 per product; forward + dgrad)"
+            peak, kern = F16X3_PEAK_TFLOPS, ("gather-GEMM convolution, forward + dgrad (3x v_mfma_f32_32x32x16_f16 per product): "
+                                             "conv_gemm_hl_kernel on the wide layers (pre-split hl32 operands by LDS-DMA, 256 x 256 "
+                                             "tiles), conv_gemm_f16_kernel on the others")
             peak_note = "fp16 MFMA dense peak %.1f / 3 products per fp32-accurate MAC (fp32 MFMA peak: %.1f)" % (
                 F16_MFMA_PEAK_TFLOPS, FP32_MFMA_PEAK_TFLOPS)
         # HBM-side traffic of the dominant kernel cannot be measured from inside the process (PMC counters need
@@ -483,7 +487,7 @@ def main():
         # MI355X_MICROARCH.md's HBM section), attached only when workload / arithmetic / call pattern match -- the
         # field name says so: it was not measured in this run
         traffic, traffic_src = None, None
-        for name in ("r2m_hbm_counters.json", "r2_hbm_counters.json", "r1g_hbm_counters.json"):
+        for name in ("r3_hbm_counters.json", "r2m_hbm_counters.json", "r2_hbm_counters.json", "r1g_hbm_counters.json"):
             try:
                 rec = json.load(open(os.path.join(ROOT, "profiles", name)))
                 if (rec["workload"] == args.workload and rec["conv_mode"] == conv_mode and not args.batch and job_ is job and
@@ -499,6 +503,11 @@ def main():
                 "launches_per_step": n / args.profile_steps, "avg_launch_us": 1e3 * ms / n,
                 "algorithmic_gflop_per_launch": fl / n / 1e9,
                 "kernel_ms_per_step": ms / args.profile_steps,
+                "hl_kernel": None if not hn else {
+                    "kernel": "conv_gemm_hl_kernel (conv_hl_kernels.hip): the wide layers' share of the launches above",
+                    "achieved": hfl / (hms * 1e-3) / 1e12, "frac": hfl / (hms * 1e-3) / 1e12 / peak,
+                    "launches_per_step": hn / args.profile_steps, "avg_launch_us": 1e3 * hms / hn,
+                    "algorithmic_gflop_per_launch": hfl / hn / 1e9, "kernel_ms_per_step": hms / args.profile_steps},
                 "conv_wgrad": {"achieved": (wfl / (wms * 1e-3) / 1e12) if wms > 0 else None,
                                "frac": (wfl / (wms * 1e-3) / 1e12 / peak) if wms > 0 else None,
                                "launches_per_step": wn / args.profile_steps,
@@ -602,11 +611,39 @@ def main():
                 "roofline": None if r32 is None else {k: r32[k] for k in ("kernel", "achieved", "peak", "frac", "kernel_ms_per_step")}})
             bb.set_conv_mode(args.conv_mode)
         if world == 1 and args.workload == "config2" and not args.batch:
-            wl4 = dict(WORKLOADS["config4"])
-            job4 = Job(args, wl4, wl4["B"], dev, rank, use_dist)
-            sec, _ = job4.timed(3, short, 0, use_dist)
-            variants["config4_one_gpu"] = summarize(job4, sec, short, {"workload": wl4["desc"]})
-            del job4
+            # every other single-GPU BASELINE config on the same driver-timed line: configs[3]'s per-GPU share (the N = 1 point of
+            # the weak-scaling curve the multi-GPU runs trace), configs[2] (B = 32, D = 16) and configs[4]'s per-GPU share
+            # (ResNet50-8s 1280 x 960), each with the roofline of its gather-GEMM launches
+            for key, name, w_, k_ in (("config4_one_gpu", "config4", 3, short), ("config3_one_gpu", "config3", 2, 5),
+                                      ("config5_one_gpu", "config5", 3, 6)):
+                wlv = dict(WORKLOADS[name])
+                jobv = Job(args, wlv, wlv["B"], dev, rank, use_dist)
+                sec, _ = jobv.timed(w_, k_, 0, use_dist)
+                rv = measure_roofline(jobv, args.conv_mode, w_ + k_ + 8) if args.profile_steps > 0 else None
+                variants[key] = summarize(jobv, sec, k_, {
+                    "workload": wlv["desc"],
+                    "roofline": None if rv is None else {k: rv[k] for k in ("achieved", "peak", "frac", "kernel_ms_per_step", "hl_kernel")}})
+                del jobv
+                torch.cuda.empty_cache()
+            variants["config4_one_gpu"]["note"] = ("the N = 1 point of the weak-scaling curve: multi-GPU lines run this workload per "
+                                                   "rank (bench.py --gpus 1 --workload config4 prints it as the headline)")
+        if world > 1 and not args.batch:
+            # the same per-rank workload on ONE GPU of this very box (rank 0 alone, the other ranks parked at the barrier, no
+            # collective): the denominator of the weak-scaling efficiency, so that the curve does not depend on another run
+            job.comm = False
+            saved_mode = grads.bucketed
+            grads.bucketed = False
+            dist.barrier()
+            if rank == 0:
+                sec1, _ = job.timed(2, short, it_next + 128, False)
+                one = 2 * B * short / sec1
+                variants["weak_scaling"] = {"one_gpu_same_box": one, "one_gpu_ms_per_step": 1e3 * sec1 / short,
+                                            "efficiency": (2 * B * world * args.steps / elapsed) / (world * one),
+                                            "note": "rank 0 alone on the per-rank workload (%s), same process, no all-reduce" % args.workload}
+            dist.barrier()
+            job.comm = True
+            grads.bucketed = saved_mode
+            __import__("dcn_hip.distributed", fromlist=["broadcast_module"]).broadcast_module(dcn)
         if world > 1 and 64 % world == 0 and args.workload == "config4" and not args.batch:
             Bs = 64 // world
             if Bs == B:
@@ -642,6 +679,10 @@ def main():
                           "forward_pair(img_a, img_b): both network calls of the step as one grouped launch sequence, batch-norm "
                           "statistics / running statistics / gradients per image batch (identical results)", "optimizer": "Adam lr 1e-4 wd 1e-4 (%s)" % ("torch.optim.Adam" if args.torch_adam else "dcn_adam_step, one pass"), "parallelism": "dp%d" % world,
                           "library": info["version"], "final_loss": final_loss,
+                          "weak_scaling_reference": ("this line IS the per-rank workload of the multi-GPU runs" if args.workload == "config4"
+                                                     else "the multi-GPU lines run config4 (B = 8 pairs) per rank: their N = 1 point is "
+                                                          "variants.config4_one_gpu, not `value`") if world == 1 else
+                          "variants.weak_scaling.one_gpu_same_box (rank 0 alone on the same per-rank workload)",
                           "train_gflop_per_image": 3 * bb.get_plan(wl["backbone"], 64, B, H, W, D).forward_flops / B / 1e9},
                "roofline": roofline, "roofline_loss_gather": loss_roof, "variants": variants,
                "allreduce_ms": comm["allreduce_ms"] if comm else None, "communication": comm}

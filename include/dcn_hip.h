@@ -242,6 +242,9 @@ int dcn_backbone_forward(dcn_plan* plan, const float* image, const float* const*
  */
 int dcn_plan_profile_begin(dcn_plan* plan);
 int dcn_plan_profile_end(dcn_plan* plan, double ms[2], int64_t launches[2], double flops[2]);
+/* The same with a third category: [2] = the part of category 0 that ran on the pre-split (hl32) LDS-DMA kernel
+ * (conv_hl_kernels.hip; an operand split pass that had to run in front of a launch is inside its bracket). */
+int dcn_plan_profile_end3(dcn_plan* plan, double ms[3], int64_t launches[3], double flops[3]);
 
 /* Backward.  grad_descriptors: [N,H,W,D]; grads[i] receives dL/d params[i] (overwritten, same layout as
  * params[i]).  `saved` is the buffer the matching forward filled; `normalize` must be the forward's flag. */
@@ -303,6 +306,13 @@ int dcn_conv_dgrad_bn_f16(const dcn_conv_desc* c, const float* dout, const void*
                           const float* dout_absmax, const float* add, float* din, const float* bn_x,
                           const unsigned char* relu_mask, const float* bn_stats, float* bn_partial, void* workspace,
                           void* stream);
+
+/* dcn_split_weights_scaled_f16 (forward images; row_scale nullable) with a range check: bit 1 of the device word *status (not
+ * cleared by the call) is raised when some |scale * row_scale * w| leaves fp16's range or is NaN -- with the engine's fixed
+ * weight scale 64 that is |w| >= 1023.  The backbone engine passes the status word behind its activation abs-max slots
+ * (dcn_plan_activation_absmax_offset). */
+int dcn_split_weights_checked_f16(int n, const float* const* w, const float* const* row_scale, void* const* hi, void* const* lo,
+                                  const int* cout, const int* taps, const int* cin, float scale, int* status, void* stream);
 
 /* ---- pre-split ("hl32") operand path of the wide layers (csrc/conv_hl_kernels.hip): the forward convolution and dgrad of
  * every stride-1 convolution with >= 256 destination channels and source channels % 32 == 0 (layers 3-4 of the backbone behind

@@ -11,7 +11,7 @@
 * loss config = training.yaml:51-61 verbatim.
 
 bench.py keeps its own copy of these few constants so that the timed MI355X path never imports
-``oracle``; tests/test_synth_consistency.py checks the two agree.
+``oracle``; tests/test_abi.py::test_synth_constants_consistent_with_bench checks the two agree.
 """
 import torch
 

@@ -389,7 +389,9 @@ int build_plan(dcn_plan& p) {
     return DCN_OK;
 }
 
-// status word behind the activation abs-max slots: bit 0 = some convolution input is not finite (inf / NaN abs-max)
+// status word behind the activation abs-max slots: bit 0 = some convolution input is not finite (inf / NaN: the abs-max
+// producers report a NaN as an infinite bound); bit 1 (set by the weight split, conv_f16_kernels.hip) = a weight outside the
+// range of its fp16 image.  The word is cleared at the start of the forward call.
 __global__ void __launch_bounds__(64)
 act_status_kernel(const float* __restrict__ actmax, int n, int* __restrict__ status) {
     int bad = 0;
@@ -399,7 +401,7 @@ act_status_kernel(const float* __restrict__ actmax, int n, int* __restrict__ sta
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) bad |= __shfl_xor(bad, o);
-    if (threadIdx.x == 0) *status = bad;
+    if (threadIdx.x == 0 && bad) atomicOr(status, 1);
 }
 
 // column sums of a [rows][ld] matrix (fc bias gradient): one workgroup per column, fixed-order reduction
@@ -480,7 +482,7 @@ struct Run {
         if (use_hl(c, 0)) {
             // (the operand image was written by the batch-norm apply pass that produced `in` -- hl_image_for --, or is made
             // here by a stand-alone pass)
-            return timed(0, c.flops, [&] {
+            return timed(2, c.flops, [&] {
                 int k = hl_src[0] == in ? 0 : (hl_src[1] == in ? 1 : -1);
                 if (k < 0) {
                     k = 0;
@@ -552,9 +554,12 @@ struct Run {
             lo.push_back(wimg(p.w_wl, c));
             cout.push_back(c.d.cout); taps.push_back(c.d.kh * c.d.kw); cin.push_back(c.d.cin); ldn.push_back(c.d.ldc);
         }
-        return dcn_split_weights_scaled_f16((int)w.size(), w.data(), fold_bn ? rs.data() : nullptr, hi.data(), lo.data(),
-                                            cout.data(), taps.data(), cin.data(), ldn.data(), transposed ? 1 : 0, kWeightScale,
-                                            st);
+        if (!transposed)   // forward images: with the weight-range check (status bit 1, see act_status_kernel)
+            return dcn_split_weights_checked_f16((int)w.size(), w.data(), fold_bn ? rs.data() : nullptr, hi.data(), lo.data(),
+                                                 cout.data(), taps.data(), cin.data(), kWeightScale,
+                                                 (int*)(S(p.s_actmax) + p.n_act), st);
+        return dcn_split_weights_scaled_f16((int)w.size(), w.data(), nullptr, hi.data(), lo.data(), cout.data(), taps.data(),
+                                            cin.data(), ldn.data(), 1, kWeightScale, st);
     }
 
     // inference: conv + folded batch norm (+ residual) (+ ReLU) in one pass; bias = the BN shift beta - mean * scale
@@ -632,24 +637,35 @@ extern "C" int dcn_plan_profile_begin(dcn_plan* plan) {
     plan->prof_flops.clear();
     return DCN_OK;
 }
-extern "C" int dcn_plan_profile_end(dcn_plan* plan, double ms[2], int64_t launches[2], double flops[2]) {
+extern "C" int dcn_plan_profile_end3(dcn_plan* plan, double ms[3], int64_t launches[3], double flops[3]) {
     if (!plan || !ms || !launches || !flops) return DCN_E_INVALID;
     plan->prof_on = false;
-    for (int c = 0; c < 2; ++c) { ms[c] = 0; launches[c] = 0; flops[c] = 0; }
+    for (int c = 0; c < 3; ++c) { ms[c] = 0; launches[c] = 0; flops[c] = 0; }
     for (size_t i = 0; i < plan->prof_cat.size(); ++i) {
         hipEvent_t e0 = plan->prof_ev[2 * i], e1 = plan->prof_ev[2 * i + 1];
         if (hipEventSynchronize(e1) != hipSuccess) return DCN_E_LAUNCH;
         float t = 0.f;
         if (hipEventElapsedTime(&t, e0, e1) != hipSuccess) return DCN_E_LAUNCH;
         const int c = plan->prof_cat[i];
-        ms[c] += (double)t;
-        launches[c] += 1;
-        flops[c] += plan->prof_flops[i];
+        for (int k : {c == 2 ? 0 : c, c == 2 ? 2 : -1}) {   // category 2 (hl32 launches) also counts as a gather-GEMM (0)
+            if (k < 0) continue;
+            ms[k] += (double)t;
+            launches[k] += 1;
+            flops[k] += plan->prof_flops[i];
+        }
     }
     plan->prof_used = 0;
     plan->prof_cat.clear();
     plan->prof_flops.clear();
     return DCN_OK;
+}
+extern "C" int dcn_plan_profile_end(dcn_plan* plan, double ms[2], int64_t launches[2], double flops[2]) {
+    if (!ms || !launches || !flops) return DCN_E_INVALID;
+    double m3[3], f3[3];
+    int64_t n3[3];
+    const int rc = dcn_plan_profile_end3(plan, m3, n3, f3);
+    for (int c = 0; c < 2; ++c) { ms[c] = m3[c]; launches[c] = n3[c]; flops[c] = f3[c]; }
+    return rc;
 }
 extern "C" int dcn_plan_num_params(const dcn_plan* plan) { return plan ? (int)plan->params.size() : DCN_E_INVALID; }
 extern "C" int dcn_plan_num_bn(const dcn_plan* plan) { return plan ? (int)plan->bns.size() : DCN_E_INVALID; }
@@ -928,7 +944,7 @@ extern "C" int dcn_backbone_backward(dcn_plan* plan, const float* grad_descripto
             }
         }
         if (R.use_hl(c, 1)) {
-            return R.timed(0, c.flops, [&] {
+            return R.timed(2, c.flops, [&] {
                 if (hl_dx_of != dx)
                     DCN_TRY(dcn_split_act_hl32(dx, amax + c.idx, R.hlbuf(0), (int64_t)c.d.n * c.d.hout * c.d.wout, c.d.ldc, st));
                 hl_dx_of = nullptr;

@@ -64,7 +64,14 @@ struct SplitTable {
     SplitEntry e[kSplitBatch];
     int n;
     float scale;
+    int* status;   // optional device word: bit 1 is raised when a weight leaves the fp16 range of its image (|scale * w| > 65504
+                   // or NaN: the fixed power-of-two scale 64 covers |w| < 1023)
 };
+
+__device__ __forceinline__ void flag_weight_range(int* status, float4 v, float s) {
+    const float m = fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))) * fabsf(s);
+    if (status && (!(m <= 65504.f) || v.x != v.x || v.y != v.y || v.z != v.z || v.w != v.w)) atomicOr(status, 2);
+}
 
 __device__ __forceinline__ int split_entry_of(const SplitTable& t, int block) {
     int e = 0;
@@ -84,7 +91,9 @@ split_rows_batched_kernel(SplitTable t) {
     float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
     if (k < E.K) v = *reinterpret_cast<const float4*>(E.w + r * E.K + k);
     h4 a, b;
-    split4(v, E.row_scale ? t.scale * E.row_scale[r] : t.scale, a, b);
+    const float sc = E.row_scale ? t.scale * E.row_scale[r] : t.scale;
+    flag_weight_range(t.status, v, sc);
+    split4(v, sc, a, b);
     if (E.hl) {   // (4 consecutive k never straddle a 32-k chunk)
         _Float16* line = E.hi + r * 2 * E.kp + (k >> 5) * 64 + (k & 31);
         *reinterpret_cast<h4*>(line) = a;
@@ -727,7 +736,13 @@ int launch_gemm_f16(GemmConv& p, void* workspace, hipStream_t st, int align = 0)
     const bool sk_inline = sk && dcn::tuning().gemm_sk_inline != 0 && !(g.wr == 2 && g.wc == 2 && g.tm == 2 && g.tn == 2);
     p.sk_count = sk_inline ? (unsigned long long*)((char*)workspace + g.sk_count_off) : nullptr;
     p.sk_bytes = sk_inline ? (unsigned)g.sk_count_off : 0u;
-    if (sk_inline) p.sk_id = next_sk_launch_id();
+    if (sk_inline) {
+        p.sk_id = next_sk_launch_id();
+        // the arrival words share the scratch with other launches' partials: cleared on the stream in front of every launch,
+        // so that the count never starts from a stale word that happens to carry this launch's id (ids wrap after 2^32 launches)
+        if (dcn::fill_bytes_async(p.sk_count, 0, (size_t)(g.mtiles * g.ntiles - g.sk_dp) * sizeof(unsigned long long), st) != DCN_OK)
+            return DCN_E_LAUNCH;
+    }
     // uniform-tap fast path: whole 32-K stages inside one filter tap, tensors addressable through 2 GiB buffer resources
     const int64_t src_bytes = (int64_t)p.M / (p.hd * p.wd) * p.hs * p.ws * p.cs * 4, w_bytes = (int64_t)p.cd * p.kp * 2;
     bool uni = ((p.cs % HBK) == 0 || p.stem8) && src_bytes <= ((int64_t)1 << 31) && w_bytes <= ((int64_t)1 << 31);
@@ -1190,7 +1205,7 @@ extern "C" int dcn_split_weights_f16(int n, const float* const* w, void* const* 
 namespace {
 int split_weights_impl(int n, const float* const* w, const float* const* row_scale, void* const* hi, void* const* lo,
                        const int* cout, const int* taps, const int* cin, const int* ldn, int transposed, float scale,
-                       void* stream, bool hl);
+                       void* stream, bool hl, int* status = nullptr);
 }
 
 extern "C" int dcn_split_weights_scaled_f16(int n, const float* const* w, const float* const* row_scale, void* const* hi,
@@ -1198,6 +1213,15 @@ extern "C" int dcn_split_weights_scaled_f16(int n, const float* const* w, const 
                                             const int* ldn, int transposed, float scale, void* stream) {
     if (!lo) return DCN_E_INVALID;
     return split_weights_impl(n, w, row_scale, hi, lo, cout, taps, cin, ldn, transposed, scale, stream, false);
+}
+
+// dcn_split_weights_scaled_f16 (forward images) that also checks the weights' range: bit 1 of *status (device int, not
+// cleared here) is raised when some |scale * row_scale * w| exceeds fp16's range or is NaN
+extern "C" int dcn_split_weights_checked_f16(int n, const float* const* w, const float* const* row_scale, void* const* hi,
+                                             void* const* lo, const int* cout, const int* taps, const int* cin, float scale,
+                                             int* status, void* stream) {
+    if (!lo) return DCN_E_INVALID;
+    return split_weights_impl(n, w, row_scale, hi, lo, cout, taps, cin, nullptr, 0, scale, stream, false, status);
 }
 
 // hl32 images (conv_hl_kernels.hip): out[i] receives [cout][taps * cin / 32][hi x32 | lo x32] or, transposed,
@@ -1210,7 +1234,7 @@ extern "C" int dcn_split_weights_hl32(int n, const float* const* w, void* const*
 namespace {
 int split_weights_impl(int n, const float* const* w, const float* const* row_scale, void* const* hi, void* const* lo,
                        const int* cout, const int* taps, const int* cin, const int* ldn, int transposed, float scale,
-                       void* stream, bool hl) {
+                       void* stream, bool hl, int* status) {
     if (n < 1 || !w || !hi || (!hl && !lo) || !cout || !taps || !cin || (transposed && (!ldn || row_scale)) || !(scale > 0.f))
         return DCN_E_INVALID;
     hipStream_t st = (hipStream_t)stream;
@@ -1218,6 +1242,7 @@ int split_weights_impl(int n, const float* const* w, const float* const* row_sca
         SplitTable t;
         t.n = n - base < kSplitBatch ? n - base : kSplitBatch;
         t.scale = scale;
+        t.status = status;
         int blocks = 0;
         for (int j = 0; j < t.n; ++j) {
             const int i = base + j;

@@ -388,7 +388,9 @@ HlShape hl_shape(int M, int cd, int K) {
     const double waste = 1.0 - rounds / (double)(int)(rounds + 0.999999);
     const double gain = ((double)(int)(rounds + 0.999999) - rounds) * g.nk;   // stage times stream-K can save
     const dcn::Tuning& tune = dcn::tuning();
-    g.sk = tiles < 8 * 256 && waste > 0.08 && g.nk >= 8 && gain >= tune.gemm_sk_min_gain;
+    // (a 256 x 256 partial is 256 KB -- parking it, reading the other contributors' and the second prologue cost a workgroup
+    // about 50 stage times: stream-K pays from there.  Measured on ResNet50-8s at 1280 x 960, profiles/r3h_convbench_r50.txt)
+    g.sk = tiles < 8 * 256 && waste > 0.08 && g.nk >= 8 && gain >= std::max(tune.gemm_sk_min_gain, 50.0);
     int wgs = 256;                                                              // one 512-work-item workgroup per CU
     if (tune.gemm_sk >= 0) {
         if (tune.gemm_sk == 0) g.sk = false;
@@ -438,7 +440,11 @@ int launch_gemm_hl(GemmConv& p, void* workspace, hipStream_t st) {
     p.sk_partial = sk ? (float*)workspace : nullptr;
     p.sk_count = sk ? (unsigned long long*)((char*)workspace + g.sk_count_off) : nullptr;
     p.sk_bytes = sk ? (unsigned)g.sk_count_off : 0u;
-    if (sk) p.sk_id = next_sk_launch_id();
+    if (sk) {
+        p.sk_id = next_sk_launch_id();
+        if (dcn::fill_bytes_async(p.sk_count, 0, (size_t)(g.mtiles * g.ntiles - g.sk_dp) * sizeof(unsigned long long), st) != DCN_OK)
+            return DCN_E_LAUNCH;   // (arrival words cleared in front of every launch: see launch_gemm_f16)
+    }
     const dim3 grid(sk ? g.sk_wgs : g.mtiles * g.ntiles), block(512);
     if (sk) {
         if (p.transposed) hipLaunchKernelGGL((conv_gemm_hl_kernel<true, true>), grid, block, 0, st, p);
@@ -475,7 +481,15 @@ extern "C" int dcn_conv_hl_eligible(const dcn_conv_desc* c, int dgrad) {
     if (dcn::tuning().gemm_hl == 2) return 1;   // (tests: every supported convolution)
     const int cs = dgrad ? c->ldc : c->cin, cd = dgrad ? c->cin : c->cout;
     const int64_t M = (int64_t)c->n * (dgrad ? c->hin * c->win : c->hout * c->wout);
-    return (cd >= 256 && (int64_t)c->kh * c->kw * cs >= 512 && M >= 4096) ? 1 : 0;
+    const int64_t K = (int64_t)c->kh * c->kw * cs;
+    if (!(cd >= 256 && K >= 512 && M >= 4096)) return 0;
+    // between one and one and a half rounds of tiles the second round leaves most of the chip idle, and splitting its tiles
+    // costs about what it saves unless the K loop is long: the fp32-operand kernel's 256 x 128 tiles quantise better there
+    // (measured: ResNet50-8s layer-3 3x3 at 1280 x 960 -5 %, its 1x1 1024 -> 256 -20 %; layer4.0.conv1 of ResNet34-8s at
+    // N = 8 -3 %; the 512 -> 512 layer-4 convolutions, K = 4608, +7 %)
+    const double rounds = (double)dcn::ceil_div64(M, 256) * dcn::ceil_div(cd, 256) / 256.0;
+    if (rounds > 1.0 && rounds < 1.5 && K < 4096) return 0;
+    return 1;
 }
 
 extern "C" int dcn_conv_num_mtiles_hl(const dcn_conv_desc* c) {

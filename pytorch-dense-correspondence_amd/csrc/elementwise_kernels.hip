@@ -41,6 +41,7 @@ nchw3_to_nhwc4_kernel(const float* __restrict__ img, float* __restrict__ out, in
         const float4 v = make_float4(s[0], s[hw], s[2 * (int64_t)hw], 0.f);
         reinterpret_cast<float4*>(out)[i] = v;
         m = fmaxf(m, fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fabsf(v.z)));
+        if (v.x != v.x || v.y != v.y || v.z != v.z) m = __builtin_huge_valf();   // (fmaxf drops a NaN: report it as inf)
     }
     if (absmax) {   // one atomic per workgroup (same-address atomics serialise in L2)
 #pragma unroll
@@ -159,7 +160,10 @@ bn_finalize_kernel(const float* __restrict__ partial, int tiles, int groups, int
         shift[g * gstride + c] = sh;
         if (save_mean) { save_mean[g * gstride + c] = (float)mean; save_invstd[g * gstride + c] = invstd; }
         mx = fmaxf(fmaxf(s_mx[0][cl], s_mx[1][cl]), fmaxf(s_mx[2][cl], s_mx[3][cl]));
-        bound = fmaxf(bound, fabsf(sc) * mx + fabsf(sh));   // (a NaN statistic makes the products NaN anyway)
+        // (fmaxf drops a NaN: a non-finite statistic -- NaN sums from NaN activations, a NaN / inf parameter -- is reported as an
+        // infinite bound, which the status word behind the abs-max slots flags)
+        const float bnd = fabsf(sc) * mx + fabsf(sh);
+        bound = (bnd != bnd) ? __builtin_huge_valf() : fmaxf(bound, bnd);
     }
     if (out_bound && training) {
         __syncthreads();   // (every work-item reaches this: the loop above has no early exit)

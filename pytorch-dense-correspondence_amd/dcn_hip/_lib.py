@@ -65,6 +65,8 @@ SYMBOLS = {
     "dcn_plan_profile_begin": (c_int, [c_void_p]),
     "dcn_plan_profile_end": (c_int, [c_void_p, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(c_int64),
                                      ctypes.POINTER(ctypes.c_double)]),
+    "dcn_plan_profile_end3": (c_int, [c_void_p, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(c_int64),
+                                      ctypes.POINTER(ctypes.c_double)]),
     "dcn_backbone_forward": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_float, c_int, c_int, c_void_p,
                                      c_void_p, c_void_p, c_void_p]),
     "dcn_backbone_backward": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
@@ -132,6 +134,8 @@ SYMBOLS = {
     "dcn_upsample_backward": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p,
                                       c_void_p]),
     "dcn_upsample_backward_tmp_bytes": (c_size_t, [c_int, c_int, c_int, c_int]),
+    "dcn_split_weights_checked_f16": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                              c_float, c_void_p, c_void_p]),
     "dcn_conv_hl_eligible": (c_int, [ctypes.POINTER(ConvDesc), c_int]),
     "dcn_conv_num_mtiles_hl": (c_int, [ctypes.POINTER(ConvDesc)]),
     "dcn_conv_gemm_workspace_hl": (c_size_t, [ctypes.POINTER(ConvDesc), c_int]),

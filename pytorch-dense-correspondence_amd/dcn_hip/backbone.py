@@ -79,12 +79,14 @@ class Plan(object):
         _lib.check(_lib.get().dcn_plan_profile_begin(self.handle), "dcn_plan_profile_begin")
 
     def profile_end(self):
-        """-> {"conv_gemm": (ms, launches, flops), "conv_wgrad": (...)} since profile_begin (synchronises)."""
-        ms = (ctypes.c_double * 2)()
-        n = (ctypes.c_int64 * 2)()
-        fl = (ctypes.c_double * 2)()
-        _lib.check(_lib.get().dcn_plan_profile_end(self.handle, ms, n, fl), "dcn_plan_profile_end")
-        return {"conv_gemm": (ms[0], int(n[0]), fl[0]), "conv_wgrad": (ms[1], int(n[1]), fl[1])}
+        """-> {"conv_gemm": (ms, launches, flops), "conv_wgrad": (...), "conv_gemm_hl": (...)} since profile_begin
+        (synchronises).  "conv_gemm_hl" is the part of "conv_gemm" that ran on the pre-split (hl32) LDS-DMA kernel."""
+        ms = (ctypes.c_double * 3)()
+        n = (ctypes.c_int64 * 3)()
+        fl = (ctypes.c_double * 3)()
+        _lib.check(_lib.get().dcn_plan_profile_end3(self.handle, ms, n, fl), "dcn_plan_profile_end3")
+        return {"conv_gemm": (ms[0], int(n[0]), fl[0]), "conv_wgrad": (ms[1], int(n[1]), fl[1]),
+                "conv_gemm_hl": (ms[2], int(n[2]), fl[2])}
 
     def __del__(self):
         try:

@@ -147,6 +147,16 @@ class DenseCorrespondenceNetwork(nn.Module):
         res = res.permute(1, 2, 0)  # [H,W,D]; contiguous, because the map is channels_last
         return res
 
+    def forward_image_tensors(self, img_tensors):
+        """Batched ``forward_single_image_tensor`` (:265-299): ``[n, 3, H, W]`` normalised images -> ``[n, H, W, D]``
+        descriptor images (contiguous: the map is channels_last) with ONE engine call -- what the descriptor export of
+        evaluation/utils.py and compute_descriptor_images.py loops over image by image."""
+        assert len(img_tensors.shape) == 4
+        img_tensors = img_tensors.detach().to(device=_device())
+        with torch.no_grad():
+            res = self.forward(img_tensors)   # [n, D, H, W]
+        return res.permute(0, 2, 3, 1)
+
     def process_network_output(self, image_pred, N):
         # :303-319 -- identical view/permute; zero-copy AND contiguous for channels_last input
         W = self._image_width

@@ -144,8 +144,9 @@ class _DilatedResnet8s(nn.Module):
 
     def last_forward_status(self):
         """(abs-max of every convolution input, status word) of the most recent forward call, as device tensors (reading
-        them synchronises).  Status bit 0 set: an activation was not finite (inf / NaN) -- every finite fp32 range is handled
-        by the split-fp16 kernels' power-of-two operand pre-scales."""
+        them synchronises).  Status bit 0: an activation (or the image) was not finite -- inf or NaN; every finite fp32 range is
+        handled by the split-fp16 kernels' power-of-two operand pre-scales.  Bit 1: a convolution weight was outside the
+        range of its fp16 image (|w| >= 1023 with the fixed weight scale 64, or NaN)."""
         plan = getattr(self, "_last_plan", None)
         if plan is None or getattr(plan, "last_activation_range", None) is None:
             raise RuntimeError("no forward call yet")

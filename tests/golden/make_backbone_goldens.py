@@ -5,6 +5,7 @@ itself is 'parity unpinned', see oracle/resnet_dilated_oracle.py):
     config 1: B=1  640x480   D=3  Resnet34_8s  1000/500/500 pairs      -> config1_oracle.npz
     config 2: B=4  640x480   D=3  Resnet34_8s  5000/2500/2500          -> config2_oracle.npz   (the headline workload)
     config 3: B=32 640x480   D=16 Resnet34_8s  10000/50000/50000       -> config3_oracle.npz
+    config 4: B=8  640x480   D=3  Resnet34_8s  5000/2500/2500          -> config4_oracle.npz   (per-GPU share of the B=64 / 8-GPU config)
     config 5: B=2  1280x960  D=32 Resnet50_8s  masked / background     -> config5_oracle.npz   (per-GPU share of B=16)
 
 Each stores a subsampled descriptor map of both image batches, the five loss terms and the hard-negative counts of every
@@ -12,9 +13,9 @@ pair, and -- from a float64 run of the same oracle -- per-parameter gradient nor
 float32 oracle's own deviation from its float64 self (the yard-stick of the gradient tolerances), so that the GPU tests
 check a full-size step without /root/reference and without a long CPU run.
 
-    python tests/golden/make_backbone_goldens.py [--config 1 2 3 5]
+    python tests/golden/make_backbone_goldens.py [--config 1 2 3 4 5]
 
-Configs 3 and 5 do not fit this container's memory with every activation kept (64 images x ~1 GB): the oracle is run
+Configs 3, 4 and 5 do not fit this container's memory with every activation kept (64 images x ~1 GB): the oracle is run
 with per-block activation checkpointing (torch.utils.checkpoint, exact same arithmetic, every block's forward is
 recomputed during backward; BN running statistics are then updated twice and are not stored for those configs).
 Wall time on 8 cores: config 1 ~20 s, 2 ~1 min, 3 ~9 min, 5 ~10 min.
@@ -34,8 +35,8 @@ sys.path.insert(0, os.path.dirname(HERE))
 from oracle import loss_oracle, resnet_dilated_oracle, step as ostep, synth  # noqa: E402
 from parity_common import probe_vectors  # noqa: E402  (tests/parity_common.py: the +-1 probe vectors shared with the GPU tests)
 
-SUBSAMPLE = {1: 16, 2: 16, 3: 32, 5: 32}     # descriptor-map stride kept in the fixture
-CHECKPOINT = {1: False, 2: False, 3: True, 5: True}
+SUBSAMPLE = {1: 16, 2: 16, 3: 32, 4: 16, 5: 32}     # descriptor-map stride kept in the fixture
+CHECKPOINT = {1: False, 2: False, 3: True, 4: True, 5: True}
 
 
 def hard_negative_counts(da, db, lists, cfg):
@@ -121,7 +122,7 @@ def make(config):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--config", type=int, nargs="+", default=[1, 2, 3, 5], choices=[1, 2, 3, 5])
+    ap.add_argument("--config", type=int, nargs="+", default=[1, 2, 3, 4, 5], choices=[1, 2, 3, 4, 5])
     args = ap.parse_args()
     torch.set_num_threads(min(os.cpu_count(), 16))
     for c in args.config:

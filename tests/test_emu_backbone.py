@@ -421,3 +421,37 @@ def test_load_imagenet_trunk_from_a_torchvision_state_dict(arch, tmp_path, conv_
         m.load_imagenet_trunk(bad)
     # DataParallel-style "module." prefixes are accepted
     m.load_imagenet_trunk({"module." + k: v for k, v in sd.items()})
+
+
+def test_status_word_flags_nan_input_and_out_of_range_weights(conv_mode):
+    """The status word behind the activation abs-max slots: bit 0 for a non-finite input -- inf AND NaN (the abs-max producers
+    use fmaxf, which drops a NaN: it is reported as an infinite bound instead) --, bit 1 for a convolution weight outside the
+    range of its fp16 image (|w| >= 1023 at the fixed weight scale 64)."""
+    if conv_mode != "f16x3":
+        pytest.skip("operand ranges belong to the split-fp16 arithmetic")
+    m, _ = _pair("Resnet18_8s", 3, 8)
+    m.train()
+    x = torch.randn(1, 3, 32, 40)
+    m(x)
+    assert int(m.last_forward_status()[1]) == 0
+    xn = x.clone(); xn[0, 1, 5, 7] = float("nan")
+    m(xn)
+    assert int(m.last_forward_status()[1]) & 1
+    xi = x.clone(); xi[0, 2, 0, 0] = float("inf")
+    m(xi)
+    assert int(m.last_forward_status()[1]) & 1
+    m(x)
+    assert int(m.last_forward_status()[1]) == 0                              # cleared by the next call
+    with torch.no_grad():
+        m.resnet18_8s.get_parameter("layer2.0.conv1.weight")[3, 2, 1, 1] = 2000.0           # 64 * 2000 > 65504
+    m(x)
+    assert int(m.last_forward_status()[1]) & 2
+    with torch.no_grad():
+        m.resnet18_8s.get_parameter("layer2.0.conv1.weight")[3, 2, 1, 1] = 900.0            # inside the range again
+    m(x)
+    assert not (int(m.last_forward_status()[1]) & 2)
+    # a NaN batch-norm parameter: the statistics path reports it through the bound
+    with torch.no_grad():
+        m.resnet18_8s.get_parameter("layer1.0.bn1.bias")[0] = float("nan")
+    m(x)
+    assert int(m.last_forward_status()[1]) & 1

@@ -147,3 +147,47 @@ def test_checkpoint_round_trip_through_model_folder(tmp_path):
     legacy.eval()
     with torch.no_grad():
         assert torch.equal(legacy.forward(x), y_ref)
+
+
+def test_batched_descriptor_image_export(tmp_path):
+    """evaluation/utils.py:109-160 and compute_descriptor_images.py:38-72: same files, names and contents as the reference's
+    one-image-at-a-time loops, computed ``batch_size`` images per engine call."""
+    import os
+    import numpy as np
+    from dense_correspondence.evaluation import utils as eval_utils
+    dcn, _ = _make()
+    H, W = 32, 48
+    g = torch.Generator().manual_seed(9)
+    images = {idx: torch.randn(3, H, W, generator=g) for idx in (3, 0, 12, 7, 1)}
+
+    class Scene(object):   # the slice of SpartanDataset the export touches
+        def get_pose_data(self, scene_name):
+            assert scene_name == "scene-a"
+            return {k: None for k in images}
+
+        def get_rgb_image_from_scene_name_and_idx(self, scene_name, idx):
+            return ("rgb", idx)
+
+        def get_rgbd_mask_pose(self, scene_name, idx):
+            return ("rgb", idx), None, None, None
+
+        def rgb_image_to_tensor(self, rgb):
+            return images[rgb[1]]
+    dcn.eval()
+    ref = {idx: dcn.forward_single_image_tensor(t).detach().clone() for idx, t in images.items()}   # the reference's loop
+    dcn.train()
+    out = str(tmp_path / "desc")
+    eval_utils.extract_descriptor_images_for_scene(dcn, Scene(), "scene-a", out, batch_size=2)
+    assert dcn.training                                           # mode restored
+    assert sorted(os.listdir(out)) == ["%06d_descriptor.npy" % i for i in sorted(images)]
+    for idx in images:
+        arr = np.load(os.path.join(out, "%06d_descriptor.npy" % idx))
+        assert arr.shape == (H, W, 3) and arr.dtype == np.float32
+        assert rel_err(torch.from_numpy(arr), ref[idx]) < 1e-5   # (batch of 2 vs batch of 1: eval mode, no batch statistics)
+    with pytest.raises(ValueError):
+        eval_utils.extract_descriptor_images_for_scene(dcn, Scene(), "scene-a", out)      # exists, overwrite=False
+    eval_utils.extract_descriptor_images_for_scene(dcn, Scene(), "scene-a", out, overwrite=True, batch_size=8)
+    out2 = str(tmp_path / "desc2")
+    n = eval_utils.compute_descriptor_images_for_single_scene(Scene(), "scene-a", dcn, out2, batch_size=3)
+    assert n == 5 and sorted(os.listdir(out2)) == ["%06d_descriptor_image.npy" % i for i in sorted(images)]
+    assert rel_err(torch.from_numpy(np.load(os.path.join(out2, "000012_descriptor_image.npy"))), ref[12]) < 1e-5

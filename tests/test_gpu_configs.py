@@ -3,7 +3,8 @@ tests/golden/make_backbone_goldens.py), on a real MI355X, through the C ABI, in 
 
     config 1: B=1  640x480  D=3  Resnet34_8s        config 2: B=4  640x480  D=3   (the headline workload)
     config 3: B=32 640x480  D=16 Resnet34_8s        config 5: B=2  1280x960 D=32  Resnet50_8s, masked / background sampling
-    (config 4 is config 2's shape at B=8 per GPU: covered by 2 and by tests/test_ddp_gloo.py)
+    config 4: B=8  640x480  D=3  Resnet34_8s -- the per-GPU share of the 8-GPU config (the multi-rank path itself:
+              tests/test_ddp_gloo.py, tests/test_gpu_ddp.py)
 
 Tolerances: descriptor maps, the five loss terms of every pair and the loss 1e-4 relative (BASELINE.json north_star);
 hard-negative counts exact up to the fixture's tie band (pairs within 1e-5 of the margin) + 2; parameter gradients
@@ -58,7 +59,7 @@ def conv_mode(request):
     backbone.set_conv_mode(None)
 
 
-@pytest.mark.parametrize("config", [1, 2, 3, 5])
+@pytest.mark.parametrize("config", [1, 2, 3, 4, 5])
 def test_full_size_step_vs_oracle_fixture(L, conv_mode, config):
     if not os.path.exists(pc.fixture_path(config)):
         pytest.fail("missing fixture %s (python tests/golden/make_backbone_goldens.py --config %d)" % (pc.fixture_path(config), config))

@@ -1,4 +1,4 @@
-"""Data-parallel schedule on REAL streams: two ranks sharing the one MI355X of the test box (backend gloo on device tensors --
+"""Data-parallel schedule on REAL streams: two and four ranks sharing the one MI355X of the test box (backend gloo on device tensors --
 RCCL refuses two ranks on one device; the 8-GPU RCCL run is the driver's), so that the part of the bucketed all-reduce that
 the CPU / gloo tests cannot see is exercised on hardware: the engine's grad-ready events, the communication stream, the
 cross-stream lifetime of the engine's gradient buffer, the join before the optimizer step."""
@@ -83,7 +83,8 @@ def _worker(rank, world, port, q):
     # ranks agree, and the average really is the average of the two ranks' own gradients
     gathered = [torch.zeros_like(buck) for _ in range(world)]
     dist.all_gather(gathered, buck)
-    res["ranks_agree"] = bool(torch.equal(gathered[0], gathered[1]))
+    res["ranks_agree"] = all(bool(torch.equal(gathered[0], t)) for t in gathered[1:])
+    res["bucket_vs_mono_rel"] = float((mono - buck).abs().max() / mono.abs().max())
     dist.barrier()
     # a full step with the real loss + Adam on both schedules from identical parameters: parameters must agree to round-off
     state = {k: v.clone() for k, v in dcn.state_dict().items()}
@@ -104,28 +105,34 @@ def _worker(rank, world, port, q):
     res["step_max_diff"] = float((outs[0] - outs[1]).abs().max())
     allp = [torch.zeros_like(outs[1]) for _ in range(world)]
     dist.all_gather(allp, outs[1])
-    res["replicas_in_sync"] = bool(torch.equal(allp[0], allp[1]))
+    res["replicas_in_sync"] = all(bool(torch.equal(allp[0], t)) for t in allp[1:])
     q.put((rank, res))
     dist.barrier()
     dist.destroy_process_group()
 
 
-@pytest.mark.timeout(900)
-def test_two_ranks_bucketed_overlap_on_device():
+@pytest.mark.timeout(1200)
+@pytest.mark.parametrize("world", [2, 4])
+def test_ranks_bucketed_overlap_on_device(world):
+    """world 2 and 4 processes on the one MI355X of the box: the bucketed schedule on real streams (grad-ready events,
+    communication stream, buffer lifetime, join) at the world sizes the driver's scaling runs use."""
     assert torch.cuda.is_available()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
     for p in procs:
         p.start()
-    res = [q.get(timeout=800) for _ in procs]
+    res = [q.get(timeout=1000) for _ in procs]
     for p in procs:
         p.join(120)
         assert p.exitcode == 0
     for rank, r in res:
         assert r["stats"] == (0, 1, 1, 0), (rank, r)
-        assert r["bitwise_pair"], (rank, r)            # world 2: a + b is commutative, so the slicing cannot change a bit
+        if world == 2:
+            assert r["bitwise_pair"], (rank, r)        # world 2: a + b is commutative, so the slicing cannot change a bit
+        else:                                          # world 4: gloo may associate the four summands differently per message size
+            assert r["bucket_vs_mono_rel"] < 1e-6, (rank, r)
         assert r["two_calls_rel"] < 1e-6 and r["two_calls_buckets"] == 2, (rank, r)
         assert r["ranks_agree"] and r["replicas_in_sync"], (rank, r)
         # two Adam steps on real (atomics-ordered) gradients: first steps are lr * sign(g), so a flipped near-zero gradient moves

@@ -31,7 +31,7 @@ HL_LAYERS = [
     (8, 60, 80, 512, 512, 3, 4, "1", 1.0),      # layer 4: 300 tiles -> 256 data-parallel + 44 stream-K
     (8, 60, 80, 128, 256, 3, 1, None, 1.0),     # layer3.0.conv1 forward (dgrad: 128 destination channels, one ragged N tile)
     (2, 60, 80, 256, 512, 3, 4, "0", 1.0),      # config 1 size, no stream-K: 38 tiles, ragged last M tile (9600 rows)
-    (3, 120, 160, 256, 1024, 1, 1, "1", 1.0),   # ResNet50-8s 1x1 expansion at 1280 x 960 (config 5): 225 x 4 tiles
+    (3, 120, 160, 256, 1024, 1, 1, None, 1.0),  # ResNet50-8s 1x1 expansion at 1280 x 960 (config 5): 225 x 4 tiles, 8 K stages
 ]
 
 

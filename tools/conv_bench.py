@@ -30,8 +30,23 @@ SHAPES = [  # name, count in the net, hin, win, cin, cout, k, stride, pad, dil
 ]
 
 
+SHAPES_R50 = [  # Resnet50_8s at 1280 x 960 (BASELINE config 5): the bottleneck layers 3-4 (160 x 120 maps)
+    ("r50 l3 conv1 1x1 1024->256", 5, 120, 160, 1024, 256, 1, 1, 0, 1),
+    ("r50 l3 conv2 3x3 d2 256->256", 6, 120, 160, 256, 256, 3, 1, 2, 2),
+    ("r50 l3 conv3 1x1 256->1024", 6, 120, 160, 256, 1024, 1, 1, 0, 1),
+    ("r50 l3.0 conv1 1x1 512->256", 1, 120, 160, 512, 256, 1, 1, 0, 1),
+    ("r50 l3.0 down 1x1 512->1024", 1, 120, 160, 512, 1024, 1, 1, 0, 1),
+    ("r50 l4 conv1 1x1 2048->512", 2, 120, 160, 2048, 512, 1, 1, 0, 1),
+    ("r50 l4 conv2 3x3 d4 512->512", 3, 120, 160, 512, 512, 3, 1, 4, 4),
+    ("r50 l4 conv3 1x1 512->2048", 3, 120, 160, 512, 2048, 1, 1, 0, 1),
+    ("r50 l4.0 conv1 1x1 1024->512", 1, 120, 160, 1024, 512, 1, 1, 0, 1),
+    ("r50 l4.0 down 1x1 1024->2048", 1, 120, 160, 1024, 2048, 1, 1, 0, 1),
+]
+
+
 def main():
     ap = argparse.ArgumentParser()
+    ap.add_argument("--shapes", default="r34", choices=["r34", "r50"], help="Resnet34_8s at 640x480 (default) or Resnet50_8s layers 3-4 at 1280x960")
     ap.add_argument("--n", type=int, default=4)
     ap.add_argument("--reps", type=int, default=10)
     ap.add_argument("--json", default="")
@@ -50,7 +65,7 @@ def main():
     st = _lib.stream_ptr()
     rows = []
     tot = {"fwd": [0.0, 0.0], "dgrad": [0.0, 0.0], "wgrad": [0.0, 0.0]}
-    for name, count, hin, win, cin, cout, k, stride, pad, dil in SHAPES:
+    for name, count, hin, win, cin, cout, k, stride, pad, dil in (SHAPES if a.shapes == "r34" else SHAPES_R50):
         if a.only and a.only not in name:
             continue
         n = a.n
