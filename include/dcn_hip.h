@@ -334,6 +334,15 @@ int dcn_conv_forward_hl(const dcn_conv_desc* c, const void* in_hl, const float* 
 int dcn_conv_dgrad_hl(const dcn_conv_desc* c, const void* dout_hl, const void* wt_hl, float w_scale, const float* dout_absmax,
                       const float* add, float* din, void* workspace, void* stream);
 
+/* Weight gradient on hl32 operands (csrc/wgrad_hl_kernels.hip; the wgrad of training.py:345 for the same wide layers): x_hl /
+ * dout_hl are the hl32 images of the convolution's input and of the output gradient (scaled by the powers of two chosen from
+ * *x_absmax / *dout_absmax).  256 x 256 tiles, pixel-major tiles by LDS-DMA, k-major fragments by transposing LDS reads.
+ * Same result as dcn_conv_wgrad_f16 (same products, other summation order); bit-reproducible. */
+int dcn_conv_wgrad_hl_eligible(const dcn_conv_desc* c);
+size_t dcn_conv_wgrad_workspace_hl(const dcn_conv_desc* c);
+int dcn_conv_wgrad_hl(const dcn_conv_desc* c, const void* x_hl, const float* x_absmax, const void* dout_hl,
+                      const float* dout_absmax, float* dw, void* slabs, void* stream);
+
 /* The backbone's stem (7x7 / stride 2 / pad 3 on 3 + 1 zero input channels; K1 of SURVEY.md section 8a) as a uniform-tap
  * convolution: a filter ROW is one 32-K chunk (8 pixels x 4 channels = 128 contiguous bytes of the NHWC4 image, the 8th
  * pixel with zero weights), so the gather is the wide layers' per-row buffer load instead of a per-element tap decode.

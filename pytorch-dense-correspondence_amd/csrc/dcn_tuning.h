@@ -24,6 +24,8 @@
 //   DCN_GEMM_HL             0: the wide layers stay on the fp32-operand gather-GEMM (conv_f16_kernels.hip) instead of the
 //                           pre-split (hl32) LDS-DMA kernel (conv_hl_kernels.hip); 2: every convolution that kernel supports
 //                           takes it, whatever its size (tests)
+//   DCN_WGRAD_HL            0: the wide layers' weight gradients stay on the fp32-operand kernel (conv_f16_kernels.hip) instead of
+//                           the pre-split (hl32) LDS-DMA kernel (wgrad_hl_kernels.hip); 2: every supported convolution (tests)
 //   DCN_HL_PRODUCERS        0: hl32 activation / gradient images are made by stand-alone split passes instead of by the
 //                           batch-norm apply kernels that produce the tensors
 #pragma once
@@ -47,6 +49,7 @@ struct Tuning {
     int wgrad_tile = 0;          // 0: unset
     int wgrad_deep = 4;
     int gemm_hl = 1;             // wide layers on the pre-split (hl32) LDS-DMA gather-GEMM
+    int wgrad_hl = 1;            // wide layers' weight gradients on the pre-split (hl32) LDS-DMA kernel
     int hl_producers = 1;        // hl32 images written by the producing batch-norm passes (0: stand-alone split passes)
     int wgrad_roles = 1;         // wide tile: wavefronts 0-3 stage the activations, 4-7 the gradient (0: copy spread over all 8)
 };

@@ -1,0 +1,351 @@
+// Weight gradient of the wide layers on PRE-SPLIT (hl32) operands: dW[n][kc] = sum over pixels m of dy[m][n] x[pix(m, tap)][c]
+// (training.py:345 through the backbone's convolutions) as a GEMM whose reduction index is the pixel -- split-fp16 ("f16x3")
+// arithmetic on v_mfma_f32_32x32x16_f16, both operands by LDS-DMA, the same two-wavefront-group schedule as the forward /
+// dgrad kernel of these layers (conv_hl_kernels.hip): 256 (n) x 256 (kc) tiles on 8 wavefronts (2 x 4, wavefront tile
+// 128 x 64), stages of 32 pixels, four phases of 12 MFMAs per stage, counted vmcnt, raw s_barrier.
+//
+// Both operands live in HBM pixel-major (hl32: per pixel and 32-channel chunk one 128-byte line [hi x32 | lo x32] fp16) but
+// the matrix instruction wants them k-major -- 8 consecutive PIXELS of one channel per lane.  The transpose costs nothing:
+//   * LDS holds pixel-major half-tiles [32 pixels][4 chunk lines = 512 B], filled by LDS-DMA -- one piece = two pixels x 512 B
+//     (lanes 0-31 / 32-63), the source offset per lane, so the input pixel of every output pixel and filter tap (and its
+//     validity: padding, image and split borders -> out-of-range offset -> zeros) is just a per-lane address;
+//   * fragments come out with `ds_read_b64_tr_b16` (measured semantics, tools/tr_probe.bin: the 16 lanes of a group supply
+//     8-byte runs S[s][0..3]; lane i receives S[4 j + (i >> 2)][i & 3], j = 0..3): a group that supplies pixel rows
+//     k0 + (s >> 2) and channels 4 (s & 3) .. + 3 hands lane i the four pixels k0 .. k0 + 3 of channel i -- two reads make
+//     the 8-k operand of one lane.
+// The 64-byte slots of a pixel's 512 bytes are XOR-swizzled with (pixel & 3) on the source side of the DMA, so that the four
+// pixel rows a 32-lane access touches fall into the four quarters of the 64 banks (row pitch 512 B = 0 mod 256 otherwise).
+// Half-tiles in the order the phases first need them, as in the forward kernel: H0 = A_0, H1 = B_0, H2 = B_1, H3 = A_1 with
+//     A_i = the dy channels {128 g + 64 i + [0, 64)} (g = 0, 1: local chunk a = 2 g + t),  B_j = the x columns
+//     {64 wn + 32 j + [0, 32)} (wn = 0..3: local chunk b = wn)
+// and the LDS-DMA discipline / WAR / RAW argument of conv_hl_kernels.hip verbatim.  Pixel ranges are split over workgroups
+// (whole 32-pixel stages), partial slabs are summed by the fixed-order reduce kernel of the other wgrad kernels:
+// bit-reproducible.
+#include <algorithm>
+#include <type_traits>
+
+#include "conv_shared.h"
+#include "dcn_tuning.h"
+#include "f16_split.h"
+
+namespace {
+
+using namespace dcnconv;
+using namespace dcnsplit;
+
+typedef __attribute__((address_space(3))) void* whl_lds_ptr;
+typedef short s4v __attribute__((ext_vector_type(4)));
+
+constexpr int kOob = (int)0x80000000;
+constexpr int kStage = 65536;   // bytes per 32-pixel stage: A_0 | A_1 | B_0 | B_1, each [32 pixels][512 B]
+constexpr int WPX = 32;         // pixels per stage
+
+__device__ __forceinline__ void glds16(__amdgpu_buffer_rsrc_t rs, void* lds_dst, int voffset, int soffset) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (whl_lds_ptr)lds_dst, 16, voffset, soffset, 0, 0);
+}
+// four pixels of one channel (see the header): the transposing 8-byte LDS read
+__device__ __forceinline__ s4v lds_tr4(const unsigned char* p) {
+    return __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s4v*)p);
+}
+
+struct WgradHl {
+    const void* xh;            // hl32 activations [n, hin, win, cin], scaled by pow2_scale(*x_absmax)
+    const void* dh;            // hl32 output gradient [M][ldo], scaled by pow2_scale(*d_absmax)
+    float* slab;               // [splits][cout][K]
+    const float* x_absmax;
+    const float* d_absmax;
+    unsigned x_bytes, d_bytes;
+    int hin, win, cin, cout, kh, kw, pad, dil, ldo, M, K, splits, stages_per_split, ntiles_n, ntiles_k, cpt;
+    FastDiv div_hw, div_w, div_cpt, div_kw;
+};
+
+__global__ void __launch_bounds__(512, 1)
+conv_wgrad_hl_kernel(WgradHl p) {
+    __shared__ __attribute__((aligned(16))) unsigned char lds[2 * kStage];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int grp = wv >> 2, wn = wv & 3;
+    const int tiles = p.ntiles_n * p.ntiles_k;
+    const int bid = xcd_remap(blockIdx.x, tiles * p.splits);
+    const int split = bid / tiles, tile = bid - split * tiles;
+    const int tn_ = tile / p.ntiles_k, tk_ = tile - tn_ * p.ntiles_k;
+    const int n0 = tn_ * 256, kc0 = tk_ * 256;
+    const int nstages = (p.M + WPX - 1) / WPX;
+    const int s_begin = split * p.stages_per_split;
+    const int s_end = min(nstages, s_begin + p.stages_per_split);
+    const int m_end = min(p.M, s_end * WPX);
+    const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.xh), 0, (int)p.x_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_d = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.dh), 0, (int)p.d_bytes, 0x00020000);
+
+    // ---- LDS-DMA pieces of this lane.  Piece e (0, 1) of every half-tile covers stage pixels 4 wv + 2 e + {0, 1}: lanes
+    // 0-31 the first, 32-63 the second; lane l fills PHYSICAL 16-byte slot l & 31 of its pixel's 512 bytes = logical 64-byte
+    // slot ((l & 31) >> 2) ^ (pixel & 3) -> (local chunk = slot >> 1, plane = slot & 1), 16-byte quarter l & 3.
+    const int lp = lane >> 5, p16 = lane & 31;
+    const int ldo4 = p.ldo * 4, cin4 = p.cin * 4;
+    int kp[2];                    // pixel index inside the stage
+    int cA[2][2], cB[2][2];       // [i | j][e]: byte offset inside the source pixel (chunk line + plane + quarter), or -1: no such chunk
+    int tdy[2][2], tdx[2][2];     // [j][e]: filter-tap offset (input pixel = output pixel + this) of the lane's x chunk
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+        kp[e] = 4 * wv + 2 * e + lp;
+        const int slot = (p16 >> 2) ^ (kp[e] & 3);
+        const int lc = slot >> 1, pl = slot & 1, q16 = p16 & 3;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {   // A_i: local chunk lc = 2 g' + t  <->  tile chunk 4 g' + 2 i + t
+            const int chunk = n0 / 32 + 4 * (lc >> 1) + 2 * i + (lc & 1);
+            cA[i][e] = chunk * 32 < p.cout ? chunk * 128 + pl * 64 + q16 * 16 : -1;
+        }
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {   // B_j: local chunk lc = wn'  <->  tile chunk 2 wn' + j  <->  (filter tap, channel chunk)
+            const int G = kc0 / 32 + 2 * lc + j;
+            const bool ok = G * 32 < p.K;
+            const int tap = fdiv(ok ? G : 0, p.div_cpt), cc = (ok ? G : 0) - tap * p.cpt;
+            const int r = fdiv(tap, p.div_kw), s = tap - r * p.kw;
+            tdy[j][e] = r * p.dil - p.pad;
+            tdx[j][e] = s * p.dil - p.pad;
+            cB[j][e] = ok ? cc * 128 + pl * 64 + q16 * 16 : -1;
+        }
+    }
+    // position of this lane's two pixels in the stage the LDS-DMA is issued for (carried from stage to stage: win >= 32)
+    int pm[2], py[2], px[2], pimg[2];
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+        pm[e] = s_begin * WPX + kp[e];
+        const int mm = pm[e] < p.M ? pm[e] : 0;
+        pimg[e] = fdiv(mm, p.div_hw);
+        const int rem = mm - pimg[e] * p.div_hw.d;
+        py[e] = fdiv(rem, p.div_w);
+        px[e] = rem - py[e] * p.div_w.d;
+    }
+    int voA[2][2], voB[2][2];
+    auto set_offsets = [&]() {
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            const bool mok = pm[e] < m_end;
+#pragma unroll
+            for (int i = 0; i < 2; ++i) voA[i][e] = (mok && cA[i][e] >= 0) ? pm[e] * ldo4 + cA[i][e] : kOob;
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int sy = py[e] + tdy[j][e], sx = px[e] + tdx[j][e];
+                const bool ok = mok & (cB[j][e] >= 0) & ((unsigned)sy < (unsigned)p.hin) & ((unsigned)sx < (unsigned)p.win);
+                voB[j][e] = ok ? ((pimg[e] * p.hin + sy) * p.win + sx) * cin4 + cB[j][e] : kOob;
+            }
+        }
+    };
+    auto advance = [&]() {   // the next stage: 32 pixels on (output width >= 32: at most one row wrap)
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            pm[e] += WPX;
+            px[e] += WPX;
+            const bool wx = px[e] >= p.win;
+            px[e] -= wx ? p.win : 0;
+            py[e] += wx ? 1 : 0;
+            const bool wy = py[e] >= p.hin;
+            py[e] = wy ? 0 : py[e];
+            pimg[e] += wy ? 1 : 0;
+        }
+        set_offsets();
+    };
+    set_offsets();
+    // half-tile h (0: A_0, 1: B_0, 2: B_1, 3: A_1) of the stage the positions point at
+    auto issue_half = [&](int buf, int h) {
+        unsigned char* base = lds + buf * kStage + (h == 0 ? 0 : h == 3 ? 16384 : h == 1 ? 32768 : 49152) + wv * 2048;
+        if (h == 0 || h == 3) {
+            const int i = h == 0 ? 0 : 1;
+            glds16(rs_d, base, voA[i][0], 0);
+            glds16(rs_d, base + 1024, voA[i][1], 0);
+        } else {
+            const int j = h == 1 ? 0 : 1;
+            glds16(rs_x, base, voB[j][0], 0);
+            glds16(rs_x, base + 1024, voB[j][1], 0);
+        }
+    };
+
+    // ---- fragments: lane (group gq = lane >> 4, s = lane & 15) supplies pixel row 16 ks + 8 (gq >> 1) + 4 h + (s >> 2),
+    // channels 16 (gq & 1) + 4 (s & 3) .. + 3 of a 32-channel tile and receives the pixels 16 ks + 8 fh + 4 h .. + 3 of channel
+    // lane & 31 (fh = lane >> 5 = gq >> 1): element 4 h + .. of the lane's 8-k MFMA operand
+    const int gq = lane >> 4, s16 = lane & 15, rq = s16 >> 2;
+    const int fi = lane & 31, fh = lane >> 5;
+    const int rowc = (8 * (gq >> 1) + rq) * 512 + (16 * (gq & 1) + 4 * (s16 & 3)) * 2;
+    int offA[2][2], offB[2];   // [t][plane], [plane]: lane constants (physical slot = logical ^ (pixel & 3), pixel & 3 = rq)
+#pragma unroll
+    for (int pl = 0; pl < 2; ++pl) {
+#pragma unroll
+        for (int t = 0; t < 2; ++t) offA[t][pl] = rowc + ((2 * (2 * grp + t) + pl) ^ rq) * 64;
+        offB[pl] = rowc + ((2 * wn + pl) ^ rq) * 64;
+    }
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    h8 fa[2][2][2], fb[2][2];   // A: [t][ks][plane], B: [ks][plane]
+    auto frag = [&](const unsigned char* q) {
+        const s4v lo = lds_tr4(q), hi = lds_tr4(q + 4 * 512);
+        typedef short s8v __attribute__((ext_vector_type(8)));
+        const s8v v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        return __builtin_bit_cast(h8, v);
+    };
+    auto read_a = [&](int buf, int i) {
+        const unsigned char* st = lds + buf * kStage + (i ? 16384 : 0);
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                for (int pl = 0; pl < 2; ++pl) fa[t][ks][pl] = frag(st + ks * (16 * 512) + offA[t][pl]);
+    };
+    auto read_b = [&](int buf, int j) {
+        const unsigned char* st = lds + buf * kStage + (j ? 49152 : 32768);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int pl = 0; pl < 2; ++pl) fb[ks][pl] = frag(st + ks * (16 * 512) + offB[pl]);
+    };
+    auto mfma_quadrant = [&](int i, int j) {
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int pt = 0; pt < 3; ++pt)
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                for (int t = 0; t < 2; ++t)
+                    acc[2 * i + t][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(pt == 0 ? fa[t][ks][1] : fa[t][ks][0],
+                                                                              pt == 1 ? fb[ks][1] : fb[ks][0], acc[2 * i + t][j], 0, 0, 0);
+        __builtin_amdgcn_s_setprio(0);
+    };
+    auto bar = [&]() { __builtin_amdgcn_sched_barrier(0); __builtin_amdgcn_s_barrier(); __builtin_amdgcn_sched_barrier(0); };
+    auto phase = [&](auto more_tag, int buf, int ph) {
+        constexpr bool MORE = decltype(more_tag)::value;
+        const int qi = ph >> 1, qj = (ph == 1 || ph == 2) ? 1 : 0;
+        if (ph == 0) { read_b(buf, 0); __builtin_amdgcn_sched_barrier(0); read_a(buf, 0); }
+        else if (ph == 1) read_b(buf, 1);
+        else if (ph == 2) read_a(buf, 1);
+        else read_b(buf, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        if (MORE) {
+            issue_half(buf ^ 1, ph);
+            if (ph == 3) advance();   // (the positions now point at stage s + 2)
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (MORE) DCN_WAIT_VMCNT(4);
+        else if (ph == 0) DCN_WAIT_VMCNT(2);
+        else if (ph == 1) DCN_WAIT_VMCNT(0);
+        DCN_WAIT_LGKMCNT0();
+        bar();
+        mfma_quadrant(qi, qj);
+        bar();
+    };
+    using T = std::true_type;
+    using F = std::false_type;
+    if (s_begin < s_end) {   // (wave-uniform: a split past the last stage has nothing to add; its slab tile stays zero)
+        issue_half(0, 0);
+        issue_half(0, 1);
+        issue_half(0, 2);
+        issue_half(0, 3);
+        advance();
+        __builtin_amdgcn_sched_barrier(0);
+        DCN_WAIT_VMCNT(4);
+        bar();
+        if (grp == 1) bar();
+        int buf = 0;
+        for (int s = s_begin; s + 1 < s_end; ++s) {
+            phase(T{}, buf, 0);
+            phase(T{}, buf, 1);
+            phase(T{}, buf, 2);
+            phase(T{}, buf, 3);
+            buf ^= 1;
+        }
+        phase(F{}, buf, 0);
+        phase(F{}, buf, 1);
+        phase(F{}, buf, 2);
+        phase(F{}, buf, 3);
+        if (grp == 0) bar();
+    }
+    // C fragment: row (r) <-> output channel n, column (lane & 31) <-> K column: 128-byte coalesced rows
+    const float inv = 1.f / ((p.d_absmax ? pow2_scale(*p.d_absmax) : 1.f) * (p.x_absmax ? pow2_scale(*p.x_absmax) : 1.f));
+    float* out = p.slab + (int64_t)split * p.cout * p.K;
+#pragma unroll
+    for (int tm = 0; tm < 4; ++tm)
+#pragma unroll
+        for (int tn = 0; tn < 2; ++tn) {
+            const int kc = kc0 + wn * 64 + tn * 32 + fi;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int n = n0 + grp * 128 + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh;
+                if (n < p.cout && kc < p.K) out[(int64_t)n * p.K + kc] = acc[tm][tn][r] * inv;
+            }
+        }
+}
+
+bool wgrad_hl_supported(const dcn_conv_desc* c) {
+    if (!c || c->n < 1 || c->hin < 1 || c->win < 32 || c->cin < 32 || c->cout < 32 || c->kh < 1 || c->kw < 1) return false;
+    if (c->stride != 1 || c->hin != c->hout || c->win != c->wout || c->ldc != c->cout) return false;
+    if ((c->cin % 32) != 0 || (c->cout % 32) != 0) return false;
+    const int64_t xb = (int64_t)c->n * c->hin * c->win * c->cin * 4, db = (int64_t)c->n * c->hout * c->wout * c->ldc * 4;
+    return xb <= ((int64_t)1 << 31) - 1 && db <= ((int64_t)1 << 31) - 1;
+}
+
+// pixel-range splits in whole 32-pixel stages: about one round of 256 workgroups (one per CU), the last round nearly full
+int wgrad_hl_splits(const dcn_conv_desc* c, int* stages_per_split) {
+    const int M = c->n * c->hout * c->wout, K = c->kh * c->kw * c->cin;
+    const int tiles = dcn::ceil_div(c->cout, 256) * dcn::ceil_div(K, 256);
+    const int nstages = dcn::ceil_div(M, WPX);
+    int best = 1;
+    double best_score = -1.0;
+    const int hi = std::min(nstages, std::max(1, 2 * 256 / tiles + 1));
+    for (int s = 1; s <= hi; ++s) {
+        const int sps = dcn::ceil_div(nstages, s), real = dcn::ceil_div(nstages, sps);
+        const int wgs = real * tiles;
+        const double eff = (double)wgs / (double)(dcn::ceil_div(wgs, 256) * 256);
+        // prefer full rounds; every split pays its prologue, its 256 KB slab tile and its share of the reduce pass
+        const double score = eff - 0.002 * real - (wgs < 256 ? 0.5 * (1.0 - wgs / 256.0) : 0.0) - (wgs > 256 ? 0.15 : 0.0);
+        if (score > best_score) { best_score = score; best = s; }
+    }
+    if (const int v = dcn::tuning().wgrad_splits) { if (v >= 1 && v <= nstages) best = v; }
+    const int sps = dcn::ceil_div(nstages, best);
+    *stages_per_split = sps;
+    return dcn::ceil_div(nstages, sps);
+}
+
+}  // namespace
+
+// Which convolutions' weight gradients take the hl32 kernel: whole 256-channel output tiles, enough K columns and pixels.
+extern "C" int dcn_conv_wgrad_hl_eligible(const dcn_conv_desc* c) {
+    if (!wgrad_hl_supported(c) || dcn::tuning().wgrad_hl == 0) return 0;
+    if (dcn::tuning().wgrad_hl == 2) return 1;   // (tests: every supported convolution)
+    return ((c->cout % 256) == 0 && c->kh * c->kw * c->cin >= 1024 && (int64_t)c->n * c->hout * c->wout >= 8192) ? 1 : 0;
+}
+
+extern "C" size_t dcn_conv_wgrad_workspace_hl(const dcn_conv_desc* c) {
+    if (!wgrad_hl_supported(c)) return 0;
+    int sps;
+    const int splits = wgrad_hl_splits(c, &sps);
+    return (size_t)splits * c->cout * c->kh * c->kw * c->cin * sizeof(float);
+}
+
+// x_hl: hl32 image of the convolution's input [n, hin, win, cin], scaled by pow2_scale(*x_absmax); dout_hl: hl32 image of
+// the output gradient [n, hout, wout, cout], scaled by pow2_scale(*dout_absmax) (dcn_split_act_hl32 or the producing
+// batch-norm passes).  dw: [cout][kh][kw][cin]; slabs: dcn_conv_wgrad_workspace_hl bytes.
+extern "C" int dcn_conv_wgrad_hl(const dcn_conv_desc* c, const void* x_hl, const float* x_absmax, const void* dout_hl,
+                                 const float* dout_absmax, float* dw, void* slabs, void* stream) {
+    if (!x_hl || !dout_hl || !dw || !slabs) return DCN_E_INVALID;
+    if (!wgrad_hl_supported(c)) return DCN_E_UNSUPPORTED;
+    WgradHl p;
+    p.xh = x_hl; p.dh = dout_hl; p.x_absmax = x_absmax; p.d_absmax = dout_absmax;
+    p.x_bytes = (unsigned)((int64_t)c->n * c->hin * c->win * c->cin * 4);
+    p.d_bytes = (unsigned)((int64_t)c->n * c->hout * c->wout * c->ldc * 4);
+    p.hin = c->hin; p.win = c->win; p.cin = c->cin; p.cout = c->cout; p.kh = c->kh; p.kw = c->kw; p.pad = c->pad; p.dil = c->dil;
+    p.ldo = c->ldc; p.M = c->n * c->hout * c->wout; p.K = c->kh * c->kw * c->cin; p.cpt = c->cin / 32;
+    p.splits = wgrad_hl_splits(c, &p.stages_per_split);
+    p.ntiles_n = dcn::ceil_div(c->cout, 256); p.ntiles_k = dcn::ceil_div(p.K, 256);
+    p.div_hw = make_fastdiv(c->hout * c->wout); p.div_w = make_fastdiv(c->wout);
+    p.div_cpt = make_fastdiv(p.cpt); p.div_kw = make_fastdiv(c->kw);
+    p.slab = p.splits == 1 ? dw : (float*)slabs;
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(conv_wgrad_hl_kernel, dim3(p.ntiles_n * p.ntiles_k * p.splits), dim3(512), 0, st, p);
+    if (p.splits > 1) launch_wgrad_reduce((const float*)slabs, dw, (int64_t)c->cout * p.K / 4, p.splits, st);
+    return dcn::check_launch();
+}

@@ -297,3 +297,44 @@ def check_conv_hl(L, dev, n, h, w, cin, cout, k, dil, set_env=None, sk=None, sca
                                    L.ptr(ws), None) == 0
     assert torch.equal(out3.cpu(), out.cpu())
     return res
+
+
+def check_wgrad_hl(L, dev, n, h, w, cin, cout, k, dil, set_env=None, splits=None, seed=0):
+    """The weight gradient on hl32 operands (wgrad_hl_kernels.hip: pixel-major tiles by LDS-DMA, k-major fragments by
+    transposing LDS reads) against autograd in float64 and against the fp32-operand split-fp16 wgrad kernel."""
+    lib = L.get()
+    g = torch.Generator().manual_seed(seed)
+    pad = dil * (k - 1) // 2
+    t = lambda a: a.to(dev).contiguous()
+    x = torch.randn(n, h, w, cin, generator=g)
+    x = torch.relu(x) if seed % 2 else x
+    dout = torch.randn(n, h, w, cout, generator=g) * 1e-3
+    M, K = n * h * w, k * k * cin
+    if splits is not None:
+        set_env(DCN_WGRAD_SPLITS=splits)
+    d = L.ConvDesc(n, h, w, cin, h, w, cout, k, k, 1, pad, dil, cout, 0)
+    xd, dd = t(x), t(dout)
+    ax, ad = t(x.abs().max().reshape(1)), t(dout.abs().max().reshape(1))
+    xi = hl32_image(L, lib, xd.reshape(M, cin), ax, dev)
+    di = hl32_image(L, lib, dd.reshape(M, cout), ad, dev)
+    slab = garbage(lib.dcn_conv_wgrad_workspace_hl(ctypes.byref(d)), dev, seed + 5)
+    dw = torch.full((cout, k, k, cin), float("nan"), device=dev)
+    assert lib.dcn_conv_wgrad_hl(ctypes.byref(d), L.ptr(xi), L.ptr(ax), L.ptr(di), L.ptr(ad), L.ptr(dw), L.ptr(slab), None) == 0
+    wz = torch.zeros(cout, cin, k, k, dtype=torch.float64, requires_grad=True)
+    out = F.conv2d(x.double().permute(0, 3, 1, 2), wz, None, 1, pad, dil)
+    (out * dout.double().permute(0, 3, 1, 2)).sum().backward()
+    ref = wz.grad.permute(0, 2, 3, 1)
+    res = {"wgrad": rel_err(dw.cpu(), ref)}
+    assert res["wgrad"] < 5e-6, res
+    # the fp32-operand kernel on the same tensors
+    dq = torch.empty(lib.dcn_grad_blocked_bytes(M, cout) // 4, device=dev)
+    assert lib.dcn_split_grad_blocked_f16(L.ptr(dd), M, cout, L.ptr(ad), L.ptr(dq), None) == 0
+    slab2 = garbage(lib.dcn_conv_wgrad_workspace_f16(ctypes.byref(d)), dev, seed + 6)
+    dw2 = torch.full_like(dw, float("nan"))
+    assert lib.dcn_conv_wgrad_f16(ctypes.byref(d), L.ptr(xd), 1, L.ptr(ax), L.ptr(dq), L.ptr(ad), L.ptr(dw2), L.ptr(slab2), None) == 0
+    res["vs_f16"] = rel_err(dw.cpu(), dw2.cpu())
+    assert res["vs_f16"] < 6e-6, res
+    dw3 = torch.full_like(dw, float("nan"))   # bit-reproducible
+    assert lib.dcn_conv_wgrad_hl(ctypes.byref(d), L.ptr(xi), L.ptr(ax), L.ptr(di), L.ptr(ad), L.ptr(dw3), L.ptr(slab), None) == 0
+    assert torch.equal(dw3.cpu(), dw.cpu())
+    return res

@@ -479,3 +479,21 @@ def test_conv_hl32_lds_dma_gather_gemm(L, case, dma, dcn_env, monkeypatch):
     monkeypatch.setenv("HIPEMU_LDS_DMA", dma)
     n, h, w, cin, cout, k, dil, sk, sx = case
     kernel_checks.check_conv_hl(L, "cpu", n, h, w, cin, cout, k, dil, set_env=dcn_env, sk=sk, scale_x=sx, seed=len(str(case)))
+
+
+WGRAD_HL_CASES = [
+    # n, h, w, cin, cout, k, dil, forced splits
+    (1, 3, 40, 32, 64, 3, 1, None),      # one ragged tile (64 of 256 output channels, K = 288 of 2 x 256), 120 pixels = 4 stages
+    (2, 5, 36, 64, 288, 3, 2, "3"),      # two channel tiles (second ragged), dilation 2, rows wrap inside stages, 3 pixel splits
+    (1, 8, 32, 256, 256, 1, 1, "2"),     # 1x1: one tap, full tiles, two splits of 4 stages
+    (1, 4, 48, 96, 32, 3, 4, None),      # dilation 4 with halos wider than the image, 3 chunks per tap (taps change inside a K tile)
+]
+
+
+@pytest.mark.parametrize("dma", ["late", "early"])
+@pytest.mark.parametrize("case", WGRAD_HL_CASES, ids=[str(c) for c in WGRAD_HL_CASES])
+def test_wgrad_hl32_transposing_lds_reads(L, case, dma, dcn_env, monkeypatch):
+    import kernel_checks
+    monkeypatch.setenv("HIPEMU_LDS_DMA", dma)
+    n, h, w, cin, cout, k, dil, splits = case
+    kernel_checks.check_wgrad_hl(L, "cpu", n, h, w, cin, cout, k, dil, set_env=dcn_env, splits=splits, seed=len(str(case)))

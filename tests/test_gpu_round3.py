@@ -75,3 +75,25 @@ def test_conv_hl32_repeated_launches_are_bit_identical(L, dcn_env):
         assert bool(torch.isfinite(outs[0]).all())
         for o in outs[1:]:
             assert torch.equal(o, outs[0]), "sk=%s" % sk
+
+
+WGRAD_HL = [
+    # n, h, w, cin, cout, k, dil, forced splits   (small: the CPU suite's cases; then the layer shapes of configs 2 and 5)
+    (1, 3, 40, 32, 64, 3, 1, None),
+    (2, 5, 36, 64, 288, 3, 2, "3"),
+    (1, 8, 32, 256, 256, 1, 1, "2"),
+    (1, 4, 48, 96, 32, 3, 4, None),
+    (8, 60, 80, 256, 256, 3, 2, None),      # layer 3 of config 2: 9 tiles x 28 pixel splits
+    (8, 60, 80, 512, 512, 3, 4, None),      # layer 4: 36 tiles x 7 splits
+    (8, 60, 80, 128, 256, 3, 1, None),      # layer3.0.conv1: K = 1152 = 4.5 tiles (ragged, taps change inside a tile)
+    (2, 120, 160, 512, 512, 3, 4, None),    # ResNet50-8s layer-4 3x3 at 1280 x 960
+]
+
+
+@pytest.mark.parametrize("case", WGRAD_HL, ids=[str(c) for c in WGRAD_HL])
+def test_wgrad_hl32_transposing_lds_reads(L, case, dcn_env):
+    n, h, w, cin, cout, k, dil, splits = case
+    for rep in range(2):
+        res = kernel_checks.check_wgrad_hl(L, "cuda", n, h, w, cin, cout, k, dil, set_env=dcn_env, splits=splits,
+                                           seed=len(str(case)) + rep)
+    print(case, res)

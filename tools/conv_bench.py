@@ -128,6 +128,23 @@ def main():
             calls["wgrad"] = wgrad_f16
             hl_f = a.mode == "hl" and lib.dcn_conv_hl_eligible(ctypes.byref(d), 0)
             hl_d = a.mode == "hl" and lib.dcn_conv_hl_eligible(ctypes.byref(d), 1)
+            hl_w = a.mode == "hl" and lib.dcn_conv_wgrad_hl_eligible(ctypes.byref(d))
+            if hl_w:
+                axw = x.abs().max().reshape(1)
+                xw_hl = torch.empty(x.numel(), device=dev)
+                dyw_hl = torch.empty(dy.numel(), device=dev)
+                slab_hl = torch.empty(max(lib.dcn_conv_wgrad_workspace_hl(ctypes.byref(d)), 4) // 4, device=dev)
+                assert lib.dcn_split_act_hl32(_lib.ptr(x), _lib.ptr(axw), _lib.ptr(xw_hl), n * hin * win, cin, st) == 0
+                assert lib.dcn_split_act_hl32(_lib.ptr(dy), _lib.ptr(amax), _lib.ptr(dyw_hl), n * hout * wout, cout, st) == 0
+
+                def wgrad_hl():
+                    rc = 0
+                    if a.hl_split:
+                        rc |= lib.dcn_split_act_hl32(_lib.ptr(dy), _lib.ptr(amax), _lib.ptr(dyw_hl), n * hout * wout, cout, st)
+                    return rc | lib.dcn_conv_wgrad_hl(ctypes.byref(d), _lib.ptr(xw_hl), _lib.ptr(axw), _lib.ptr(dyw_hl), _lib.ptr(amax),
+                                                     _lib.ptr(dw), _lib.ptr(slab_hl), st)
+                calls["wgrad"] = wgrad_hl
+                name = name + " [hl wgrad]"
             if hl_f or hl_d:
                 P, I = ctypes.c_void_p, ctypes.c_int
                 arr = lambda ty, v: (ty * 1)(v)
