@@ -39,6 +39,8 @@ struct ConvL {
     size_t wsplit = 0;        // offset (halves) of this conv's fp16 weight image inside w_wh / w_wl (forward or dgrad image)
     size_t whl = 0;           // offset (floats) of its hl32 weight image inside w_whl (conv_hl_kernels.hip), forward or dgrad image
     bool hl_any = false;      // some launch of this convolution may take the hl32 path (an image slot is reserved)
+    size_t hl_x = 0;          // saved-arena offset of the hl32 image of this convolution's INPUT (weight gradient on hl32 operands)
+    bool has_hl_x = false;
     int idx = 0;
     int in_act = -1;          // abs-max slot of the activation tensor this convolution reads (split-fp16 operand pre-scale)
     std::string name;
@@ -59,6 +61,10 @@ struct BlockL {
     int64_t in_rows = 0;
     int act_in = -1, act_mid[2] = {-1, -1}, act_out = -1;   // abs-max slots of the block's input / mid / output activations
     int act_down = -1;                                      // ... and of the downsample branch's batch-norm output
+    // saved hl32 images (wgrad_hl_kernels.hip reads the activations as hl32 tensors): of the mid activations and of the block's
+    // INPUT (= the previous block's output), where a convolution of this block takes the hl32 weight-gradient kernel
+    size_t hl_mid[2] = {0, 0}, hl_in = 0;
+    bool has_hl_mid[2] = {false, false}, has_hl_in = false;
 };
 struct ParamInfo {
     std::string name;
@@ -295,6 +301,26 @@ int build_plan(dcn_plan& p) {
     p.fc = B.add_conv("fc", N, h, wd, inplanes, p.D, 1, 1, 0, 1, true, p.Dp);
     p.convs[p.fc].in_act = cur_act;
     p.s_low = B.alloc_saved((size_t)N * h * wd * p.Dp);  // low-resolution descriptor map (needed by the normalise backward)
+    for (BlockL& blk : p.blocks) {   // hl32 copies of the activations whose consumer's weight gradient takes the hl32 kernel
+        for (int i = 0; i < blk.nconv; ++i) {
+            const ConvL& c = p.convs[blk.conv[i]];
+            if (!dcn_conv_wgrad_hl_eligible(&c.d)) continue;
+            const size_t fl = (size_t)c.d.n * c.d.hin * c.d.win * c.d.cin;
+            if (i == 0) { if (!blk.has_hl_in) { blk.hl_in = B.alloc_saved(fl); blk.has_hl_in = true; } }
+            else if (!blk.has_hl_mid[i - 1]) { blk.hl_mid[i - 1] = B.alloc_saved(fl); blk.has_hl_mid[i - 1] = true; }
+            p.convs[blk.conv[i]].hl_x = i == 0 ? blk.hl_in : blk.hl_mid[i - 1];
+            p.convs[blk.conv[i]].has_hl_x = true;
+        }
+        if (blk.down >= 0 && dcn_conv_wgrad_hl_eligible(&p.convs[blk.down].d)) {
+            ConvL& c = p.convs[blk.down];
+            if (!blk.has_hl_in) {
+                blk.hl_in = B.alloc_saved((size_t)c.d.n * c.d.hin * c.d.win * c.d.cin);
+                blk.has_hl_in = true;
+            }
+            c.hl_x = blk.hl_in;
+            c.has_hl_x = true;
+        }
+    }
     p.n_act = n_act;
     p.s_actmax = B.alloc_saved((size_t)n_act + 1);        // abs-max of every convolution input (kept for wgrad) + status word
     p.saved_floats = B.saved;
@@ -322,7 +348,8 @@ int build_plan(dcn_plan& p) {
     for (const ConvL& c : p.convs) {
         const size_t welems = (size_t)c.d.ldc * c.d.kh * c.d.kw * c.d.cin;
         if (welems > max_w) max_w = welems;
-        const size_t sl = std::max(dcn_conv_wgrad_workspace(&c.d), dcn_conv_wgrad_workspace_f16(&c.d)) / sizeof(float);
+        const size_t sl = std::max(std::max(dcn_conv_wgrad_workspace(&c.d), dcn_conv_wgrad_workspace_f16(&c.d)),
+                                   dcn_conv_wgrad_workspace_hl(&c.d)) / sizeof(float);
         if (sl > max_slab) max_slab = sl;
         for (int dg = 0; dg < 2; ++dg) {
             const size_t sk = std::max(std::max(dcn_conv_gemm_workspace(&c.d, dg), dcn_conv_gemm_workspace_f16(&c.d, dg)),
@@ -430,6 +457,12 @@ struct Run {
     hipStream_t st;
     bool stem8 = false;   // this call runs the stem through dcn_conv_stem_forward_f16
     const float* hl_src[2] = {nullptr, nullptr};   // the fp32 tensors whose hl32 images currently sit in w_hl / w_hl2
+    std::vector<std::pair<const float*, const float*>> hl_saved;   // (fp32 tensor, its hl32 image in the SAVED arena) of this call
+    const float* saved_hl_of(const float* t) const {
+        for (const auto& e : hl_saved)
+            if (e.first == t) return e.second;
+        return nullptr;
+    }
 
     // bracket one matrix-core launch with events when profiling is on
     template <class F> int timed(int cat, double flops, F&& launch) {
@@ -483,13 +516,17 @@ struct Run {
             // (the operand image was written by the batch-norm apply pass that produced `in` -- hl_image_for --, or is made
             // here by a stand-alone pass)
             return timed(2, c.flops, [&] {
-                int k = hl_src[0] == in ? 0 : (hl_src[1] == in ? 1 : -1);
-                if (k < 0) {
-                    k = 0;
-                    DCN_TRY(dcn_split_act_hl32(in, A(c.in_act), hlbuf(0), (int64_t)c.d.n * c.d.hin * c.d.win, c.d.cin, st));
-                    hl_src[0] = in;
+                const float* img = saved_hl_of(in);
+                if (!img) {
+                    int k = hl_src[0] == in ? 0 : (hl_src[1] == in ? 1 : -1);
+                    if (k < 0) {
+                        k = 0;
+                        DCN_TRY(dcn_split_act_hl32(in, A(c.in_act), hlbuf(0), (int64_t)c.d.n * c.d.hin * c.d.win, c.d.cin, st));
+                        hl_src[0] = in;
+                    }
+                    img = hlbuf(k);
                 }
-                return dcn_conv_forward_hl(&c.d, hlbuf(k), A(c.in_act), whl(c), kWeightScale, bias, out, part, SKhl(c, 0), st);
+                return dcn_conv_forward_hl(&c.d, img, A(c.in_act), whl(c), kWeightScale, bias, out, part, SKhl(c, 0), st);
             });
         }
         return timed(0, c.flops, [&] {
@@ -500,6 +537,12 @@ struct Run {
 
     void* wimg(size_t plane, const ConvL& c) const { return (void*)((_Float16*)Wk(plane) + c.wsplit); }
 
+    // the saved hl32 copy of activation y (channels C, absmax slot act) by a stand-alone pass, when the apply pass that produced
+    // y did not write it (DCN_HL_PRODUCERS=0)
+    int ensure_saved_hl(const float* y, float* slot, int64_t rows, int C, int act) {
+        if (!slot || dcn::tuning().hl_producers != 0) return DCN_OK;
+        return dcn_split_act_hl32(y, A(act), slot, rows, C, st);
+    }
     // ---- pre-split (hl32) path of the wide layers (conv_hl_kernels.hip)
     bool use_hl(const ConvL& c, int dgrad) const {
         return p.conv_mode == DCN_CONV_F16X3 && c.hl_any && dcn_conv_hl_eligible(&c.d, dgrad) != 0;
@@ -508,7 +551,13 @@ struct Run {
     float* hlbuf(int k) const { return Wk(k == 0 ? p.w_hl : p.w_hl2); }
     // buffer k will hold the hl32 image of the activation `y` (written by the bn_apply pass that is about to produce y), if a
     // convolution that reads y takes the hl32 path; returns the buffer or null
-    void* hl_image_for(const float* y, int k, const ConvL* consumer_a, const ConvL* consumer_b = nullptr) {
+    // `slot` (optional): the tensor has an hl32 copy in the saved arena (its consumer's weight gradient reads it in the
+    // backward pass): the image goes there, whoever reads it in this call
+    void* hl_image_for(const float* y, int k, const ConvL* consumer_a, const ConvL* consumer_b = nullptr, float* slot = nullptr) {
+        if (slot) {
+            hl_saved.emplace_back(y, slot);
+            return dcn::tuning().hl_producers != 0 ? (void*)slot : nullptr;   // (producers off: ensure_saved_hl makes it)
+        }
         if (dcn::tuning().hl_producers == 0) return nullptr;
         const bool want = (consumer_a && use_hl(*consumer_a, 0)) || (consumer_b && use_hl(*consumer_b, 0));
         if (!want) return nullptr;
@@ -522,6 +571,11 @@ struct Run {
     int fwd_mtiles(const ConvL& c) const {
         if (p.conv_mode == DCN_CONV_FP32) return dcn_conv_num_mtiles(&c.d);
         return use_hl(c, 0) ? dcn_conv_num_mtiles_hl(&c.d) : dcn_conv_num_mtiles_f16(&c.d);
+    }
+    // weight gradient on hl32 operands (wgrad_hl_kernels.hip): the plan reserved a saved hl32 image of the convolution's input
+    // (written by every training-mode forward call in the split-fp16 arithmetic)
+    bool use_wgrad_hl(const ConvL& c) const {
+        return p.conv_mode == DCN_CONV_F16X3 && c.has_hl_x && dcn_conv_wgrad_hl_eligible(&c.d) != 0;
     }
     int split_hl_weights(bool transposed) {
         std::vector<const float*> w;
@@ -716,6 +770,7 @@ extern "C" int dcn_backbone_forward(dcn_plan* plan, const float* image, const fl
     dcn::launch_nchw3_to_nhwc4(image, R.S(p.s_in4), N, p.H * p.W, R.A(stem.in_act), st);
     dcn::launch_pad_c3_to_c4(R.P(stem.w), R.Wk(p.w_wstem), (int64_t)p.base * 49, st);
     const bool fused_eval = !training && p.conv_mode == DCN_CONV_F16X3;
+    const bool f16_mode = p.conv_mode == DCN_CONV_F16X3;
     if (fused_eval) {
         // Inference: the BN scale / shift only depend on the running statistics, so they are computed up front, the scale
         // is folded into the fp16 weight images and every conv + BN (+ residual) + ReLU is ONE kernel pass.
@@ -770,6 +825,11 @@ extern "C" int dcn_backbone_forward(dcn_plan* plan, const float* image, const fl
         dcn::launch_maxpool_fwd(R.S(p.s_stem_y), R.S(p.s_pool), (unsigned char*)R.S(p.s_argmax), N, stem.d.hout,
                                 stem.d.wout, hp, wp, b.C, st);
     }
+    if (training && f16_mode && p.blocks[0].has_hl_in) {   // (the first block's input is the max-pool output: no apply pass writes it)
+        const BlockL& b0 = p.blocks[0];
+        R.hl_saved.emplace_back(R.S(b0.in), R.S(b0.hl_in));
+        DCN_TRY(dcn_split_act_hl32(R.S(b0.in), R.A(b0.act_in), R.S(b0.hl_in), b0.in_rows, b0.in_c, st));
+    }
     for (const BlockL& blk : p.blocks) {
         const float* in = R.S(blk.in);
         const float* cur = in;
@@ -783,9 +843,11 @@ extern "C" int dcn_backbone_forward(dcn_plan* plan, const float* image, const fl
                 DCN_TRY(R.conv_bn(c, cur, R.P(c.w), bn_running, momentum, eps, training, blk.act_mid[i]));
                 const BnL& b = p.bns[c.bn];
                 const float* s = R.S(b.stats);
-                void* hl = training ? R.hl_image_for(R.S(blk.mid[i]), 1, &p.convs[blk.conv[i + 1]]) : nullptr;
+                float* slot = (training && f16_mode && blk.has_hl_mid[i]) ? R.S(blk.hl_mid[i]) : nullptr;
+                void* hl = training ? R.hl_image_for(R.S(blk.mid[i]), 1, &p.convs[blk.conv[i + 1]], nullptr, slot) : nullptr;
                 dcn::launch_bn_apply(R.S(c.x), s, nullptr, nullptr, 1, R.S(blk.mid[i]), R.M(blk.mid[i]), b.C, b.rows, p.groups, st,
                                      hl, R.A(blk.act_mid[i]));
+                DCN_TRY(R.ensure_saved_hl(R.S(blk.mid[i]), slot, b.rows, b.C, blk.act_mid[i]));
                 cur = R.S(blk.mid[i]);
             } else {
                 DCN_TRY(R.conv_bn(c, cur, R.P(c.w), bn_running, momentum, eps, training, blk.act_out,
@@ -797,7 +859,9 @@ extern "C" int dcn_backbone_forward(dcn_plan* plan, const float* image, const fl
         const float* sl = R.S(bl.stats);
         // the block's output feeds the next block's first convolution (and its downsample branch)
         const BlockL* nb = (&blk != &p.blocks.back()) ? &blk + 1 : nullptr;
-        void* hl = (training && nb) ? R.hl_image_for(R.S(blk.out), 0, &p.convs[nb->conv[0]], nb->down >= 0 ? &p.convs[nb->down] : nullptr)
+        float* slot = (training && f16_mode && nb && nb->has_hl_in) ? R.S(nb->hl_in) : nullptr;
+        void* hl = (training && nb) ? R.hl_image_for(R.S(blk.out), 0, &p.convs[nb->conv[0]], nb->down >= 0 ? &p.convs[nb->down] : nullptr,
+                                                     slot)
                                     : nullptr;
         if (blk.down >= 0) {
             const ConvL& dc = p.convs[blk.down];
@@ -808,6 +872,7 @@ extern "C" int dcn_backbone_forward(dcn_plan* plan, const float* image, const fl
             dcn::launch_bn_apply(R.S(last.x), sl, in, nullptr, 1, R.S(blk.out), R.M(blk.out), bl.C, bl.rows, p.groups, st, hl,
                                  R.A(blk.act_out));
         }
+        DCN_TRY(R.ensure_saved_hl(R.S(blk.out), slot, bl.rows, bl.C, blk.act_out));
     }
     }   // !fused_eval
     // scoring layer (1x1 conv + bias) into the padded low-resolution map, then bilinear upsample
@@ -868,6 +933,7 @@ extern "C" int dcn_backbone_backward(dcn_plan* plan, const float* grad_descripto
     int n_bn = 0, cur = 0;              // BN-backward launches so far; buffer holding the newest split gradient
     bool wg_pending[2] = {false, false};
     float* const dqbuf[2] = {R.Wk(p.w_dq), R.Wk(p.w_dq2)};
+    float* const hlimg[2] = {R.hlbuf(0), R.hlbuf(1)};   // hl32 images of dx, alternating like dqbuf (same events order their users)
     const float* dq_of = nullptr;       // gradient tensor whose pixel-blocked split copy is in dqbuf[cur]
     // BN backward of conv c's batch norm: dy (+ optional relu mask from relu_out) -> dx; g_out optional
     // Fused reduction (split-fp16 mode): the dgrad that produces a batch norm's upstream gradient dy also masks it with the
@@ -892,17 +958,38 @@ extern "C" int dcn_backbone_backward(dcn_plan* plan, const float* grad_descripto
         if (tiles > 0) { relu_out = nullptr; mask = nullptr; g_out = nullptr; ++p.fused_bn_bwd; }   // dy is already the masked gradient
         // the dgrad of this convolution on the hl32 path: the apply pass writes dx as the hl32 image INSTEAD of the fp32 tensor
         // (wgrad reads the pixel-blocked image, nobody reads the fp32 one)
-        const bool hl_d = f16 && !fuse_red && dcn::tuning().hl_producers != 0 && R.use_hl(c, 1);
-        hl_dx_of = hl_d ? dx : nullptr;
+        const bool prod = f16 && dcn::tuning().hl_producers != 0;
+        const bool hl_d = prod && !fuse_red && R.use_hl(c, 1);       // this convolution's dgrad reads the hl32 image
+        const bool hl_w = prod && R.use_wgrad_hl(c);                  // ... its weight gradient too: no pixel-blocked image then
+        hl_dx_of = (hl_d || hl_w) ? dx : nullptr;
         dcn::launch_bn_bwd(dy, relu_out, mask, R.S(c.x), s, R.P(b.g), b.C, b.rows, p.groups, part, grads[b.g],
-                           grads[b.b], k123, dx, g_out, f16 ? amax + c.idx : nullptr, f16 ? (void*)dqbuf[cur] : nullptr, st,
-                           tiles, dy2, hl_d ? (void*)R.hlbuf(0) : nullptr, 0);
+                           grads[b.b], k123, dx, g_out, f16 ? amax + c.idx : nullptr,
+                           (f16 && !hl_w) ? (void*)dqbuf[cur] : nullptr, st, tiles, dy2,
+                           (hl_d || hl_w) ? (void*)hlimg[cur] : nullptr, hl_d ? 0 : 1);
         if (overlap) RT(hipEventRecord(p.ev_dq[cur], st));
         ++n_bn;
-        dq_of = f16 ? dx : nullptr;   // the pixel-blocked split copy of this dx now sits in dqbuf[cur]
+        dq_of = (f16 && !hl_w) ? dx : nullptr;   // the pixel-blocked split copy of this dx now sits in dqbuf[cur]
     };
     auto wgrad = [&](const ConvL& c, const float* in, const float* dx, float* dw) -> int {
         if (!f16) return R.timed(1, c.flops, [&] { return dcn_conv_wgrad(&c.d, in, dx, dw, slab, st); });
+        if (R.use_wgrad_hl(c)) {   // both operands as hl32 tensors: the saved image of the input, the image of dx
+            const float* ximg = R.S(c.hl_x);
+            if (hl_dx_of != dx) {  // (DCN_HL_PRODUCERS=0, or a gradient that no batch-norm backward produced)
+                DCN_TRY(dcn_split_act_hl32(dx, amax + c.idx, hlimg[cur], (int64_t)c.d.n * c.d.hout * c.d.wout, c.d.ldc, st));
+                if (overlap) RT(hipEventRecord(p.ev_dq[cur], st));
+                hl_dx_of = dx;
+            }
+            if (overlap) {
+                RT(hipStreamWaitEvent(p.side, p.ev_dq[cur], 0));
+                DCN_TRY(dcn_conv_wgrad_hl(&c.d, ximg, R.A(c.in_act), hlimg[cur], amax + c.idx, dw, slab, p.side));
+                RT(hipEventRecord(p.ev_wg[cur], p.side));
+                wg_pending[cur] = true;
+                return DCN_OK;
+            }
+            return R.timed(1, c.flops, [&] {
+                return dcn_conv_wgrad_hl(&c.d, ximg, R.A(c.in_act), hlimg[cur], amax + c.idx, dw, slab, st);
+            });
+        }
         // The activation operand is the fp32 tensor itself, split on the fly inside the kernel: measured faster than a
         // split pass + pre-split operand on every layer of ResNet34 / ResNet50 (the pass costs more than the conversions).
         if (dq_of != dx) {   // (BN backward emits it directly; only the scoring layer's gradient needs the separate pass)
@@ -945,10 +1032,13 @@ extern "C" int dcn_backbone_backward(dcn_plan* plan, const float* grad_descripto
         }
         if (R.use_hl(c, 1)) {
             return R.timed(2, c.flops, [&] {
-                if (hl_dx_of != dx)
-                    DCN_TRY(dcn_split_act_hl32(dx, amax + c.idx, R.hlbuf(0), (int64_t)c.d.n * c.d.hout * c.d.wout, c.d.ldc, st));
-                hl_dx_of = nullptr;
-                return dcn_conv_dgrad_hl(&c.d, R.hlbuf(0), R.whl(c), kWeightScale, amax + c.idx, add, din, R.SKhl(c, 1), st);
+                if (hl_dx_of != dx) {
+                    // (the side stream's weight-gradient kernel may still be reading hlimg[cur]: the image is only rewritten when
+                    // it holds another tensor, i.e. after the wait at the top of the bn_bwd that owns the buffer)
+                    DCN_TRY(dcn_split_act_hl32(dx, amax + c.idx, hlimg[cur], (int64_t)c.d.n * c.d.hout * c.d.wout, c.d.ldc, st));
+                    hl_dx_of = dx;
+                }
+                return dcn_conv_dgrad_hl(&c.d, hlimg[cur], R.whl(c), kWeightScale, amax + c.idx, add, din, R.SKhl(c, 1), st);
             });
         }
         return R.timed(0, c.flops, [&] {   // (transposed weight images: split_all_weights(true) below)

@@ -455,7 +455,7 @@ bn_bwd_apply_blocked_kernel(const float* __restrict__ dy, const float* dy2, cons
                 o[r][0] = o[r][1] = o[r][2] = o[r][3] = 0.f;
             }
         }
-        dcnsplit::store_blocked_quad(dq, q, cq, c4n, o, s);
+        if (dq) dcnsplit::store_blocked_quad(dq, q, cq, c4n, o, s);   // (null: the weight gradient reads the hl32 image)
     }
 }
 
@@ -743,7 +743,7 @@ void launch_bn_bwd(const float* dy, const float* relu_out, const unsigned char* 
     hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(ceil_div(C, 4)), dim3(256), 0, st, (const float*)partial, chunks,
                        groups, C, (double)rpg, gamma, invstd, 4 * C, dgamma, dbeta, k123, absmax);
     const int64_t total4 = rows * (C / 4);
-    if (dq && absmax) {
+    if ((dq || (hl_dx && (C % 32) == 0)) && absmax) {
         hipLaunchKernelGGL(bn_bwd_apply_blocked_kernel, dim3(blocks_for(((rows + 3) / 4) * (C / 4), kGridCap)), dim3(256), 0, st,
                            dy, dy2, relu_out, relu_mask, x, mean, invstd, (const float*)k123, (const float*)(k123 + C),
                            (const float*)(k123 + 2 * C), (hl_dx && (C % 32) == 0 && !keep_dx) ? nullptr : dx, g_out,

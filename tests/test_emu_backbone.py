@@ -298,7 +298,8 @@ def test_grouped_pair_forward_equals_two_forward_calls(arch, bw, shape):
     ("Resnet18_8s", 32, (2, 128, 128), 2, 1)])
 def test_wide_layers_through_the_hl32_path(arch, bw, shape, groups, producers, dcn_env, conv_mode):
     """DCN_GEMM_HL=2: every convolution the pre-split (hl32) LDS-DMA kernel supports takes it (forward and dgrad, engine
-    workspace, weight images per call).  Forward: against the engine's own fp32-operand kernels and the float64 oracle.
+    workspace, weight images per call), DCN_WGRAD_HL=2: every weight gradient the hl32 wgrad kernel supports (saved hl32 images
+    of the activations, hl32 images of the gradients from the batch-norm backward passes).  Forward: against the engine's own fp32-operand kernels and the float64 oracle.
     Backward: on the SAME forward pass (saved arena written with DCN_GEMM_HL=0, so that both backward passes see identical
     ReLU masks -- a pre-activation within round-off of zero otherwise moves a whole channel's gradient by per cent in
     whichever arithmetic it flips) the hl32 dgrads must reproduce the fp32-operand ones.  With two statistics groups
@@ -321,9 +322,11 @@ def test_wide_layers_through_the_hl32_path(arch, bw, shape, groups, producers, d
         if groups == 2:
             return torch.cat(net.forward_pair(x[:N // 2], x[N // 2:]))
         return net(x)
-    dcn_env(DCN_GEMM_HL=2, DCN_HL_PRODUCERS=producers)
+    from dcn_hip import backbone as _bb
+    dcn_env(DCN_GEMM_HL=2, DCN_WGRAD_HL=2, DCN_HL_PRODUCERS=producers)
+    _bb._PLANS.clear()                     # (plans reserve the saved hl32 images when they are built: after the switches are set)
     y = fwd(m)
-    dcn_env(DCN_GEMM_HL=0)
+    dcn_env(DCN_GEMM_HL=0, DCN_WGRAD_HL=2, DCN_HL_PRODUCERS=producers)
     y2, y3 = fwd(m2), fwd(m3)
     if groups == 1:
         yo, y64 = o(x), o64(x.double())
@@ -334,11 +337,13 @@ def test_wide_layers_through_the_hl32_path(arch, bw, shape, groups, producers, d
         assert rel_err(y, y2) < 1e-4
     for (k, b), b2 in zip(m.named_buffers(), m2.buffers()):
         assert rel_err(b.float(), b2.float()) < 1e-4 or float((b.float() - b2.float()).abs().max()) < 1e-5, k
-    (y2 * gy).sum().backward()             # fp32-operand dgrads
-    dcn_env(DCN_GEMM_HL=2, DCN_HL_PRODUCERS=producers)
-    (y3 * gy).sum().backward()             # hl32 dgrads on an identical saved arena
+    dcn_env(DCN_GEMM_HL=0, DCN_WGRAD_HL=0)
+    (y2 * gy).sum().backward()             # fp32-operand dgrads and weight gradients
+    dcn_env(DCN_GEMM_HL=2, DCN_WGRAD_HL=2, DCN_HL_PRODUCERS=producers)
+    (y3 * gy).sum().backward()             # hl32 dgrads and weight gradients on an identical saved arena
     for (k, p2), p3 in zip(m2.named_parameters(), m3.parameters()):
         assert rel_err(p3.grad, p2.grad) < 3e-5, (k, rel_err(p3.grad, p2.grad))
+    _bb._PLANS.clear()
 
 
 def _torchvision_like_state_dict(arch, bw, seed=3):
