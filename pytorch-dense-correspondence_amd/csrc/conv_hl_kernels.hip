@@ -489,6 +489,9 @@ extern "C" int dcn_conv_hl_eligible(const dcn_conv_desc* c, int dgrad) {
     // N = 8 -3 %; the 512 -> 512 layer-4 convolutions, K = 4608, +7 %)
     const double rounds = (double)dcn::ceil_div64(M, 256) * dcn::ceil_div(cd, 256) / 256.0;
     if (rounds > 1.0 && rounds < 1.5 && K < 4096) return 0;
+    // fewer than ~120 tiles leave more than half of the 256 CUs idle (no stream-K below one round): config 1 (two images,
+    // 38 x 2 tiles on layer 4) measured -3.5 % on the step with this kernel (profiles/r3l_config1_ab.txt)
+    if (rounds < 120.0 / 256.0) return 0;
     return 1;
 }
 

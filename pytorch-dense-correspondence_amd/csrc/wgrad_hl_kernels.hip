@@ -316,7 +316,9 @@ int wgrad_hl_splits(const dcn_conv_desc* c, int* stages_per_split) {
 extern "C" int dcn_conv_wgrad_hl_eligible(const dcn_conv_desc* c) {
     if (!wgrad_hl_supported(c) || dcn::tuning().wgrad_hl == 0) return 0;
     if (dcn::tuning().wgrad_hl == 2) return 1;   // (tests: every supported convolution)
-    return ((c->cout % 256) == 0 && c->kh * c->kw * c->cin >= 1024 && (int64_t)c->n * c->hout * c->wout >= 8192) ? 1 : 0;
+    // (M >= 16384: at two images, M = 9600, the pixel splits are 30-40 stages long and the kernel loses 0.5 % on the step,
+    // profiles/r3l_config1_ab.txt)
+    return ((c->cout % 256) == 0 && c->kh * c->kw * c->cin >= 1024 && (int64_t)c->n * c->hout * c->wout >= 16384) ? 1 : 0;
 }
 
 extern "C" size_t dcn_conv_wgrad_workspace_hl(const dcn_conv_desc* c) {
