@@ -486,13 +486,14 @@ def main():
         # rocprofv3): it is the COMMITTED measurement of this very command (profiles/, collected and corrected per
         # MI355X_MICROARCH.md's HBM section), attached only when workload / arithmetic / call pattern match -- the
         # field name says so: it was not measured in this run
-        traffic, traffic_src = None, None
+        traffic, traffic_src, traffic_hl = None, None, None
         for name in ("r3_hbm_counters.json", "r2m_hbm_counters.json", "r2_hbm_counters.json", "r1g_hbm_counters.json"):
             try:
                 rec = json.load(open(os.path.join(ROOT, "profiles", name)))
                 if (rec["workload"] == args.workload and rec["conv_mode"] == conv_mode and not args.batch and job_ is job and
                         (rec["forward_calls"] == "pair") == (not args.separate_forwards)):
                     traffic = rec["hbm_bytes_per_launch"]
+                    traffic_hl = (rec.get("hl_kernel") or {}).get("hbm_bytes_per_launch")
                     traffic_src = "committed rocprofv3 --pmc measurement of this command, profiles/%s: %s" % (name, rec["correction"])
                     break
             except (OSError, KeyError, ValueError):
@@ -507,7 +508,8 @@ def main():
                     "kernel": "conv_gemm_hl_kernel (conv_hl_kernels.hip): the wide layers' share of the launches above",
                     "achieved": hfl / (hms * 1e-3) / 1e12, "frac": hfl / (hms * 1e-3) / 1e12 / peak,
                     "launches_per_step": hn / args.profile_steps, "avg_launch_us": 1e3 * hms / hn,
-                    "algorithmic_gflop_per_launch": hfl / hn / 1e9, "kernel_ms_per_step": hms / args.profile_steps},
+                    "algorithmic_gflop_per_launch": hfl / hn / 1e9, "kernel_ms_per_step": hms / args.profile_steps,
+                    "traffic": traffic_hl},
                 "conv_wgrad": {"achieved": (wfl / (wms * 1e-3) / 1e12) if wms > 0 else None,
                                "frac": (wfl / (wms * 1e-3) / 1e12 / peak) if wms > 0 else None,
                                "launches_per_step": wn / args.profile_steps,

@@ -166,10 +166,9 @@ split_stem8_kernel(const float* __restrict__ w4, _Float16* __restrict__ hi, _Flo
 // ----------------------------------------------------------------------------------------------- gather-GEMM, f16x3
 // WR: wavefront rows of the workgroup (WR x 2 wavefronts, 128 WR work-items): 2 -> tiles of 64 TM x 64 TN, two workgroups
 // per CU; 4 -> 128 TM x 64 TN on 8 wavefronts, ONE workgroup per CU (same 8 wavefronts per CU, but a quarter fewer
-// operand bytes per MFMA through the vector-memory path and the LDS store path).
-// WC: wavefront columns (WR x WC wavefronts).  WR = 2, WC = 4: 128 x 256 tiles on 8 wavefronts -- the doubled operand is
-// the WEIGHT image (pre-split, a pure copy), so per MFMA the gathered operand's loads, fp32 -> (hi, lo) conversions and LDS
-// stores are half those of the 256 x 128 shape (which doubles the converting operand).
+// operand bytes per MFMA through the vector-memory path and the LDS store path, profiles/EXPERIMENTS.md).
+// WC: wavefront columns (WR x WC wavefronts; 2 everywhere -- the 128 x 256 shape WR = 2, WC = 4 measured as a wash in round 2
+// and was removed in round 3: the wide layers now run on conv_hl_kernels.hip).
 template <int TM, int TN, int WR = 2, int WC = 2> struct F16Geo {
     static constexpr int NTH = 64 * WR * WC, BM = 32 * TM * WR, BN = 32 * TN * WC, RA = NTH / 8, RB = NTH / 4, PA = BM / RA,
                          PB = BN / RB, kStageHalves = 2 * (BM + BN) * LDH;   // A hi, A lo, B hi, B lo
@@ -664,18 +663,12 @@ F16Shape f16_shape(int M, int cd, int K, int align = 0) {
     g.wr = 2; g.wc = 2;
     if (g.tn == 2 && M >= 4096) { g.tm = 2; g.wr = 4; }
     const dcn::Tuning& tune = dcn::tuning();
-    // 128 x 256 on 8 wavefronts (2 x 4) where the destination has whole 256-channel tiles: the doubled operand is the
-    // pre-split weight image instead of the gathered, converted one.
-    // Measured (profiles/r2f_gemm_tile_n_ab.txt): a wash -- layer 3 +1 %, layer 4 -0.3 %, the step unchanged: the loop is not
-    // bound by the gathered operand's conversions.  Opt-in (DCN_GEMM_TILE_N=256).
-    if (g.wr == 4 && cd >= 256 && (cd % 256) == 0 && tune.gemm_tile_n == 256) { g.wr = 2; g.wc = 4; }
     if (tune.gemm_tile_m) {
         const int v = tune.gemm_tile_m;
         if (v == 64) { g.tm = 1; g.wr = 2; g.wc = 2; }
         if (v == 128 && g.wc == 2) { g.tm = 2; g.wr = 2; }
         if (v == 256 && g.tn == 2) { g.tm = 2; g.wr = 4; g.wc = 2; }
     }
-    if (tune.gemm_tile_n == 256 && g.tn == 2) { g.tm = 2; g.wr = 2; g.wc = 4; }   // (as an override: any M, ragged N)
     if (align > 0 && (align % (32 * g.tm * g.wr)) != 0) { g.wr = 2; g.wc = 2; if ((align % (64 * g.tm)) != 0) g.tm = 1; }
     const int bm = 32 * g.tm * g.wr, bn = 32 * g.tn * g.wc;
     g.mtiles = dcn::ceil_div(M, bm);
@@ -768,8 +761,7 @@ int launch_gemm_f16(GemmConv& p, void* workspace, hipStream_t st, int align = 0)
             else DCN_GEMM16_K(TM, TN, WR, WC, false, false);                                           \
         }                                                                                              \
     } while (0)
-    if (g.wc == 4) DCN_GEMM16(2, 2, 2, 4);
-    else if (g.wr == 4) DCN_GEMM16(2, 2, 4, 2);
+    if (g.wr == 4) DCN_GEMM16(2, 2, 4, 2);
     else if (g.tm == 1) { if (g.tn == 1) DCN_GEMM16(1, 1, 2, 2); else DCN_GEMM16(1, 2, 2, 2); }
     else { if (g.tn == 1) DCN_GEMM16(2, 1, 2, 2); else DCN_GEMM16(2, 2, 2, 2); }
 #undef DCN_GEMM16_K

@@ -3,8 +3,6 @@
 //   DCN_CONV_MODE           fp32 | f16x3    default arithmetic of new plans
 //   DCN_BACKWARD_OVERLAP    0: weight-gradient GEMMs stay on the caller's stream
 //   DCN_GEMM_TILE_M         32 | 64 | 128 | 256   workgroup-tile height of the gather-GEMM kernels
-//   DCN_GEMM_TILE_N         256: 128 x 256 tiles (2 x 4 wavefronts) instead of 256 x 128 in the split-fp16 gather-GEMM
-//                           (measured: no gain, profiles/r2f_gemm_tile_n_ab.txt)
 //   DCN_STEM8               0: the 7x7 stem runs the generic gather path (1: as a uniform-tap convolution over filter rows)
 //   DCN_GEMM_SK             0: no stream-K, 1: as decided, N > 1: force N workgroups
 //   DCN_GEMM_SK_MIN_GAIN    stage times stream-K must save to be chosen (split-fp16 kernel)
@@ -37,7 +35,6 @@ struct Tuning {
     int conv_mode_invalid = 0;   // DCN_CONV_MODE holds something else than fp32 / f16x3
     int backward_overlap = 1;
     int gemm_tile_m = 0;         // 0: unset
-    int gemm_tile_n = 0;         // 0: unset
     int gemm_sk = -1;            // -1: unset
     double gemm_sk_min_gain = 20.0;
     int gemm_uni = 1;

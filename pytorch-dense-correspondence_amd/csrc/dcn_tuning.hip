@@ -23,7 +23,6 @@ void read_env(Tuning& t) {
     }
     if (const char* e = getenv("DCN_BACKWARD_OVERLAP")) t.backward_overlap = atoi(e) != 0;
     if (const char* e = getenv("DCN_GEMM_TILE_M")) t.gemm_tile_m = atoi(e);
-    if (const char* e = getenv("DCN_GEMM_TILE_N")) t.gemm_tile_n = atoi(e);
     if (const char* e = getenv("DCN_GEMM_SK")) t.gemm_sk = atoi(e);
     if (const char* e = getenv("DCN_GEMM_SK_MIN_GAIN")) t.gemm_sk_min_gain = atof(e);
     if (const char* e = getenv("DCN_STEM8")) t.stem8 = atoi(e) != 0;

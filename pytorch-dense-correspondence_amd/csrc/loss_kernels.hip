@@ -49,9 +49,14 @@ __global__ void __launch_bounds__(kThreads)
 loss_fwd_kernel(const float* __restrict__ A, const float* __restrict__ B, int64_t hw, int D,
                 const int64_t* __restrict__ idx_a, const int64_t* __restrict__ idx_b,
                 const int64_t* __restrict__ offsets, dcn_loss_config cfg, double* __restrict__ part_sum,
-                int* __restrict__ part_cnt, float* __restrict__ per_term, int* __restrict__ status) {
+                int* __restrict__ part_cnt, float* __restrict__ per_term, int* __restrict__ part_oob) {
+    // part_oob[workgroup]: 1 if the workgroup met an index outside [0, hw) -- OR-ed into the status word by the finalize
+    // kernel (no cleared status word needed in front of this launch)
     __shared__ double s_sum[kThreads / dcn::kWave];
     __shared__ int s_cnt[kThreads / dcn::kWave];
+    __shared__ int s_oob;
+    if (threadIdx.x == 0) s_oob = 0;
+    __syncthreads();
     constexpr int GROUPS = kThreads / LP, PPB = GROUPS * kItems;
     const int seg = blockIdx.y, p = seg >> 2, t = seg & 3;
     const int64_t beg = offsets[seg], len = offsets[seg + 1] - beg;
@@ -75,7 +80,7 @@ loss_fwd_kernel(const float* __restrict__ A, const float* __restrict__ B, int64_
             const int64_t ia = live ? idx_a[beg + j] : -1, ib = live ? idx_b[beg + j] : -1;
             const bool skip = ia < 0 || ib < 0;        // the reference's `[-1]` "empty list" sentinel
             const bool oob = !skip && (ia >= hw || ib >= hw);
-            if (oob && sub == 0) *status = 1;
+            if (oob && sub == 0) s_oob = 1;
             const bool ok = !skip && !oob;
             float s = 0.f;
             if (ok) {
@@ -116,9 +121,10 @@ loss_fwd_kernel(const float* __restrict__ A, const float* __restrict__ B, int64_
     }
     const double bs = dcn::block_sum<kThreads>(sum, s_sum);
     const int bc = dcn::block_sum<kThreads>(cnt, s_cnt);
-    if (threadIdx.x == 0) {
+    if (threadIdx.x == 0) {   // (block_sum's barriers order the s_oob writes before this read)
         part_sum[(int64_t)seg * gridDim.x + blockIdx.x] = bs;
         part_cnt[(int64_t)seg * gridDim.x + blockIdx.x] = bc;
+        part_oob[(int64_t)seg * gridDim.x + blockIdx.x] = s_oob;
     }
 }
 
@@ -157,26 +163,26 @@ __device__ __forceinline__ PairScales pair_scales(const dcn_loss_config& cfg, co
 // One workgroup PER IMAGE PAIR: adds that pair's partials in a fixed order in fp64 and composes its 5-tuple; the per-pair
 // losses go to pair_loss[] and a second, tiny kernel averages them in pair order (deterministic; a single workgroup walking
 // all pairs took 200 us at 32 pairs x 110 000 pixel pairs).
-__global__ void __launch_bounds__(kThreads)
-loss_finalize_kernel(const double* __restrict__ part_sum, const int* __restrict__ part_cnt, int chunks,
-                     const int64_t* __restrict__ offsets, dcn_loss_config cfg, float* __restrict__ terms,
-                     float* __restrict__ sums, int* __restrict__ hard_neg, double* __restrict__ pair_loss) {
-    __shared__ double s_sum[kThreads / dcn::kWave];
-    __shared__ int s_cnt[kThreads / dcn::kWave];
-    __shared__ double s_S[4];
-    __shared__ int s_h[4];
-    const int p = blockIdx.x;
+// finalizes image pair p (all work-items of the workgroup take part); returns, in work-item 0, whether the pair met an
+// out-of-range index
+__device__ __forceinline__ int finalize_pair(int p, const double* __restrict__ part_sum, const int* __restrict__ part_cnt,
+                                             const int* __restrict__ part_oob, int chunks, const int64_t* __restrict__ offsets,
+                                             const dcn_loss_config& cfg, float* __restrict__ terms, float* __restrict__ sums,
+                                             int* __restrict__ hard_neg, double* __restrict__ pair_loss, double* s_sum, int* s_cnt,
+                                             double* s_S, int* s_h) {
+    int oob = 0;
     for (int t = 0; t < 4; ++t) {
         double a = 0.0;
-        int c = 0;
+        int c = 0, o = 0;
         const int64_t base = (int64_t)(4 * p + t) * chunks;
-        for (int i = threadIdx.x; i < chunks; i += kThreads) { a += part_sum[base + i]; c += part_cnt[base + i]; }
+        for (int i = threadIdx.x; i < chunks; i += kThreads) { a += part_sum[base + i]; c += part_cnt[base + i]; o |= part_oob[base + i]; }
         a = dcn::block_sum<kThreads>(a, s_sum);
         c = dcn::block_sum<kThreads>(c, s_cnt);
-        if (threadIdx.x == 0) { s_S[t] = a; s_h[t] = c; }
+        o = dcn::block_sum<kThreads>(o, s_cnt);
+        if (threadIdx.x == 0) { s_S[t] = a; s_h[t] = c; oob |= o; }
     }
     __syncthreads();
-    if (threadIdx.x != 0) return;
+    if (threadIdx.x != 0) return 0;
     int64_t len[4];
     int h[4];
     for (int t = 0; t < 4; ++t) { len[t] = offsets[4 * p + t + 1] - offsets[4 * p + t]; h[t] = s_h[t]; }
@@ -210,14 +216,58 @@ loss_finalize_kernel(const double* __restrict__ part_sum, const int* __restrict_
     for (int k = 0; k < 5; ++k) terms[5 * p + k] = out[k];
     for (int t = 0; t < 4; ++t) { sums[4 * p + t] = (float)s_S[t]; hard_neg[4 * p + t] = h[t]; }
     pair_loss[p] = (double)out[0];
+    return oob ? 1 : 0;
+}
+
+// many pairs: one workgroup per pair (pair_oob[p] = out-of-range flag), then loss_mean_kernel
+__global__ void __launch_bounds__(kThreads)
+loss_finalize_kernel(const double* __restrict__ part_sum, const int* __restrict__ part_cnt, const int* __restrict__ part_oob,
+                     int chunks, const int64_t* __restrict__ offsets, dcn_loss_config cfg, float* __restrict__ terms,
+                     float* __restrict__ sums, int* __restrict__ hard_neg, double* __restrict__ pair_loss,
+                     int* __restrict__ pair_oob) {
+    __shared__ double s_sum[kThreads / dcn::kWave];
+    __shared__ int s_cnt[kThreads / dcn::kWave];
+    __shared__ double s_S[4];
+    __shared__ int s_h[4];
+    const int o = finalize_pair(blockIdx.x, part_sum, part_cnt, part_oob, chunks, offsets, cfg, terms, sums, hard_neg, pair_loss,
+                                s_sum, s_cnt, s_S, s_h);
+    if (threadIdx.x == 0) pair_oob[blockIdx.x] = o;
 }
 
 __global__ void __launch_bounds__(64)
-loss_mean_kernel(const double* __restrict__ pair_loss, int num_pairs, float* __restrict__ loss) {
+loss_mean_kernel(const double* __restrict__ pair_loss, const int* __restrict__ pair_oob, int num_pairs, float* __restrict__ loss,
+                 int* __restrict__ status) {
     if (threadIdx.x != 0) return;
     double total = 0.0;
-    for (int p = 0; p < num_pairs; ++p) total += pair_loss[p];   // pair order: the sum the single-workgroup version formed
+    int o = 0;
+    for (int p = 0; p < num_pairs; ++p) { total += pair_loss[p]; o |= pair_oob[p]; }   // pair order: deterministic
     loss[0] = (float)(total / (double)num_pairs);
+    status[0] = o;
+}
+
+// few pairs (the training configurations: 1-8 per step): ONE workgroup finalizes the pairs one after the other, averages them
+// in pair order and writes the status word -- one launch instead of three (status clear, finalize, mean)
+__global__ void __launch_bounds__(kThreads)
+loss_finalize_all_kernel(const double* __restrict__ part_sum, const int* __restrict__ part_cnt, const int* __restrict__ part_oob,
+                         int chunks, int num_pairs, const int64_t* __restrict__ offsets, dcn_loss_config cfg,
+                         float* __restrict__ terms, float* __restrict__ sums, int* __restrict__ hard_neg,
+                         double* __restrict__ pair_loss, float* __restrict__ loss, int* __restrict__ status) {
+    __shared__ double s_sum[kThreads / dcn::kWave];
+    __shared__ int s_cnt[kThreads / dcn::kWave];
+    __shared__ double s_S[4];
+    __shared__ int s_h[4];
+    double total = 0.0;
+    int o = 0;
+    for (int p = 0; p < num_pairs; ++p) {
+        o |= finalize_pair(p, part_sum, part_cnt, part_oob, chunks, offsets, cfg, terms, sums, hard_neg, pair_loss, s_sum, s_cnt,
+                           s_S, s_h);
+        if (threadIdx.x == 0) total += pair_loss[p];
+        __syncthreads();   // (s_S / s_h are rewritten by the next pair)
+    }
+    if (threadIdx.x == 0) {
+        loss[0] = (float)(total / (double)num_pairs);
+        status[0] = o;
+    }
 }
 
 // grid = (chunks, 4*num_pairs).  Scatter-adds d loss / d descriptor with hardware fp32 atomics (lane mapping above).
@@ -425,7 +475,7 @@ namespace {
 
 extern "C" size_t dcn_loss_workspace_bytes(int num_pairs, int64_t max_list_len) {
     const size_t n = (size_t)4 * (size_t)num_pairs * (size_t)chunks_for(max_list_len, 0);
-    return n * sizeof(double) + (size_t)num_pairs * sizeof(double) + n * sizeof(int) + 64;
+    return n * sizeof(double) + (size_t)num_pairs * sizeof(double) + 2 * n * sizeof(int) + (size_t)num_pairs * sizeof(int) + 64;
 }
 
 extern "C" int dcn_contrastive_loss_forward(const float* desc_a, const float* desc_b, int num_pairs, int64_t hw, int d,
@@ -445,11 +495,12 @@ extern "C" int dcn_contrastive_loss_forward(const float* desc_a, const float* de
     double* part_sum = (double*)workspace;
     double* pair_loss = part_sum + n;
     int* part_cnt = (int*)(pair_loss + num_pairs);
-    if (dcn::fill_bytes_async(status, 0, sizeof(int32_t), st) != DCN_OK) return DCN_E_LAUNCH;
+    int* part_oob = part_cnt + n;
+    int* pair_oob = part_oob + n;
     const dim3 grid(chunks, 4 * num_pairs), block(kThreads);
 #define DCN_LAUNCH_FWD(LP, SINGLE)                                                                                       \
     hipLaunchKernelGGL((loss_fwd_kernel<LP, SINGLE>), grid, block, 0, st, desc_a, desc_b, hw, d, idx_a, idx_b, offsets_dev, \
-                       *cfg, part_sum, part_cnt, per_term, (int*)status)
+                       *cfg, part_sum, part_cnt, per_term, part_oob)
     switch (lanes_per_pair(d)) {
         case 4: DCN_LAUNCH_FWD(4, true); break;
         case 8: DCN_LAUNCH_FWD(8, true); break;
@@ -460,9 +511,15 @@ extern "C" int dcn_contrastive_loss_forward(const float* desc_a, const float* de
             break;
     }
 #undef DCN_LAUNCH_FWD
-    hipLaunchKernelGGL(loss_finalize_kernel, dim3(num_pairs), block, 0, st, part_sum, part_cnt, chunks, offsets_dev, *cfg,
-                       terms, sums, (int*)hard_neg, pair_loss);
-    hipLaunchKernelGGL(loss_mean_kernel, dim3(1), dim3(64), 0, st, (const double*)pair_loss, num_pairs, loss);
+    if (num_pairs <= 8) {
+        hipLaunchKernelGGL(loss_finalize_all_kernel, dim3(1), block, 0, st, part_sum, part_cnt, part_oob, chunks, num_pairs,
+                           offsets_dev, *cfg, terms, sums, (int*)hard_neg, pair_loss, loss, (int*)status);
+    } else {
+        hipLaunchKernelGGL(loss_finalize_kernel, dim3(num_pairs), block, 0, st, part_sum, part_cnt, part_oob, chunks, offsets_dev,
+                           *cfg, terms, sums, (int*)hard_neg, pair_loss, pair_oob);
+        hipLaunchKernelGGL(loss_mean_kernel, dim3(1), dim3(64), 0, st, (const double*)pair_loss, (const int*)pair_oob, num_pairs,
+                           loss, (int*)status);
+    }
     return dcn::check_launch();
 }
 
@@ -478,8 +535,12 @@ extern "C" int dcn_contrastive_loss_backward(const float* desc_a, const float* d
     if (!pair_grad && (!hard_neg || !grad_loss)) return DCN_E_INVALID;
     hipStream_t st = (hipStream_t)stream;
     const size_t bytes = (size_t)num_pairs * (size_t)hw * (size_t)d * sizeof(float);
-    if (dcn::fill_bytes_async(grad_a, 0, bytes, st) != DCN_OK) return DCN_E_LAUNCH;
-    if (dcn::fill_bytes_async(grad_b, 0, bytes, st) != DCN_OK) return DCN_E_LAUNCH;
+    if ((char*)grad_b == (char*)grad_a + bytes) {   // the two maps are one allocation (dcn_hip/loss.py): one fill launch
+        if (dcn::fill_bytes_async(grad_a, 0, 2 * bytes, st) != DCN_OK) return DCN_E_LAUNCH;
+    } else {
+        if (dcn::fill_bytes_async(grad_a, 0, bytes, st) != DCN_OK) return DCN_E_LAUNCH;
+        if (dcn::fill_bytes_async(grad_b, 0, bytes, st) != DCN_OK) return DCN_E_LAUNCH;
+    }
     const int64_t ml = max_len(offsets_host, num_pairs);
     if (ml == 0) return DCN_OK;
     const dim3 grid(chunks_for(ml, d), 4 * num_pairs), block(kThreads);

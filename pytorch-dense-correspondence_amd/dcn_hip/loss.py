@@ -139,8 +139,8 @@ class _ContrastiveLossFn(torch.autograd.Function):
         desc_a, desc_b, sums, hard = ctx.saved_tensors
         lists, cfg = ctx.lists, ctx.cfg
         P, HW, D = desc_a.shape
-        ga = torch.empty_like(desc_a)
-        gb = torch.empty_like(desc_b)
+        g2 = torch.empty((2,) + tuple(desc_a.shape), dtype=desc_a.dtype, device=desc_a.device)   # one allocation: the kernel side
+        ga, gb = g2[0], g2[1]                                                                     # zero-fills both maps in one launch
         gl = grad_loss.reshape(1).to(torch.float32).contiguous()
         rc = lib.dcn_contrastive_loss_backward(
             _lib.ptr(desc_a), _lib.ptr(desc_b), P, HW, D, _lib.ptr(lists.idx_a), _lib.ptr(lists.idx_b),

@@ -184,20 +184,11 @@ F16_CASES = [
 ]
 
 
-# tile_m 256 = the 8-wavefront 256 x 128 tile, n256 = the 8-wavefront 128 x 256 tile (only taken when the destination has
-# more than 64 channels)
-@pytest.mark.parametrize("tile_m,sk", [("64", "0"), ("128", "0"), ("64", "3"), ("128", "2"), ("256", "0"), ("256", "3"),
-                                       ("n256", "0"), ("n256", "3")])
+# tile_m 256 = the 8-wavefront 256 x 128 tile (only taken when the destination has more than 64 channels)
+@pytest.mark.parametrize("tile_m,sk", [("64", "0"), ("128", "0"), ("64", "3"), ("128", "2"), ("256", "0"), ("256", "3")])
 @pytest.mark.parametrize("case", F16_CASES, ids=[str(c) for c in F16_CASES])
 def test_conv_f16x3_forward_dgrad(L, case, tile_m, sk, dcn_env):
     """Split-fp16 gather-GEMM (fp16 MFMA, hi/lo operands): must reproduce the fp32 convolution to ~1e-6."""
-    _env = dcn_env
-
-    def dcn_env(**kw):   # "n256": DCN_GEMM_TILE_N=256 instead of a DCN_GEMM_TILE_M value
-        if kw.get("DCN_GEMM_TILE_M") == "n256":
-            kw.pop("DCN_GEMM_TILE_M")
-            kw["DCN_GEMM_TILE_N"] = "256"
-        _env(**kw)
     dcn_env(DCN_GEMM_TILE_M=tile_m, DCN_GEMM_SK=sk)
     lib = L.get()
     n, hin, win, cin, cout, k, stride, pad, dil = case

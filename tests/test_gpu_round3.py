@@ -97,3 +97,28 @@ def test_wgrad_hl32_transposing_lds_reads(L, case, dcn_env):
         res = kernel_checks.check_wgrad_hl(L, "cuda", n, h, w, cin, cout, k, dil, set_env=dcn_env, splits=splits,
                                            seed=len(str(case)) + rep)
     print(case, res)
+
+
+@pytest.mark.parametrize("env", [
+    dict(DCN_GEMM_HL=0, DCN_WGRAD_HL=0),                          # round-2 kernels everywhere
+    dict(DCN_GEMM_HL=1, DCN_WGRAD_HL=1, DCN_HL_PRODUCERS=0),      # hl32 kernels, operand images by stand-alone split passes
+    dict(DCN_GEMM_HL=1, DCN_WGRAD_HL=0),                          # hl32 forward / dgrad, fp32-operand weight gradients
+    dict(DCN_GEMM_HL=2, DCN_WGRAD_HL=2),                          # every supported convolution (narrow layers included)
+], ids=["hl-off", "split-passes", "gemm-only", "forced-everywhere"])
+def test_headline_step_vs_fixture_under_hl32_switches(L, env, dcn_env):
+    """The headline workload (config 2, forward_pair) against its float32 / float64 oracle fixture with the hl32 path switched
+    off, fed by stand-alone split passes, half on, and forced onto every supported layer: same tolerances as the default
+    (tests/test_gpu_configs.py)."""
+    import parity_common as pc
+    from dcn_hip import backbone
+    from test_gpu_configs import _check
+    backbone.set_conv_mode("f16x3")
+    try:
+        dcn_env(**env)
+        backbone._PLANS.clear()        # (plans reserve the saved hl32 images when they are built)
+        r = pc.run_config_against_fixture(2, pair_call=True)
+        _check(r, 2)
+    finally:
+        backbone._PLANS.clear()
+        backbone.set_conv_mode(None)
+        torch.cuda.empty_cache()

@@ -2,7 +2,7 @@
 # One GPU-box session (run through gpurun from the repo root): parity report, GPU test-suite, smoke, bench lines, profile.
 # Usage: bash tools/gpu_session.sh <tag> [steps...]   steps: report tests smoke bench forcedist config3 configs prof pmc pmc3 prof3 convbench
 #        A/B steps (same box, alternating): ab (stream-K completion x BN reduction), abenv (AB_ENV="NAME a b"), abw / wgab (wgrad tile),
-#        wdab (wgrad deep prefetch), gnab (gather-GEMM tile), skab (stream-K threshold), sqw (SQ counters of the wgrad tiles), tests2b, parity
+#        wdab (wgrad deep prefetch), skab (stream-K threshold), sqw (SQ counters of the wgrad tiles), tests2b, parity
 # Everything lands in gpurun_out/<tag>_*; nothing here reads /root/reference.
 tag=${1:-r2}; shift
 steps=${*:-report tests smoke bench forcedist config3 prof}
@@ -26,13 +26,6 @@ for s in $steps; do
                timeout 600 env DCN_GEMM_SK=0 python tools/conv_bench.py --mode f16 --n 16 --kinds fwd,dgrad --json gpurun_out/${tag}_conv_per_layer_nosk.json > gpurun_out/${tag}_conv_per_layer_nosk.txt 2>&1; cat gpurun_out/${tag}_conv_per_layer_nosk.txt | cut -c1-120 ;;
     prof3)     (cd /tmp && timeout 900 env DCN_BACKWARD_OVERLAP=0 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/${tag}_prof3 -- python $GRAFT_REPO_ROOT/bench.py --workload config3 --steps 3 --warmup 1 --cpu-baseline-steps 0 --no-variants --profile-steps 0 > $GRAFT_REPO_ROOT/gpurun_out/${tag}_prof3_bench.log 2>&1); python tools/stats_summary.py gpurun_out/${tag}_prof3 > gpurun_out/${tag}_kernel_stats_config3.txt 2>&1; grep -i "loss\|fill\|upsample\|total" gpurun_out/${tag}_kernel_stats_config3.txt ;;
     tests2b)   timeout 1200 python -m pytest tests/test_gpu_round2b.py -m gpu -q -s -p no:cacheprovider > gpurun_out/${tag}_pytest_2b.log 2>&1; tail -30 gpurun_out/${tag}_pytest_2b.log | cut -c1-300 ;;
-    gnab)      # gather-GEMM tile A/B per layer (128 x 256 vs 256 x 128 on destinations with whole 256-channel tiles), N = 8, + check
-               for t in 0 128; do echo "--- DCN_GEMM_TILE_N=$t (0 = default: 128 x 256 where cd % 256 == 0), N = 8" | tee -a gpurun_out/${tag}_gnab.txt
-                 timeout 300 env DCN_GEMM_TILE_N=$t python tools/conv_bench.py --mode f16 --n 8 --kinds fwd,dgrad --only layer --reps 20 $( [ $t = 0 ] && echo --check ) 2>&1 | grep -v "Warn\|amdgpu.ids" | cut -c1-150 | tee -a gpurun_out/${tag}_gnab.txt
-               done
-               for rep in 1 2 3; do for t in 0 128; do
-                 timeout 300 env DCN_GEMM_TILE_N=$t python bench.py --steps 20 --warmup 5 --cpu-baseline-steps 0 --no-variants --profile-steps 0 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('abn gemm_tile_n=$t rep=$rep  %.1f images/s  %.3f ms/step' % (d['value'], d['ms_per_step']))" | tee -a gpurun_out/${tag}_gnab.txt
-               done; done ;;
     skab)      # stream-K threshold A/B (stage times stream-K must save to be chosen), per layer at N = 8 and on the step
                for g in 20 10 5; do echo "--- DCN_GEMM_SK_MIN_GAIN=$g, N = 8" | tee -a gpurun_out/${tag}_skab.txt
                  timeout 300 env DCN_GEMM_SK_MIN_GAIN=$g python tools/conv_bench.py --mode f16 --n 8 --kinds fwd,dgrad --only layer --reps 20 2>&1 | grep -v "Warn\|amdgpu.ids" | cut -c1-150 | tee -a gpurun_out/${tag}_skab.txt

@@ -28,7 +28,7 @@ def main():
     with open(out, "w") as o:
         o.write("# " + header + "\n")
         for name in sorted(tot, key=lambda k: -sum(dur.get(k, [0]))):
-            if "wgrad_f16" not in name and "conv_gemm_f16" not in name and "gemm_hl" not in name and "conv_gemm_hl" not in name:
+            if "wgrad_f16" not in name and "conv_gemm_f16" not in name and "gemm_hl" not in name and "wgrad_hl" not in name:
                 continue
             d = dur.get(name, [])
             o.write("%s   (%d launches, %.1f us average while counting)\n" % (name, len(d), sum(d) / max(len(d), 1)))
