@@ -337,6 +337,7 @@ class Job(object):
         t0 = time.perf_counter()
         for it in range(steps):
             loss = self.step(first_it + warmup + it)
+        self.host_enqueue_ms = 1e3 * (time.perf_counter() - t0) / steps   # (host time to ENQUEUE a step; the GPU runs behind)
         torch.cuda.synchronize()
         if use_dist:
             dist.barrier()
@@ -422,6 +423,7 @@ def main():
     step = job.step
 
     elapsed, loss = job.timed(args.warmup, args.steps, 0, use_dist)
+    host_enqueue_ms = job.host_enqueue_ms
     final_loss = float(loss.item())
 
     # ---- gradient all-reduce: the collective alone (whole flat buffer, RCCL), and what the step really pays for it
@@ -665,7 +667,7 @@ def main():
                else "training images/sec (%s)" % args.workload,
                "value": images_per_step * args.steps / elapsed, "unit": "images/s", "n_gpus": world,
                "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
-               "scaling": "weak", "vs_baseline": None,
+               "scaling": "weak", "vs_baseline": None, "host_enqueue_ms_per_step": host_enqueue_ms,
                "dtype": "f32 (f16x3 products)" if args.conv_mode == "f16x3" else "f32", "data": "synthetic",
                "arithmetic": ("fp32 tensors and accumulation; convolution products as 3 fp16 MFMAs on exact hi/lo operand "
                               "splits (~22 mantissa bits per operand; parity with the fp32 reference at 1e-4, tests/test_gpu_parity.py)"

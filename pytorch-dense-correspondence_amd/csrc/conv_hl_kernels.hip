@@ -26,6 +26,18 @@
 // the latest publication still precedes the earliest read.  WAR: H_p(s + 1) overwrites H_p(s - 1), last read in LOAD(s - 1, 3)
 // of group 1, two barriers before LOAD(s, 0) of group 0.  ALL shared memory of the kernel is ONE array (a second
 // __shared__ object makes hipcc drain vmcnt in front of every fragment read, cdna_hip_programming.md section 5).
+//
+// 192-row variant (MT = 3: tile 192 x 256, wavefront tile 96 x 64 = 6 accumulators; hl_shape picks it when it quantises
+// better -- 38 400 rows are 150 tiles of 256 rows but 200 of 192 on the 256 CUs).  A stage is THREE phases, phase p = the
+// p-th 32-row block of the wavefront tile x both column blocks (12 MFMAs); the B fragments of a stage are read once, in
+// LOAD(s, 0).  Pieces per wavefront and stage: A_0, A_1, A_2 (one each, rows 96 g + 32 i + 8 wn + [0, 8), private to the
+// group) and Bf, Bs (two each, as B_0 / B_1 above).  Issue order, two stages ahead for what phase 0 needs:
+//     LOAD(s, 0): A_1, A_2 of s + 1     LOAD(s, 1): Bf of s + 2     LOAD(s, 2): Bs, A_0 of s + 2
+// RAW (a read in LOAD(x) needs every wavefront's wait by the end of the slot before it -- group 1 runs one barrier late):
+//     end of LOAD(s, 0): A_1(s) landed = all but the 8 youngest pieces;  LOAD(s, 1): A_2(s), 9;  LOAD(s, 2): B, A_0 of s + 1, 7
+// (the last two stages issue less and wait for 8 / 7 / 2 and 1 / 0).  WAR: B(s) and A_0(s) are read in LOAD(s, 0) only, of
+// group 1 at the latest -- one barrier before LOAD(s, 1) of group 0, the first slot that overwrites them with stage s + 2;
+// A_1 / A_2 of s + 1 replace those of s - 1 (same group, last read in LOAD(s - 1, 2)).
 #include <algorithm>
 #include <atomic>
 #include <type_traits>
@@ -69,14 +81,18 @@ split_act_hl32_kernel(const float* __restrict__ src, const float* __restrict__ a
 }
 
 // One (tile, K-stage range) of the gather-GEMM.  TR: dgrad (the gather runs over the output gradient with mirrored taps).
-template <bool TR>
+// MT: 32-row blocks per wavefront (4: tile 256 x 256, 3: tile 192 x 256).
+template <bool TR, int MT>
 __device__ __forceinline__ void gemm_segment_hl(const GemmConv& p, unsigned char* lds, int tile, int k0, int k1, int nk,
                                                 float* slot) {
+    static_assert(MT == 3 || MT == 4, "wavefront tiles of 96 or 128 rows");
+    constexpr int BM = 64 * MT, GR = 32 * MT;   // rows per tile / per wavefront group
+    constexpr int NA = MT == 4 ? 4 : 3;         // A pieces per wavefront and stage
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int grp = wv >> 2, wn = wv & 3;
     const int mt = fdiv(tile, p.div_nt), nt = tile - mt * p.ntiles;
-    const int m0 = mt * 256, n0 = nt * 256;
+    const int m0 = mt * BM, n0 = nt * 256;
     const __amdgpu_buffer_rsrc_t rs_a = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.src), 0, (int)p.src_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rs_b = __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16*>(p.wh), 0, (int)p.w_bytes, 0x00020000);
 
@@ -85,22 +101,22 @@ __device__ __forceinline__ void gemm_segment_hl(const GemmConv& p, unsigned char
     // logical 16-byte slot (l & 7) ^ ((row >> 1) & 7) of the row's 128-byte line
     const int l8 = lane >> 3, ls = lane & 7;
     const int cs4 = p.cs * 4;              // bytes per pixel of the activation image
-    int by[2][2], bx[2][2], rowoff[2][2], voa[2][2], vob[2][2];
+    // A piece a of this wavefront: MT = 4: (i, e) = (a >> 1, a & 1) as above; MT = 3: block i = a, rows 96 g + 32 a + 8 wn + [0, 8)
+    auto a_piece_row = [&](int a) { return MT == 4 ? grp * 128 + (a >> 1) * 64 + (2 * wn + (a & 1)) * 8 : grp * 96 + a * 32 + wn * 8; };
+    int by[NA], bx[NA], rowoff[NA], voa[NA], vob[2][2];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int e = 0; e < 2; ++e) {
-            const int row = grp * 128 + i * 64 + (2 * wn + e) * 8 + l8;
-            const int sl = ls ^ ((row >> 1) & 7);
-            const int m = m0 + row;
-            const bool ok = m < p.M;
-            const int mm = ok ? m : 0;
-            const int img = fdiv(mm, p.div_hw), rem = mm - img * p.div_hw.d;
-            const int y = fdiv(rem, p.div_w), x = rem - y * p.div_w.d;
-            by[i][e] = ok ? (TR ? y + p.pad : y - p.pad) : -(1 << 28);   // (stride 1; rows past M: never inside the image)
-            bx[i][e] = TR ? x + p.pad : x - p.pad;
-            rowoff[i][e] = ok ? (img * p.hs * p.ws + by[i][e] * p.ws + bx[i][e]) * cs4 + sl * 16 : 0;
-        }
+    for (int a = 0; a < NA; ++a) {
+        const int row = a_piece_row(a) + l8;
+        const int sl = ls ^ ((row >> 1) & 7);
+        const int m = m0 + row;
+        const bool ok = m < p.M;
+        const int mm = ok ? m : 0;
+        const int img = fdiv(mm, p.div_hw), rem = mm - img * p.div_hw.d;
+        const int y = fdiv(rem, p.div_w), x = rem - y * p.div_w.d;
+        by[a] = ok ? (TR ? y + p.pad : y - p.pad) : -(1 << 28);   // (stride 1; rows past M: never inside the image)
+        bx[a] = TR ? x + p.pad : x - p.pad;
+        rowoff[a] = ok ? (img * p.hs * p.ws + by[a] * p.ws + bx[a]) * cs4 + sl * 16 : 0;
+    }
 #pragma unroll
     for (int j = 0; j < 2; ++j)
 #pragma unroll
@@ -121,18 +137,16 @@ __device__ __forceinline__ void gemm_segment_hl(const GemmConv& p, unsigned char
         const int dy = r * p.dil, dx = s * p.dil;
         const int delta = (dy * p.ws + dx) * cs4;
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int e = 0; e < 2; ++e) {
-                bool ok;
-                if (TR) {
-                    const int ny = by[i][e] - dy, nx = bx[i][e] - dx;
-                    ok = ((ny | nx) >= 0) & (ny < p.hs) & (nx < p.ws);
-                } else {
-                    ok = ((unsigned)(by[i][e] + dy) < (unsigned)p.hs) & ((unsigned)(bx[i][e] + dx) < (unsigned)p.ws);
-                }
-                voa[i][e] = ok ? (TR ? rowoff[i][e] - delta : rowoff[i][e] + delta) : kOob;
+        for (int a = 0; a < NA; ++a) {
+            bool ok;
+            if (TR) {
+                const int ny = by[a] - dy, nx = bx[a] - dx;
+                ok = ((ny | nx) >= 0) & (ny < p.hs) & (nx < p.ws);
+            } else {
+                ok = ((unsigned)(by[a] + dy) < (unsigned)p.hs) & ((unsigned)(bx[a] + dx) < (unsigned)p.ws);
             }
+            voa[a] = ok ? (TR ? rowoff[a] - delta : rowoff[a] + delta) : kOob;
+        }
     };
     {
         const int per_grp = taps * kcg;
@@ -152,21 +166,24 @@ __device__ __forceinline__ void gemm_segment_hl(const GemmConv& p, unsigned char
             }
         }
     };
-    // half-tile h (0: A_0, 1: B_0, 2: B_1, 3: A_1) of the stage the traversal state points at, into stage buffer `buf`
+    // pieces of the stage the traversal state points at, into stage buffer `buf`
+    auto issue_a = [&](int buf, int a) {
+        glds16(rs_a, lds + buf * kHlStage + a_piece_row(a) * 128, voa[a], (u_grp * kcg + u_c) * 128);
+    };
+    auto issue_b = [&](int buf, int j) {
+        unsigned char* d = lds + buf * kHlStage + 32768 + ((wv >> 1) * 64 + j * 32 + 2 * (wv & 1) * 8) * 128;
+        const int soff = (u_tap * cpt + u_grp * kcg + u_c) * 128;
+        glds16(rs_b, d, vob[j][0], soff);
+        glds16(rs_b, d + 1024, vob[j][1], soff);
+    };
+    // MT = 4: half-tile h (0: A_0, 1: B_0, 2: B_1, 3: A_1)
     auto issue_half = [&](int buf, int h) {
-        const int chunk = u_grp * kcg + u_c;
-        unsigned char* base = lds + buf * kHlStage;
         if (h == 0 || h == 3) {
             const int i = h == 0 ? 0 : 1;
-            unsigned char* d = base + (grp * 128 + i * 64 + 2 * wn * 8) * 128;
-            glds16(rs_a, d, voa[i][0], chunk * 128);
-            glds16(rs_a, d + 1024, voa[i][1], chunk * 128);
+            issue_a(buf, 2 * i);
+            issue_a(buf, 2 * i + 1);
         } else {
-            const int j = h == 1 ? 0 : 1;
-            unsigned char* d = base + 32768 + ((wv >> 1) * 64 + j * 32 + 2 * (wv & 1) * 8) * 128;
-            const int soff = (u_tap * cpt + chunk) * 128;
-            glds16(rs_b, d, vob[j][0], soff);
-            glds16(rs_b, d + 1024, vob[j][1], soff);
+            issue_b(buf, h == 1 ? 0 : 1);
         }
     };
 
@@ -177,15 +194,20 @@ __device__ __forceinline__ void gemm_segment_hl(const GemmConv& p, unsigned char
     for (int pl = 0; pl < 2; ++pl)
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) foff[pl][ks] = ((pl * 4 + ks * 2 + fh) ^ swz) * 16;
-    const int a_row = (grp * 128 + fi) * 128, b_row = 32768 + (wn * 64 + fi) * 128;
+    const int a_row = (grp * GR + fi) * 128, b_row = 32768 + (wn * 64 + fi) * 128;
 
-    f32x16 acc[4][2];   // [tm = 2 i + t][tn = j]: rows 128 g + 32 tm, columns 64 wn + 32 tn  (the common epilogue's map)
+    f32x16 acc[MT][2];   // [tm][tn]: rows GR g + 32 tm, columns 64 wn + 32 tn  (the common epilogue's map; MT = 4: tm = 2 i + t)
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < MT; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    using T = std::true_type;
+    using F = std::false_type;
+    // raw s_barrier: no fence, LDS-DMA stays in flight across it
+    auto bar = [&]() { __builtin_amdgcn_sched_barrier(0); __builtin_amdgcn_s_barrier(); __builtin_amdgcn_sched_barrier(0); };
+  if constexpr (MT == 4) {
     h8 fa[2][2][2], fb[2][2];   // A: [t][ks][plane], B: [ks][plane]
     auto read_a = [&](int buf, int i) {
         const unsigned char* st = lds + buf * kHlStage + a_row + i * 8192;
@@ -216,8 +238,6 @@ __device__ __forceinline__ void gemm_segment_hl(const GemmConv& p, unsigned char
                                                                               pt == 1 ? fb[ks][1] : fb[ks][0], acc[2 * i + t][j], 0, 0, 0);
         __builtin_amdgcn_s_setprio(0);
     };
-    // raw s_barrier: no fence, LDS-DMA stays in flight across it
-    auto bar = [&]() { __builtin_amdgcn_sched_barrier(0); __builtin_amdgcn_s_barrier(); __builtin_amdgcn_sched_barrier(0); };
     // one phase of stage s (LDS buffer s & 1).  MORE: stage s + 1 exists -- issue its half-tile p and leave two half-tiles
     // in flight; otherwise drain what the next phases read.
     auto phase = [&](auto more_tag, int buf, int ph) {
@@ -241,9 +261,6 @@ __device__ __forceinline__ void gemm_segment_hl(const GemmConv& p, unsigned char
         mfma_quadrant(qi, qj);
         bar();
     };
-    using T = std::true_type;
-    using F = std::false_type;
-
     issue_half(0, 0);
     issue_half(0, 1);
     issue_half(0, 2);
@@ -265,24 +282,124 @@ __device__ __forceinline__ void gemm_segment_hl(const GemmConv& p, unsigned char
     phase(F{}, buf, 1);
     phase(F{}, buf, 2);
     phase(F{}, buf, 3);
+  } else {
+    h8 fa[2][2], fb[2][2][2];   // A: [ks][plane] of the phase's row block, B: [j][ks][plane] of the stage
+    auto read_a = [&](int buf, int tm) {
+        const unsigned char* st = lds + buf * kHlStage + a_row + tm * 4096;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int pl = 0; pl < 2; ++pl) fa[ks][pl] = *reinterpret_cast<const h8*>(st + foff[pl][ks]);
+    };
+    auto read_b = [&](int buf) {
+        const unsigned char* st = lds + buf * kHlStage + b_row;
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                for (int pl = 0; pl < 2; ++pl) fb[j][ks][pl] = *reinterpret_cast<const h8*>(st + j * 4096 + foff[pl][ks]);
+    };
+    auto mfma_block = [&](int tm) {
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int pt = 0; pt < 3; ++pt)
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    acc[tm][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(pt == 0 ? fa[ks][1] : fa[ks][0],
+                                                                        pt == 1 ? fb[j][ks][1] : fb[j][ks][0], acc[tm][j], 0, 0, 0);
+        __builtin_amdgcn_s_setprio(0);
+    };
+    // one phase of stage s (LDS buffer s & 1).  AHEAD: how many later stages of the segment exist (2 = at least two).
+    auto phase = [&](auto ahead_tag, int buf, int ph) {
+        constexpr int AHEAD = decltype(ahead_tag)::value;
+        if (ph == 0) { read_b(buf); __builtin_amdgcn_sched_barrier(0); }
+        read_a(buf, ph);
+        __builtin_amdgcn_sched_barrier(0);
+        if (ph == 0 && AHEAD >= 1) {
+            issue_a(buf ^ 1, 1);
+            issue_a(buf ^ 1, 2);
+            advance();               // (the traversal state now points at stage s + 2)
+        }
+        if (ph == 1 && AHEAD == 2) issue_b(buf, 0);
+        if (ph == 2 && AHEAD == 2) { issue_b(buf, 1); issue_a(buf, 0); }
+        __builtin_amdgcn_sched_barrier(0);
+        if (AHEAD == 2) {
+            if (ph == 0) DCN_WAIT_VMCNT(8);
+            else if (ph == 1) DCN_WAIT_VMCNT(9);
+            else DCN_WAIT_VMCNT(7);
+        } else if (AHEAD == 1) {
+            if (ph == 0) DCN_WAIT_VMCNT(8);
+            else if (ph == 1) DCN_WAIT_VMCNT(7);
+            else DCN_WAIT_VMCNT(2);
+        } else {
+            if (ph == 0) DCN_WAIT_VMCNT(1);
+            else if (ph == 1) DCN_WAIT_VMCNT(0);
+        }
+        DCN_WAIT_LGKMCNT0();
+        bar();
+        mfma_block(ph);
+        bar();
+    };
+    using A0 = std::integral_constant<int, 0>;
+    using A1 = std::integral_constant<int, 1>;
+    using A2 = std::integral_constant<int, 2>;
+
+    issue_b(0, 0);
+    issue_b(0, 1);
+    issue_a(0, 0);
+    issue_a(0, 1);
+    issue_a(0, 2);
+    if (k0 + 1 < k1) {
+        advance();
+        issue_b(1, 0);
+        issue_b(1, 1);
+        issue_a(1, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        DCN_WAIT_VMCNT(7);
+    } else {
+        __builtin_amdgcn_sched_barrier(0);
+        DCN_WAIT_VMCNT(2);
+    }
+    bar();
+    if (grp == 1) bar();
+    int buf = 0;
+    for (int s = k0; s + 2 < k1; ++s) {
+        phase(A2{}, buf, 0);
+        phase(A2{}, buf, 1);
+        phase(A2{}, buf, 2);
+        buf ^= 1;
+    }
+    if (k0 + 1 < k1) {
+        phase(A1{}, buf, 0);
+        phase(A1{}, buf, 1);
+        phase(A1{}, buf, 2);
+        buf ^= 1;
+    }
+    phase(A0{}, buf, 0);
+    phase(A0{}, buf, 1);
+    phase(A0{}, buf, 2);
+  }
     if (grp == 0) bar();
     __syncthreads();
 
     const float sa = p.a_absmax ? pow2_scale(*p.a_absmax) : 1.f;   // (the scale the producer of the hl32 image applied)
     const float inv = p.b_inv_scale / sa;
 #pragma unroll
-    for (int tm = 0; tm < 4; ++tm)
+    for (int tm = 0; tm < MT; ++tm)
 #pragma unroll
         for (int tn = 0; tn < 2; ++tn)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[tm][tn][r] *= inv;
     if (k0 == 0 && k1 == nk) {
-        gemm_epilogue<2, 4, 2, 16, 4>(p, acc, mt, nt, reinterpret_cast<float*>(lds));
+        gemm_epilogue<2, MT, 2, 16, 4>(p, acc, mt, nt, reinterpret_cast<float*>(lds));
         return;
     }
     // ---- stream-K partial: parked device-coherently, completed by the last contributor inside the launch
     // (conv_f16_kernels.hip, gemm_segment_f16: same protocol and slot layout [wavefront][tm][tn][r / 4][lane][r % 4])
-    constexpr int TM = 4, TN = 2;
+    constexpr int TM = MT, TN = 2;
     const __amdgpu_buffer_rsrc_t rs_p = __builtin_amdgcn_make_buffer_rsrc(p.sk_partial, 0, (int)p.sk_bytes, 0x00020000);
     constexpr int kSc1 = 16;
     const int lane_off = (wv * (TM * TN * 16 * 64) + lane * 4) * 4;
@@ -315,12 +432,13 @@ __device__ __forceinline__ void gemm_segment_hl(const GemmConv& p, unsigned char
             for (int tn = 0; tn < TN; ++tn)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[tm][tn][r] = 0.f;
-        // (each contributor's partial in batches of 16 loads of 16 B issued back to back, then added: left to itself the
+        // (each contributor's partial in batches of 16 (12) loads of 16 B issued back to back, then added: left to itself the
         // compiler waits for every 4 loads -- device-coherent round trips on the critical path of the launch)
-        constexpr int kPieces = TM * TN * 4, kBatch = 16;
+        constexpr int kPieces = TM * TN * 4, kBatch = TM == 4 ? 16 : 12;
+        static_assert(kPieces % kBatch == 0, "whole batches");
         for (int g = ga; g <= gb; ++g) {               // fixed order, own partial included: deterministic
             const int first_tile = (g * p.sk_units) / nk;
-            const int so = (2 * g + (first_tile == rel ? 0 : 1)) * (256 * 256 * 4);
+            const int so = (2 * g + (first_tile == rel ? 0 : 1)) * (BM * 256 * 4);
 #pragma unroll
             for (int b0 = 0; b0 < kPieces; b0 += kBatch) {
                 u32x4 t[kBatch];
@@ -338,24 +456,24 @@ __device__ __forceinline__ void gemm_segment_hl(const GemmConv& p, unsigned char
             }
         }
         __syncthreads();                               // (s_last has been read by everyone: the epilogue reuses the array)
-        gemm_epilogue<2, 4, 2, 16, 4>(p, acc, mt, nt, reinterpret_cast<float*>(lds));
+        gemm_epilogue<2, MT, 2, 16, 4>(p, acc, mt, nt, reinterpret_cast<float*>(lds));
         if (tid == 0) atomicExch(p.sk_count + rel, 0ull);
     }
 }
 
-template <bool TR, bool SK>
+template <bool TR, bool SK, int MT>
 __global__ void __launch_bounds__(512, 1)
 conv_gemm_hl_kernel(GemmConv p) {
     __shared__ __attribute__((aligned(16))) unsigned char lds[2 * kHlStage];
     const int nk = p.K / HLK;
     if (!SK) {
-        gemm_segment_hl<TR>(p, lds, xcd_remap(blockIdx.x, p.mtiles * p.ntiles), 0, nk, nk, nullptr);
+        gemm_segment_hl<TR, MT>(p, lds, xcd_remap(blockIdx.x, p.mtiles * p.ntiles), 0, nk, nk, nullptr);
     } else {
         // hybrid schedule (as conv_gemm_f16_kernel): whole rounds of tiles data-parallel, then ONE stream-K pass that splits
         // the K stages of the leftover tiles evenly
         const int g = xcd_remap(blockIdx.x, gridDim.x);
         for (int tile = g; tile < p.sk_dp; tile += gridDim.x) {
-            gemm_segment_hl<TR>(p, lds, tile, 0, nk, nk, nullptr);
+            gemm_segment_hl<TR, MT>(p, lds, tile, 0, nk, nk, nullptr);
             __syncthreads();
         }
         int u = p.sk_dp * nk + g * p.sk_units;
@@ -365,7 +483,7 @@ conv_gemm_hl_kernel(GemmConv p) {
         while (u < u_end) {
             const int tile = fdiv(u, p.div_nk), k0 = u - tile * nk;
             const int k1 = min(nk, k0 + (u_end - u));
-            gemm_segment_hl<TR>(p, lds, tile, k0, k1, nk, p.sk_partial + (int64_t)(2 * g + (first ? 0 : 1)) * (256 * 256));
+            gemm_segment_hl<TR, MT>(p, lds, tile, k0, k1, nk, p.sk_partial + (int64_t)(2 * g + (first ? 0 : 1)) * (64 * MT * 256));
             u += k1 - k0;
             first = false;
             __syncthreads();
@@ -374,13 +492,14 @@ conv_gemm_hl_kernel(GemmConv p) {
 }
 
 struct HlShape {
-    int mtiles, ntiles, nk, sk_wgs, sk_units, sk_dp;
+    int rows, mtiles, ntiles, nk, sk_wgs, sk_units, sk_dp;
     bool sk;
     size_t ws_bytes, sk_count_off;
 };
-HlShape hl_shape(int M, int cd, int K) {
+HlShape hl_shape_rows(int M, int cd, int K, int rows) {
     HlShape g;
-    g.mtiles = dcn::ceil_div(M, 256);
+    g.rows = rows;
+    g.mtiles = dcn::ceil_div(M, rows);
     g.ntiles = dcn::ceil_div(cd, 256);
     g.nk = K / HLK;
     const int tiles = g.mtiles * g.ntiles;
@@ -410,7 +529,7 @@ HlShape hl_shape(int M, int cd, int K) {
         if (g.sk_dp == 0 && wgs > total / 2) wgs = (int)(total / 2) > 0 ? (int)(total / 2) : 1;
         g.sk_units = (int)((total + wgs - 1) / wgs);
         g.sk_wgs = g.sk_dp > 0 ? wgs : (int)((total + g.sk_units - 1) / g.sk_units);
-        g.ws_bytes = (size_t)2 * g.sk_wgs * 256 * 256 * sizeof(float);
+        g.ws_bytes = (size_t)2 * g.sk_wgs * rows * 256 * sizeof(float);
         g.sk_count_off = g.ws_bytes;
         g.ws_bytes += (size_t)(tiles - g.sk_dp) * sizeof(unsigned long long);
         if (g.sk_count_off >= ((size_t)1 << 31)) { g.sk = false; g.sk_wgs = 0; g.sk_units = 0; g.sk_dp = 0; g.ws_bytes = 0; g.sk_count_off = 0; }
@@ -418,18 +537,51 @@ HlShape hl_shape(int M, int cd, int K) {
     return g;
 }
 
+// Tile height: 256 rows unless 192 quantises better on the 256 CUs.  Cost = rounds of tiles x rows, a stream-K'd launch
+// counting its fractional rounds plus what the fix-up costs a workgroup (~50 stage times with 256 KB partials, ~30 with
+// 192 KB); a 192-row tile moves 1.17x the LDS bytes per FLOP and measures ~8 % slower per row.  Calibrated on the N = 8 layer
+// shapes (profiles/r3q_hl_rows_per_layer.txt): 256 -> 256 3x3, 150 / 200 tiles: 160 -> 139 us; 512 -> 512 3x3, 300 / 400
+// tiles, both stream-K'd: 491 -> 450 us.  group_rows: rows per statistics group of the forward epilogue (0: none) -- a
+// group is made of whole tiles.
+HlShape hl_shape(int M, int cd, int K, int group_rows) {
+    const HlShape g4 = hl_shape_rows(M, cd, K, 256);
+    const int force = dcn::tuning().gemm_hl_rows;
+    const bool ok3 = group_rows <= 0 || (group_rows % 192) == 0, ok4 = group_rows <= 0 || (group_rows % 256) == 0;
+    if (!ok3 || force == 256) return g4;
+    const HlShape g3 = hl_shape_rows(M, cd, K, 192);
+    if (force == 192 || !ok4) return g3;
+    auto cost = [](const HlShape& g) {
+        const double rounds = g.mtiles * g.ntiles / 256.0;
+        const double per_row = g.rows == 192 ? 1.08 : 1.0, fixup = g.rows == 192 ? 30.0 : 50.0;
+        return (g.sk ? rounds + fixup / g.nk : (double)(int)(rounds + 0.999999)) * g.rows * per_row;
+    };
+    return cost(g3) < 0.97 * cost(g4) ? g3 : g4;
+}
+
 bool valid_desc_hl(const dcn_conv_desc* c) {
     return c && c->n > 0 && c->hin > 0 && c->win > 0 && c->cin > 0 && c->hout > 0 && c->wout > 0 && c->cout > 0 && c->kh > 0 &&
            c->kw > 0 && c->stride > 0 && c->dil > 0 && c->pad >= 0 && c->ldc >= c->cout;
 }
 
-int launch_gemm_hl(GemmConv& p, void* workspace, hipStream_t st) {
+template <int MT>
+void launch_gemm_hl_rows(const GemmConv& p, bool sk, dim3 grid, hipStream_t st) {
+    const dim3 block(512);
+    if (sk) {
+        if (p.transposed) hipLaunchKernelGGL((conv_gemm_hl_kernel<true, true, MT>), grid, block, 0, st, p);
+        else hipLaunchKernelGGL((conv_gemm_hl_kernel<false, true, MT>), grid, block, 0, st, p);
+    } else {
+        if (p.transposed) hipLaunchKernelGGL((conv_gemm_hl_kernel<true, false, MT>), grid, block, 0, st, p);
+        else hipLaunchKernelGGL((conv_gemm_hl_kernel<false, false, MT>), grid, block, 0, st, p);
+    }
+}
+
+int launch_gemm_hl(GemmConv& p, int group_rows, void* workspace, hipStream_t st) {
     p.sshift = 0;
     p.div_hw = make_fastdiv(p.hd * p.wd);
     p.div_w = make_fastdiv(p.wd);
     p.div_cs = make_fastdiv(p.cs);
     p.div_kw = make_fastdiv(p.kw);
-    const HlShape g = hl_shape(p.M, p.cd, p.K);
+    const HlShape g = hl_shape(p.M, p.cd, p.K, group_rows);
     const bool sk = g.sk && workspace != nullptr;
     p.mtiles = g.mtiles;
     p.ntiles = g.ntiles;
@@ -445,21 +597,16 @@ int launch_gemm_hl(GemmConv& p, void* workspace, hipStream_t st) {
         if (dcn::fill_bytes_async(p.sk_count, 0, (size_t)(g.mtiles * g.ntiles - g.sk_dp) * sizeof(unsigned long long), st) != DCN_OK)
             return DCN_E_LAUNCH;   // (arrival words cleared in front of every launch: see launch_gemm_f16)
     }
-    const dim3 grid(sk ? g.sk_wgs : g.mtiles * g.ntiles), block(512);
-    if (sk) {
-        if (p.transposed) hipLaunchKernelGGL((conv_gemm_hl_kernel<true, true>), grid, block, 0, st, p);
-        else hipLaunchKernelGGL((conv_gemm_hl_kernel<false, true>), grid, block, 0, st, p);
-    } else {
-        if (p.transposed) hipLaunchKernelGGL((conv_gemm_hl_kernel<true, false>), grid, block, 0, st, p);
-        else hipLaunchKernelGGL((conv_gemm_hl_kernel<false, false>), grid, block, 0, st, p);
-    }
+    const dim3 grid(sk ? g.sk_wgs : g.mtiles * g.ntiles);
+    if (g.rows == 192) launch_gemm_hl_rows<3>(p, sk, grid, st);
+    else launch_gemm_hl_rows<4>(p, sk, grid, st);
     return dcn::check_launch();
 }
 
 }  // namespace
 
 // What the kernel can compute at all: whole 32-channel source chunks, stride 1, tensors addressable through 2 GiB buffer
-// resources, statistics groups made of whole 256-row tiles.
+// resources, statistics groups made of whole 256- or 192-row tiles.
 static bool hl_supported(const dcn_conv_desc* c, int dgrad) {
     if (!valid_desc_hl(c)) return false;
     if (c->stride != 1 || (c->ldc % 4) != 0) return false;
@@ -468,7 +615,7 @@ static bool hl_supported(const dcn_conv_desc* c, int dgrad) {
     const int64_t K = (int64_t)c->kh * c->kw * cs;
     if ((cs % HLK) != 0 || (dgrad && c->ldc != c->cout) || (cd % 4) != 0 || M >= ((int64_t)1 << 30)) return false;
     if (dgrad && (c->hin != c->hout || c->win != c->wout)) return false;       // (stride-1 "same" convolutions)
-    if (!dgrad && c->group_rows > 0 && (c->group_rows % 256) != 0) return false;
+    if (!dgrad && c->group_rows > 0 && (c->group_rows % 256) != 0 && (c->group_rows % 192) != 0) return false;
     const int64_t src_bytes = (int64_t)c->n * (dgrad ? c->hout * c->wout : c->hin * c->win) * cs * 4;
     const int64_t w_bytes = (int64_t)cd * K * 4;
     return src_bytes <= ((int64_t)1 << 31) - 1 && w_bytes <= ((int64_t)1 << 31) - 1;
@@ -497,13 +644,20 @@ extern "C" int dcn_conv_hl_eligible(const dcn_conv_desc* c, int dgrad) {
 
 extern "C" int dcn_conv_num_mtiles_hl(const dcn_conv_desc* c) {
     if (!valid_desc_hl(c)) return DCN_E_INVALID;
-    return dcn::ceil_div(c->n * c->hout * c->wout, 256);
+    return hl_shape(c->n * c->hout * c->wout, c->cout, c->kh * c->kw * c->cin, c->group_rows).mtiles;
+}
+
+// Rows per tile the launch of this convolution will use (256 or 192): the granularity of its batch-norm partial statistics.
+extern "C" int dcn_conv_tile_rows_hl(const dcn_conv_desc* c, int dgrad) {
+    if (!valid_desc_hl(c)) return DCN_E_INVALID;
+    if (dgrad) return hl_shape(c->n * c->hin * c->win, c->cin, c->kh * c->kw * c->ldc, 0).rows;
+    return hl_shape(c->n * c->hout * c->wout, c->cout, c->kh * c->kw * c->cin, c->group_rows).rows;
 }
 
 extern "C" size_t dcn_conv_gemm_workspace_hl(const dcn_conv_desc* c, int dgrad) {
     if (!valid_desc_hl(c)) return 0;
-    if (dgrad) return hl_shape(c->n * c->hin * c->win, c->cin, c->kh * c->kw * c->ldc).ws_bytes;
-    return hl_shape(c->n * c->hout * c->wout, c->cout, c->kh * c->kw * c->cin).ws_bytes;
+    if (dgrad) return hl_shape(c->n * c->hin * c->win, c->cin, c->kh * c->kw * c->ldc, 0).ws_bytes;
+    return hl_shape(c->n * c->hout * c->wout, c->cout, c->kh * c->kw * c->cin, c->group_rows).ws_bytes;
 }
 
 extern "C" int dcn_split_act_hl32(const float* src, const float* absmax, void* dst, int64_t rows, int channels, void* stream) {
@@ -529,7 +683,7 @@ extern "C" int dcn_conv_forward_hl(const dcn_conv_desc* c, const void* in_hl, co
     p.M = c->n * c->hout * c->wout; p.K = c->kh * c->kw * c->cin; p.kp = p.K; p.transposed = 0; p.relu = 0;
     p.src_bytes = (unsigned)((int64_t)c->n * c->hin * c->win * c->cin * 4);
     p.w_bytes = (unsigned)((int64_t)c->cout * p.K * 4);
-    return launch_gemm_hl(p, workspace, (hipStream_t)stream);
+    return launch_gemm_hl(p, c->group_rows, workspace, (hipStream_t)stream);
 }
 
 // dout_hl: hl32 image of the output gradient [n, hout, wout, ldc], scaled by pow2_scale(*dout_absmax); wt_hl: hl32 image of
@@ -546,5 +700,5 @@ extern "C" int dcn_conv_dgrad_hl(const dcn_conv_desc* c, const void* dout_hl, co
     p.M = c->n * c->hin * c->win; p.K = c->kh * c->kw * c->ldc; p.kp = p.K; p.transposed = 1; p.relu = 0;
     p.src_bytes = (unsigned)((int64_t)c->n * c->hout * c->wout * c->ldc * 4);
     p.w_bytes = (unsigned)((int64_t)c->cin * p.K * 4);
-    return launch_gemm_hl(p, workspace, (hipStream_t)stream);
+    return launch_gemm_hl(p, 0, workspace, (hipStream_t)stream);
 }

@@ -46,6 +46,7 @@ struct Tuning {
     int wgrad_tile = 0;          // 0: unset
     int wgrad_deep = 4;
     int gemm_hl = 1;             // wide layers on the pre-split (hl32) LDS-DMA gather-GEMM
+    int gemm_hl_rows = 0;        // hl32 gather-GEMM tile height: 0 = by tile quantisation, 192 / 256 = forced
     int wgrad_hl = 1;            // wide layers' weight gradients on the pre-split (hl32) LDS-DMA kernel
     int hl_producers = 1;        // hl32 images written by the producing batch-norm passes (0: stand-alone split passes)
     int wgrad_roles = 1;         // wide tile: wavefronts 0-3 stage the activations, 4-7 the gradient (0: copy spread over all 8)

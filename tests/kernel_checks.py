@@ -213,7 +213,7 @@ def hl32_decode(img, rows, C):
     return h[:, :, 0, :].reshape(rows, C), h[:, :, 1, :].reshape(rows, C)
 
 
-def check_conv_hl(L, dev, n, h, w, cin, cout, k, dil, set_env=None, sk=None, scale_x=1.0, seed=0):
+def check_conv_hl(L, dev, n, h, w, cin, cout, k, dil, set_env=None, sk=None, scale_x=1.0, seed=0, rows=None):
     """The pre-split (hl32) LDS-DMA gather-GEMM, forward and dgrad, against F.conv2d / its autograd in float64 and against
     the fp32-operand split-fp16 kernel; the operand split, the weight images and the batch-norm partial sums on the way."""
     lib = L.get()
@@ -225,8 +225,13 @@ def check_conv_hl(L, dev, n, h, w, cin, cout, k, dil, set_env=None, sk=None, sca
     wt_ = torch.randn(cout, k, k, cin, generator=g) * 0.1
     dout = torch.randn(n, h, w, cout, generator=g) * 1e-3 * scale_x
     M = n * h * w
+    env = {}
     if sk is not None:
-        set_env(DCN_GEMM_SK=sk)
+        env["DCN_GEMM_SK"] = sk
+    if rows is not None:
+        env["DCN_GEMM_HL_ROWS"] = rows      # tile height 256 / 192 (conv_hl_kernels.hip: two different software pipelines)
+    if env:
+        set_env(**env)
     d = L.ConvDesc(n, h, w, cin, h, w, cout, k, k, 1, pad, dil, cout, 0)
     xd, dd = t(x), t(dout)
     ax, ad = t(x.abs().max().reshape(1)), t(dout.abs().max().reshape(1))
@@ -256,7 +261,9 @@ def check_conv_hl(L, dev, n, h, w, cin, cout, k, dil, set_env=None, sk=None, sca
         assert rel_err((thi + tlo) / 64.0, wtr.cpu()) < 3e-7
     # ---- forward
     mt = lib.dcn_conv_num_mtiles_hl(ctypes.byref(d))
-    assert mt == (M + 255) // 256
+    tr = lib.dcn_conv_tile_rows_hl(ctypes.byref(d), 0)
+    assert tr in (192, 256) and (rows is None or tr == int(rows)) and mt == (M + tr - 1) // tr
+    assert lib.dcn_conv_tile_rows_hl(ctypes.byref(d), 1) in ((192, 256) if rows is None else (int(rows),))
     nws = max(lib.dcn_conv_gemm_workspace_hl(ctypes.byref(d), 0), lib.dcn_conv_gemm_workspace_hl(ctypes.byref(d), 1))
     if sk is not None and str(sk) != "0":
         assert nws > 8, "stream-K is not exercised by this shape"

@@ -453,14 +453,17 @@ HL_CASES = [
     (1, 12, 20, 32, 40, 3, 2, None, 1.0),     # one ragged 256 x 256 tile, ragged channels, dilation 2, one chunk per tap
     (2, 16, 24, 64, 288, 3, 1, None, 1.0),    # 3 x 2 tiles, second N tile ragged, two chunks per tap (chunk groups of 2)
     (2, 16, 24, 64, 288, 3, 1, "5", 1e4),     # the same through stream-K: segments cross tiles, partials completed in-launch
-    (1, 20, 20, 128, 256, 1, 1, "3", 1.0),    # 1x1: taps = 1, chunk groups of 4; M = 400 (ragged second tile)
+    (1, 20, 20, 128, 256, 1, 1, "5", 1.0),    # 1x1: taps = 1, chunk groups of 4; M = 400 (ragged second tile)
     (1, 9, 30, 96, 256, 3, 4, "3", 1e-6),     # dilation 4 with halos wider than the border, 3 chunks per tap, tiny operands
+    (1, 10, 30, 32, 64, 1, 1, None, 1.0),     # K = 32: ONE stage (prologue straight into the last-stage phases), 2 M tiles
+    (1, 10, 30, 64, 64, 1, 1, None, 1.0),     # K = 64: two stages (no steady-state stage)
 ]
 
 
+@pytest.mark.parametrize("rows", ["256", "192"])
 @pytest.mark.parametrize("dma", ["late", "early"])
 @pytest.mark.parametrize("case", HL_CASES, ids=[str(c) for c in HL_CASES])
-def test_conv_hl32_lds_dma_gather_gemm(L, case, dma, dcn_env, monkeypatch):
+def test_conv_hl32_lds_dma_gather_gemm(L, case, dma, rows, dcn_env, monkeypatch):
     """conv_hl_kernels.hip on the host: LDS-DMA pieces land either when the issuing work-item's counted wait retires them
     (the latest moment the hardware allows: catches reads that are not covered by wait + barrier) or at issue (the earliest:
     catches a buffer restaged while it is still being read)."""
@@ -469,7 +472,8 @@ def test_conv_hl32_lds_dma_gather_gemm(L, case, dma, dcn_env, monkeypatch):
         pytest.skip("one tile, plain launch: covered by the late mode")
     monkeypatch.setenv("HIPEMU_LDS_DMA", dma)
     n, h, w, cin, cout, k, dil, sk, sx = case
-    kernel_checks.check_conv_hl(L, "cpu", n, h, w, cin, cout, k, dil, set_env=dcn_env, sk=sk, scale_x=sx, seed=len(str(case)))
+    kernel_checks.check_conv_hl(L, "cpu", n, h, w, cin, cout, k, dil, set_env=dcn_env, sk=sk, scale_x=sx, seed=len(str(case)),
+                                rows=rows)
 
 
 WGRAD_HL_CASES = [

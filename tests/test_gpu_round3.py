@@ -22,12 +22,14 @@ HL_SMALL = [
     (1, 12, 20, 32, 40, 3, 2, None, 1.0),
     (2, 16, 24, 64, 288, 3, 1, None, 1.0),
     (2, 16, 24, 64, 288, 3, 1, "5", 1e4),
-    (1, 20, 20, 128, 256, 1, 1, "3", 1.0),
+    (1, 20, 20, 128, 256, 1, 1, "5", 1.0),
     (1, 9, 30, 96, 256, 3, 4, "3", 1e-6),
+    (1, 10, 30, 32, 64, 1, 1, None, 1.0),       # one K stage
+    (1, 10, 30, 64, 64, 1, 1, None, 1.0),       # two K stages
 ]
 HL_LAYERS = [
     (8, 60, 80, 256, 256, 3, 2, None, 1.0),     # layer 3 of config 2: 150 tiles on 256 CUs, less than a round: data-parallel
-    (8, 60, 80, 256, 256, 3, 2, "200", 1.0),    # ... and forced over 200 stream-K workgroups
+    (8, 60, 80, 256, 256, 3, 2, "170", 1.0),    # ... and forced over 170 stream-K workgroups (200 tiles of 192 rows: 170 + 30)
     (8, 60, 80, 512, 512, 3, 4, "1", 1.0),      # layer 4: 300 tiles -> 256 data-parallel + 44 stream-K
     (8, 60, 80, 128, 256, 3, 1, None, 1.0),     # layer3.0.conv1 forward (dgrad: 128 destination channels, one ragged N tile)
     (2, 60, 80, 256, 512, 3, 4, "0", 1.0),      # config 1 size, no stream-K: 38 tiles, ragged last M tile (9600 rows)
@@ -35,13 +37,14 @@ HL_LAYERS = [
 ]
 
 
+@pytest.mark.parametrize("rows", ["256", "192"])   # (tile height: two software pipelines, conv_hl_kernels.hip)
 @pytest.mark.parametrize("case", HL_SMALL + HL_LAYERS, ids=[str(c) for c in HL_SMALL + HL_LAYERS])
-def test_conv_hl32_lds_dma_gather_gemm(L, case, dcn_env):
+def test_conv_hl32_lds_dma_gather_gemm(L, case, rows, dcn_env):
     n, h, w, cin, cout, k, dil, sk, sx = case
     for rep in range(3):   # (again on the workspace the previous launches left behind; other seeds, other data)
         res = kernel_checks.check_conv_hl(L, "cuda", n, h, w, cin, cout, k, dil, set_env=dcn_env, sk=sk, scale_x=sx,
-                                          seed=len(str(case)) + rep)
-    print(case, res)
+                                          seed=len(str(case)) + rep, rows=rows)
+    print(case, rows, res)
 
 
 def test_conv_hl32_repeated_launches_are_bit_identical(L, dcn_env):
@@ -62,8 +65,8 @@ def test_conv_hl32_repeated_launches_are_bit_identical(L, dcn_env):
     assert lib.dcn_split_weights_hl32(1, arr(P, wt_.data_ptr()), arr(P, w_hl.data_ptr()), arr(I, cout), arr(I, k * k), arr(I, cin),
                                       arr(I, cout), 0, 64.0, None) == 0
     d = L.ConvDesc(n, h, w, cin, h, w, cout, k, k, 1, dil, dil, cout, 0)
-    for sk in ("1", "0", "200"):
-        dcn_env(DCN_GEMM_SK=sk)
+    for sk, rows in (("1", "256"), ("0", "256"), ("200", "256"), ("1", "192"), ("0", "192"), ("200", "192")):
+        dcn_env(DCN_GEMM_SK=sk, DCN_GEMM_HL_ROWS=rows)
         ws = kernel_checks.garbage(max(lib.dcn_conv_gemm_workspace_hl(ctypes.byref(d), 0), 8), "cuda", 1)
         outs = []
         for _ in range(20):
@@ -74,7 +77,7 @@ def test_conv_hl32_repeated_launches_are_bit_identical(L, dcn_env):
         torch.cuda.synchronize()
         assert bool(torch.isfinite(outs[0]).all())
         for o in outs[1:]:
-            assert torch.equal(o, outs[0]), "sk=%s" % sk
+            assert torch.equal(o, outs[0]), "sk=%s rows=%s" % (sk, rows)
 
 
 WGRAD_HL = [
@@ -104,7 +107,9 @@ def test_wgrad_hl32_transposing_lds_reads(L, case, dcn_env):
     dict(DCN_GEMM_HL=1, DCN_WGRAD_HL=1, DCN_HL_PRODUCERS=0),      # hl32 kernels, operand images by stand-alone split passes
     dict(DCN_GEMM_HL=1, DCN_WGRAD_HL=0),                          # hl32 forward / dgrad, fp32-operand weight gradients
     dict(DCN_GEMM_HL=2, DCN_WGRAD_HL=2),                          # every supported convolution (narrow layers included)
-], ids=["hl-off", "split-passes", "gemm-only", "forced-everywhere"])
+    dict(DCN_GEMM_HL=2, DCN_GEMM_HL_ROWS=192),                    # ... all of them on 192-row tiles
+    dict(DCN_GEMM_HL_ROWS=256),                                   # the round-3a launch shapes
+], ids=["hl-off", "split-passes", "gemm-only", "forced-everywhere", "forced-192", "rows-256"])
 def test_headline_step_vs_fixture_under_hl32_switches(L, env, dcn_env):
     """The headline workload (config 2, forward_pair) against its float32 / float64 oracle fixture with the hl32 path switched
     off, fed by stand-alone split passes, half on, and forced onto every supported layer: same tolerances as the default
