@@ -160,29 +160,10 @@ __device__ __forceinline__ PairScales pair_scales(const dcn_loss_config& cfg, co
     return s;
 }
 
-// One workgroup PER IMAGE PAIR: adds that pair's partials in a fixed order in fp64 and composes its 5-tuple; the per-pair
-// losses go to pair_loss[] and a second, tiny kernel averages them in pair order (deterministic; a single workgroup walking
-// all pairs took 200 us at 32 pairs x 110 000 pixel pairs).
-// finalizes image pair p (all work-items of the workgroup take part); returns, in work-item 0, whether the pair met an
-// out-of-range index
-__device__ __forceinline__ int finalize_pair(int p, const double* __restrict__ part_sum, const int* __restrict__ part_cnt,
-                                             const int* __restrict__ part_oob, int chunks, const int64_t* __restrict__ offsets,
+// composes image pair p's 5-tuple from its four fp64 sums S[] and hard-negative counts hcnt[] (ONE work-item)
+__device__ __forceinline__ void compose_pair(int p, const double* s_S, const int* s_h, const int64_t* __restrict__ offsets,
                                              const dcn_loss_config& cfg, float* __restrict__ terms, float* __restrict__ sums,
-                                             int* __restrict__ hard_neg, double* __restrict__ pair_loss, double* s_sum, int* s_cnt,
-                                             double* s_S, int* s_h) {
-    int oob = 0;
-    for (int t = 0; t < 4; ++t) {
-        double a = 0.0;
-        int c = 0, o = 0;
-        const int64_t base = (int64_t)(4 * p + t) * chunks;
-        for (int i = threadIdx.x; i < chunks; i += kThreads) { a += part_sum[base + i]; c += part_cnt[base + i]; o |= part_oob[base + i]; }
-        a = dcn::block_sum<kThreads>(a, s_sum);
-        c = dcn::block_sum<kThreads>(c, s_cnt);
-        o = dcn::block_sum<kThreads>(o, s_cnt);
-        if (threadIdx.x == 0) { s_S[t] = a; s_h[t] = c; oob |= o; }
-    }
-    __syncthreads();
-    if (threadIdx.x != 0) return 0;
+                                             int* __restrict__ hard_neg, double* __restrict__ pair_loss) {
     int64_t len[4];
     int h[4];
     for (int t = 0; t < 4; ++t) { len[t] = offsets[4 * p + t + 1] - offsets[4 * p + t]; h[t] = s_h[t]; }
@@ -216,6 +197,32 @@ __device__ __forceinline__ int finalize_pair(int p, const double* __restrict__ p
     for (int k = 0; k < 5; ++k) terms[5 * p + k] = out[k];
     for (int t = 0; t < 4; ++t) { sums[4 * p + t] = (float)s_S[t]; hard_neg[4 * p + t] = h[t]; }
     pair_loss[p] = (double)out[0];
+}
+
+// One workgroup PER IMAGE PAIR: adds that pair's partials in a fixed order in fp64 and composes its 5-tuple; the per-pair
+// losses go to pair_loss[] and a second, tiny kernel averages them in pair order (deterministic; a single workgroup walking
+// all pairs took 200 us at 32 pairs x 110 000 pixel pairs).
+// finalizes image pair p (all work-items of the workgroup take part); returns, in work-item 0, whether the pair met an
+// out-of-range index
+__device__ __forceinline__ int finalize_pair(int p, const double* __restrict__ part_sum, const int* __restrict__ part_cnt,
+                                             const int* __restrict__ part_oob, int chunks, const int64_t* __restrict__ offsets,
+                                             const dcn_loss_config& cfg, float* __restrict__ terms, float* __restrict__ sums,
+                                             int* __restrict__ hard_neg, double* __restrict__ pair_loss, double* s_sum, int* s_cnt,
+                                             double* s_S, int* s_h) {
+    int oob = 0;
+    for (int t = 0; t < 4; ++t) {
+        double a = 0.0;
+        int c = 0, o = 0;
+        const int64_t base = (int64_t)(4 * p + t) * chunks;
+        for (int i = threadIdx.x; i < chunks; i += kThreads) { a += part_sum[base + i]; c += part_cnt[base + i]; o |= part_oob[base + i]; }
+        a = dcn::block_sum<kThreads>(a, s_sum);
+        c = dcn::block_sum<kThreads>(c, s_cnt);
+        o = dcn::block_sum<kThreads>(o, s_cnt);
+        if (threadIdx.x == 0) { s_S[t] = a; s_h[t] = c; oob |= o; }
+    }
+    __syncthreads();
+    if (threadIdx.x != 0) return 0;
+    compose_pair(p, s_S, s_h, offsets, cfg, terms, sums, hard_neg, pair_loss);
     return oob ? 1 : 0;
 }
 
@@ -245,28 +252,43 @@ loss_mean_kernel(const double* __restrict__ pair_loss, const int* __restrict__ p
     status[0] = o;
 }
 
-// few pairs (the training configurations: 1-8 per step): ONE workgroup finalizes the pairs one after the other, averages them
-// in pair order and writes the status word -- one launch instead of three (status clear, finalize, mean)
+// few pairs (the training configurations: 1-8 per step): ONE workgroup -- each wavefront reduces (pair, term) sums with a
+// fixed shuffle tree, then one work-item per pair composes its 5-tuple and work-item 0 averages in pair order and writes the
+// status word: one launch instead of three (status clear, finalize, mean), no serial walk over the pairs
 __global__ void __launch_bounds__(kThreads)
 loss_finalize_all_kernel(const double* __restrict__ part_sum, const int* __restrict__ part_cnt, const int* __restrict__ part_oob,
                          int chunks, int num_pairs, const int64_t* __restrict__ offsets, dcn_loss_config cfg,
                          float* __restrict__ terms, float* __restrict__ sums, int* __restrict__ hard_neg,
                          double* __restrict__ pair_loss, float* __restrict__ loss, int* __restrict__ status) {
-    __shared__ double s_sum[kThreads / dcn::kWave];
-    __shared__ int s_cnt[kThreads / dcn::kWave];
-    __shared__ double s_S[4];
-    __shared__ int s_h[4];
-    double total = 0.0;
-    int o = 0;
-    for (int p = 0; p < num_pairs; ++p) {
-        o |= finalize_pair(p, part_sum, part_cnt, part_oob, chunks, offsets, cfg, terms, sums, hard_neg, pair_loss, s_sum, s_cnt,
-                           s_S, s_h);
-        if (threadIdx.x == 0) total += pair_loss[p];
-        __syncthreads();   // (s_S / s_h are rewritten by the next pair)
+    __shared__ double s_S[8][4];
+    __shared__ int s_h[8][4];
+    __shared__ int s_o[8][4];
+    const int lane = threadIdx.x & (dcn::kWave - 1), wv = threadIdx.x / dcn::kWave;
+    for (int q = wv; q < 4 * num_pairs; q += kThreads / dcn::kWave) {
+        double a = 0.0;
+        int c = 0, o = 0;
+        const int64_t base = (int64_t)q * chunks;
+        for (int i = lane; i < chunks; i += dcn::kWave) { a += part_sum[base + i]; c += part_cnt[base + i]; o |= part_oob[base + i]; }
+#pragma unroll
+        for (int m = dcn::kWave / 2; m >= 1; m >>= 1) {
+            a += __shfl_xor(a, m, dcn::kWave);
+            c += __shfl_xor(c, m, dcn::kWave);
+            o |= __shfl_xor(o, m, dcn::kWave);
+        }
+        if (lane == 0) { s_S[q >> 2][q & 3] = a; s_h[q >> 2][q & 3] = c; s_o[q >> 2][q & 3] = o; }
     }
+    __syncthreads();
+    if ((int)threadIdx.x < num_pairs) compose_pair(threadIdx.x, s_S[threadIdx.x], s_h[threadIdx.x], offsets, cfg, terms, sums, hard_neg, pair_loss);
+    __syncthreads();
     if (threadIdx.x == 0) {
+        double total = 0.0;
+        int o = 0;
+        for (int p = 0; p < num_pairs; ++p) {
+            total += pair_loss[p];
+            o |= s_o[p][0] | s_o[p][1] | s_o[p][2] | s_o[p][3];
+        }
         loss[0] = (float)(total / (double)num_pairs);
-        status[0] = o;
+        status[0] = o ? 1 : 0;
     }
 }
 
