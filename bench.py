@@ -545,37 +545,12 @@ def main():
         e1.record()
         torch.cuda.synchronize()
         ms = e0.elapsed_time(e1) / reps
-        # the same call replayed from a captured hipGraph: the GPU time of its launches without the host's per-call work
-        # (autograd bookkeeping, argument marshalling -- at this size the eager loop above is host-bound)
-        ms_graph = None
-        try:
-            cs = torch.cuda.Stream()
-            cs.wait_stream(torch.cuda.current_stream())
-            with torch.cuda.stream(cs):
-                loss_fwd_bwd(da, db, pair_lists, pcl)
-            torch.cuda.current_stream().wait_stream(cs)
-            torch.cuda.synchronize()
-            gl = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(gl):
-                keep = loss_fwd_bwd(da, db, pair_lists, pcl)
-            gl.replay()
-            torch.cuda.synchronize()
-            e0.record()
-            for _ in range(reps):
-                gl.replay()
-            e1.record()
-            torch.cuda.synchronize()
-            ms_graph = e0.elapsed_time(e1) / reps
-            del gl, keep
-        except Exception:  # noqa: BLE001 -- capture unavailable: the eager figure stands alone
-            torch.cuda.synchronize()
         npairs = pair_lists.total
         pair_bytes = (16 * D + 16) * npairs              # 2 descriptor reads + 2 int64 indices + 2 gradient accumulations
         fill_bytes = 2 * B * H * W * D * 4               # zero-fill of the two dense gradient maps
         loss_roof = {"bound": "hbm", "kernel": "loss_fwd_kernel + loss_finalize_kernel + loss_mean_kernel + loss_bwd_kernel (+ zero-fill of the two gradient maps)",
                      "achieved": (pair_bytes + fill_bytes) / (ms * 1e-3) / 1e9, "peak": 8000.0, "unit": "GB/s",
                      "frac": (pair_bytes + fill_bytes) / (ms * 1e-3) / 1e9 / 8000.0, "us_per_call": 1e3 * ms,
-                     "us_per_call_graph_replay": None if ms_graph is None else 1e3 * ms_graph,
                      "pixel_pairs": npairs, "algorithmic_bytes": {"pairs": pair_bytes, "zero_fill": fill_bytes},
                      "note": "latency-bound at this size: %d random %d-byte gathers per call" % (2 * npairs, 4 * D)}
 
@@ -644,7 +619,7 @@ def main():
             # the weak-scaling curve the multi-GPU runs trace), configs[2] (B = 32, D = 16) and configs[4]'s per-GPU share
             # (ResNet50-8s 1280 x 960), each with the roofline of its gather-GEMM launches
             for key, name, w_, k_ in (("config4_one_gpu", "config4", 3, short), ("config3_one_gpu", "config3", 2, 5),
-                                      ("config5_one_gpu", "config5", 3, 6)):
+                                      ("config5_one_gpu", "config5", 6, 8)):
                 wlv = dict(WORKLOADS[name])
                 jobv = Job(args, wlv, wlv["B"], dev, rank, use_dist)
                 sec, _ = jobv.timed(w_, k_, 0, use_dist)

@@ -24,9 +24,9 @@ PY
     pmc)   for ctr in FETCH_SIZE WRITE_SIZE; do (cd /tmp && timeout 900 rocprofv3 --kernel-trace --pmc $ctr --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/${tag}_pmc_$ctr -- python $GRAFT_REPO_ROOT/bench.py --steps 4 --warmup 2 --cpu-baseline-steps 0 --no-variants --profile-steps 0 > $GRAFT_REPO_ROOT/gpurun_out/${tag}_pmc_$ctr.log 2>&1); done
            python tools/pmc_summary.py gpurun_out/${tag}_pmc_FETCH_SIZE gpurun_out/${tag}_pmc_WRITE_SIZE gpurun_out/${tag}_hbm_counters.txt gpurun_out/${tag}_hbm_counters.json "rocprofv3 --kernel-trace --pmc FETCH_SIZE | WRITE_SIZE (separate passes) -- python bench.py --steps 4 --warmup 2 --cpu-baseline-steps 0 --no-variants --profile-steps 0" 2>&1 | tail -3; head -14 gpurun_out/${tag}_hbm_counters.txt | cut -c1-150 ;;
     sq)    i=0; for pass in "SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES GRBM_GUI_ACTIVE SQ_WAIT_INST_ANY SQ_WAIT_ANY" "SQ_WAVE_CYCLES SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT"; do i=$((i+1))
-             (cd /tmp && timeout 300 rocprofv3 --kernel-trace --pmc $pass --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/${tag}_sq_$i -- python $GRAFT_REPO_ROOT/tools/conv_bench.py --mode hl --n 8 --kinds fwd,dgrad,wgrad --x-direct --no-split --only "layer4 3x3" --reps 5 --relu-x > $GRAFT_REPO_ROOT/gpurun_out/${tag}_sq_$i.log 2>&1)
+             (cd /tmp && timeout 300 rocprofv3 --kernel-trace --pmc $pass --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/${tag}_sq_$i -- python $GRAFT_REPO_ROOT/tools/conv_bench.py --mode hl --n 8 --kinds fwd,dgrad,wgrad --x-direct --no-split --only "3x3 d" --reps 5 --relu-x > $GRAFT_REPO_ROOT/gpurun_out/${tag}_sq_$i.log 2>&1)
            done
-           python tools/sq_summary.py gpurun_out/${tag}_hl_sq_counters.txt "rocprofv3 --kernel-trace --pmc <two passes> -- python tools/conv_bench.py --mode hl --n 8 --kinds fwd,dgrad,wgrad --x-direct --no-split --only 'layer4 3x3' --reps 5 --relu-x" gpurun_out/${tag}_sq_1 gpurun_out/${tag}_sq_2; cat gpurun_out/${tag}_hl_sq_counters.txt | cut -c1-120 ;;
+           python tools/sq_summary.py gpurun_out/${tag}_hl_sq_counters.txt "rocprofv3 --kernel-trace --pmc <two passes> -- python tools/conv_bench.py --mode hl --n 8 --kinds fwd,dgrad,wgrad --x-direct --no-split --only '3x3 d' --reps 5 --relu-x" gpurun_out/${tag}_sq_1 gpurun_out/${tag}_sq_2; cat gpurun_out/${tag}_hl_sq_counters.txt | cut -c1-120 ;;
     *) echo "unknown step $s" ;;
   esac
 done
