@@ -163,6 +163,39 @@ def test_index_out_of_range_sets_status_and_is_skipped():
     np.testing.assert_allclose(out[0].item(), ref.item(), rtol=1e-6)
 
 
+@pytest.mark.parametrize("P", [8, 9])   # 8: the single-launch finalize of the training configs; 9: one workgroup per pair + mean
+def test_both_finalize_paths_agree_with_per_pair_calls_and_carry_the_status(P):
+    """The per-pair 5-tuples, the mean and the out-of-range flag (raised by the LAST pair only, in its background list) through
+    the few-pair finalize kernel and through the finalize + mean pair of kernels: each pair must equal a call of its own."""
+    from dcn_hip import loss as K
+    g = torch.Generator().manual_seed(11)
+    HW, D = 400, 3
+    A = (torch.rand(P, HW, D, generator=g) - 0.5) * 0.8
+    B = (torch.rand(P, HW, D, generator=g) - 0.5) * 0.8
+    cfg = K.make_config([1.0, 0.5, 0.5, 0.5], 20)
+    lists = []
+    for b in range(P):
+        n = [5 + 37 * b, 3 + 11 * b, 2 + 29 * (P - b)]
+        t = [torch.randint(0, HW, (k,), generator=g) for k in n for _ in range(2)]
+        lists.append((t[0], t[1], t[2], t[3], t[4], t[5], None, None))
+    ok = K.contrastive_loss(A, B, K.PairLists.from_lists(lists, "cpu"), cfg)
+    assert int(ok[4]) == 0
+    singles = [K.contrastive_loss(A[b:b + 1], B[b:b + 1], K.PairLists.from_lists([lists[b]], "cpu"), cfg) for b in range(P)]
+    for b in range(P):
+        np.testing.assert_allclose(ok[1][b].numpy(), singles[b][1][0].numpy(), rtol=1e-6, atol=1e-12)
+        assert torch.equal(ok[3][b], singles[b][3][0])
+    np.testing.assert_allclose(ok[0].item(), np.mean([s_[0].item() for s_ in singles]), rtol=1e-6)
+    bad = list(lists)
+    last = list(bad[-1])
+    last[5] = last[5].clone()
+    last[5][-1] = HW                       # out of range: skipped, flagged
+    bad[-1] = tuple(last)
+    flagged = K.contrastive_loss(A, B, K.PairLists.from_lists(bad, "cpu"), cfg)
+    assert int(flagged[4]) == 1
+    for b in range(P - 1):
+        np.testing.assert_allclose(flagged[1][b].numpy(), ok[1][b].numpy(), rtol=0, atol=0)
+
+
 def test_host_lists_are_range_checked_and_debug_surfaces_the_device_status():
     """an index >= H*W (lists built for another image size) must not silently train on a partial loss.  Lists
     that arrive on the host raise IndexError like the reference's index_select; for device-resident lists the kernel's
