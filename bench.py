@@ -631,9 +631,10 @@ def main():
                 torch.cuda.empty_cache()
             variants["config4_one_gpu"]["note"] = ("the N = 1 point of the weak-scaling curve: multi-GPU lines run this workload per "
                                                    "rank (bench.py --gpus 1 --workload config4 prints it as the headline)")
-        if world > 1 and not args.batch:
+        if use_dist and not args.batch:
             # the same per-rank workload on ONE GPU of this very box (rank 0 alone, the other ranks parked at the barrier, no
             # collective): the denominator of the weak-scaling efficiency, so that the curve does not depend on another run
+            # (--force-dist with one rank: what the RCCL path costs a step when there is nobody to talk to)
             job.comm = False
             saved_mode = grads.bucketed
             grads.bucketed = False
