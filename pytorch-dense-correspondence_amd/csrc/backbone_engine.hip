@@ -844,9 +844,14 @@ extern "C" int dcn_backbone_forward(dcn_plan* plan, const float* image, const fl
                 const BnL& b = p.bns[c.bn];
                 const float* s = R.S(b.stats);
                 float* slot = (training && f16_mode && blk.has_hl_mid[i]) ? R.S(blk.hl_mid[i]) : nullptr;
-                void* hl = training ? R.hl_image_for(R.S(blk.mid[i]), 1, &p.convs[blk.conv[i + 1]], nullptr, slot) : nullptr;
-                dcn::launch_bn_apply(R.S(c.x), s, nullptr, nullptr, 1, R.S(blk.mid[i]), R.M(blk.mid[i]), b.C, b.rows, p.groups, st,
-                                     hl, R.A(blk.act_mid[i]));
+                const ConvL& nxt = p.convs[blk.conv[i + 1]];
+                void* hl = training ? R.hl_image_for(R.S(blk.mid[i]), 1, &nxt, nullptr, slot) : nullptr;
+                // the tensor's readers: the next convolution, that convolution's weight gradient (the batch norm's own backward
+                // pass takes the ReLU mask).  Both on the hl32 kernels: the image in the saved arena is the only copy written
+                const bool hl_only = hl && slot && hl == (void*)slot && (b.C % 32) == 0 && dcn::tuning().hl_only_mid != 0 &&
+                                     R.use_hl(nxt, 0) && R.use_wgrad_hl(nxt);
+                dcn::launch_bn_apply(R.S(c.x), s, nullptr, nullptr, 1, hl_only ? nullptr : R.S(blk.mid[i]), R.M(blk.mid[i]), b.C,
+                                     b.rows, p.groups, st, hl, R.A(blk.act_mid[i]));
                 DCN_TRY(R.ensure_saved_hl(R.S(blk.mid[i]), slot, b.rows, b.C, blk.act_mid[i]));
                 cur = R.S(blk.mid[i]);
             } else {

@@ -205,7 +205,7 @@ bn_apply_kernel(const float* __restrict__ x, const float* __restrict__ s1, const
             o.x += r.x; o.y += r.y; o.z += r.z; o.w += r.w;
         }
         if (relu) { o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f); }
-        reinterpret_cast<float4*>(y)[i] = o;
+        if (y) reinterpret_cast<float4*>(y)[i] = o;   // (null: every reader of this tensor takes the hl32 image below)
         // which of the four outputs are positive: ONE byte per float4, so that the backward passes read 1 byte instead
         // of 16 to rebuild the ReLU mask
         if (relu_mask)

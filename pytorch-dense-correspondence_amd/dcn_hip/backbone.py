@@ -140,6 +140,17 @@ def _grad_views(flat, plan):
     return views
 
 
+
+POISON_ARENAS = False   # tests: fill the saved / workspace arenas with 0xFF bytes (NaN as fp32 and as fp16) before every call,
+                        # so that a kernel reading a byte nobody wrote in this step shows up in the results
+
+
+def _arena(nbytes, dev):
+    if POISON_ARENAS:
+        return torch.full((nbytes,), 255, dtype=torch.uint8, device=dev)
+    return torch.empty(nbytes, dtype=torch.uint8, device=dev)
+
+
 class _BackboneFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, image, plan, bn_running, training, normalize, momentum, eps, *params):
@@ -155,8 +166,8 @@ class _BackboneFn(torch.autograd.Function):
         pptr = (ctypes.c_void_p * len(kparams))(*[p.data_ptr() for p in kparams])
         rptr = (ctypes.c_void_p * len(bn_running))(*[b.data_ptr() for b in bn_running])
         desc = torch.empty((plan.n, plan.h, plan.w, plan.d), dtype=torch.float32, device=dev)
-        saved = torch.empty(plan.saved_bytes, dtype=torch.uint8, device=dev)
-        ws = torch.empty(plan.workspace_bytes, dtype=torch.uint8, device=dev)
+        saved = _arena(plan.saved_bytes, dev)
+        ws = _arena(plan.workspace_bytes, dev)
         rc = lib.dcn_backbone_forward(plan.handle, _lib.ptr(image), pptr, rptr, float(momentum), float(eps),
                                       int(bool(training)), int(bool(normalize)), _lib.ptr(desc), _lib.ptr(saved),
                                       _lib.ptr(ws), _lib.stream_ptr())
@@ -201,7 +212,7 @@ class _BackboneFn(torch.autograd.Function):
         else:
             g = grad_descs[0].permute(0, 2, 3, 1).contiguous()  # NHWC; no copy when grad is channels_last
         dev = g.device
-        ws = torch.empty(plan.workspace_bytes, dtype=torch.uint8, device=dev)
+        ws = _arena(plan.workspace_bytes, dev)
         flat = torch.empty(plan.grad_offsets[-1], dtype=torch.float32, device=dev)
         for i, nmel in enumerate(plan.param_numel):   # the <= 3 alignment floats behind a tensor are never written by the
             if nmel % 4:                              # engine: keep them zero, the buffer is ADDED into the shared sink

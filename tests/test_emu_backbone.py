@@ -346,6 +346,47 @@ def test_wide_layers_through_the_hl32_path(arch, bw, shape, groups, producers, d
     _bb._PLANS.clear()
 
 
+@pytest.mark.parametrize("arch,bw,shape,groups", [("Resnet18_8s", 32, (1, 32, 256), 1),     # maps 4 x 32 at 1/8: layers 2-4 qualify
+                                                  ("Resnet50_8s", 32, (1, 32, 256), 1),     # two such tensors per block
+                                                  ("Resnet18_8s", 32, (2, 128, 128), 2)])   # layer 1 (32 x 32 maps), two groups
+def test_mid_block_activation_without_its_fp32_copy(arch, bw, shape, groups, dcn_env, conv_mode):
+    """Inside a block, the activation between two convolutions has two readers -- the next convolution and that convolution's
+    weight gradient (the batch norm's own backward takes the ReLU mask).  When both run on the hl32 kernels the apply pass
+    writes the hl32 image only (DCN_HL_ONLY_MID, default on).  Arenas poisoned with NaN bytes: forward output, running
+    statistics and every gradient must equal, bit for bit, the run that also writes the fp32 tensor."""
+    if conv_mode != "f16x3":
+        pytest.skip("the hl32 path belongs to the split-fp16 arithmetic")
+    from dcn_hip import backbone as _bb
+    N, H, W = shape
+    D = 3
+    m, _ = _pair(arch, D, bw)
+    m2 = copy.deepcopy(m)
+    g = torch.Generator().manual_seed(9)
+    x = torch.randn(N, 3, H, W, generator=g)
+    gy = torch.randn(N, D, H, W, generator=g)
+
+    def run(net):
+        net.train()
+        y = torch.cat(net.forward_pair(x[:N // 2], x[N // 2:])) if groups == 2 else net(x)
+        (y * gy).sum().backward()
+        return y.detach()
+    _bb.POISON_ARENAS = True
+    try:
+        dcn_env(DCN_GEMM_HL=2, DCN_WGRAD_HL=2, DCN_HL_ONLY_MID=1)
+        _bb._PLANS.clear()
+        ya = run(m)
+        dcn_env(DCN_GEMM_HL=2, DCN_WGRAD_HL=2, DCN_HL_ONLY_MID=0)
+        yb = run(m2)
+    finally:
+        _bb.POISON_ARENAS = False
+        _bb._PLANS.clear()
+    assert bool(torch.isfinite(ya).all()) and torch.equal(ya, yb)
+    for (k, p1), p2 in zip(m.named_parameters(), m2.parameters()):
+        assert bool(torch.isfinite(p1.grad).all()) and torch.equal(p1.grad, p2.grad), k
+    for (k, b1), b2 in zip(m.named_buffers(), m2.buffers()):
+        assert torch.equal(b1, b2), k
+
+
 def _torchvision_like_state_dict(arch, bw, seed=3):
     """A state dict with the keys and shapes of stock ``torchvision.models.resnetNN`` (no torchvision in this image: the
     layout is rebuilt from the published architecture -- stem, four stages of BasicBlock / Bottleneck, 1000-way fc)."""

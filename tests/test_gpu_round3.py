@@ -127,3 +127,43 @@ def test_headline_step_vs_fixture_under_hl32_switches(L, env, dcn_env):
         backbone._PLANS.clear()
         backbone.set_conv_mode(None)
         torch.cuda.empty_cache()
+
+
+def test_mid_block_activation_without_its_fp32_copy_full_size(L, dcn_env):
+    """Config-2 shapes (forward_pair of 4 + 4 images, 640 x 480): inside the blocks of layers 3-4 the batch-norm apply pass
+    writes the hl32 image only (both readers take it).  Saved arena and workspace poisoned with NaN bytes before every call:
+    descriptors, running statistics and all gradients bit-identical to the run that also writes the fp32 tensors."""
+    import copy
+    from dcn_hip import backbone
+    from pytorch_segmentation_detection.models import resnet_dilated as prod
+    backbone.set_conv_mode("f16x3")
+    torch.manual_seed(3)
+    m = prod.Resnet34_8s(num_classes=3).cuda().train()
+    m2 = copy.deepcopy(m)
+    g = torch.Generator().manual_seed(4)
+    xa = torch.randn(4, 3, 480, 640, generator=g).cuda()
+    xb = torch.randn(4, 3, 480, 640, generator=g).cuda()
+    gy = torch.randn(8, 3, 480, 640, generator=g).cuda()
+
+    def run(net):
+        y = torch.cat(net.forward_pair(xa, xb))
+        (y * gy).sum().backward()
+        torch.cuda.synchronize()
+        return y.detach()
+    backbone.POISON_ARENAS = True
+    try:
+        dcn_env(DCN_HL_ONLY_MID=1)
+        backbone._PLANS.clear()
+        ya = run(m)
+        dcn_env(DCN_HL_ONLY_MID=0)
+        yb = run(m2)
+    finally:
+        backbone.POISON_ARENAS = False
+        backbone._PLANS.clear()
+        backbone.set_conv_mode(None)
+        torch.cuda.empty_cache()
+    assert bool(torch.isfinite(ya).all()) and torch.equal(ya, yb)
+    for (k, p1), p2 in zip(m.named_parameters(), m2.parameters()):
+        assert bool(torch.isfinite(p1.grad).all()) and torch.equal(p1.grad, p2.grad), k
+    for (k, b1), b2 in zip(m.named_buffers(), m2.buffers()):
+        assert torch.equal(b1, b2), k
