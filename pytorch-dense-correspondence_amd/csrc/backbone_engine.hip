@@ -820,10 +820,17 @@ extern "C" int dcn_backbone_forward(dcn_plan* plan, const float* image, const fl
     {
         const BnL& b = p.bns[stem.bn];
         const float* s = R.S(b.stats);
-        dcn::launch_bn_apply(R.S(stem.x), s, nullptr, nullptr, 1, R.S(p.s_stem_y), R.M(p.s_stem_y), b.C, b.rows, p.groups, st);
         const int hp = (stem.d.hout + 2 - 3) / 2 + 1, wp = (stem.d.wout + 2 - 3) / 2 + 1;
-        dcn::launch_maxpool_fwd(R.S(p.s_stem_y), R.S(p.s_pool), (unsigned char*)R.S(p.s_argmax), N, stem.d.hout,
-                                stem.d.wout, hp, wp, b.C, st);
+        if (dcn::tuning().stem_pool_fused != 0) {
+            // batch norm + ReLU applied inside the pooling pass: the stem's activation (the largest tensor of the network) is
+            // never stored; its sign mask -- what the batch norm's backward pass reads -- is
+            dcn::launch_maxpool_fwd(R.S(stem.x), R.S(p.s_pool), (unsigned char*)R.S(p.s_argmax), N, stem.d.hout, stem.d.wout, hp,
+                                    wp, b.C, st, s, p.groups, R.M(p.s_stem_y));
+        } else {
+            dcn::launch_bn_apply(R.S(stem.x), s, nullptr, nullptr, 1, R.S(p.s_stem_y), R.M(p.s_stem_y), b.C, b.rows, p.groups, st);
+            dcn::launch_maxpool_fwd(R.S(p.s_stem_y), R.S(p.s_pool), (unsigned char*)R.S(p.s_argmax), N, stem.d.hout,
+                                    stem.d.wout, hp, wp, b.C, st);
+        }
     }
     if (training && f16_mode && p.blocks[0].has_hl_in) {   // (the first block's input is the max-pool output: no apply pass writes it)
         const BlockL& b0 = p.blocks[0];

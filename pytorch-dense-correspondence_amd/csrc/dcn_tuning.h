@@ -28,6 +28,8 @@
 //                           the pre-split (hl32) LDS-DMA kernel (wgrad_hl_kernels.hip); 2: every supported convolution (tests)
 //   DCN_HL_PRODUCERS        0: hl32 activation / gradient images are made by stand-alone split passes instead of by the
 //                           batch-norm apply kernels that produce the tensors
+//   DCN_STEM_POOL_FUSED     0: the stem's batch norm + ReLU as an apply pass of its own in front of the max pool (default 1: applied
+//                           inside the pooling pass, the activation itself is never stored)
 //   DCN_HL_ONLY_MID         0: the batch-norm apply pass inside a block also writes the fp32 activation when both of its readers
 //                           (the next convolution and that convolution's weight gradient) take the hl32 image (default 1: it does not)
 #pragma once
@@ -54,6 +56,7 @@ struct Tuning {
     int wgrad_hl = 1;            // wide layers' weight gradients on the pre-split (hl32) LDS-DMA kernel
     int hl_producers = 1;        // hl32 images written by the producing batch-norm passes (0: stand-alone split passes)
     int hl_only_mid = 1;         // mid-block activations whose two readers (next conv, its wgrad) take the hl32 image: no fp32 copy (0: keep it)
+    int stem_pool_fused = 1;     // the stem's batch norm + ReLU applied inside the max-pool pass (0: an apply pass of its own)
     int wgrad_roles = 1;         // wide tile: wavefronts 0-3 stage the activations, 4-7 the gradient (0: copy spread over all 8)
 };
 

@@ -37,6 +37,7 @@ void read_env(Tuning& t) {
     if (const char* e = getenv("DCN_GEMM_HL")) t.gemm_hl = atoi(e);
     if (const char* e = getenv("DCN_GEMM_HL_ROWS")) t.gemm_hl_rows = atoi(e);
     if (const char* e = getenv("DCN_HL_ONLY_MID")) t.hl_only_mid = atoi(e);
+    if (const char* e = getenv("DCN_STEM_POOL_FUSED")) t.stem_pool_fused = atoi(e);
     if (const char* e = getenv("DCN_WGRAD_HL")) t.wgrad_hl = atoi(e);
     if (const char* e = getenv("DCN_HL_PRODUCERS")) t.hl_producers = atoi(e) != 0;
 }

@@ -43,8 +43,11 @@ void launch_bn_bwd(const float* dy, const float* relu_out, const unsigned char* 
 // (pass relu_out = relu_mask = nullptr)
 void launch_add(const float* a, const float* b, float* out, int64_t n, hipStream_t st);
 
+// bn_stats (optional): [groups][scale C | shift C | mean C | invstd C] of the batch norm whose output is pooled -- `in` is then
+// the convolution output, y = relu(in * scale + shift) is formed on the fly and relu_mask receives y's sign mask
 void launch_maxpool_fwd(const float* in, float* out, unsigned char* argmax, int n, int hin, int win, int hout,
-                        int wout, int C, hipStream_t st);
+                        int wout, int C, hipStream_t st, const float* bn_stats = nullptr, int groups = 1,
+                        unsigned char* relu_mask = nullptr);
 void launch_maxpool_bwd(const float* gout, const unsigned char* argmax, float* gin, int n, int hin, int win, int hout,
                         int wout, int C, hipStream_t st, const float* gout2 = nullptr);   // gout2 (optional): gradient = gout + gout2
 

@@ -478,9 +478,14 @@ add_kernel(const float* __restrict__ a, const float* __restrict__ b, float* __re
 }
 
 // ---------------------------------------------------------------------------------------------- max pool 3x3 / 2 / pad 1
+// scale / shift (optional): the input is a convolution output whose batch norm + ReLU is applied HERE, on the way into the
+// window maximum -- y = relu(in * scale + shift) is never stored (the stem: 157 MB per 8 images read and written by an apply
+// pass of its own otherwise).  relu_mask then receives the one-byte-per-float4 sign mask of y that the batch norm's backward
+// pass reads (every input belongs to at least one window; windows overlap: the same byte is written up to four times).
 __global__ void __launch_bounds__(256)
 maxpool_fwd_kernel(const float* __restrict__ in, float* __restrict__ out, unsigned char* __restrict__ argmax, int hin,
-                   int win, int hout, int wout, int c4n, int64_t total4) {
+                   int win, int hout, int wout, int c4n, int64_t total4, const float* __restrict__ scale,
+                   const float* __restrict__ shift, int gstride, int64_t group_n, unsigned char* __restrict__ relu_mask) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;  // over n*hout*wout*c4n
     if (i >= total4) return;
     const int c4 = (int)(i % c4n);
@@ -488,6 +493,12 @@ maxpool_fwd_kernel(const float* __restrict__ in, float* __restrict__ out, unsign
     const int ox = (int)(pix % wout); pix /= wout;
     const int oy = (int)(pix % hout);
     const int64_t n = pix / hout;
+    float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), sh = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (scale) {
+        const int c = c4 * 4 + (n >= group_n ? gstride : 0);   // (at most two statistics groups)
+        sc = *reinterpret_cast<const float4*>(scale + c);
+        sh = *reinterpret_cast<const float4*>(shift + c);
+    }
     float4 best = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
     int bx = -1, by = -1, bz = -1, bw = -1;
     for (int r = 0; r < 3; ++r) {
@@ -496,7 +507,14 @@ maxpool_fwd_kernel(const float* __restrict__ in, float* __restrict__ out, unsign
         for (int s = 0; s < 3; ++s) {
             const int ix = ox * 2 - 1 + s;
             if (ix < 0 || ix >= win) continue;
-            const float4 v = reinterpret_cast<const float4*>(in)[((n * hin + iy) * win + ix) * c4n + c4];
+            const int64_t src = ((n * hin + iy) * win + ix) * c4n + c4;
+            float4 v = reinterpret_cast<const float4*>(in)[src];
+            if (scale) {   // (the expressions of bn_apply_kernel: same bits)
+                v = make_float4(v.x * sc.x + sh.x, v.y * sc.y + sh.y, v.z * sc.z + sh.z, v.w * sc.w + sh.w);
+                v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+                if (relu_mask)
+                    relu_mask[src] = (unsigned char)((v.x > 0.f ? 1 : 0) | (v.y > 0.f ? 2 : 0) | (v.z > 0.f ? 4 : 0) | (v.w > 0.f ? 8 : 0));
+            }
             const int t = r * 3 + s;
             if (v.x > best.x || bx < 0 || v.x != v.x) { best.x = v.x; bx = t; }
             if (v.y > best.y || by < 0 || v.y != v.y) { best.y = v.y; by = t; }
@@ -759,10 +777,11 @@ void launch_add(const float* a, const float* b, float* out, int64_t n, hipStream
     hipLaunchKernelGGL(add_kernel, dim3(blocks_for(n / 4, kGridCap)), dim3(256), 0, st, a, b, out, n / 4);
 }
 void launch_maxpool_fwd(const float* in, float* out, unsigned char* argmax, int n, int hin, int win, int hout,
-                        int wout, int C, hipStream_t st) {
+                        int wout, int C, hipStream_t st, const float* bn_stats, int groups, unsigned char* relu_mask) {
     const int64_t total4 = (int64_t)n * hout * wout * (C / 4);
     hipLaunchKernelGGL(maxpool_fwd_kernel, dim3(blocks_for(total4)), dim3(256), 0, st, in, out, argmax, hin, win, hout,
-                       wout, C / 4, total4);
+                       wout, C / 4, total4, bn_stats, bn_stats ? bn_stats + C : nullptr, 4 * C,
+                       (int64_t)(groups > 1 ? n / groups : n), bn_stats ? relu_mask : nullptr);
 }
 void launch_maxpool_bwd(const float* gout, const unsigned char* argmax, float* gin, int n, int hin, int win, int hout,
                         int wout, int C, hipStream_t st, const float* gout2) {

@@ -349,13 +349,13 @@ def test_wide_layers_through_the_hl32_path(arch, bw, shape, groups, producers, d
 @pytest.mark.parametrize("arch,bw,shape,groups", [("Resnet18_8s", 32, (1, 32, 256), 1),     # maps 4 x 32 at 1/8: layers 2-4 qualify
                                                   ("Resnet50_8s", 32, (1, 32, 256), 1),     # two such tensors per block
                                                   ("Resnet18_8s", 32, (2, 128, 128), 2)])   # layer 1 (32 x 32 maps), two groups
-def test_mid_block_activation_without_its_fp32_copy(arch, bw, shape, groups, dcn_env, conv_mode):
+def test_activations_that_are_never_stored(arch, bw, shape, groups, dcn_env, conv_mode):
     """Inside a block, the activation between two convolutions has two readers -- the next convolution and that convolution's
     weight gradient (the batch norm's own backward takes the ReLU mask).  When both run on the hl32 kernels the apply pass
-    writes the hl32 image only (DCN_HL_ONLY_MID, default on).  Arenas poisoned with NaN bytes: forward output, running
-    statistics and every gradient must equal, bit for bit, the run that also writes the fp32 tensor."""
-    if conv_mode != "f16x3":
-        pytest.skip("the hl32 path belongs to the split-fp16 arithmetic")
+    writes the hl32 image only (DCN_HL_ONLY_MID, default on).  The stem's activation is not stored either: its batch norm +
+    ReLU is applied inside the max-pool pass, which also writes the sign mask (DCN_STEM_POOL_FUSED, default on; both
+    arithmetics).  Arenas poisoned with NaN bytes: forward output, running statistics and every gradient must equal, bit for
+    bit, the run that writes those tensors."""
     from dcn_hip import backbone as _bb
     N, H, W = shape
     D = 3
@@ -372,10 +372,10 @@ def test_mid_block_activation_without_its_fp32_copy(arch, bw, shape, groups, dcn
         return y.detach()
     _bb.POISON_ARENAS = True
     try:
-        dcn_env(DCN_GEMM_HL=2, DCN_WGRAD_HL=2, DCN_HL_ONLY_MID=1)
+        dcn_env(DCN_GEMM_HL=2, DCN_WGRAD_HL=2, DCN_HL_ONLY_MID=1, DCN_STEM_POOL_FUSED=1)
         _bb._PLANS.clear()
         ya = run(m)
-        dcn_env(DCN_GEMM_HL=2, DCN_WGRAD_HL=2, DCN_HL_ONLY_MID=0)
+        dcn_env(DCN_GEMM_HL=2, DCN_WGRAD_HL=2, DCN_HL_ONLY_MID=0, DCN_STEM_POOL_FUSED=0)
         yb = run(m2)
     finally:
         _bb.POISON_ARENAS = False

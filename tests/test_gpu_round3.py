@@ -129,10 +129,11 @@ def test_headline_step_vs_fixture_under_hl32_switches(L, env, dcn_env):
         torch.cuda.empty_cache()
 
 
-def test_mid_block_activation_without_its_fp32_copy_full_size(L, dcn_env):
+def test_activations_that_are_never_stored_full_size(L, dcn_env):
     """Config-2 shapes (forward_pair of 4 + 4 images, 640 x 480): inside the blocks of layers 3-4 the batch-norm apply pass
-    writes the hl32 image only (both readers take it).  Saved arena and workspace poisoned with NaN bytes before every call:
-    descriptors, running statistics and all gradients bit-identical to the run that also writes the fp32 tensors."""
+    writes the hl32 image only (both readers take it), and the stem's batch norm + ReLU is applied inside the max-pool pass
+    (its activation is never stored).  Saved arena and workspace poisoned with NaN bytes before every call: descriptors,
+    running statistics and all gradients bit-identical to the run that writes those tensors."""
     import copy
     from dcn_hip import backbone
     from pytorch_segmentation_detection.models import resnet_dilated as prod
@@ -152,10 +153,10 @@ def test_mid_block_activation_without_its_fp32_copy_full_size(L, dcn_env):
         return y.detach()
     backbone.POISON_ARENAS = True
     try:
-        dcn_env(DCN_HL_ONLY_MID=1)
+        dcn_env(DCN_HL_ONLY_MID=1, DCN_STEM_POOL_FUSED=1)
         backbone._PLANS.clear()
         ya = run(m)
-        dcn_env(DCN_HL_ONLY_MID=0)
+        dcn_env(DCN_HL_ONLY_MID=0, DCN_STEM_POOL_FUSED=0)
         yb = run(m2)
     finally:
         backbone.POISON_ARENAS = False
