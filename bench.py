@@ -480,8 +480,8 @@ def main():
             # one fp32-accurate multiply-add = 3 fp16 MFMA products (hi*hi + hi*lo + lo*hi): the ceiling for
             # ALGORITHMIC flops is a third of the fp16 pipe's dense peak
             peak, kern = F16X3_PEAK_TFLOPS, ("gather-GEMM convolution, forward + dgrad (3x v_mfma_f32_32x32x16_f16 per product): "
-                                             "conv_gemm_hl_kernel on the wide layers (pre-split hl32 operands by LDS-DMA, 256 x 256 "
-                                             "tiles), conv_gemm_f16_kernel on the others")
+                                             "conv_gemm_hl_kernel on the wide layers (pre-split hl32 operands by LDS-DMA, 256 x 256 or "
+                                             "192 x 256 tiles), conv_gemm_f16_kernel on the others")
             peak_note = "fp16 MFMA dense peak %.1f / 3 products per fp32-accurate MAC (fp32 MFMA peak: %.1f)" % (
                 F16_MFMA_PEAK_TFLOPS, FP32_MFMA_PEAK_TFLOPS)
         # HBM-side traffic of the dominant kernel cannot be measured from inside the process (PMC counters need
@@ -618,7 +618,7 @@ def main():
             # every other single-GPU BASELINE config on the same driver-timed line: configs[3]'s per-GPU share (the N = 1 point of
             # the weak-scaling curve the multi-GPU runs trace), configs[2] (B = 32, D = 16) and configs[4]'s per-GPU share
             # (ResNet50-8s 1280 x 960), each with the roofline of its gather-GEMM launches
-            for key, name, w_, k_ in (("config4_one_gpu", "config4", 3, short), ("config3_one_gpu", "config3", 2, 5),
+            for key, name, w_, k_ in (("config4_one_gpu", "config4", 6, short), ("config3_one_gpu", "config3", 3, 5),
                                       ("config5_one_gpu", "config5", 6, 8)):
                 wlv = dict(WORKLOADS[name])
                 jobv = Job(args, wlv, wlv["B"], dev, rank, use_dist)
