@@ -356,6 +356,8 @@ def test_activations_that_are_never_stored(arch, bw, shape, groups, dcn_env, con
     ReLU is applied inside the max-pool pass, which also writes the sign mask (DCN_STEM_POOL_FUSED, default on; both
     arithmetics).  Arenas poisoned with NaN bytes: forward output, running statistics and every gradient must equal, bit for
     bit, the run that writes those tensors."""
+    if conv_mode == "fp32" and (arch != "Resnet18_8s" or groups != 1):
+        pytest.skip("fp32 arithmetic: only the stem fusion applies; one network covers it")
     from dcn_hip import backbone as _bb
     N, H, W = shape
     D = 3
