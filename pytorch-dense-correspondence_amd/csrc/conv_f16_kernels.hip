@@ -509,7 +509,7 @@ __device__ __forceinline__ void gemm_segment_f16(const GemmConv& p, _Float16* ld
             // L2s), so they are written and read with device-coherent accesses (sc1: write-through / L2-bypassing) and ordered
             // against the arrival word by counter waits only -- NO device-scope fence: a release / acquire fence writes back
             // and invalidates the whole L2 of the XCD under the 31 other CUs that are in the middle of their K loops
-            // (measured: +50 us per launch, profiles/r2b_ab.txt).
+            // (measured: +50 us per launch, profiles/r2b_ab_fence_variant.txt).
             __shared__ int s_last;
             const __amdgpu_buffer_rsrc_t rs_p = __builtin_amdgcn_make_buffer_rsrc(p.sk_partial, 0, (int)p.sk_bytes, 0x00020000);
             constexpr int kSc1 = 16;                           // cache-policy bit of buffer loads / stores: device scope

@@ -11,7 +11,7 @@
 //                           contributing workgroup of the GEMM launch itself (split-fp16 kernel)
 //   DCN_BN_BWD_FUSED        1: the batch-norm backward reduction runs in the epilogue of the dgrad that produces its upstream
 //                           gradient (split-fp16 mode) instead of as a separate pass.  Default 0: measured SLOWER on the
-//                           MI355X (+1.3 ms per config-2 step, profiles/r2b_ab.txt: the one-workgroup-per-CU GEMM exposes the
+//                           MI355X (+1.3 ms per config-2 step, profiles/r2b_ab_fence_variant.txt: the one-workgroup-per-CU GEMM exposes the
 //                           epilogue's extra loads, the separate pass streams at HBM speed)
 //   DCN_DEFER_RESIDUAL_ADD  0: the residual branch's gradient is added in the dgrad epilogue (1: in the BN backward passes)
 //   DCN_WGRAD_TILE          128: keep the 128-channel / 4-wavefront tile of the split-fp16 wgrad kernel on wide layers

@@ -23,7 +23,7 @@ import parity_common as pc
 pytestmark = pytest.mark.gpu
 TOL = 1e-4
 # Gradients: relative L2 error of every tensor against the float64 oracle; asserted on the distribution over the tensors
-# (r.m.s. and worst tensor) against the float32 oracle's own -- measured on MI355X (profiles/r2_parity_report.json): r.m.s.
+# (r.m.s. and worst tensor) against the float32 oracle's own -- measured on MI355X (profiles/r2u_parity_report.json): r.m.s.
 # 0.96 - 1.24 x the float32 oracle's in both arithmetics on all four configs.
 GRAD_FACTOR = 1.5
 

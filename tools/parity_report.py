@@ -2,7 +2,7 @@
 """Prints (and optionally stores as JSON) the measured deviation of one full-size training step of every BASELINE config
 from its committed oracle fixture, in both convolution arithmetics -- the numbers behind tests/test_gpu_configs.py.
 
-    python tools/parity_report.py [--config 1 2 3 5] [--json profiles/r2_parity_report.json]
+    python tools/parity_report.py [--config 1 2 3 5] [--json profiles/rN_parity_report.json]
 """
 import argparse
 import json
