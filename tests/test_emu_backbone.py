@@ -346,9 +346,9 @@ def test_wide_layers_through_the_hl32_path(arch, bw, shape, groups, producers, d
     _bb._PLANS.clear()
 
 
-@pytest.mark.parametrize("arch,bw,shape,groups", [("Resnet18_8s", 32, (1, 32, 256), 1),     # maps 4 x 32 at 1/8: layers 2-4 qualify
-                                                  ("Resnet50_8s", 32, (1, 32, 256), 1),     # two such tensors per block
-                                                  ("Resnet18_8s", 32, (2, 128, 128), 2)])   # layer 1 (32 x 32 maps), two groups
+@pytest.mark.parametrize("arch,bw,shape,groups", [("Resnet18_8s", 32, (1, 16, 256), 1),     # maps 2 x 32 at 1/8: layers 1-4 qualify
+                                                  ("Resnet50_8s", 16, (1, 16, 256), 1),     # two such tensors per block (layers 2-4)
+                                                  ("Resnet18_8s", 32, (2, 64, 128), 2)])    # layer 1 (16 x 32 maps), two groups
 def test_activations_that_are_never_stored(arch, bw, shape, groups, dcn_env, conv_mode):
     """Inside a block, the activation between two convolutions has two readers -- the next convolution and that convolution's
     weight gradient (the batch norm's own backward takes the ReLU mask).  When both run on the hl32 kernels the apply pass
