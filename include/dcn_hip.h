@@ -235,6 +235,13 @@ int dcn_backbone_forward(dcn_plan* plan, const float* image, const float* const*
                          float* const* bn_running, float momentum, float eps, int training, int normalize,
                          float* descriptors, void* saved, void* workspace, void* stream);
 
+/* The same call for a grouped plan (dcn_plan_create_grouped, groups == 2) whose two image batches are separate tensors:
+ * images [0, N/2) are read from image_a, [N/2, N) from image_b ([N/2,3,H,W] each) -- forward(img_a), forward(img_b) of
+ * training.py:329-333 as one launch sequence without a concatenated copy of the batches. */
+int dcn_backbone_forward_pair(dcn_plan* plan, const float* image_a, const float* image_b, const float* const* params,
+                              float* const* bn_running, float momentum, float eps, int training, int normalize,
+                              float* descriptors, void* saved, void* workspace, void* stream);
+
 /*
  * Launch-level timing of the two matrix-core kernels (for bench.py's roofline): between begin and end every
  * conv_gemm_kernel (forward + dgrad; category 0) and conv_wgrad_kernel (category 1) launch made through this
@@ -247,11 +254,36 @@ int dcn_plan_profile_end(dcn_plan* plan, double ms[2], int64_t launches[2], doub
 /* The same with a third category: [2] = the part of category 0 that ran on the pre-split (hl32) LDS-DMA kernel
  * (conv_hl_kernels.hip; an operand split pass that had to run in front of a launch is inside its bracket). */
 int dcn_plan_profile_end3(dcn_plan* plan, double ms[3], int64_t launches[3], double flops[3]);
+/* EVERY launch the engine makes between begin and end, by category (bench.py: `roofline_elementwise`, `kernel_ms_sum`):
+ * work[c] = algorithmic FLOPs for the three matrix-core categories, algorithmic HBM bytes (4 B x elements read and
+ * written, the operands a pass needs once) for the streaming ones, 0 where neither is meaningful.  Category
+ * DCN_PROF_GEMM_HL is a subset of DCN_PROF_GEMM (as in dcn_plan_profile_end3); the others are disjoint, so the launches
+ * of a step are  sum over c != DCN_PROF_GEMM_HL.  Arrays of DCN_PROF_NCAT entries. */
+enum {
+    DCN_PROF_GEMM = 0,           /* gather-GEMM convolutions, forward + dgrad (all kernels) */
+    DCN_PROF_WGRAD = 1,          /* weight-gradient GEMMs (their slab-reduce launch included) */
+    DCN_PROF_GEMM_HL = 2,        /* the part of DCN_PROF_GEMM on the pre-split (hl32) kernel */
+    DCN_PROF_BN_APPLY = 3,       /* batch-norm apply (+ residual, ReLU, mask, hl32 image): one streaming pass */
+    DCN_PROF_BN_BWD_REDUCE = 4,  /* batch-norm backward reduction pass */
+    DCN_PROF_BN_BWD_APPLY = 5,   /* batch-norm backward apply pass (+ the gradient's operand images) */
+    DCN_PROF_BN_FINALIZE = 6,    /* the two per-channel finalize kernels (latency-bound) */
+    DCN_PROF_RESAMPLE = 7,       /* max pool, bilinear upsample (forward and backward), NCHW -> NHWC4 of the input */
+    DCN_PROF_OTHER = 8,          /* fills, weight splits, stand-alone operand splits, status / bias-gradient kernels */
+    DCN_PROF_NCAT = 9
+};
+int dcn_plan_profile_end_all(dcn_plan* plan, double ms[DCN_PROF_NCAT], int64_t launches[DCN_PROF_NCAT],
+                             double work[DCN_PROF_NCAT]);
 
 /* Backward.  grad_descriptors: [N,H,W,D]; grads[i] receives dL/d params[i] (overwritten, same layout as
  * params[i]).  `saved` is the buffer the matching forward filled; `normalize` must be the forward's flag. */
 int dcn_backbone_backward(dcn_plan* plan, const float* grad_descriptors, const float* const* params,
                           const void* saved, void* workspace, float* const* grads, int normalize, void* stream);
+/* Grouped plan, the two batches' descriptor gradients as separate [N/2,H,W,D] tensors (the two outputs of a
+ * dcn_backbone_forward_pair call receive their gradients separately).  Both backward entry points return DCN_E_INVALID when
+ * `saved` was not filled by a training-mode forward call of this plan in the plan's current arithmetic, or when the tuning
+ * switches (dcn_reload_env) changed since in a way that would make the pass read a tensor that call did not write. */
+int dcn_backbone_backward_pair(dcn_plan* plan, const float* grad_a, const float* grad_b, const float* const* params,
+                               const void* saved, void* workspace, float* const* grads, int normalize, void* stream);
 
 /* =====================================================================================================
  * 3. Individual kernels, exported for unit tests and micro-benchmarks (same conventions).

@@ -100,8 +100,18 @@ struct dcn_plan {
     bool prof_on = false;
     std::vector<hipEvent_t> prof_ev;   // start/stop pairs
     std::vector<int> prof_cat;
-    std::vector<double> prof_flops;
+    std::vector<double> prof_flops;    // algorithmic FLOPs (matrix-core categories) or HBM bytes (streaming categories)
     size_t prof_used = 0;
+    // What a training-mode forward call decided, keyed by its saved arena: the backward pass of that arena must agree with it
+    // (the tuning table or the plan's conv mode may have changed in between -- dcn_reload_env, dcn_plan_set_conv_mode -- and a
+    // backward pass that re-derived the decisions would then read tensors the forward pass never wrote)
+    struct FwdRecord {
+        const void* saved = nullptr;
+        int conv_mode = 0;
+        std::vector<unsigned char> mid_hl_only;   // per convolution: its INPUT activation exists as the saved hl32 image only
+        std::vector<unsigned char> hl_x_written;  // per convolution: the saved hl32 image of its input was written
+    };
+    std::vector<FwdRecord> fwd_records;           // newest last; a handful at most (one per forward call awaiting its backward)
     // backward pass, split-fp16 mode: the weight-gradient GEMMs run on a second, low-priority stream next to the
     // dgrad -> BN-backward chain of the following layer (created on first use; DCN_BACKWARD_OVERLAP=0 disables)
     hipStream_t side = nullptr;
@@ -393,16 +403,19 @@ int build_plan(dcn_plan& p) {
     }
     {   // hl32 weight images (conv_hl_kernels.hip) of the convolutions whose forward or dgrad may take that path (the image of
         // the forward pass and the one of the backward pass share the slot), and ONE transient hl32 activation / gradient image
-        size_t fl = 0;
+        size_t fl = 0, max_img = 0;
         for (ConvL& c : p.convs) {
             if (c.idx == p.stem || c.idx == p.fc || c.d.stride != 1 || ((c.d.cin % 32) != 0 && (c.d.ldc % 32) != 0)) continue;
             c.hl_any = true;
             c.whl = fl;
             fl += align64((size_t)c.d.kh * c.d.kw * std::max((size_t)c.d.cout * c.d.cin, (size_t)c.d.cin * c.d.ldc));
+            // the transient images are those of such a convolution's input (forward) or output gradient (backward): sized by
+            // them, not by the network's largest tensor (the stem's, which never takes this path)
+            max_img = std::max(max_img, std::max((size_t)c.d.n * c.d.hin * c.d.win * c.d.cin, (size_t)c.d.n * c.d.hout * c.d.wout * c.d.ldc));
         }
         p.w_whl = alloc(fl);
-        p.w_hl = alloc(p.max_act);    // image of a block's input / output (forward), of a batch-norm backward's dx (backward)
-        p.w_hl2 = alloc(p.max_act);   // image of a block's mid activation
+        p.w_hl = alloc(max_img);    // image of a block's input / output (forward), of a batch-norm backward's dx (backward)
+        p.w_hl2 = alloc(max_img);   // image of a block's mid activation
     }
     p.w_amax = alloc(p.convs.size());   // abs-max of the gradient w.r.t. each convolution's output
     {   // pixel-blocked split (fp16 hi | lo) copy of one gradient tensor: wgrad's dy operand, written by the BN backward pass
@@ -464,24 +477,46 @@ struct Run {
         return nullptr;
     }
 
-    // bracket one matrix-core launch with events when profiling is on
-    template <class F> int timed(int cat, double flops, F&& launch) {
-        if (!p.prof_on) return launch();
+    // bracket one launch (or one launcher call) with events when profiling is on
+    static bool prof_open(dcn_plan& p, int cat, double work, hipStream_t s) {
         if (p.prof_used + 2 > p.prof_ev.size()) {
             hipEvent_t a, b;
-            if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) return DCN_E_LAUNCH;
+            if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) return false;
             p.prof_ev.push_back(a);
             p.prof_ev.push_back(b);
         }
-        hipEvent_t e0 = p.prof_ev[p.prof_used], e1 = p.prof_ev[p.prof_used + 1];
         p.prof_used += 2;
         p.prof_cat.push_back(cat);
-        p.prof_flops.push_back(flops);
-        if (hipEventRecord(e0, st) != hipSuccess) return DCN_E_LAUNCH;
-        const int rc = launch();
-        if (hipEventRecord(e1, st) != hipSuccess) return DCN_E_LAUNCH;
-        return rc;
+        p.prof_flops.push_back(work);
+        return hipEventRecord(p.prof_ev[p.prof_used - 2], s) == hipSuccess;
     }
+    static bool prof_close(dcn_plan& p, hipStream_t s) { return hipEventRecord(p.prof_ev[p.prof_used - 1], s) == hipSuccess; }
+    template <class F> int timed(int cat, double flops, F&& launch) {
+        if (!p.prof_on) return launch();
+        const dcn::LaunchObserver* outer = dcn::launch_observer;
+        dcn::launch_observer = nullptr;            // (launchers called inside this bracket are part of it)
+        if (!prof_open(p, cat, flops, st)) { dcn::launch_observer = outer; return DCN_E_LAUNCH; }
+        const int rc = launch();
+        const bool ok = prof_close(p, st);
+        dcn::launch_observer = outer;
+        return ok ? rc : DCN_E_LAUNCH;
+    }
+    // While a plan is being profiled, the launchers of elementwise_kernels.hip report every kernel they launch to this
+    // observer (elementwise_kernels.h): category + algorithmic bytes, bracketed by events like the matrix-core launches
+    struct ObserverGuard {
+        dcn::LaunchObserver obs;
+        const dcn::LaunchObserver* outer;
+        bool on;
+        explicit ObserverGuard(dcn_plan& pl) : outer(dcn::launch_observer), on(pl.prof_on) {
+            obs.ctx = &pl;
+            obs.begin = [](void* c, int cat, double bytes, hipStream_t s) { prof_open(*(dcn_plan*)c, cat, bytes, s); };
+            obs.end = [](void* c, hipStream_t s) { prof_close(*(dcn_plan*)c, s); };
+            if (on) dcn::launch_observer = &obs;
+        }
+        ~ObserverGuard() { if (on) dcn::launch_observer = outer; }
+    };
+    // engine-level launches outside the launchers (fills, weight / operand splits, status and bias-gradient kernels)
+    template <class F> int other(F&& launch) { return timed(DCN_PROF_OTHER, 0.0, launch); }
 
     // stream-K scratch for one gather-GEMM launch, or null (no stream-K) when the tile shape selected by the tuning table
     // of the moment needs more than the plan reserved (the table may have changed since the plan was made)
@@ -541,7 +576,7 @@ struct Run {
     // y did not write it (DCN_HL_PRODUCERS=0)
     int ensure_saved_hl(const float* y, float* slot, int64_t rows, int C, int act) {
         if (!slot || dcn::tuning().hl_producers != 0) return DCN_OK;
-        return dcn_split_act_hl32(y, A(act), slot, rows, C, st);
+        return other([&] { return dcn_split_act_hl32(y, A(act), slot, rows, C, st); });
     }
     // ---- pre-split (hl32) path of the wide layers (conv_hl_kernels.hip)
     bool use_hl(const ConvL& c, int dgrad) const {
@@ -588,8 +623,10 @@ struct Run {
             cout.push_back(c.d.cout); taps.push_back(c.d.kh * c.d.kw); cin.push_back(c.d.cin); ldn.push_back(c.d.ldc);
         }
         if (w.empty()) return DCN_OK;
-        return dcn_split_weights_hl32((int)w.size(), w.data(), out.data(), cout.data(), taps.data(), cin.data(), ldn.data(),
-                                      transposed ? 1 : 0, kWeightScale, st);
+        return other([&] {
+            return dcn_split_weights_hl32((int)w.size(), w.data(), out.data(), cout.data(), taps.data(), cin.data(), ldn.data(),
+                                          transposed ? 1 : 0, kWeightScale, st);
+        });
     }
 
     // fp16 hi / lo images of every convolution's weights in one launch: forward images, or the channel-transposed dgrad
@@ -609,11 +646,15 @@ struct Run {
             cout.push_back(c.d.cout); taps.push_back(c.d.kh * c.d.kw); cin.push_back(c.d.cin); ldn.push_back(c.d.ldc);
         }
         if (!transposed)   // forward images: with the weight-range check (status bit 1, see act_status_kernel)
-            return dcn_split_weights_checked_f16((int)w.size(), w.data(), fold_bn ? rs.data() : nullptr, hi.data(), lo.data(),
-                                                 cout.data(), taps.data(), cin.data(), kWeightScale,
-                                                 (int*)(S(p.s_actmax) + p.n_act), st);
-        return dcn_split_weights_scaled_f16((int)w.size(), w.data(), nullptr, hi.data(), lo.data(), cout.data(), taps.data(),
-                                            cin.data(), ldn.data(), 1, kWeightScale, st);
+            return other([&] {
+                return dcn_split_weights_checked_f16((int)w.size(), w.data(), fold_bn ? rs.data() : nullptr, hi.data(), lo.data(),
+                                                     cout.data(), taps.data(), cin.data(), kWeightScale,
+                                                     (int*)(S(p.s_actmax) + p.n_act), st);
+            });
+        return other([&] {
+            return dcn_split_weights_scaled_f16((int)w.size(), w.data(), nullptr, hi.data(), lo.data(), cout.data(), taps.data(),
+                                                cin.data(), ldn.data(), 1, kWeightScale, st);
+        });
     }
 
     // inference: conv + folded batch norm (+ residual) (+ ReLU) in one pass; bias = the BN shift beta - mean * scale
@@ -691,27 +732,38 @@ extern "C" int dcn_plan_profile_begin(dcn_plan* plan) {
     plan->prof_flops.clear();
     return DCN_OK;
 }
-extern "C" int dcn_plan_profile_end3(dcn_plan* plan, double ms[3], int64_t launches[3], double flops[3]) {
-    if (!plan || !ms || !launches || !flops) return DCN_E_INVALID;
+extern "C" int dcn_plan_profile_end_all(dcn_plan* plan, double ms[DCN_PROF_NCAT], int64_t launches[DCN_PROF_NCAT],
+                                        double work[DCN_PROF_NCAT]) {
+    if (!plan || !ms || !launches || !work) return DCN_E_INVALID;
     plan->prof_on = false;
-    for (int c = 0; c < 3; ++c) { ms[c] = 0; launches[c] = 0; flops[c] = 0; }
+    for (int c = 0; c < DCN_PROF_NCAT; ++c) { ms[c] = 0; launches[c] = 0; work[c] = 0; }
+    int rc = DCN_OK;
     for (size_t i = 0; i < plan->prof_cat.size(); ++i) {
         hipEvent_t e0 = plan->prof_ev[2 * i], e1 = plan->prof_ev[2 * i + 1];
-        if (hipEventSynchronize(e1) != hipSuccess) return DCN_E_LAUNCH;
         float t = 0.f;
-        if (hipEventElapsedTime(&t, e0, e1) != hipSuccess) return DCN_E_LAUNCH;
+        if (hipEventSynchronize(e1) != hipSuccess || hipEventElapsedTime(&t, e0, e1) != hipSuccess) { rc = DCN_E_LAUNCH; break; }
         const int c = plan->prof_cat[i];
-        for (int k : {c == 2 ? 0 : c, c == 2 ? 2 : -1}) {   // category 2 (hl32 launches) also counts as a gather-GEMM (0)
+        if (c < 0 || c >= DCN_PROF_NCAT) continue;
+        // category 2 (hl32 launches) also counts as a gather-GEMM (0)
+        for (int k : {c == DCN_PROF_GEMM_HL ? (int)DCN_PROF_GEMM : c, c == DCN_PROF_GEMM_HL ? (int)DCN_PROF_GEMM_HL : -1}) {
             if (k < 0) continue;
             ms[k] += (double)t;
             launches[k] += 1;
-            flops[k] += plan->prof_flops[i];
+            work[k] += plan->prof_flops[i];
         }
     }
     plan->prof_used = 0;
     plan->prof_cat.clear();
     plan->prof_flops.clear();
-    return DCN_OK;
+    return rc;
+}
+extern "C" int dcn_plan_profile_end3(dcn_plan* plan, double ms[3], int64_t launches[3], double flops[3]) {
+    if (!ms || !launches || !flops) return DCN_E_INVALID;
+    double m[DCN_PROF_NCAT], f[DCN_PROF_NCAT];
+    int64_t n[DCN_PROF_NCAT];
+    const int rc = dcn_plan_profile_end_all(plan, m, n, f);
+    for (int c = 0; c < 3; ++c) { ms[c] = m[c]; launches[c] = n[c]; flops[c] = f[c]; }
+    return rc;
 }
 extern "C" int dcn_plan_profile_end(dcn_plan* plan, double ms[2], int64_t launches[2], double flops[2]) {
     if (!ms || !launches || !flops) return DCN_E_INVALID;
@@ -754,21 +806,37 @@ extern "C" size_t dcn_plan_saved_bytes(const dcn_plan* plan) { return plan ? pla
 extern "C" size_t dcn_plan_workspace_bytes(const dcn_plan* plan) { return plan ? plan->ws_floats * sizeof(float) : 0; }
 extern "C" double dcn_plan_forward_flops(const dcn_plan* plan) { return plan ? plan->flops : 0.0; }
 
-extern "C" int dcn_backbone_forward(dcn_plan* plan, const float* image, const float* const* params,
-                                    float* const* bn_running, float momentum, float eps, int training, int normalize,
-                                    float* descriptors, void* saved, void* workspace, void* stream) {
+namespace {
+
+// image_b (optional, grouped plans): the second batch of a forward_pair call -- images [N/2, N) come from there instead of
+// from image + N/2 images (no concatenated copy of the two batches is needed)
+int forward_impl(dcn_plan* plan, const float* image, const float* image_b, const float* const* params,
+                 float* const* bn_running, float momentum, float eps, int training, int normalize,
+                 float* descriptors, void* saved, void* workspace, void* stream) {
     if (!plan || !image || !params || !descriptors || !saved || !workspace) return DCN_E_INVALID;
     dcn_plan& p = *plan;
+    if (image_b && p.groups != 2) return DCN_E_INVALID;
     Run R{p, params, (float*)saved, (float*)workspace, (hipStream_t)stream};
+    Run::ObserverGuard observe(p);
     hipStream_t st = R.st;
     const int N = p.N;
 
     // abs-max slots of the activation tensors (+ the status word behind them)
-    if (dcn::fill_bytes_async(R.S(p.s_actmax), 0, ((size_t)p.n_act + 1) * sizeof(float), st) != DCN_OK) return DCN_E_LAUNCH;
+    DCN_TRY(R.other([&] { return dcn::fill_bytes_async(R.S(p.s_actmax), 0, ((size_t)p.n_act + 1) * sizeof(float), st); }));
     // stem: NCHW(3) -> NHWC(4), weight [w][7][7][3] -> [w][7][7][4]
     const ConvL& stem = p.convs[p.stem];
-    dcn::launch_nchw3_to_nhwc4(image, R.S(p.s_in4), N, p.H * p.W, R.A(stem.in_act), st);
+    if (image_b) {
+        dcn::launch_nchw3_to_nhwc4(image, R.S(p.s_in4), N / 2, p.H * p.W, R.A(stem.in_act), st);
+        dcn::launch_nchw3_to_nhwc4(image_b, R.S(p.s_in4) + (size_t)(N / 2) * p.H * p.W * 4, N / 2, p.H * p.W, R.A(stem.in_act), st);
+    } else {
+        dcn::launch_nchw3_to_nhwc4(image, R.S(p.s_in4), N, p.H * p.W, R.A(stem.in_act), st);
+    }
     dcn::launch_pad_c3_to_c4(R.P(stem.w), R.Wk(p.w_wstem), (int64_t)p.base * 49, st);
+    dcn_plan::FwdRecord rec;
+    rec.saved = saved;
+    rec.conv_mode = p.conv_mode;
+    rec.mid_hl_only.assign(p.convs.size(), 0);
+    rec.hl_x_written.assign(p.convs.size(), 0);
     const bool fused_eval = !training && p.conv_mode == DCN_CONV_F16X3;
     const bool f16_mode = p.conv_mode == DCN_CONV_F16X3;
     if (fused_eval) {
@@ -813,7 +881,7 @@ extern "C" int dcn_backbone_forward(dcn_plan* plan, const float* image, const fl
     if (p.conv_mode == DCN_CONV_F16X3 && dcn::tuning().stem8 != 0 && dcn::tuning().gemm_uni != 0 && stem.d.win >= 8 && stem.d.kh == 7 &&
         stem.d.cin == 4 && (int64_t)stem.d.n * stem.d.hin * stem.d.win * 16 <= ((int64_t)1 << 31)) {
         _Float16* hi = (_Float16*)R.Wk(p.w_stem8);
-        DCN_TRY(dcn_split_stem_weights_f16(R.Wk(p.w_wstem), hi, hi + (size_t)p.base * 224, p.base, kWeightScale, st));
+        DCN_TRY(R.other([&] { return dcn_split_stem_weights_f16(R.Wk(p.w_wstem), hi, hi + (size_t)p.base * 224, p.base, kWeightScale, st); }));
         R.stem8 = true;
     }
     DCN_TRY(R.conv_bn(stem, R.S(p.s_in4), R.Wk(p.w_wstem), bn_running, momentum, eps, training, p.blocks[0].act_in));
@@ -835,8 +903,10 @@ extern "C" int dcn_backbone_forward(dcn_plan* plan, const float* image, const fl
     if (training && f16_mode && p.blocks[0].has_hl_in) {   // (the first block's input is the max-pool output: no apply pass writes it)
         const BlockL& b0 = p.blocks[0];
         R.hl_saved.emplace_back(R.S(b0.in), R.S(b0.hl_in));
-        DCN_TRY(dcn_split_act_hl32(R.S(b0.in), R.A(b0.act_in), R.S(b0.hl_in), b0.in_rows, b0.in_c, st));
+        DCN_TRY(R.other([&] { return dcn_split_act_hl32(R.S(b0.in), R.A(b0.act_in), R.S(b0.hl_in), b0.in_rows, b0.in_c, st); }));
     }
+    if (training && f16_mode)   // every saved hl32 image the plan reserved is written by this call (producers or stand-alone passes)
+        for (const ConvL& c : p.convs) rec.hl_x_written[c.idx] = c.has_hl_x ? 1 : 0;
     for (const BlockL& blk : p.blocks) {
         const float* in = R.S(blk.in);
         const float* cur = in;
@@ -857,6 +927,7 @@ extern "C" int dcn_backbone_forward(dcn_plan* plan, const float* image, const fl
                 // pass takes the ReLU mask).  Both on the hl32 kernels: the image in the saved arena is the only copy written
                 const bool hl_only = hl && slot && hl == (void*)slot && (b.C % 32) == 0 && dcn::tuning().hl_only_mid != 0 &&
                                      R.use_hl(nxt, 0) && R.use_wgrad_hl(nxt);
+                rec.mid_hl_only[nxt.idx] = hl_only ? 1 : 0;
                 dcn::launch_bn_apply(R.S(c.x), s, nullptr, nullptr, 1, hl_only ? nullptr : R.S(blk.mid[i]), R.M(blk.mid[i]), b.C,
                                      b.rows, p.groups, st, hl, R.A(blk.act_mid[i]));
                 DCN_TRY(R.ensure_saved_hl(R.S(blk.mid[i]), slot, b.rows, b.C, blk.act_mid[i]));
@@ -890,22 +961,70 @@ extern "C" int dcn_backbone_forward(dcn_plan* plan, const float* image, const fl
     // scoring layer (1x1 conv + bias) into the padded low-resolution map, then bilinear upsample
     const ConvL& fc = p.convs[p.fc];
     const size_t low_bytes = (size_t)N * p.hl * p.wl * p.Dp * sizeof(float);
-    if (dcn::fill_bytes_async(R.S(p.s_low), 0, low_bytes, st) != DCN_OK) return DCN_E_LAUNCH;
+    DCN_TRY(R.other([&] { return dcn::fill_bytes_async(R.S(p.s_low), 0, low_bytes, st); }));
     DCN_TRY(R.conv_fwd(fc, R.S(p.blocks.back().out), R.P(fc.w), R.P(fc.b), R.S(p.s_low), nullptr));
     dcn::launch_upsample_fwd(R.S(p.s_low), N, p.hl, p.wl, p.Dp, p.D, p.H, p.W, normalize, descriptors, st);
-    hipLaunchKernelGGL(act_status_kernel, dim3(1), dim3(64), 0, st, (const float*)R.S(p.s_actmax), p.n_act,
-                       (int*)(R.S(p.s_actmax) + p.n_act));
+    DCN_TRY(R.other([&] {
+        hipLaunchKernelGGL(act_status_kernel, dim3(1), dim3(64), 0, st, (const float*)R.S(p.s_actmax), p.n_act,
+                           (int*)(R.S(p.s_actmax) + p.n_act));
+        return dcn::check_launch();
+    }));
+    if (training) {   // what the backward pass of this arena must agree with (dcn_plan::FwdRecord)
+        for (size_t i = 0; i < p.fwd_records.size();)
+            if (p.fwd_records[i].saved == saved) p.fwd_records.erase(p.fwd_records.begin() + i);
+            else ++i;
+        if (p.fwd_records.size() >= 8) p.fwd_records.erase(p.fwd_records.begin());
+        p.fwd_records.push_back(std::move(rec));
+    }
     return dcn::check_launch();
 }
 
-extern "C" int dcn_backbone_backward(dcn_plan* plan, const float* grad_descriptors, const float* const* params,
-                                     const void* saved, void* workspace, float* const* grads, int normalize,
-                                     void* stream) {
+}  // namespace
+
+extern "C" int dcn_backbone_forward(dcn_plan* plan, const float* image, const float* const* params,
+                                    float* const* bn_running, float momentum, float eps, int training, int normalize,
+                                    float* descriptors, void* saved, void* workspace, void* stream) {
+    return forward_impl(plan, image, nullptr, params, bn_running, momentum, eps, training, normalize, descriptors, saved,
+                        workspace, stream);
+}
+extern "C" int dcn_backbone_forward_pair(dcn_plan* plan, const float* image_a, const float* image_b,
+                                         const float* const* params, float* const* bn_running, float momentum, float eps,
+                                         int training, int normalize, float* descriptors, void* saved, void* workspace,
+                                         void* stream) {
+    if (!image_b) return DCN_E_INVALID;
+    return forward_impl(plan, image_a, image_b, params, bn_running, momentum, eps, training, normalize, descriptors, saved,
+                        workspace, stream);
+}
+
+namespace {
+
+// grad_b (optional, grouped plans): the gradient of the second batch's descriptors (images [N/2, N)) when the two
+// gradients of a forward_pair call are separate tensors
+int backward_impl(dcn_plan* plan, const float* grad_descriptors, const float* grad_b, const float* const* params,
+                  const void* saved, void* workspace, float* const* grads, int normalize, void* stream) {
     if (!plan || !grad_descriptors || !params || !saved || !workspace || !grads) return DCN_E_INVALID;
     dcn_plan& p = *plan;
+    if (grad_b && p.groups != 2) return DCN_E_INVALID;
     Run R{p, params, (float*)saved, (float*)workspace, (hipStream_t)stream};
+    Run::ObserverGuard observe(p);
     hipStream_t st = R.st;
     const int N = p.N;
+    // the forward call that filled this arena: its decisions must still hold (see dcn_plan::FwdRecord)
+    dcn_plan::FwdRecord rec;
+    {
+        bool found = false;
+        for (size_t i = p.fwd_records.size(); i-- > 0;)   // (kept: the same arena may be differentiated again)
+            if (p.fwd_records[i].saved == saved) {
+                rec = p.fwd_records[i];
+                found = true;
+                break;
+            }
+        if (!found || rec.conv_mode != p.conv_mode) return DCN_E_INVALID;   // no training-mode forward of this arena, or another arithmetic
+        for (const ConvL& c : p.convs) {
+            if (R.use_wgrad_hl(c) && !rec.hl_x_written[c.idx]) return DCN_E_INVALID;    // would read an hl32 image nobody wrote
+            if (rec.mid_hl_only[c.idx] && !R.use_wgrad_hl(c)) return DCN_E_INVALID;     // would read an fp32 activation nobody wrote
+        }
+    }
     float* part = R.Wk(p.w_part);
     float* k123 = R.Wk(p.w_k123);
     float* wt = R.Wk(p.w_wt);
@@ -987,7 +1106,7 @@ extern "C" int dcn_backbone_backward(dcn_plan* plan, const float* grad_descripto
         if (R.use_wgrad_hl(c)) {   // both operands as hl32 tensors: the saved image of the input, the image of dx
             const float* ximg = R.S(c.hl_x);
             if (hl_dx_of != dx) {  // (DCN_HL_PRODUCERS=0, or a gradient that no batch-norm backward produced)
-                DCN_TRY(dcn_split_act_hl32(dx, amax + c.idx, hlimg[cur], (int64_t)c.d.n * c.d.hout * c.d.wout, c.d.ldc, st));
+                DCN_TRY(R.other([&] { return dcn_split_act_hl32(dx, amax + c.idx, hlimg[cur], (int64_t)c.d.n * c.d.hout * c.d.wout, c.d.ldc, st); }));
                 if (overlap) RT(hipEventRecord(p.ev_dq[cur], st));
                 hl_dx_of = dx;
             }
@@ -1005,7 +1124,7 @@ extern "C" int dcn_backbone_backward(dcn_plan* plan, const float* grad_descripto
         // The activation operand is the fp32 tensor itself, split on the fly inside the kernel: measured faster than a
         // split pass + pre-split operand on every layer of ResNet34 / ResNet50 (the pass costs more than the conversions).
         if (dq_of != dx) {   // (BN backward emits it directly; only the scoring layer's gradient needs the separate pass)
-            DCN_TRY(dcn_split_grad_blocked_f16(dx, c.d.n * c.d.hout * c.d.wout, c.d.ldc, amax + c.idx, dqbuf[0], st));
+            DCN_TRY(R.other([&] { return dcn_split_grad_blocked_f16(dx, c.d.n * c.d.hout * c.d.wout, c.d.ldc, amax + c.idx, dqbuf[0], st); }));
             return R.timed(1, c.flops, [&] {
                 return dcn_conv_wgrad_f16(&c.d, in, 1, R.A(c.in_act), dqbuf[0], amax + c.idx, dw, slab, st);
             });
@@ -1026,7 +1145,7 @@ extern "C" int dcn_backbone_backward(dcn_plan* plan, const float* grad_descripto
     auto dgrad = [&](const ConvL& c, const float* dx, const float* add, float* din, const ConvL* bn_of = nullptr,
                      const float* relu_out = nullptr) -> int {
         if (!f16) {
-            DCN_TRY(dcn_transpose_weight(R.P(c.w), wt, c.d.cout, c.d.kh * c.d.kw, c.d.cin, c.d.ldc, st));
+            DCN_TRY(R.other([&] { return dcn_transpose_weight(R.P(c.w), wt, c.d.cout, c.d.kh * c.d.kw, c.d.cin, c.d.ldc, st); }));
             return R.timed(0, c.flops, [&] { return dcn_conv_dgrad(&c.d, dx, wt, add, din, R.SK(c, 1), st); });
         }
         if (fuse_red && bn_of) {
@@ -1063,21 +1182,31 @@ extern "C" int dcn_backbone_backward(dcn_plan* plan, const float* grad_descripto
         DCN_TRY(R.split_hl_weights(true));
     }
     // split-fp16 mode: every gradient tensor that feeds a convolution records its abs-max (pre-scale selection)
-    if (f16 && dcn::fill_bytes_async(amax, 0, p.convs.size() * sizeof(float), st) != DCN_OK) return DCN_E_LAUNCH;
+    if (f16) DCN_TRY(R.other([&] { return dcn::fill_bytes_async(amax, 0, p.convs.size() * sizeof(float), st); }));
 
     // ---- upsample + scoring layer
     float* glow = R.Wk(p.w_glow);
     if (normalize) {  // network.py:256-259 was fused into the forward upsample: undo it first
-        dcn::launch_normalize_bwd(R.S(p.s_low), N, p.hl, p.wl, p.Dp, p.D, p.H, p.W, grad_descriptors, R.Wk(p.w_gnorm), st);
+        if (grad_b) {
+            const size_t lo = (size_t)(N / 2) * p.hl * p.wl * p.Dp, hi = (size_t)(N / 2) * p.H * p.W * p.D;
+            dcn::launch_normalize_bwd(R.S(p.s_low), N / 2, p.hl, p.wl, p.Dp, p.D, p.H, p.W, grad_descriptors, R.Wk(p.w_gnorm), st);
+            dcn::launch_normalize_bwd(R.S(p.s_low) + lo, N / 2, p.hl, p.wl, p.Dp, p.D, p.H, p.W, grad_b, R.Wk(p.w_gnorm) + hi, st);
+            grad_b = nullptr;
+        } else {
+            dcn::launch_normalize_bwd(R.S(p.s_low), N, p.hl, p.wl, p.Dp, p.D, p.H, p.W, grad_descriptors, R.Wk(p.w_gnorm), st);
+        }
         grad_descriptors = R.Wk(p.w_gnorm);
     }
     dcn::launch_upsample_bwd(grad_descriptors, N, p.hl, p.wl, p.Dp, p.D, p.H, p.W, R.Wk(p.w_ups), glow,
-                             f16 ? amax + p.convs[p.fc].idx : nullptr, st);
+                             f16 ? amax + p.convs[p.fc].idx : nullptr, st, grad_b);
     const ConvL& fc = p.convs[p.fc];
     const float* feat = R.S(p.blocks.back().out);
     DCN_TRY(wgrad(fc, feat, glow, grads[fc.w]));
-    hipLaunchKernelGGL(colsum_kernel, dim3(p.D), dim3(256), 0, st, (const float*)glow, (int64_t)N * p.hl * p.wl, p.Dp,
-                       grads[fc.b]);
+    DCN_TRY(R.other([&] {
+        hipLaunchKernelGGL(colsum_kernel, dim3(p.D), dim3(256), 0, st, (const float*)glow, (int64_t)N * p.hl * p.wl, p.Dp,
+                           grads[fc.b]);
+        return dcn::check_launch();
+    }));
     float* dout = R.Wk(p.w_buf[0]);   // gradient w.r.t. the current block's output
     float* dnext = R.Wk(p.w_buf[1]);  // gradient w.r.t. its input (swapped after every block)
     float* gbuf = R.Wk(p.w_buf[2]);   // relu-masked dout (residual branch)
@@ -1169,4 +1298,18 @@ extern "C" int dcn_backbone_backward(dcn_plan* plan, const float* grad_descripto
     if (p.bucket_state == 1) RT(hipEventRecord(p.ev_bucket.back(), st));   // last bucket: the whole backward pass
     if (rt_fail) return DCN_E_LAUNCH;
     return dcn::check_launch();
+}
+
+}  // namespace
+
+extern "C" int dcn_backbone_backward(dcn_plan* plan, const float* grad_descriptors, const float* const* params,
+                                     const void* saved, void* workspace, float* const* grads, int normalize,
+                                     void* stream) {
+    return backward_impl(plan, grad_descriptors, nullptr, params, saved, workspace, grads, normalize, stream);
+}
+extern "C" int dcn_backbone_backward_pair(dcn_plan* plan, const float* grad_a, const float* grad_b,
+                                          const float* const* params, const void* saved, void* workspace,
+                                          float* const* grads, int normalize, void* stream) {
+    if (!grad_b) return DCN_E_INVALID;
+    return backward_impl(plan, grad_a, grad_b, params, saved, workspace, grads, normalize, stream);
 }

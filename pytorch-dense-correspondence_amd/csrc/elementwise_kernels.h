@@ -4,6 +4,25 @@
 
 namespace dcn {
 
+// Launch observer (bench.py's roofline_elementwise / kernel_ms_sum): while a plan is being profiled
+// (dcn_plan_profile_begin) the engine installs one for the calling thread, and every launcher below reports each kernel
+// it launches as begin(category, algorithmic HBM bytes) ... end() around the launch -- the engine brackets it with HIP
+// events on the launch stream.  Null (the default): no cost.  Categories: DCN_PROF_* of include/dcn_hip.h.
+struct LaunchObserver {
+    void* ctx;
+    void (*begin)(void* ctx, int cat, double bytes, hipStream_t st);
+    void (*end)(void* ctx, hipStream_t st);
+};
+extern thread_local const LaunchObserver* launch_observer;
+struct ObservedLaunch {   // RAII bracket of ONE kernel launch
+    hipStream_t st;
+    const LaunchObserver* o;
+    ObservedLaunch(int cat, double bytes, hipStream_t s) : st(s), o(launch_observer) { if (o) o->begin(o->ctx, cat, bytes, st); }
+    ~ObservedLaunch() { if (o) o->end(o->ctx, st); }
+    ObservedLaunch(const ObservedLaunch&) = delete;
+    ObservedLaunch& operator=(const ObservedLaunch&) = delete;
+};
+
 // absmax (optional): raised to max |img|
 void launch_nchw3_to_nhwc4(const float* img, float* out, int n, int hw, float* absmax, hipStream_t st);
 void launch_pad_c3_to_c4(const float* w, float* wp, int64_t rows, hipStream_t st);
@@ -57,7 +76,8 @@ size_t upsample_bwd_tmp_bytes(int n, int hl, int w, int d);
 // gv = gradient w.r.t. the un-normalised upsampled map, given gout = gradient w.r.t. the L2-normalised one
 void launch_normalize_bwd(const float* low, int n, int hl, int wl, int ldl, int d, int h, int w, const float* gout,
                           float* gv, hipStream_t st);
+// gout_b (optional, n even): the gradient of images [n / 2, n) lives in a tensor of its own (forward_pair's second output)
 void launch_upsample_bwd(const float* gout, int n, int hl, int wl, int ldl, int d, int h, int w, float* tmp,
-                         float* glow, float* absmax, hipStream_t st);
+                         float* glow, float* absmax, hipStream_t st, const float* gout_b = nullptr);
 
 }  // namespace dcn

@@ -707,22 +707,29 @@ static inline unsigned blocks_for(int64_t n, int cap = 0) {
 }
 constexpr int kGridCap = 256 * 8;  // grid-stride kernels: 8 workgroups per CU
 
+thread_local const LaunchObserver* launch_observer = nullptr;
+
 void launch_nchw3_to_nhwc4(const float* img, float* out, int n, int hw, float* absmax, hipStream_t st) {
     const int64_t total = (int64_t)n * hw;
+    ObservedLaunch obs(DCN_PROF_RESAMPLE, 28.0 * (double)total, st);   // 3 floats in, 4 out per pixel
     hipLaunchKernelGGL(nchw3_to_nhwc4_kernel, dim3(blocks_for(total, kGridCap)), dim3(256), 0, st, img, out, hw, total, absmax);
 }
 void launch_pad_c3_to_c4(const float* w, float* wp, int64_t rows, hipStream_t st) {
+    ObservedLaunch obs(DCN_PROF_OTHER, 28.0 * (double)rows, st);
     hipLaunchKernelGGL(pad_c3_to_c4_kernel, dim3(blocks_for(rows)), dim3(256), 0, st, w, wp, rows);
 }
 void launch_unpad_c4_to_c3(const float* wp, float* w, int64_t rows, hipStream_t st) {
+    ObservedLaunch obs(DCN_PROF_OTHER, 28.0 * (double)rows, st);
     hipLaunchKernelGGL(unpad_c4_to_c3_kernel, dim3(blocks_for(rows)), dim3(256), 0, st, wp, w, rows);
 }
 void launch_pad_rows(const float* src, float* dst, int64_t rows, int d, int ld, hipStream_t st) {
+    ObservedLaunch obs(DCN_PROF_OTHER, 4.0 * (double)rows * (d + ld), st);
     hipLaunchKernelGGL(pad_rows_kernel, dim3(blocks_for(rows * ld)), dim3(256), 0, st, src, dst, rows, d, ld);
 }
 void launch_bn_finalize(const float* partial, int tiles_per_group, int groups, int C, double count_per_group,
                         const float* gamma, const float* beta, float* rmean, float* rvar, float momentum, float eps,
                         int training, float* stats, float* out_bound, const float* res_bound, hipStream_t st) {
+    ObservedLaunch obs(DCN_PROF_BN_FINALIZE, training ? 12.0 * (double)tiles_per_group * groups * C : 0.0, st);
     hipLaunchKernelGGL(bn_finalize_kernel, dim3(ceil_div(C, 4)), dim3(256), 0, st, partial, tiles_per_group, groups, C,
                        count_per_group, gamma, beta, rmean, rvar, momentum, eps, training, stats, stats + C, stats + 2 * C,
                        stats + 3 * C, 4 * C, out_bound, res_bound);
@@ -732,6 +739,9 @@ void launch_bn_apply(const float* x, const float* stats1, const float* res, cons
                      const float* hl_absmax) {
     const int64_t total4 = rows * (C / 4);
     if ((C % 32) != 0 || !hl_absmax) hl_out = nullptr;
+    // bytes per element: x (+ the residual) in; y, the hl32 image (the size of y) and a quarter byte of ReLU mask out
+    ObservedLaunch obs(DCN_PROF_BN_APPLY, (double)rows * C * (4.0 + (res ? 4.0 : 0.0) + (y ? 4.0 : 0.0) + (hl_out ? 4.0 : 0.0) +
+                                                             (relu_mask ? 0.25 : 0.0)), st);
     hipLaunchKernelGGL(bn_apply_kernel, dim3(blocks_for(total4, kGridCap)), dim3(256), 0, st, x, stats1, stats1 + C, res,
                        stats2, stats2 ? stats2 + C : nullptr, relu, y, relu_mask, C / 4, total4, total4 / groups, 4 * C,
                        (dcnsplit::u32x2*)hl_out, hl_absmax);
@@ -752,16 +762,25 @@ void launch_bn_bwd(const float* dy, const float* relu_out, const unsigned char* 
     const float* mean = stats + 2 * C;
     const float* invstd = stats + 3 * C;
     int chunks = reduced_tiles_per_group;
+    // bytes per element read by both streaming passes: dy (+ dy2), x, the ReLU mask byte per float4 (or the activation)
+    const double in_bytes = 8.0 + (dy2 ? 4.0 : 0.0) + (relu_mask ? 0.25 : (relu_out ? 4.0 : 0.0));
     if (chunks <= 0) {
         chunks = bn_bwd_chunks(rpg);   // per group
         const int rpc = (int)ceil_div64(rpg, chunks);
+        ObservedLaunch obs(DCN_PROF_BN_BWD_REDUCE, (double)rows * C * in_bytes, st);
         hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(ceil_div(C, 64), chunks * groups), dim3(256), 0, st, dy, dy2, relu_out,
                            relu_mask, x, mean, invstd, C, rpg, chunks, 4 * C, rpc, partial);
     }
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(ceil_div(C, 4)), dim3(256), 0, st, (const float*)partial, chunks,
-                       groups, C, (double)rpg, gamma, invstd, 4 * C, dgamma, dbeta, k123, absmax);
+    {
+        ObservedLaunch obs(DCN_PROF_BN_FINALIZE, 16.0 * (double)chunks * groups * C, st);
+        hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(ceil_div(C, 4)), dim3(256), 0, st, (const float*)partial, chunks,
+                           groups, C, (double)rpg, gamma, invstd, 4 * C, dgamma, dbeta, k123, absmax);
+    }
     const int64_t total4 = rows * (C / 4);
     if ((dq || (hl_dx && (C % 32) == 0)) && absmax) {
+        const bool hl = hl_dx && (C % 32) == 0;
+        ObservedLaunch obs(DCN_PROF_BN_BWD_APPLY, (double)rows * C * (in_bytes + ((hl && !keep_dx) ? 0.0 : 4.0) + (g_out ? 4.0 : 0.0) +
+                                                                      (dq ? 4.0 : 0.0) + (hl ? 4.0 : 0.0)), st);
         hipLaunchKernelGGL(bn_bwd_apply_blocked_kernel, dim3(blocks_for(((rows + 3) / 4) * (C / 4), kGridCap)), dim3(256), 0, st,
                            dy, dy2, relu_out, relu_mask, x, mean, invstd, (const float*)k123, (const float*)(k123 + C),
                            (const float*)(k123 + 2 * C), (hl_dx && (C % 32) == 0 && !keep_dx) ? nullptr : dx, g_out,
@@ -769,16 +788,21 @@ void launch_bn_bwd(const float* dy, const float* relu_out, const unsigned char* 
                            (C % 32) == 0 ? (dcnsplit::u32x2*)hl_dx : nullptr);
         return;
     }
+    ObservedLaunch obs(DCN_PROF_BN_BWD_APPLY, (double)rows * C * (in_bytes + 4.0 + (g_out ? 4.0 : 0.0)), st);
     hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(blocks_for(total4, kGridCap)), dim3(256), 0, st, dy, dy2, relu_out, relu_mask,
                        x, mean, invstd, (const float*)k123, (const float*)(k123 + C), (const float*)(k123 + 2 * C), dx, g_out,
                        C / 4, total4, total4 / groups, 4 * C, 3 * C);
 }
 void launch_add(const float* a, const float* b, float* out, int64_t n, hipStream_t st) {
+    ObservedLaunch obs(DCN_PROF_OTHER, 12.0 * (double)n, st);
     hipLaunchKernelGGL(add_kernel, dim3(blocks_for(n / 4, kGridCap)), dim3(256), 0, st, a, b, out, n / 4);
 }
 void launch_maxpool_fwd(const float* in, float* out, unsigned char* argmax, int n, int hin, int win, int hout,
                         int wout, int C, hipStream_t st, const float* bn_stats, int groups, unsigned char* relu_mask) {
     const int64_t total4 = (int64_t)n * hout * wout * (C / 4);
+    // input read once (the 3x3 / 2 windows' overlap is served by the caches), pooled output + argmax bytes (+ the sign mask) out
+    ObservedLaunch obs(DCN_PROF_RESAMPLE, (double)n * C * ((double)hin * win * (4.0 + (bn_stats && relu_mask ? 0.25 : 0.0)) +
+                                                          (double)hout * wout * (4.0 + (argmax ? 1.0 : 0.0))), st);
     hipLaunchKernelGGL(maxpool_fwd_kernel, dim3(blocks_for(total4)), dim3(256), 0, st, in, out, argmax, hin, win, hout,
                        wout, C / 4, total4, bn_stats, bn_stats ? bn_stats + C : nullptr, 4 * C,
                        (int64_t)(groups > 1 ? n / groups : n), bn_stats ? relu_mask : nullptr);
@@ -786,6 +810,7 @@ void launch_maxpool_fwd(const float* in, float* out, unsigned char* argmax, int 
 void launch_maxpool_bwd(const float* gout, const unsigned char* argmax, float* gin, int n, int hin, int win, int hout,
                         int wout, int C, hipStream_t st, const float* gout2) {
     const int64_t total4 = (int64_t)n * hin * win * (C / 4);
+    ObservedLaunch obs(DCN_PROF_RESAMPLE, (double)n * C * ((double)hin * win * 4.0 + (double)hout * wout * (5.0 + (gout2 ? 4.0 : 0.0))), st);
     hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(blocks_for(total4)), dim3(256), 0, st, gout, gout2, argmax, gin, hin, win,
                        hout, wout, C / 4, total4);
 }
@@ -793,6 +818,7 @@ static inline float ac_scale(int in, int out) { return out > 1 ? (float)(in - 1)
 void launch_upsample_fwd(const float* low, int n, int hl, int wl, int ldl, int d, int h, int w, int normalize,
                          float* out, hipStream_t st) {
     const int64_t total = (int64_t)n * h * w;
+    ObservedLaunch obs(DCN_PROF_RESAMPLE, 4.0 * ((double)n * hl * wl * ldl + (double)total * d), st);
     hipLaunchKernelGGL(upsample_fwd_kernel, dim3(blocks_for(total)), dim3(256), 0, st, low, hl, wl, ldl, d, h, w,
                        ac_scale(hl, h), ac_scale(wl, w), normalize, out, total);
 }
@@ -800,18 +826,35 @@ size_t upsample_bwd_tmp_bytes(int n, int hl, int w, int d) { return (size_t)n * 
 void launch_normalize_bwd(const float* low, int n, int hl, int wl, int ldl, int d, int h, int w, const float* gout,
                           float* gv, hipStream_t st) {
     const int64_t total = (int64_t)n * h * w;
+    ObservedLaunch obs(DCN_PROF_RESAMPLE, 4.0 * ((double)n * hl * wl * ldl + 2.0 * (double)total * d), st);
     hipLaunchKernelGGL(normalize_bwd_kernel, dim3(blocks_for(total)), dim3(256), 0, st, low, hl, wl, ldl, d, h, w,
                        ac_scale(hl, h), ac_scale(wl, w), gout, gv, total);
 }
 void launch_upsample_bwd(const float* gout, int n, int hl, int wl, int ldl, int d, int h, int w, float* tmp,
-                         float* glow, float* absmax, hipStream_t st) {
+                         float* glow, float* absmax, hipStream_t st, const float* gout_b) {
     const int64_t t1 = (int64_t)n * hl * w * d;
-    hipLaunchKernelGGL(upsample_bwd_rows_kernel, dim3(blocks_for(t1)), dim3(256), 0, st, gout, hl, d, h, w,
-                       ac_scale(hl, h), tmp, t1);
+    if (gout_b) {   // two halves, two launches of the row pass (the column pass reads the common intermediate)
+        const int64_t th = t1 / 2;
+        for (int k = 0; k < 2; ++k) {
+            ObservedLaunch obs(DCN_PROF_RESAMPLE, 4.0 * ((double)(n / 2) * h * w * d + (double)th), st);
+            hipLaunchKernelGGL(upsample_bwd_rows_kernel, dim3(blocks_for(th)), dim3(256), 0, st, k ? gout_b : gout, hl, d, h, w,
+                               ac_scale(hl, h), tmp + k * th, th);
+        }
+    } else {
+        ObservedLaunch obs(DCN_PROF_RESAMPLE, 4.0 * ((double)n * h * w * d + (double)t1), st);   // the dense gradient map in
+        hipLaunchKernelGGL(upsample_bwd_rows_kernel, dim3(blocks_for(t1)), dim3(256), 0, st, gout, hl, d, h, w,
+                           ac_scale(hl, h), tmp, t1);
+    }
     const int64_t t2 = (int64_t)n * hl * wl * ldl;
-    hipLaunchKernelGGL(upsample_bwd_cols_kernel, dim3(blocks_for(t2)), dim3(256), 0, st, (const float*)tmp, hl, wl, ldl,
-                       d, w, ac_scale(wl, w), glow, t2);
-    if (absmax) hipLaunchKernelGGL(absmax_kernel, dim3(blocks_for(t2, 256)), dim3(256), 0, st, (const float*)glow, t2, absmax);
+    {
+        ObservedLaunch obs(DCN_PROF_RESAMPLE, 4.0 * ((double)t1 + (double)t2), st);
+        hipLaunchKernelGGL(upsample_bwd_cols_kernel, dim3(blocks_for(t2)), dim3(256), 0, st, (const float*)tmp, hl, wl, ldl,
+                           d, w, ac_scale(wl, w), glow, t2);
+    }
+    if (absmax) {
+        ObservedLaunch obs(DCN_PROF_OTHER, 4.0 * (double)t2, st);
+        hipLaunchKernelGGL(absmax_kernel, dim3(blocks_for(t2, 256)), dim3(256), 0, st, (const float*)glow, t2, absmax);
+    }
 }
 
 }  // namespace dcn

@@ -67,9 +67,15 @@ SYMBOLS = {
                                      ctypes.POINTER(ctypes.c_double)]),
     "dcn_plan_profile_end3": (c_int, [c_void_p, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(c_int64),
                                       ctypes.POINTER(ctypes.c_double)]),
+    "dcn_plan_profile_end_all": (c_int, [c_void_p, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(c_int64),
+                                         ctypes.POINTER(ctypes.c_double)]),
     "dcn_backbone_forward": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_float, c_int, c_int, c_void_p,
                                      c_void_p, c_void_p, c_void_p]),
     "dcn_backbone_backward": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
+    "dcn_backbone_forward_pair": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_float, c_int, c_int,
+                                          c_void_p, c_void_p, c_void_p, c_void_p]),
+    "dcn_backbone_backward_pair": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int,
+                                           c_void_p]),
     "dcn_conv_forward": (c_int, [ctypes.POINTER(ConvDesc), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                  c_void_p]),
     "dcn_conv_gemm_workspace": (c_size_t, [ctypes.POINTER(ConvDesc), c_int]),

@@ -52,6 +52,20 @@ class Plan(object):
         self.grad_buckets = [(self.grad_offsets[a], self.grad_offsets[b]) for a, b in zip(firsts, ends)]
         self.num_activation_slots = int(lib.dcn_plan_num_activation_slots(handle))
         self.activation_absmax_offset = int(lib.dcn_plan_activation_absmax_offset(handle))
+        # the <= 3 alignment floats behind a gradient tensor whose size is not a multiple of 4 (never written by the engine)
+        self._pad_positions = [o + n + k for o, n, e in zip(self.grad_offsets[:-1], self.param_numel, self.grad_offsets[1:])
+                               for k in range(e - o - n)]
+        self._pad_index = {}
+
+    def grad_pad_index(self, dev):
+        """int64 device tensor with the positions of the flat gradient buffer's alignment floats (or None): ONE index_fill_
+        zeroes them, instead of one fill launch per odd-sized tensor."""
+        if not self._pad_positions:
+            return None
+        idx = self._pad_index.get(dev)
+        if idx is None:
+            idx = self._pad_index[dev] = torch.tensor(self._pad_positions, dtype=torch.int64, device=dev)
+        return idx
 
     @property
     def conv_mode(self):
@@ -78,15 +92,20 @@ class Plan(object):
     def profile_begin(self):
         _lib.check(_lib.get().dcn_plan_profile_begin(self.handle), "dcn_plan_profile_begin")
 
+    PROFILE_CATEGORIES = ("conv_gemm", "conv_wgrad", "conv_gemm_hl", "bn_apply", "bn_bwd_reduce", "bn_bwd_apply", "bn_finalize",
+                          "resample", "other")   # DCN_PROF_* of include/dcn_hip.h
+
     def profile_end(self):
-        """-> {"conv_gemm": (ms, launches, flops), "conv_wgrad": (...), "conv_gemm_hl": (...)} since profile_begin
-        (synchronises).  "conv_gemm_hl" is the part of "conv_gemm" that ran on the pre-split (hl32) LDS-DMA kernel."""
-        ms = (ctypes.c_double * 3)()
-        n = (ctypes.c_int64 * 3)()
-        fl = (ctypes.c_double * 3)()
-        _lib.check(_lib.get().dcn_plan_profile_end3(self.handle, ms, n, fl), "dcn_plan_profile_end3")
-        return {"conv_gemm": (ms[0], int(n[0]), fl[0]), "conv_wgrad": (ms[1], int(n[1]), fl[1]),
-                "conv_gemm_hl": (ms[2], int(n[2]), fl[2])}
+        """-> {category: (ms, launches, work)} of EVERY engine launch since profile_begin (synchronises).  work = algorithmic
+        FLOPs for "conv_gemm" (forward + dgrad), "conv_wgrad" and "conv_gemm_hl" (the part of "conv_gemm" on the pre-split
+        hl32 kernel), algorithmic HBM bytes for the streaming passes ("bn_apply", "bn_bwd_reduce", "bn_bwd_apply", "resample" =
+        max pool / upsample / input layout), 0 for "bn_finalize" (latency-bound) and "other" (fills, weight splits ...)."""
+        k = len(self.PROFILE_CATEGORIES)
+        ms = (ctypes.c_double * k)()
+        n = (ctypes.c_int64 * k)()
+        fl = (ctypes.c_double * k)()
+        _lib.check(_lib.get().dcn_plan_profile_end_all(self.handle, ms, n, fl), "dcn_plan_profile_end_all")
+        return {name: (ms[i], int(n[i]), fl[i]) for i, name in enumerate(self.PROFILE_CATEGORIES)}
 
     def __del__(self):
         try:
@@ -153,13 +172,19 @@ def _arena(nbytes, dev):
 
 class _BackboneFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, image, plan, bn_running, training, normalize, momentum, eps, *params):
+    def forward(ctx, image, image_b, plan, bn_running, training, normalize, momentum, eps, *params):
+        """image_b (grouped plans): the second batch as a tensor of its own -- images [N/2, N) -- instead of a concatenated copy."""
         lib = _lib.get()
         _lib.require_device(image, *params)
-        if image.dim() != 4 or image.shape[1] != 3 or image.dtype != torch.float32:
-            raise ValueError("expected a float32 [N,3,H,W] image batch, got %s %s" % (tuple(image.shape), image.dtype))
-        if tuple(image.shape) != (plan.n, 3, plan.h, plan.w):
-            raise ValueError("plan %s does not match input %s" % (plan.key, tuple(image.shape)))
+        n_here = plan.n // 2 if image_b is not None else plan.n
+        for im in (image,) + ((image_b,) if image_b is not None else ()):
+            if im.dim() != 4 or im.shape[1] != 3 or im.dtype != torch.float32:
+                raise ValueError("expected a float32 [N,3,H,W] image batch, got %s %s" % (tuple(im.shape), im.dtype))
+            if tuple(im.shape) != (n_here, 3, plan.h, plan.w):
+                raise ValueError("plan %s does not match input %s" % (plan.key, tuple(im.shape)))
+        if image_b is not None:
+            _lib.require_device(image_b)
+            image_b = image_b.contiguous()
         image = image.contiguous()
         dev = image.device
         kparams = [_kernel_layout(p.detach()) for p in params]
@@ -168,9 +193,14 @@ class _BackboneFn(torch.autograd.Function):
         desc = torch.empty((plan.n, plan.h, plan.w, plan.d), dtype=torch.float32, device=dev)
         saved = _arena(plan.saved_bytes, dev)
         ws = _arena(plan.workspace_bytes, dev)
-        rc = lib.dcn_backbone_forward(plan.handle, _lib.ptr(image), pptr, rptr, float(momentum), float(eps),
-                                      int(bool(training)), int(bool(normalize)), _lib.ptr(desc), _lib.ptr(saved),
-                                      _lib.ptr(ws), _lib.stream_ptr())
+        if image_b is not None:
+            rc = lib.dcn_backbone_forward_pair(plan.handle, _lib.ptr(image), _lib.ptr(image_b), pptr, rptr, float(momentum),
+                                               float(eps), int(bool(training)), int(bool(normalize)), _lib.ptr(desc),
+                                               _lib.ptr(saved), _lib.ptr(ws), _lib.stream_ptr())
+        else:
+            rc = lib.dcn_backbone_forward(plan.handle, _lib.ptr(image), pptr, rptr, float(momentum), float(eps),
+                                          int(bool(training)), int(bool(normalize)), _lib.ptr(desc), _lib.ptr(saved),
+                                          _lib.ptr(ws), _lib.stream_ptr())
         _lib.check(rc, "dcn_backbone_forward")
         ctx.plan = plan
         # the n + 1 range scalars are COPIED out (a small device-to-device copy, no sync): views would keep the whole saved
@@ -199,29 +229,36 @@ class _BackboneFn(torch.autograd.Function):
         plan = ctx.plan
         if not ctx.trained:
             raise RuntimeError("dcn_hip: backward through an eval-mode forward is not supported")
+        g_b = None
         if plan.groups == 2:
+            # the two outputs' gradients are handed to the engine as they arrive (two pointers): NHWC views of
+            # channels_last tensors are contiguous, so nothing is copied; a missing one is a zero map
             half = plan.n // 2
-            ref = next(g for g in grad_descs if g is not None)
-            g = torch.empty((plan.n, plan.h, plan.w, plan.d), dtype=torch.float32, device=ref.device)
-            for k, gk in enumerate(grad_descs):
-                dst = g[k * half:(k + 1) * half]
+            ref = next(gk for gk in grad_descs if gk is not None)
+            gs = []
+            for gk in grad_descs:
                 if gk is None:
-                    dst.zero_()
+                    gs.append(torch.zeros((half, plan.h, plan.w, plan.d), dtype=torch.float32, device=ref.device))
                 else:
-                    dst.copy_(gk.permute(0, 2, 3, 1))   # NHWC; a plain copy when the gradient is channels_last
+                    gs.append(gk.permute(0, 2, 3, 1).contiguous())
+            g, g_b = gs
         else:
             g = grad_descs[0].permute(0, 2, 3, 1).contiguous()  # NHWC; no copy when grad is channels_last
         dev = g.device
         ws = _arena(plan.workspace_bytes, dev)
         flat = torch.empty(plan.grad_offsets[-1], dtype=torch.float32, device=dev)
-        for i, nmel in enumerate(plan.param_numel):   # the <= 3 alignment floats behind a tensor are never written by the
-            if nmel % 4:                              # engine: keep them zero, the buffer is ADDED into the shared sink
-                flat[plan.grad_offsets[i] + nmel:plan.grad_offsets[i + 1]].zero_()
+        pad = plan.grad_pad_index(dev)   # the <= 3 alignment floats behind a tensor are never written by the engine:
+        if pad is not None:              # keep them zero, the buffer is ADDED into the shared sink (one launch for all)
+            flat.index_fill_(0, pad, 0.0)
         base = flat.data_ptr()
         gptr = (ctypes.c_void_p * len(plan.param_numel))(*[base + 4 * o for o in plan.grad_offsets[:-1]])
         pptr = (ctypes.c_void_p * len(ctx.kparams))(*[p.data_ptr() for p in ctx.kparams])
-        rc = lib.dcn_backbone_backward(plan.handle, _lib.ptr(g), pptr, _lib.ptr(ctx.saved_arena), _lib.ptr(ws), gptr,
-                                       int(ctx.normalize), _lib.stream_ptr())
+        if g_b is not None:
+            rc = lib.dcn_backbone_backward_pair(plan.handle, _lib.ptr(g), _lib.ptr(g_b), pptr, _lib.ptr(ctx.saved_arena),
+                                                _lib.ptr(ws), gptr, int(ctx.normalize), _lib.stream_ptr())
+        else:
+            rc = lib.dcn_backbone_backward(plan.handle, _lib.ptr(g), pptr, _lib.ptr(ctx.saved_arena), _lib.ptr(ws), gptr,
+                                           int(ctx.normalize), _lib.stream_ptr())
         _lib.check(rc, "dcn_backbone_backward")
         ctx.saved_arena = None
         sink = ctx.grad_sink
@@ -238,10 +275,10 @@ class _BackboneFn(torch.autograd.Function):
                 owner.accumulate_and_reduce_buckets(plan, flat)
             else:
                 sink.add_(flat)
-            return (None,) * (7 + len(plan.param_numel))
+            return (None,) * (8 + len(plan.param_numel))
         if sink is not None and ctx.grad_owner is not None:
             ctx.grad_owner.note_detached()   # e.g. optimizer.zero_grad(set_to_none=True) dropped the views: see all_reduce_mean
-        return (None, None, None, None, None, None, None) + tuple(_grad_views(flat, plan))
+        return (None, None, None, None, None, None, None, None) + tuple(_grad_views(flat, plan))
 
 
 class _RunningList(list):
@@ -251,11 +288,12 @@ class _RunningList(list):
 
 
 def backbone_forward(image, plan, params, bn_running, training, normalize=False, momentum=0.1, eps=1e-5, grad_sink=None,
-                     grad_owner=None):
+                     grad_owner=None, image_b=None):
     """image [N,3,H,W] -> descriptors, logical [N,D,H,W] in channels_last memory.
+    ``image_b`` (plans with two groups): the second batch as its own tensor; ``image`` is then the first batch only.
     ``params`` / ``bn_running`` follow ``plan.param_names`` / ``plan.bn_names`` (running_mean, running_var per BN).
     ``grad_sink``: flat fp32 buffer laid out like ``plan.grad_offsets`` that the parameters' ``.grad`` alias."""
     rl = _RunningList(bn_running)
     rl.grad_sink = grad_sink
     rl.grad_owner = grad_owner   # dcn_hip.distributed.FlatGradients that owns grad_sink (bucketed all-reduce), or None
-    return _BackboneFn.apply(image, plan, rl, training, normalize, momentum, eps, *params)
+    return _BackboneFn.apply(image, image_b, plan, rl, training, normalize, momentum, eps, *params)

@@ -128,11 +128,16 @@ class _DilatedResnet8s(nn.Module):
             tracked.append(node.num_batches_tracked)
         return params, running, tracked
 
-    def forward(self, x, normalize=False, groups=1):
-        """``groups`` = 2: ``x`` stacks two independent batches (``cat([img_a, img_b])``) and a PAIR of outputs is returned;
+    def forward(self, x, normalize=False, groups=1, x_b=None):
+        """``groups`` = 2: ``x`` stacks two independent batches (``cat([img_a, img_b])``) -- or ``x`` is the first and ``x_b`` the
+        second batch, no concatenated copy -- and a PAIR of outputs is returned;
         the result equals two consecutive forward calls -- batch-norm statistics, their gradients and the running-statistics updates are per batch -- but
         runs as ONE launch sequence (fills the 256 CUs better at small batch).  See ``forward_pair``."""
         n, _, h, w = x.shape
+        if x_b is not None:
+            if int(groups) != 2 or x_b.shape != x.shape:
+                raise ValueError("x_b needs groups=2 and the shape of x")
+            n = 2 * n
         plan = _bb.get_plan(self.arch, self.base_width, int(n), int(h), int(w), self.num_classes, int(groups))
         params, running, tracked = self._tables()
         if self.training:
@@ -140,7 +145,7 @@ class _DilatedResnet8s(nn.Module):
         owner = getattr(self, "_flat_grad_owner", None)   # dcn_hip.distributed.FlatGradients, if one manages the gradients
         self._last_plan = plan
         return _bb.backbone_forward(x, plan, params, running, self.training, normalize, self.bn_momentum, self.bn_eps,
-                                    grad_sink=owner.flat if owner is not None else None, grad_owner=owner)
+                                    grad_sink=owner.flat if owner is not None else None, grad_owner=owner, image_b=x_b)
 
     def last_forward_status(self):
         """(abs-max of every convolution input, status word) of the most recent forward call, as device tensors (reading
@@ -157,7 +162,7 @@ class _DilatedResnet8s(nn.Module):
         Falls back to two calls when the shapes differ or a batch's rows are not tile-aligned."""
         if x_a.shape == x_b.shape:
             try:
-                y = self.forward(torch.cat([x_a, x_b], 0), normalize, groups=2)
+                y = self.forward(x_a, normalize, groups=2, x_b=x_b)   # (two base pointers: no concatenated copy)
             except ValueError as e:
                 y = None
                 key = tuple(x_a.shape)
