@@ -253,8 +253,9 @@ def respawn_under_torchrun(n):
 class Job(object):
     """One workload on this rank: model, optimizer, flat gradients, resident synthetic batch, and the step closure."""
 
-    def __init__(self, args, wl, B, dev, rank, use_dist):
+    def __init__(self, args, wl, B, dev, rank, use_dist, separate_forwards=None):
         from dcn_hip.distributed import FlatGradients, broadcast_module
+        self.separate = separate = args.separate_forwards if separate_forwards is None else bool(separate_forwards)
         from dcn_hip.loss import PairLists
         from dcn_hip.optim import Adam
         from dense_correspondence.loss_functions import loss_composer
@@ -280,7 +281,7 @@ class Job(object):
 
         def forward_backward():
             opt.zero_grad()              # training.py:325 (the attached flat buffer is zeroed in place, one kernel)
-            if args.separate_forwards:   # literally training.py:329-333
+            if separate:                 # literally training.py:329-333
                 ya, yb = dcn.forward(img_a), dcn.forward(img_b)
             else:                        # the same two network calls as ONE grouped launch sequence (BN statistics per image batch)
                 ya, yb = dcn.forward_pair(img_a, img_b)
@@ -425,6 +426,14 @@ def main():
     elapsed, loss = job.timed(args.warmup, args.steps, 0, use_dist)
     host_enqueue_ms = job.host_enqueue_ms
     final_loss = float(loss.item())
+    # every rank's host time to enqueue a step (8 ranks share the box's usable cores: a rank whose enqueue time approaches the
+    # step time is host-bound) -- gathered so that the multi-rank line shows it per rank
+    host_enqueue_per_rank = [host_enqueue_ms]
+    if use_dist:
+        t = torch.zeros(world, dtype=torch.float64, device=dev)
+        t[rank] = host_enqueue_ms
+        dist.all_reduce(t)
+        host_enqueue_per_rank = [float(v) for v in t.tolist()]
 
     # ---- gradient all-reduce: the collective alone (whole flat buffer, RCCL), and what the step really pays for it
     # (same steps with the communication switched off; the bucketed schedule hides all but the last bucket)
@@ -461,12 +470,13 @@ def main():
     # ---- roofline of the dominant kernel: extra steps, every conv_gemm / conv_wgrad launch bracketed by HIP events
     def measure_roofline(job_, conv_mode, first_it):
         wl_, B_ = job_.wl, job_.B
-        plan = bb.get_plan(wl_["backbone"], 64, B_, wl_["H"], wl_["W"], wl_["D"]) if args.separate_forwards else \
+        plan = bb.get_plan(wl_["backbone"], 64, B_, wl_["H"], wl_["W"], wl_["D"]) if job_.separate else \
             bb.get_plan(wl_["backbone"], 64, 2 * B_, wl_["H"], wl_["W"], wl_["D"], 2)
         plan.profile_begin()
         for it in range(args.profile_steps):
             job_.step(first_it + it, eager=True)   # the engine's per-launch events do not exist inside a graph
         prof = plan.profile_end()
+        job_.last_profile = prof
         ms, n, fl = prof["conv_gemm"]
         wms, wn, wfl = prof["conv_wgrad"]
         hms, hn, hfl = prof["conv_gemm_hl"]
@@ -493,7 +503,7 @@ def main():
             try:
                 rec = json.load(open(os.path.join(ROOT, "profiles", name)))
                 if (rec["workload"] == args.workload and rec["conv_mode"] == conv_mode and not args.batch and job_ is job and
-                        (rec["forward_calls"] == "pair") == (not args.separate_forwards)):
+                        (rec["forward_calls"] == "pair") == (not job_.separate)):
                     traffic = rec["hbm_bytes_per_launch"]
                     traffic_hl = (rec.get("hl_kernel") or {}).get("hbm_bytes_per_launch")
                     traffic_src = "committed rocprofv3 --pmc measurement of this command, profiles/%s: %s" % (name, rec["correction"])
@@ -518,8 +528,86 @@ def main():
                                "avg_launch_us": (1e3 * wms / wn) if wn else None,
                                "kernel_ms_per_step": wms / args.profile_steps}}
 
+    HBM_PEAK_GBPS = 8000.0
+
+    def elementwise_roofline(prof):
+        """K7 / K8: the streaming passes of the step against the HBM roofline -- algorithmic bytes (4 B x
+        elements a pass reads and writes once; the launchers of elementwise_kernels.hip state them) / the pass's launch
+        durations (per-launch HIP events of the profiled steps, serial schedule) / 8 TB/s."""
+        if prof is None:
+            return None
+        rows = {}
+        tot_b, tot_ms = 0.0, 0.0
+        for k in ("bn_apply", "bn_bwd_reduce", "bn_bwd_apply", "resample"):
+            ms, n, b = prof[k]
+            if n == 0 or ms <= 0:
+                continue
+            rows[k] = {"GBps": b / (ms * 1e-3) / 1e9, "frac": b / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+                       "launches_per_step": n / args.profile_steps, "avg_launch_us": 1e3 * ms / n,
+                       "kernel_ms_per_step": ms / args.profile_steps, "algorithmic_MB_per_step": b / args.profile_steps / 1e6}
+            tot_b += b
+            tot_ms += ms
+        if tot_ms <= 0:
+            return None
+        fms, fn, _ = prof["bn_finalize"]
+        return {"bound": "hbm", "kernel": "bn_apply_kernel, bn_bwd_reduce_kernel, bn_bwd_apply(_blocked)_kernel (batch norm forward / "
+                                          "backward streaming passes, K7) + max pool / bilinear upsample / input layout passes (K8)",
+                "achieved": tot_b / (tot_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                "frac": tot_b / (tot_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, "kernel_ms_per_step": tot_ms / args.profile_steps,
+                "algorithmic_MB_per_step": tot_b / args.profile_steps / 1e6, "passes": rows,
+                "bn_finalize": {"launches_per_step": fn / args.profile_steps, "avg_launch_us": (1e3 * fms / fn) if fn else None,
+                                "kernel_ms_per_step": fms / args.profile_steps, "note": "per-channel finalize kernels: latency-bound, no byte count"}}
+
+    def step_breakdown(job_, prof, ms_per_step_):
+        """Kernel-time sum of a step next to its wall time (is the step launch-bound?): every ENGINE launch from the profiled
+        steps (serial schedule, per-launch events), the loss call and the optimizer step timed on their own with events."""
+        if prof is None:
+            return None
+        eng_ms = sum(v[0] for k, v in prof.items() if k != "conv_gemm_hl") / args.profile_steps
+        eng_n = sum(v[1] for k, v in prof.items() if k != "conv_gemm_hl") / args.profile_steps
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        reps = 10
+        job_.opt.zero_grad()
+        loss_ = job_.forward_backward()
+        torch.cuda.synchronize()
+        e0.record()
+        for _ in range(reps):
+            job_.opt.step()
+            job_.opt.zero_grad()
+        e1.record()
+        torch.cuda.synchronize()
+        opt_ms = e0.elapsed_time(e1) / reps
+        with torch.no_grad():
+            da_ = job_.dcn.process_network_output(job_.dcn.forward(job_.img_a), job_.B).detach().contiguous()
+            db_ = job_.dcn.process_network_output(job_.dcn.forward(job_.img_b), job_.B).detach().contiguous()
+        da_.requires_grad_(True)
+        db_.requires_grad_(True)
+        def one():
+            l = loss_composer.get_loss_batched(job_.pcl, job_.match_type, da_, db_, job_.pair_lists)[0]
+            return torch.autograd.grad(l, [da_, db_])
+        for _ in range(3):
+            one()
+        e0.record()
+        for _ in range(reps):
+            one()
+        e1.record()
+        torch.cuda.synchronize()
+        loss_ms = e0.elapsed_time(e1) / reps
+        ksum = eng_ms + opt_ms + loss_ms
+        return {"ms_per_step": ms_per_step_, "kernel_ms_sum": ksum, "engine_kernel_ms": eng_ms, "engine_launches_per_step": eng_n,
+                "loss_call_ms": loss_ms, "optimizer_ms": opt_ms, "host_enqueue_ms_per_step": job_.host_enqueue_ms,
+                "engine_ms_by_category": {k: v[0] / args.profile_steps for k, v in prof.items()},
+                "engine_launches_by_category": {k: v[1] / args.profile_steps for k, v in prof.items()},
+                "note": "kernel_ms_sum = engine launches one by one (serial schedule, HIP events around each) + loss forward/backward "
+                        "call + optimizer.step()/zero_grad(), each timed alone; ms_per_step is the timed region of the default "
+                        "schedule (weight-gradient GEMMs overlapped on a side stream).  ms_per_step >> kernel_ms_sum would mean "
+                        "launch / dependency gaps; host_enqueue_ms_per_step close to ms_per_step would mean a host-bound step"}
+
     it_next = args.warmup + args.steps + 64
     roofline = measure_roofline(job, args.conv_mode, it_next) if args.profile_steps > 0 else None
+    headline_profile = getattr(job, "last_profile", None)
+    roofline_elementwise = elementwise_roofline(headline_profile)
+    headline_breakdown = step_breakdown(job, headline_profile, 1e3 * elapsed / args.steps) if headline_profile else None
 
     # ---- HBM roofline of the loss gather (K9): forward + backward of the fused contrastive loss alone, on the
     # descriptor maps of the last step, timed with events on the launch stream
@@ -618,15 +706,27 @@ def main():
             # every other single-GPU BASELINE config on the same driver-timed line: configs[3]'s per-GPU share (the N = 1 point of
             # the weak-scaling curve the multi-GPU runs trace), configs[2] (B = 32, D = 16) and configs[4]'s per-GPU share
             # (ResNet50-8s 1280 x 960), each with the roofline of its gather-GEMM launches
-            for key, name, w_, k_ in (("config4_one_gpu", "config4", 6, short), ("config3_one_gpu", "config3", 3, 5),
-                                      ("config5_one_gpu", "config5", 6, 8)):
+            # (key, workload, warm-up, steps, two forward calls instead of forward_pair, step breakdown)
+            for key, name, w_, k_, sep_, brk_ in (
+                    ("separate_forwards", "config2", 4, short, True, False),      # the headline workload, LITERAL training.py:329-333 call pattern
+                    ("config1_one_gpu", "config1", 8, 20, False, True),           # B = 1: the reference's own batch size (training.yaml:14)
+                    ("config1_separate_forwards", "config1", 8, 20, True, True),
+                    ("config4_one_gpu", "config4", 6, short, False, False), ("config3_one_gpu", "config3", 3, 5, False, False),
+                    ("config5_one_gpu", "config5", 6, 8, False, False)):
+                if sep_ and args.separate_forwards:
+                    continue   # (the headline itself already runs the two-call pattern)
                 wlv = dict(WORKLOADS[name])
-                jobv = Job(args, wlv, wlv["B"], dev, rank, use_dist)
+                jobv = Job(args, wlv, wlv["B"], dev, rank, use_dist, separate_forwards=sep_ or args.separate_forwards)
                 sec, _ = jobv.timed(w_, k_, 0, use_dist)
                 rv = measure_roofline(jobv, args.conv_mode, w_ + k_ + 8) if args.profile_steps > 0 else None
                 variants[key] = summarize(jobv, sec, k_, {
                     "workload": wlv["desc"],
-                    "roofline": None if rv is None else {k: rv[k] for k in ("achieved", "peak", "frac", "kernel_ms_per_step", "hl_kernel")}})
+                    "forward_calls": "forward(img_a), forward(img_b) -- training.py:329-333 as written" if jobv.separate else "forward_pair(img_a, img_b)",
+                    "roofline": None if rv is None else {k: rv[k] for k in ("achieved", "peak", "frac", "kernel_ms_per_step", "hl_kernel", "conv_wgrad")}})
+                if brk_ and rv is not None:
+                    variants[key]["breakdown"] = step_breakdown(jobv, jobv.last_profile, 1e3 * sec / k_)
+                    ew = elementwise_roofline(jobv.last_profile)
+                    variants[key]["roofline_elementwise"] = None if ew is None else {k: ew[k] for k in ("achieved", "peak", "frac", "kernel_ms_per_step")}
                 del jobv
                 torch.cuda.empty_cache()
             variants["config4_one_gpu"]["note"] = ("the N = 1 point of the weak-scaling curve: multi-GPU lines run this workload per "
@@ -640,7 +740,15 @@ def main():
             grads.bucketed = False
             dist.barrier()
             if rank == 0:
+                # (rank 0 steps alone: its parameters, BN buffers AND optimizer state are put back afterwards, so that the
+                # replicas -- Adam moments and step counts included -- are identical again for whatever is measured next)
+                import copy
+                snap_model = {k: v.clone() for k, v in dcn.state_dict().items()}
+                snap_opt = copy.deepcopy(job.opt.state_dict())
                 sec1, _ = job.timed(2, short, it_next + 128, False)
+                dcn.load_state_dict(snap_model)
+                job.opt.load_state_dict(snap_opt)
+                del snap_model, snap_opt
                 one = 2 * B * short / sec1
                 variants["weak_scaling"] = {"one_gpu_same_box": one, "one_gpu_ms_per_step": 1e3 * sec1 / short,
                                             "efficiency": (2 * B * world * args.steps / elapsed) / (world * one),
@@ -669,6 +777,7 @@ def main():
                "value": images_per_step * args.steps / elapsed, "unit": "images/s", "n_gpus": world,
                "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
                "scaling": "weak", "vs_baseline": None, "host_enqueue_ms_per_step": host_enqueue_ms,
+               "host_enqueue_ms_per_rank": host_enqueue_per_rank, "host_usable_cpus": usable_cpus(),
                "dtype": "f32 (f16x3 products)" if args.conv_mode == "f16x3" else "f32", "data": "synthetic",
                "arithmetic": ("fp32 tensors and accumulation; convolution products as 3 fp16 MFMAs on exact hi/lo operand "
                               "splits (~22 mantissa bits per operand; parity with the fp32 reference at 1e-4, tests/test_gpu_parity.py)"
@@ -689,7 +798,8 @@ def main():
                                                           "variants.config4_one_gpu, not `value`") if world == 1 else
                           "variants.weak_scaling.one_gpu_same_box (rank 0 alone on the same per-rank workload)",
                           "train_gflop_per_image": 3 * bb.get_plan(wl["backbone"], 64, B, H, W, D).forward_flops / B / 1e9},
-               "roofline": roofline, "roofline_loss_gather": loss_roof, "variants": variants,
+               "roofline": roofline, "roofline_elementwise": roofline_elementwise, "breakdown": headline_breakdown,
+               "roofline_loss_gather": loss_roof, "variants": variants,
                "allreduce_ms": comm["allreduce_ms"] if comm else None, "communication": comm}
         if world == 1 and args.cpu_baseline_steps > 0:
             out["cpu_baseline"] = cpu_baseline(wl, args.cpu_baseline_steps, 1)

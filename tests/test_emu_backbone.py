@@ -503,3 +503,83 @@ def test_status_word_flags_nan_input_and_out_of_range_weights(conv_mode):
         m.resnet18_8s.get_parameter("layer1.0.bn1.bias")[0] = float("nan")
     m(x)
     assert int(m.last_forward_status()[1]) & 1
+
+
+def test_backward_refuses_an_arena_whose_forward_decisions_no_longer_hold(dcn_env, conv_mode):
+    """The forward pass records, per saved arena, what it decided under the tuning switches of the moment (which activations
+    exist as the hl32 image only, which saved images were written, the arithmetic).  A backward pass under switches that would
+    make it read a tensor that forward call never wrote returns DCN_E_INVALID instead of silently wrong gradients."""
+    if conv_mode != "f16x3":
+        pytest.skip("the hl32 decisions belong to the split-fp16 arithmetic")
+    from dcn_hip import backbone as _bb
+    m, _ = _pair("Resnet18_8s", 3, 32)
+    g = torch.Generator().manual_seed(4)
+    x = torch.randn(1, 3, 16, 256, generator=g)
+    m.train()
+    try:
+        dcn_env(DCN_GEMM_HL=2, DCN_WGRAD_HL=2, DCN_HL_ONLY_MID=1)
+        _bb._PLANS.clear()
+        y = m(x)                                   # mid activations of the qualifying blocks: hl32 image only
+        dcn_env(DCN_GEMM_HL=2, DCN_WGRAD_HL=0)     # their weight gradients would now read the fp32 tensors
+        with pytest.raises(RuntimeError, match="DCN_E_INVALID"):
+            y.sum().backward()
+        dcn_env(DCN_GEMM_HL=2, DCN_WGRAD_HL=2, DCN_HL_ONLY_MID=1)
+        y = m(x)
+        _bb.set_conv_mode("fp32")                  # another arithmetic than the one that filled the arena
+        with pytest.raises(RuntimeError, match="DCN_E_INVALID"):
+            y.sum().backward()
+        _bb.set_conv_mode("f16x3")
+        m.zero_grad()
+        y.sum().backward()                         # the arena is still differentiable under the switches it was made with
+        assert all(p.grad is not None and bool(torch.isfinite(p.grad).all()) for p in m.parameters())
+    finally:
+        _bb._PLANS.clear()
+
+
+def test_profile_reports_every_engine_launch_by_category(conv_mode):
+    """dcn_plan_profile_end_all: between begin and end every launch of the engine is bracketed and attributed to a category
+    with its algorithmic work (FLOPs for the matrix-core categories, HBM bytes for the streaming passes)."""
+    from dcn_hip import backbone as _bb
+    arch, bw, (N, H, W), D = "Resnet18_8s", 8, (2, 32, 40), 3
+    m, _ = _pair(arch, D, bw)
+    m.train()
+    x = torch.randn(N, 3, H, W, generator=torch.Generator().manual_seed(1))
+    plan = _bb.get_plan(arch, bw, N, H, W, D)
+    plan.profile_begin()
+    m(x).sum().backward()
+    prof = plan.profile_end()
+    assert set(prof) == set(_bb.Plan.PROFILE_CATEGORIES)
+    n_bn, n_conv = len(plan.bn_names), len(plan.bn_names) + 1            # every convolution but the scoring layer has a batch norm
+    assert prof["bn_finalize"][1] == 2 * n_bn                             # forward + backward finalize per batch norm
+    assert prof["bn_bwd_reduce"][1] == n_bn and prof["bn_bwd_apply"][1] == n_bn
+    # one apply pass per batch norm, except the stem's (applied inside the max pool) and the three downsample branches'
+    # (folded into their block's last pass)
+    assert prof["bn_apply"][1] == n_bn - 1 - 3
+    assert prof["conv_gemm"][1] == n_conv + (n_conv - 1)                  # forward of every convolution + dgrad of all but the stem
+    assert prof["conv_wgrad"][1] == n_conv
+    assert abs(prof["conv_gemm"][2] + prof["conv_wgrad"][2] - (3 * plan.forward_flops - 2.0 * N * (H // 2) * (W // 2) * bw * 147)) \
+        < 1e-6 * plan.forward_flops                                      # 3 x forward - the stem's missing dgrad
+    for k in ("bn_apply", "bn_bwd_reduce", "bn_bwd_apply", "resample"):
+        assert prof[k][2] > 0, k
+    assert prof["resample"][1] == 1 + 2 + 1 + 2   # input layout, max pool forward / backward, upsample forward, upsample backward (2 passes)
+    assert prof["other"][1] >= 6
+    # nothing is recorded outside a begin / end window
+    m(x).sum().backward()
+    plan.profile_begin()
+    assert all(v[1] == 0 for v in plan.profile_end().values())
+
+
+def test_product_state_dict_layout_equals_the_committed_fixture(conv_mode):
+    """Keys, order and shapes of the product module's checkpoint == tests/golden/resnet34_8s_d3_state_dict_layout.txt (the
+    fixture tests/test_oracle.py holds the oracle and the second statement of the architecture against)."""
+    if conv_mode != "f16x3":
+        pytest.skip("layout does not depend on the arithmetic")
+    import os
+    from pytorch_segmentation_detection.models import resnet_dilated as prod
+    want = []
+    for line in open(os.path.join(os.path.dirname(__file__), "golden", "resnet34_8s_d3_state_dict_layout.txt")):
+        if not line.startswith("#") and line.strip():
+            k, shp = line.split()
+            want.append((k, () if shp == "scalar" else tuple(int(v) for v in shp.split("x"))))
+    got = [(k, tuple(v.shape)) for k, v in prod.Resnet34_8s(num_classes=3).state_dict().items()]
+    assert got == want

@@ -150,3 +150,86 @@ def test_evaluation_oracle_matches_reference_golden():
                          ("average_l2_distance_for_false_positives", "average_l2_distance_for_false_positives"),
                          ("average_l2_distance_for_false_positives_masked", "average_l2_distance_for_false_positives_masked")):
             np.testing.assert_allclose(float(s[k_o]), float(z[k_g][q]), rtol=1e-12, err_msg=k_o)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# The backbone is un-vendored: no reference-held vector can pin it.  What CAN be done is to remove the
+# single-derivation risk: a second statement of the architecture, derived the other way round (stock ResNet + FCN surgery
+# as a pass over a flat record list, functional interpreter -- tests/backbone_second_statement.py), must agree with the
+# oracle bit for bit, and the checkpoint layout of oracle, product and second statement must equal a committed fixture.
+def _layout_fixture(name):
+    rows = []
+    for line in open(os.path.join(os.path.dirname(__file__), "golden", name)):
+        if line.startswith("#") or not line.strip():
+            continue
+        k, shp = line.split()
+        rows.append((k, () if shp == "scalar" else tuple(int(v) for v in shp.split("x"))))
+    return rows
+
+
+@pytest.mark.parametrize("arch,D,fixture", [("Resnet34_8s", 3, "resnet34_8s_d3_state_dict_layout.txt"),
+                                            ("Resnet50_8s", 32, "resnet50_8s_d32_state_dict_layout.txt")])
+def test_state_dict_layout_fixture(arch, D, fixture):
+    """Ordered key / shape list of the checkpoint (`_fcn.` + these keys under DenseCorrespondenceNetwork, network.py:43):
+    oracle == committed fixture == the layout derived from the stock-ResNet record list; the trunk part (everything but fc)
+    is key for key the layout of a stock torchvision checkpoint, which is what `pretrained=True` of the original loads."""
+    import backbone_second_statement as second
+    want = _layout_fixture(fixture)
+    o = resnet_dilated_oracle.build(arch, D)
+    got = [(k, tuple(v.shape)) for k, v in o.state_dict().items()]
+    assert got == want
+    assert second.expected_state_dict_layout(arch, D) == want
+    pref = arch.lower() + "."
+    assert all(k.startswith(pref) for k, _ in want)
+    trunk = [k[len(pref):] for k, _ in want if not k.startswith(pref + "fc.")]
+    assert trunk[:6] == ["conv1.weight", "bn1.weight", "bn1.bias", "bn1.running_mean", "bn1.running_var", "bn1.num_batches_tracked"]
+    assert "layer2.0.downsample.0.weight" in trunk and "layer1.0.downsample.0.weight" not in trunk or arch == "Resnet50_8s"
+    assert sum(int(np.prod(s)) for k, s in want if not k.endswith(("running_mean", "running_var", "num_batches_tracked"))) == \
+        sum(p.numel() for p in o.parameters())
+
+
+@pytest.mark.parametrize("arch,bw,shape,D", [("Resnet18_8s", 8, (2, 40, 56), 3), ("Resnet34_8s", 16, (2, 32, 48), 3),
+                                             ("Resnet50_8s", 8, (1, 48, 40), 5)])
+def test_second_statement_of_the_backbone_equals_the_oracle_bitwise(arch, bw, shape, D):
+    import backbone_second_statement as second
+    N, H, W = shape
+    o = resnet_dilated_oracle.build(arch, D, seed=2, base_width=bw)
+    o.train()
+    sd = {k: v.clone() for k, v in o.state_dict().items()}
+    for k, v in sd.items():
+        if v.dtype.is_floating_point and not k.endswith(("running_mean", "running_var")):
+            v.requires_grad_(True)
+    x = torch.randn(N, 3, H, W, generator=torch.Generator().manual_seed(5))
+    gy = torch.randn(N, D, H, W, generator=torch.Generator().manual_seed(6))
+    y1 = o(x)
+    y2 = second.run(arch, sd, x, base_width=bw)
+    assert y1.shape == (N, D, H, W) and torch.equal(y1, y2)
+    (y1 * gy).sum().backward()
+    (y2 * gy).sum().backward()
+    for k, p in o.named_parameters():
+        assert torch.equal(p.grad, sd[k].grad), k
+    for k, b in o.named_buffers():          # running statistics and counters follow nn.BatchNorm2d in both
+        assert torch.equal(b, sd[k].detach()), k
+    # the surgery really did what the fork does: the FIRST block of layer3 / layer4 is dilated, strides 1, padding = dilation
+    net = second.to_output_stride(second.stock_spec(arch, bw))
+    first3 = [b for b in net["blocks"] if b["convs"][0]["name"].startswith("layer3.0.")][0]
+    first4 = [b for b in net["blocks"] if b["convs"][0]["name"].startswith("layer4.0.")][0]
+    assert {c["dil"] for c in first3["convs"] if c["k"] == 3} == {2} and {c["dil"] for c in first4["convs"] if c["k"] == 3} == {4}
+    assert all(c["stride"] == 1 for b in (first3, first4) for c in b["convs"] + [b["proj"]])
+    trunk = getattr(o, arch.lower())
+    assert trunk.layer3[0].conv2.dilation == (2, 2) and trunk.layer4[0].conv2.padding == (4, 4) and trunk.layer4[0].conv2.stride == (1, 1)
+
+
+def test_torchvision_surgery_equals_the_oracle_bitwise():
+    """The same check against a network made from the installed torchvision by the fork's surgery (skipped where torchvision
+    is not installed -- the authoring image and the GPU image have none)."""
+    pytest.importorskip("torchvision")
+    import backbone_second_statement as second
+    o = resnet_dilated_oracle.build("Resnet34_8s", 3, seed=1)
+    tv = second.torchvision_surgery("Resnet34_8s", 3)
+    sd = {k[len("resnet34_8s."):]: v for k, v in o.state_dict().items()}
+    tv.tv.load_state_dict({k: v for k, v in sd.items() if not k.startswith("fc.")}, strict=False)
+    tv.fc.load_state_dict({"weight": sd["fc.weight"], "bias": sd["fc.bias"]})
+    o.train(); tv.train()
+    x = torch.randn(1, 3, 64, 96, generator=torch.Generator().manual_seed(2))
+    assert torch.equal(o(x), tv(x))
