@@ -158,3 +158,99 @@ def run_config_against_fixture(config, pair_call=False):
         out["running_mean_bn1"] = float((rm - torch.tensor(z["running_mean_bn1"])).abs().max() /
                                         np.abs(z["running_mean_bn1"]).max())
     return out
+
+
+def run_trajectory(dcn, oracle, B, H, W, steps, device, pairs=(400, 200, 200), decay_every=5, decay=0.9, lr=1.0e-4,
+                   separate_forwards=True, fc_scale=1.0, seed=1):
+    """`steps` iterations of the reference's training loop (training.py:325-346: zero_grad, forward x2, loss, backward,
+    Adam step, with adjust_learning_rate of :544-558 -- lr *= decay whenever iteration % decay_every == 0) on one fixed
+    synthetic batch, from identical weights, by THREE runners: the product (`dcn` on `device`, dcn_hip.optim.Adam), the
+    oracle in float32 and the oracle in float64 (CPU, torch.optim.Adam).  Returns a dict:
+      loss_p / loss_o32 / loss_o64   the three loss sequences
+      dev_p / dev_o32                 per step |loss - loss_o64| / loss_o64 of the product and of the float32 oracle
+      desc_p / desc_o32               relative deviation of the eval-mode descriptor map after the last step from the float64
+                                      oracle's, up to a constant offset per channel (see below)
+      slack                           per step: hard-negative tie slack product vs float32 oracle (see below)
+    Why a yard-stick and not a fixed bound: Adam's update is lr * m / (sqrt(v) + eps) -- in the first iterations lr * sign(g)
+    for EVERY weight, however small its gradient -- so weights whose gradient is round-off-dominated take full-size steps in
+    round-off-determined directions, and every ReLU / hinge / hard-negative count is a discontinuity of the gradient.  The
+    float32 oracle's trajectory leaves the float64 one's by 1e-4 after ONE step and by 1e-2 within ten (Resnet34_8s, 96 x 128,
+    measured), whichever float32 implementation runs it: what can be asserted is that the product stays as close to the float64
+    trajectory as the float32 reference implementation does.
+    Tie slack: the loss divides the non-match sums by the number of hard negatives (loss_composer.py:107-119), a count of
+    pairs whose hinge is non-zero -- a pair within round-off of its margin is counted by one float32 implementation and not by
+    the other (the tie band of SURVEY.md 8c), which moves the loss by (count difference) / count.
+    Descriptor offset: the scoring layer's bias has an identically zero gradient in exact arithmetic (loss and matching only see
+    descriptor DIFFERENCES), so what Adam normalises into a step of +-lr per iteration is the sign of round-off -- in the oracle
+    as much as in the product; a common offset of the map is no observable of the method."""
+    import copy
+    from dense_correspondence.loss_functions import loss_composer
+    from dense_correspondence.loss_functions.pixelwise_contrastive_loss import PixelwiseContrastiveLoss
+    from dcn_hip.loss import PairLists
+    from dcn_hip.optim import Adam
+    from oracle import step as ostep, synth
+    img_a, img_b, lists = synth.make_batch(B, H, W, pairs[0], pairs[1], pairs[2], seed=seed)
+    if fc_scale != 1.0:
+        with torch.no_grad():   # (tests on tiny networks scale the scoring layer so that both sides of the hinge occur)
+            for net in (dcn.fcn, oracle):
+                trunk = getattr(net, [n for n, _ in net.named_children()][0])
+                trunk.get_parameter("fc.weight").mul_(fc_scale)
+    o64 = copy.deepcopy(oracle).double()
+    dcn.train(); oracle.train(); o64.train()
+    opt_o = torch.optim.Adam(oracle.parameters(), lr=lr, weight_decay=1e-4)
+    opt_6 = torch.optim.Adam(o64.parameters(), lr=lr, weight_decay=1e-4)
+    opt_p = Adam(dcn.parameters(), lr=lr, weight_decay=1e-4)
+    pcl = PixelwiseContrastiveLoss(image_shape=dcn.image_shape, config=synth.LOSS_CONFIG)
+    xa, xb = img_a.to(device), img_b.to(device)
+    pl = PairLists.from_lists([tuple(L[k] for k in KEYS) for L in lists], device, hw=H * W)
+    lp, lo, l6, slack = [], [], [], []
+    for it in range(1, steps + 1):
+        for opt in (opt_o, opt_6, opt_p):
+            if it % decay_every == 0:
+                for g in opt.param_groups:
+                    g["lr"] = g["lr"] * decay
+        loss_o, _, da_o, db_o = ostep.train_step(oracle, opt_o, img_a, img_b, lists, synth.LOSS_CONFIG)
+        loss_6 = ostep.train_step(o64, opt_6, img_a.double(), img_b.double(), lists, synth.LOSS_CONFIG)[0]
+        opt_p.zero_grad()
+        if separate_forwards:
+            ya, yb = dcn.forward(xa), dcn.forward(xb)
+        else:
+            ya, yb = dcn.forward_pair(xa, xb)
+        loss_p, _, hard_p = loss_composer.get_loss_batched(pcl, 0, dcn.process_network_output(ya, B), dcn.process_network_output(yb, B), pl)
+        loss_p.backward()
+        opt_p.step()
+        lp.append(float(loss_p.item()))
+        lo.append(float(loss_o.item()))
+        l6.append(float(loss_6.item()))
+        hp = hard_p.cpu()
+        s_it = 0.0
+        for b in range(B):   # the float32 oracle's own counts, from the descriptor maps its step produced
+            pa, pb = ostep.process_network_output(da_o[b:b + 1], 1), ostep.process_network_output(db_o[b:b + 1], 1)
+            h_o = sum(ostep.PixelwiseContrastiveLoss.non_match_descriptor_loss(
+                pa, pb, lists[b][n + "_non_matches_a"], lists[b][n + "_non_matches_b"], M=synth.LOSS_CONFIG["M_" + n])[1]
+                for n in ("masked", "background"))
+            h_p = int(hp[b, 1]) + int(hp[b, 2])
+            s_it = max(s_it, abs(h_p - h_o) / max(min(h_p, h_o), 1))
+        slack.append(s_it)
+    with torch.no_grad():
+        dcn.eval(); oracle.eval(); o64.eval()
+        yp = dcn.forward(xa).cpu().double()
+        y3 = oracle(img_a).double()
+        y6 = o64(img_a.double())
+        dcn.train(); oracle.train()
+    centre = lambda y: y - y.mean(dim=(0, 2, 3), keepdim=True)
+    yp, y3, y6 = centre(yp), centre(y3), centre(y6)
+    rel = lambda a, b: [abs(x - y) / abs(y) for x, y in zip(a, b)]
+    return {"loss_p": lp, "loss_o32": lo, "loss_o64": l6, "dev_p": rel(lp, l6), "dev_o32": rel(lo, l6), "slack": slack,
+            "desc_p": float((yp - y6).abs().max() / y6.abs().max()), "desc_o32": float((y3 - y6).abs().max() / y6.abs().max())}
+
+
+def assert_trajectory_as_close_as_float32(r, factor=3.0, floor=1e-4, first=1e-4):
+    """Every step's loss deviation from the float64 trajectory within `factor` x the largest deviation the float32 oracle has
+    shown up to that step (+ floor + tie slack); the first step -- no optimizer step behind it -- within the north star's 1e-4."""
+    assert r["dev_p"][0] < first + r["slack"][0], r
+    env = 0.0
+    for t, (dp, do, sl) in enumerate(zip(r["dev_p"], r["dev_o32"], r["slack"])):
+        env = max(env, do)
+        assert dp <= factor * env + floor + 1.5 * sl, (t, dp, env, sl, r)
+    assert r["desc_p"] <= factor * r["desc_o32"] + 10 * floor, r
