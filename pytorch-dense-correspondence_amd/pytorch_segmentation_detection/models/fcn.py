@@ -8,7 +8,12 @@ _WHY = ("pytorch_segmentation_detection.models.fcn.%s is not provided: the dense
         "implements on the MI355X engine")
 
 
+class NotProvided(AttributeError, NotImplementedError):
+    """An AttributeError (so that ``hasattr`` / ``getattr(module, name, default)`` / inspect / mock / pickle helpers keep
+    working) that also says WHY the name is missing; still catchable as NotImplementedError."""
+
+
 def __getattr__(name):
     if name.startswith("__"):
         raise AttributeError(name)
-    raise NotImplementedError(_WHY % name)
+    raise NotProvided(_WHY % name)

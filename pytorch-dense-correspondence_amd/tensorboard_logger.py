@@ -4,9 +4,44 @@ this image (no network).  ``Logger`` keeps the reference's two-call surface and 
 ``<logdir>/scalars.tsv`` -- enough for the training loop to run and for its curves to be read back; it is host-side
 bookkeeping, not part of the MI355X path."""
 import os
+import sys
 import threading
 
 __all__ = ["Logger", "configure", "log_value"]
+
+
+def _real_package():
+    """The real ``tensorboard_logger`` if one is installed: this shim sits on the package path under the same name and must
+    not shadow it (training would silently write scalars.tsv instead of TensorBoard event files).  Looked up with this file's
+    directory taken off the search path."""
+    import importlib.machinery
+    import importlib.util
+    here = os.path.dirname(os.path.abspath(__file__))
+    try:   # (PathFinder on an explicit path list: importlib.util.find_spec would hand back THIS module, already in sys.modules)
+        spec = importlib.machinery.PathFinder.find_spec(
+            "tensorboard_logger", [p for p in sys.path if os.path.abspath(p or os.getcwd()) != here])
+    except (ImportError, ValueError):
+        spec = None
+    if spec is None or not spec.origin or os.path.abspath(spec.origin) == os.path.abspath(__file__):
+        return None
+    mod = importlib.util.module_from_spec(spec)
+    shim = sys.modules.get(__name__)
+    sys.modules[__name__] = mod        # `import tensorboard_logger` now yields the real package everywhere
+    try:
+        spec.loader.exec_module(mod)
+    except Exception:                  # a broken installation: fall back to the shim
+        if shim is not None:
+            sys.modules[__name__] = shim
+        else:
+            sys.modules.pop(__name__, None)
+        return None
+    return mod
+
+
+_REAL = None if __name__ != "tensorboard_logger" else _real_package()
+if _REAL is None and os.environ.get("DCN_QUIET_SHIMS") != "1":
+    sys.stderr.write("tensorboard_logger: the real package is not installed -- using the dcn_hip shim (scalars are appended "
+                     "to <logdir>/scalars.tsv; log_histogram / log_images are not provided)\n")
 
 
 class Logger(object):

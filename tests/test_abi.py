@@ -115,6 +115,8 @@ def test_import_time_shims_of_the_reference_training_script():
     fcns = importlib.import_module("pytorch_segmentation_detection.models.fcn")
     with pytest.raises(NotImplementedError):
         fcns.FCN_8s
+    # ... as an AttributeError too, so that attribute probing (inspect, mock, pickle helpers) keeps working
+    assert not hasattr(fcns, "FCN_8s") and getattr(fcns, "FCN_8s", None) is None
     tr = importlib.import_module("pytorch_segmentation_detection.transforms")
     for name in ("ComposeJoint", "RandomHorizontalFlipJoint", "RandomScaleJoint", "CropOrPad", "ResizeAspectRatioPreserve",
                  "RandomCropJoint", "Split2D"):
@@ -128,3 +130,17 @@ def test_import_time_shims_of_the_reference_training_script():
         lg.log_value("learning rate", 1e-4, 7)
         rows = open(os.path.join(d, "scalars.tsv")).read().strip().split("\n")
         assert rows[0].split("\t") == ["7", "train loss", "0.25"] and len(rows) == 2
+
+
+def test_tensorboard_logger_shim_steps_aside_for_an_installed_package(tmp_path):
+    """A real ``tensorboard_logger`` further down the search path wins over the shim of the same name on the package path."""
+    real = tmp_path / "site"
+    real.mkdir()
+    (real / "tensorboard_logger.py").write_text("MARK = 'the installed package'\nclass Logger(object):\n    pass\n")
+    code = ("import sys; sys.path.insert(0, %r); sys.path.append(%r); import tensorboard_logger as t; "
+            "print(getattr(t, 'MARK', 'shim'))" % (PKG, str(real)))
+    out = subprocess.run([sys.executable, "-c", code], stdout=subprocess.PIPE, stderr=subprocess.PIPE, check=True)
+    assert out.stdout.decode().strip() == "the installed package", out
+    code = "import sys; sys.path.insert(0, %r); import tensorboard_logger as t; print(getattr(t, 'MARK', 'shim'))" % PKG
+    out = subprocess.run([sys.executable, "-c", code], stdout=subprocess.PIPE, stderr=subprocess.PIPE, check=True)
+    assert out.stdout.decode().strip() == "shim" and b"using the dcn_hip shim" in out.stderr
