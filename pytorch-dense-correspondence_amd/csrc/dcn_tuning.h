@@ -32,6 +32,10 @@
 //                           inside the pooling pass, the activation itself is never stored)
 //   DCN_HL_ONLY_MID         0: the batch-norm apply pass inside a block also writes the fp32 activation when both of its readers
 //                           (the next convolution and that convolution's weight gradient) take the hl32 image (default 1: it does not)
+//   DCN_BN_REVERSE          bit mask: the batch-norm streaming passes walk their tensors BACK TO FRONT (1: the forward apply pass,
+//                           whose input the convolution has just written front to back; 2: the backward apply pass, whose two
+//                           inputs the reduce pass has just read front to back) -- what was touched last is then read first
+//                           and is still in the 256 MB Infinity Cache when the tensors do not fit it whole.  Same results bit for bit.
 #pragma once
 
 namespace dcn {
@@ -57,6 +61,7 @@ struct Tuning {
     int hl_producers = 1;        // hl32 images written by the producing batch-norm passes (0: stand-alone split passes)
     int hl_only_mid = 1;         // mid-block activations whose two readers (next conv, its wgrad) take the hl32 image: no fp32 copy (0: keep it)
     int stem_pool_fused = 1;     // the stem's batch norm + ReLU applied inside the max-pool pass (0: an apply pass of its own)
+    int bn_reverse = 0;          // see DCN_BN_REVERSE above
     int wgrad_roles = 1;         // wide tile: wavefronts 0-3 stage the activations, 4-7 the gradient (0: copy spread over all 8)
 };
 

@@ -40,6 +40,7 @@ void read_env(Tuning& t) {
     if (const char* e = getenv("DCN_STEM_POOL_FUSED")) t.stem_pool_fused = atoi(e);
     if (const char* e = getenv("DCN_WGRAD_HL")) t.wgrad_hl = atoi(e);
     if (const char* e = getenv("DCN_HL_PRODUCERS")) t.hl_producers = atoi(e) != 0;
+    if (const char* e = getenv("DCN_BN_REVERSE")) t.bn_reverse = atoi(e);
 }
 
 }  // namespace

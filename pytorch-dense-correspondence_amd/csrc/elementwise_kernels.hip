@@ -8,6 +8,7 @@
 //   max pool 3x3/2 pad 1 (first maximum in window scan order wins, like ATen's CPU kernel)
 //   bilinear upsample, align_corners=True  == F.upsample_bilinear (called from Resnet34_8s.forward [NOT IN TREE])
 //   optional per-pixel L2 normalisation of the descriptor (dense_correspondence_network.py:256-259)
+#include "dcn_tuning.h"
 #include "elementwise_kernels.h"
 #include "f16_split.h"
 
@@ -183,13 +184,14 @@ __global__ void __launch_bounds__(256)
 bn_apply_kernel(const float* __restrict__ x, const float* __restrict__ s1, const float* __restrict__ b1,
                 const float* __restrict__ res, const float* __restrict__ s2, const float* __restrict__ b2, int relu,
                 float* __restrict__ y, unsigned char* __restrict__ relu_mask, int c4n, int64_t total4, int64_t group4,
-                int gstride, dcnsplit::u32x2* __restrict__ hl, const float* __restrict__ hl_absmax) {
+                int gstride, dcnsplit::u32x2* __restrict__ hl, const float* __restrict__ hl_absmax, int rev) {
     // hl (optional, c4n % 8 == 0): y also as the "hl32" image the pre-split convolution kernel reads (conv_hl_kernels.hip) --
     // per 32-channel chunk one 128-byte line [hi x32 | lo x32] fp16 of s y, s = the power of two chosen from *hl_absmax (the
     // bound of max |y| that bn_finalize_kernel stored before this pass): the consumer's operand split costs 4 B / element
     // of extra stores here instead of a pass of its own
     const float hs = hl ? dcnsplit::pow2_scale(*hl_absmax) : 1.f;
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total4; i += (int64_t)gridDim.x * 256) {
+    for (int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x; j < total4; j += (int64_t)gridDim.x * 256) {
+        const int64_t i = rev ? total4 - 1 - j : j;   // (rev: back to front, DCN_BN_REVERSE)
         const int c = (int)(i % c4n) * 4 + (i >= group4 ? gstride : 0);   // (at most two groups: second group's statistics)
         const float4 v = reinterpret_cast<const float4*>(x)[i];
         const float4 s = *reinterpret_cast<const float4*>(s1 + c);
@@ -383,8 +385,9 @@ bn_bwd_apply_kernel(const float* __restrict__ dy, const float* dy2, const float*
                     const unsigned char* __restrict__ relu_mask, const float* __restrict__ x,
                     const float* __restrict__ mean, const float* __restrict__ invstd, const float* __restrict__ k1,
                     const float* __restrict__ k2, const float* __restrict__ k3, float* __restrict__ dx,
-                    float* g_out, int c4n, int64_t total4, int64_t group4, int gstride, int kstride) {
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total4; i += (int64_t)gridDim.x * 256) {
+                    float* g_out, int c4n, int64_t total4, int64_t group4, int gstride, int kstride, int rev) {
+    for (int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x; j < total4; j += (int64_t)gridDim.x * 256) {
+        const int64_t i = rev ? total4 - 1 - j : j;
         const int c0 = (int)(i % c4n) * 4;
         const bool second = i >= group4;                          // (at most two groups)
         const int c = c0 + (second ? gstride : 0), ck = c0 + (second ? kstride : 0);
@@ -415,12 +418,13 @@ bn_bwd_apply_blocked_kernel(const float* __restrict__ dy, const float* dy2, cons
                             const float* __restrict__ k2, const float* __restrict__ k3, float* __restrict__ dx,
                             float* g_out, dcnsplit::u32x4* __restrict__ dq, const float* __restrict__ absmax,
                             int c4n, int64_t rows, int64_t rows_per_group, int gstride, int kstride,
-                            dcnsplit::u32x2* __restrict__ hl) {
+                            dcnsplit::u32x2* __restrict__ hl, int rev) {
     // hl (optional, c4n % 8 == 0): dx as the hl32 image the pre-split dgrad reads (same scale as dq); dx itself may then be
     // null -- nobody else reads the fp32 tensor
     const float s = dcnsplit::pow2_scale(*absmax);
     const int64_t total = ((rows + 3) >> 2) * c4n;
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    for (int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x; j < total; j += (int64_t)gridDim.x * 256) {
+        const int64_t i = rev ? total - 1 - j : j;
         const int64_t q = i / c4n;
         const int cq = (int)(i - q * c4n);
         const bool second = q * 4 >= rows_per_group;
@@ -744,7 +748,7 @@ void launch_bn_apply(const float* x, const float* stats1, const float* res, cons
                                                              (relu_mask ? 0.25 : 0.0)), st);
     hipLaunchKernelGGL(bn_apply_kernel, dim3(blocks_for(total4, kGridCap)), dim3(256), 0, st, x, stats1, stats1 + C, res,
                        stats2, stats2 ? stats2 + C : nullptr, relu, y, relu_mask, C / 4, total4, total4 / groups, 4 * C,
-                       (dcnsplit::u32x2*)hl_out, hl_absmax);
+                       (dcnsplit::u32x2*)hl_out, hl_absmax, tuning().bn_reverse & 1);
 }
 int bn_bwd_chunks(int64_t rows_per_group) {
     // enough row chunks that even a 64-channel layer launches >= ~1000 workgroups (HBM-bound pass: fill all 256 CUs)
@@ -785,13 +789,13 @@ void launch_bn_bwd(const float* dy, const float* relu_out, const unsigned char* 
                            dy, dy2, relu_out, relu_mask, x, mean, invstd, (const float*)k123, (const float*)(k123 + C),
                            (const float*)(k123 + 2 * C), (hl_dx && (C % 32) == 0 && !keep_dx) ? nullptr : dx, g_out,
                            (dcnsplit::u32x4*)dq, (const float*)absmax, C / 4, rows, rpg, 4 * C, 3 * C,
-                           (C % 32) == 0 ? (dcnsplit::u32x2*)hl_dx : nullptr);
+                           (C % 32) == 0 ? (dcnsplit::u32x2*)hl_dx : nullptr, (tuning().bn_reverse >> 1) & 1);
         return;
     }
     ObservedLaunch obs(DCN_PROF_BN_BWD_APPLY, (double)rows * C * (in_bytes + 4.0 + (g_out ? 4.0 : 0.0)), st);
     hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(blocks_for(total4, kGridCap)), dim3(256), 0, st, dy, dy2, relu_out, relu_mask,
                        x, mean, invstd, (const float*)k123, (const float*)(k123 + C), (const float*)(k123 + 2 * C), dx, g_out,
-                       C / 4, total4, total4 / groups, 4 * C, 3 * C);
+                       C / 4, total4, total4 / groups, 4 * C, 3 * C, (tuning().bn_reverse >> 1) & 1);
 }
 void launch_add(const float* a, const float* b, float* out, int64_t n, hipStream_t st) {
     ObservedLaunch obs(DCN_PROF_OTHER, 12.0 * (double)n, st);

@@ -583,3 +583,27 @@ def test_product_state_dict_layout_equals_the_committed_fixture(conv_mode):
             want.append((k, () if shp == "scalar" else tuple(int(v) for v in shp.split("x"))))
     got = [(k, tuple(v.shape)) for k, v in prod.Resnet34_8s(num_classes=3).state_dict().items()]
     assert got == want
+
+
+def test_bn_passes_walked_back_to_front_are_bit_identical(dcn_env, conv_mode):
+    """DCN_BN_REVERSE: the apply passes of the batch norm (forward and backward) walk their tensors back to front -- a pure
+    re-ordering of independent elements: outputs, running statistics and gradients equal bit for bit (two groups included)."""
+    m, _ = _pair("Resnet18_8s", 3, 8)
+    m2 = copy.deepcopy(m)
+    g = torch.Generator().manual_seed(2)
+    xa, xb = torch.randn(1, 3, 64, 64, generator=g), torch.randn(1, 3, 64, 64, generator=g)
+    gy = torch.randn(1, 3, 64, 64, generator=g)
+    outs = []
+    for net, rev in ((m, 0), (m2, 3)):
+        dcn_env(DCN_BN_REVERSE=rev)
+        net.train()
+        ya, yb = net.forward_pair(xa, xb)
+        y1 = net(xa)
+        ((ya * gy).sum() + (yb * gy).sum() + (y1 * gy).sum()).backward()
+        outs.append((ya.detach(), yb.detach(), y1.detach()))
+    for a, b in zip(*outs):
+        assert torch.equal(a, b)
+    for (k, p), p2 in zip(m.named_parameters(), m2.parameters()):
+        assert torch.equal(p.grad, p2.grad), k
+    for (k, b), b2 in zip(m.named_buffers(), m2.buffers()):
+        assert torch.equal(b, b2), k
