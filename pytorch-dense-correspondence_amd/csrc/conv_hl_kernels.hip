@@ -38,6 +38,20 @@
 // (the last two stages issue less and wait for 8 / 7 / 2 and 1 / 0).  WAR: B(s) and A_0(s) are read in LOAD(s, 0) only, of
 // group 1 at the latest -- one barrier before LOAD(s, 1) of group 0, the first slot that overwrites them with stage s + 2;
 // A_1 / A_2 of s + 1 replace those of s - 1 (same group, last read in LOAD(s - 1, 2)).
+//
+// 320-row variant (MT = 5, round 4: tile 320 x 256, wavefront tile 160 x 64 = 10 accumulators = 160 registers; stage =
+// 40 KB of A + 32 KB of B, two buffers = 144 KB of the 160 KB LDS).  Why: 38 400 rows x 512 channels (layer 4 at 8 images)
+// are 240 such tiles -- ONE data-parallel round on 256 CUs, no stream-K partials at all -- where 192-row tiles need 1.56
+// rounds (256 + 144 stream-K'd tiles whose K ranges share no operand in L2: 0.6 GB of fabric reads per launch,
+// profiles/r3f_hbm_counters.txt), and the tile moves 0.93x the LDS bytes per FLOP of the 256-row one.  The schedule is the
+// 192-row one with FIVE phases per stage (phase p = the p-th 32-row block x both column blocks, 12 MFMAs; B fragments read once
+// per stage).  Pieces per wavefront and stage: A_0 .. A_4 (one each) and Bf, Bs (two each); issue order
+//     LOAD(s, 0): A_1, A_2 of s + 1     LOAD(s, 1): A_3, A_4 of s + 1     LOAD(s, 2): Bf of s + 2     LOAD(s, 3): Bs of s + 2
+//     LOAD(s, 4): A_0 of s + 2
+// so every piece has >= 6 phases to land.  RAW (youngest pieces that may still be in flight at the end of the slot):
+//     LOAD(s, 0): A_1(s) landed = all but 10;  (s, 1): A_2(s), 11;  (s, 2): A_3(s), 12;  (s, 3): A_4(s), 13;  (s, 4): B, A_0 of
+//     s + 1, 9 (the last two stages of a segment issue less: 10 / 11 / 10 / 9 / 4 and 3 / 2 / 1 / 0).  WAR as above: B(s) and
+// A_0(s) are read in LOAD(s, 0) only and overwritten from LOAD(s, 2) on; A_i(s + 1) replaces A_i(s - 1), read five slots earlier.
 #include <algorithm>
 #include <atomic>
 #include <type_traits>
@@ -55,6 +69,10 @@ typedef __attribute__((address_space(3))) void* hl_lds_ptr;
 
 constexpr int kOob = (int)0x80000000;   // voffset that fails the bounds check of any buffer <= 2 GiB: LDS receives zeros
 constexpr int kHlStage = 65536;         // bytes per 32-K stage: [A rows 0..255][B rows 0..255] x 128 B
+// per tile height: bytes of the A part of a stage (B follows it: 256 rows x 128 B) and of the whole stage
+template <int MT> struct HlStage {
+    static constexpr int kA = MT == 5 ? 320 * 128 : 32768, kStage = kA + 32768;
+};
 constexpr int HLK = 32;
 
 // (a NON-template function: inside a template this builtin breaks the host-side kernel stub with this compiler)
@@ -85,9 +103,10 @@ split_act_hl32_kernel(const float* __restrict__ src, const float* __restrict__ a
 template <bool TR, int MT>
 __device__ __forceinline__ void gemm_segment_hl(const GemmConv& p, unsigned char* lds, int tile, int k0, int k1, int nk,
                                                 float* slot) {
-    static_assert(MT == 3 || MT == 4, "wavefront tiles of 96 or 128 rows");
+    static_assert(MT == 3 || MT == 4 || MT == 5, "wavefront tiles of 96, 128 or 160 rows");
     constexpr int BM = 64 * MT, GR = 32 * MT;   // rows per tile / per wavefront group
-    constexpr int NA = MT == 4 ? 4 : 3;         // A pieces per wavefront and stage
+    constexpr int NA = MT == 4 ? 4 : MT;        // A pieces per wavefront and stage
+    constexpr int kHlStage = HlStage<MT>::kStage, kAB = HlStage<MT>::kA;   // (shadow the 256-row constants)
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int grp = wv >> 2, wn = wv & 3;
@@ -102,8 +121,13 @@ __device__ __forceinline__ void gemm_segment_hl(const GemmConv& p, unsigned char
     const int l8 = lane >> 3, ls = lane & 7;
     const int cs4 = p.cs * 4;              // bytes per pixel of the activation image
     // A piece a of this wavefront: MT = 4: (i, e) = (a >> 1, a & 1) as above; MT = 3: block i = a, rows 96 g + 32 a + 8 wn + [0, 8)
-    auto a_piece_row = [&](int a) { return MT == 4 ? grp * 128 + (a >> 1) * 64 + (2 * wn + (a & 1)) * 8 : grp * 96 + a * 32 + wn * 8; };
+    auto a_piece_row = [&](int a) { return MT == 4 ? grp * 128 + (a >> 1) * 64 + (2 * wn + (a & 1)) * 8 : grp * GR + a * 32 + wn * 8; };
     int by[NA], bx[NA], rowoff[NA], voa[NA], vob[2][2];
+    // MT = 5 (160 accumulator registers): instead of the position (by, bx) and the current offset (voa) of every piece, ONE
+    // word per piece with a validity bit per filter tap (taps <= 32: hl_shape) -- the offset of a piece is formed when it is
+    // issued: rowoff +- the tap's (wave-uniform) displacement, or the out-of-range offset.  10 registers instead of 20.
+    unsigned vmask[NA];
+    int cur_delta = 0, cur_bit = 0;
 #pragma unroll
     for (int a = 0; a < NA; ++a) {
         const int row = a_piece_row(a) + l8;
@@ -116,6 +140,22 @@ __device__ __forceinline__ void gemm_segment_hl(const GemmConv& p, unsigned char
         by[a] = ok ? (TR ? y + p.pad : y - p.pad) : -(1 << 28);   // (stride 1; rows past M: never inside the image)
         bx[a] = TR ? x + p.pad : x - p.pad;
         rowoff[a] = ok ? (img * p.hs * p.ws + by[a] * p.ws + bx[a]) * cs4 + sl * 16 : 0;
+        vmask[a] = 0u;
+        if constexpr (MT == 5) {
+            const int ntap = p.kh * p.kw;
+            for (int tap = 0; tap < ntap; ++tap) {
+                const int r = fdiv(tap, p.div_kw), s = tap - r * p.kw;
+                const int dy = r * p.dil, dx = s * p.dil;
+                bool v;
+                if (TR) {
+                    const int ny = by[a] - dy, nx = bx[a] - dx;
+                    v = ((ny | nx) >= 0) & (ny < p.hs) & (nx < p.ws);
+                } else {
+                    v = ((unsigned)(by[a] + dy) < (unsigned)p.hs) & ((unsigned)(bx[a] + dx) < (unsigned)p.ws);
+                }
+                vmask[a] |= (v ? 1u : 0u) << tap;
+            }
+        }
     }
 #pragma unroll
     for (int j = 0; j < 2; ++j)
@@ -136,6 +176,11 @@ __device__ __forceinline__ void gemm_segment_hl(const GemmConv& p, unsigned char
         const int r = fdiv(tap, p.div_kw), s = tap - r * p.kw;
         const int dy = r * p.dil, dx = s * p.dil;
         const int delta = (dy * p.ws + dx) * cs4;
+        if constexpr (MT == 5) {
+            cur_delta = TR ? -delta : delta;
+            cur_bit = tap;
+            return;
+        }
 #pragma unroll
         for (int a = 0; a < NA; ++a) {
             bool ok;
@@ -168,10 +213,11 @@ __device__ __forceinline__ void gemm_segment_hl(const GemmConv& p, unsigned char
     };
     // pieces of the stage the traversal state points at, into stage buffer `buf`
     auto issue_a = [&](int buf, int a) {
-        glds16(rs_a, lds + buf * kHlStage + a_piece_row(a) * 128, voa[a], (u_grp * kcg + u_c) * 128);
+        const int vo = MT == 5 ? (((vmask[a] >> cur_bit) & 1u) ? rowoff[a] + cur_delta : kOob) : voa[a];
+        glds16(rs_a, lds + buf * kHlStage + a_piece_row(a) * 128, vo, (u_grp * kcg + u_c) * 128);
     };
     auto issue_b = [&](int buf, int j) {
-        unsigned char* d = lds + buf * kHlStage + 32768 + ((wv >> 1) * 64 + j * 32 + 2 * (wv & 1) * 8) * 128;
+        unsigned char* d = lds + buf * kHlStage + kAB + ((wv >> 1) * 64 + j * 32 + 2 * (wv & 1) * 8) * 128;
         const int soff = (u_tap * cpt + u_grp * kcg + u_c) * 128;
         glds16(rs_b, d, vob[j][0], soff);
         glds16(rs_b, d + 1024, vob[j][1], soff);
@@ -194,7 +240,7 @@ __device__ __forceinline__ void gemm_segment_hl(const GemmConv& p, unsigned char
     for (int pl = 0; pl < 2; ++pl)
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) foff[pl][ks] = ((pl * 4 + ks * 2 + fh) ^ swz) * 16;
-    const int a_row = (grp * GR + fi) * 128, b_row = 32768 + (wn * 64 + fi) * 128;
+    const int a_row = (grp * GR + fi) * 128, b_row = kAB + (wn * 64 + fi) * 128;
 
     f32x16 acc[MT][2];   // [tm][tn]: rows GR g + 32 tm, columns 64 wn + 32 tn  (the common epilogue's map; MT = 4: tm = 2 i + t)
 #pragma unroll
@@ -318,25 +364,58 @@ __device__ __forceinline__ void gemm_segment_hl(const GemmConv& p, unsigned char
         if (ph == 0) { read_b(buf); __builtin_amdgcn_sched_barrier(0); }
         read_a(buf, ph);
         __builtin_amdgcn_sched_barrier(0);
-        if (ph == 0 && AHEAD >= 1) {
-            issue_a(buf ^ 1, 1);
-            issue_a(buf ^ 1, 2);
-            advance();               // (the traversal state now points at stage s + 2)
-        }
-        if (ph == 1 && AHEAD == 2) issue_b(buf, 0);
-        if (ph == 2 && AHEAD == 2) { issue_b(buf, 1); issue_a(buf, 0); }
-        __builtin_amdgcn_sched_barrier(0);
-        if (AHEAD == 2) {
-            if (ph == 0) DCN_WAIT_VMCNT(8);
-            else if (ph == 1) DCN_WAIT_VMCNT(9);
-            else DCN_WAIT_VMCNT(7);
-        } else if (AHEAD == 1) {
-            if (ph == 0) DCN_WAIT_VMCNT(8);
-            else if (ph == 1) DCN_WAIT_VMCNT(7);
-            else DCN_WAIT_VMCNT(2);
+        if constexpr (MT == 3) {
+            if (ph == 0 && AHEAD >= 1) {
+                issue_a(buf ^ 1, 1);
+                issue_a(buf ^ 1, 2);
+                advance();               // (the traversal state now points at stage s + 2)
+            }
+            if (ph == 1 && AHEAD == 2) issue_b(buf, 0);
+            if (ph == 2 && AHEAD == 2) { issue_b(buf, 1); issue_a(buf, 0); }
         } else {
-            if (ph == 0) DCN_WAIT_VMCNT(1);
-            else if (ph == 1) DCN_WAIT_VMCNT(0);
+            if (ph == 0 && AHEAD >= 1) { issue_a(buf ^ 1, 1); issue_a(buf ^ 1, 2); }
+            if (ph == 1 && AHEAD >= 1) {
+                issue_a(buf ^ 1, 3);
+                issue_a(buf ^ 1, 4);
+                advance();               // (the traversal state now points at stage s + 2)
+            }
+            if (ph == 2 && AHEAD == 2) issue_b(buf, 0);
+            if (ph == 3 && AHEAD == 2) issue_b(buf, 1);
+            if (ph == 4 && AHEAD == 2) issue_a(buf, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (MT == 3) {
+            if (AHEAD == 2) {
+                if (ph == 0) DCN_WAIT_VMCNT(8);
+                else if (ph == 1) DCN_WAIT_VMCNT(9);
+                else DCN_WAIT_VMCNT(7);
+            } else if (AHEAD == 1) {
+                if (ph == 0) DCN_WAIT_VMCNT(8);
+                else if (ph == 1) DCN_WAIT_VMCNT(7);
+                else DCN_WAIT_VMCNT(2);
+            } else {
+                if (ph == 0) DCN_WAIT_VMCNT(1);
+                else if (ph == 1) DCN_WAIT_VMCNT(0);
+            }
+        } else {   // (the table of the file header)
+            if (AHEAD == 2) {
+                if (ph == 0) DCN_WAIT_VMCNT(10);
+                else if (ph == 1) DCN_WAIT_VMCNT(11);
+                else if (ph == 2) DCN_WAIT_VMCNT(12);
+                else if (ph == 3) DCN_WAIT_VMCNT(13);
+                else DCN_WAIT_VMCNT(9);
+            } else if (AHEAD == 1) {
+                if (ph == 0) DCN_WAIT_VMCNT(10);
+                else if (ph == 1) DCN_WAIT_VMCNT(11);
+                else if (ph == 2) DCN_WAIT_VMCNT(10);
+                else if (ph == 3) DCN_WAIT_VMCNT(9);
+                else DCN_WAIT_VMCNT(4);
+            } else {
+                if (ph == 0) DCN_WAIT_VMCNT(3);
+                else if (ph == 1) DCN_WAIT_VMCNT(2);
+                else if (ph == 2) DCN_WAIT_VMCNT(1);
+                else if (ph == 3) DCN_WAIT_VMCNT(0);
+            }
         }
         DCN_WAIT_LGKMCNT0();
         bar();
@@ -346,41 +425,40 @@ __device__ __forceinline__ void gemm_segment_hl(const GemmConv& p, unsigned char
     using A0 = std::integral_constant<int, 0>;
     using A1 = std::integral_constant<int, 1>;
     using A2 = std::integral_constant<int, 2>;
+    auto stage = [&](auto tag, int buf) {
+#pragma unroll
+        for (int ph = 0; ph < MT; ++ph) phase(tag, buf, ph);
+    };
 
+    // prologue: stage k0 whole -- what phase 0 reads first --, then B and A_0 of stage k0 + 1: the order of the steady state
     issue_b(0, 0);
     issue_b(0, 1);
     issue_a(0, 0);
-    issue_a(0, 1);
-    issue_a(0, 2);
+#pragma unroll
+    for (int a = 1; a < MT; ++a) issue_a(0, a);
     if (k0 + 1 < k1) {
         advance();
         issue_b(1, 0);
         issue_b(1, 1);
         issue_a(1, 0);
         __builtin_amdgcn_sched_barrier(0);
-        DCN_WAIT_VMCNT(7);
+        if constexpr (MT == 3) DCN_WAIT_VMCNT(7); else DCN_WAIT_VMCNT(9);
     } else {
         __builtin_amdgcn_sched_barrier(0);
-        DCN_WAIT_VMCNT(2);
+        if constexpr (MT == 3) DCN_WAIT_VMCNT(2); else DCN_WAIT_VMCNT(4);
     }
     bar();
     if (grp == 1) bar();
     int buf = 0;
     for (int s = k0; s + 2 < k1; ++s) {
-        phase(A2{}, buf, 0);
-        phase(A2{}, buf, 1);
-        phase(A2{}, buf, 2);
+        stage(A2{}, buf);
         buf ^= 1;
     }
     if (k0 + 1 < k1) {
-        phase(A1{}, buf, 0);
-        phase(A1{}, buf, 1);
-        phase(A1{}, buf, 2);
+        stage(A1{}, buf);
         buf ^= 1;
     }
-    phase(A0{}, buf, 0);
-    phase(A0{}, buf, 1);
-    phase(A0{}, buf, 2);
+    stage(A0{}, buf);
   }
     if (grp == 0) bar();
     __syncthreads();
@@ -434,7 +512,7 @@ __device__ __forceinline__ void gemm_segment_hl(const GemmConv& p, unsigned char
                 for (int r = 0; r < 16; ++r) acc[tm][tn][r] = 0.f;
         // (each contributor's partial in batches of 16 (12) loads of 16 B issued back to back, then added: left to itself the
         // compiler waits for every 4 loads -- device-coherent round trips on the critical path of the launch)
-        constexpr int kPieces = TM * TN * 4, kBatch = TM == 4 ? 16 : 12;
+        constexpr int kPieces = TM * TN * 4, kBatch = TM == 4 ? 16 : (TM == 3 ? 12 : 10);
         static_assert(kPieces % kBatch == 0, "whole batches");
         for (int g = ga; g <= gb; ++g) {               // fixed order, own partial included: deterministic
             const int first_tile = (g * p.sk_units) / nk;
@@ -464,7 +542,7 @@ __device__ __forceinline__ void gemm_segment_hl(const GemmConv& p, unsigned char
 template <bool TR, bool SK, int MT>
 __global__ void __launch_bounds__(512, 1)
 conv_gemm_hl_kernel(GemmConv p) {
-    __shared__ __attribute__((aligned(16))) unsigned char lds[2 * kHlStage];
+    __shared__ __attribute__((aligned(16))) unsigned char lds[2 * HlStage<MT>::kStage];
     const int nk = p.K / HLK;
     if (!SK) {
         gemm_segment_hl<TR, MT>(p, lds, xcd_remap(blockIdx.x, p.mtiles * p.ntiles), 0, nk, nk, nullptr);
@@ -543,19 +621,38 @@ HlShape hl_shape_rows(int M, int cd, int K, int rows) {
 // shapes (profiles/r3q_hl_rows_per_layer.txt): 256 -> 256 3x3, 150 / 200 tiles: 160 -> 139 us; 512 -> 512 3x3, 300 / 400
 // tiles, both stream-K'd: 491 -> 450 us.  group_rows: rows per statistics group of the forward epilogue (0: none) -- a
 // group is made of whole tiles.
-HlShape hl_shape(int M, int cd, int K, int group_rows) {
+// taps: filter taps of the convolution (the 320-row kernel keeps one validity bit per tap in a 32-bit word)
+HlShape hl_shape(int M, int cd, int K, int group_rows, int taps) {
     const HlShape g4 = hl_shape_rows(M, cd, K, 256);
     const int force = dcn::tuning().gemm_hl_rows;
     const bool ok3 = group_rows <= 0 || (group_rows % 192) == 0, ok4 = group_rows <= 0 || (group_rows % 256) == 0;
-    if (!ok3 || force == 256) return g4;
-    const HlShape g3 = hl_shape_rows(M, cd, K, 192);
-    if (force == 192 || !ok4) return g3;
+    const bool ok5 = (group_rows <= 0 || (group_rows % 320) == 0) && taps <= 32;
+    // 320-row tiles (round 4) run data-parallel only: they are for the launches they fit in whole rounds (38 400 x 512 outputs
+    // = 240 tiles = ONE round without any stream-K partial)
+    auto shape5 = [&]() {
+        HlShape g5 = hl_shape_rows(M, cd, K, 320);
+        g5.sk = false; g5.sk_wgs = 0; g5.sk_units = 0; g5.sk_dp = 0; g5.ws_bytes = 0; g5.sk_count_off = 0;
+        return g5;
+    };
+    if (force == 320 && ok5) return shape5();
+    if ((!ok3 && !ok5) || force == 256) return g4;
     auto cost = [](const HlShape& g) {
         const double rounds = g.mtiles * g.ntiles / 256.0;
         const double per_row = g.rows == 192 ? 1.08 : 1.0, fixup = g.rows == 192 ? 30.0 : 50.0;
         return (g.sk ? rounds + fixup / g.nk : (double)(int)(rounds + 0.999999)) * g.rows * per_row;
     };
-    return cost(g3) < 0.97 * cost(g4) ? g3 : g4;
+    if (force == 192 && ok3) return hl_shape_rows(M, cd, K, 192);
+    HlShape best = g4;
+    double best_cost = ok4 ? cost(g4) : 1e300;
+    if (ok3) {
+        const HlShape g3 = hl_shape_rows(M, cd, K, 192);
+        if (cost(g3) < 0.97 * best_cost) { best = g3; best_cost = cost(g3); }
+    }
+    if (ok5 && dcn::tuning().gemm_hl_rows != -320) {   // (DCN_GEMM_HL_ROWS=-320: never 320 -- the round-3 choice, for A/B runs)
+        const HlShape g5 = shape5();
+        if (cost(g5) < 0.97 * best_cost) { best = g5; best_cost = cost(g5); }
+    }
+    return best;
 }
 
 bool valid_desc_hl(const dcn_conv_desc* c) {
@@ -566,10 +663,14 @@ bool valid_desc_hl(const dcn_conv_desc* c) {
 template <int MT>
 void launch_gemm_hl_rows(const GemmConv& p, bool sk, dim3 grid, hipStream_t st) {
     const dim3 block(512);
-    if (sk) {
-        if (p.transposed) hipLaunchKernelGGL((conv_gemm_hl_kernel<true, true, MT>), grid, block, 0, st, p);
-        else hipLaunchKernelGGL((conv_gemm_hl_kernel<false, true, MT>), grid, block, 0, st, p);
-    } else {
+    if constexpr (MT != 5) {   // (320-row tiles: data-parallel launches only, hl_shape)
+        if (sk) {
+            if (p.transposed) hipLaunchKernelGGL((conv_gemm_hl_kernel<true, true, MT>), grid, block, 0, st, p);
+            else hipLaunchKernelGGL((conv_gemm_hl_kernel<false, true, MT>), grid, block, 0, st, p);
+            return;
+        }
+    }
+    {
         if (p.transposed) hipLaunchKernelGGL((conv_gemm_hl_kernel<true, false, MT>), grid, block, 0, st, p);
         else hipLaunchKernelGGL((conv_gemm_hl_kernel<false, false, MT>), grid, block, 0, st, p);
     }
@@ -581,7 +682,7 @@ int launch_gemm_hl(GemmConv& p, int group_rows, void* workspace, hipStream_t st)
     p.div_w = make_fastdiv(p.wd);
     p.div_cs = make_fastdiv(p.cs);
     p.div_kw = make_fastdiv(p.kw);
-    const HlShape g = hl_shape(p.M, p.cd, p.K, group_rows);
+    const HlShape g = hl_shape(p.M, p.cd, p.K, group_rows, p.kh * p.kw);
     const bool sk = g.sk && workspace != nullptr;
     p.mtiles = g.mtiles;
     p.ntiles = g.ntiles;
@@ -599,6 +700,7 @@ int launch_gemm_hl(GemmConv& p, int group_rows, void* workspace, hipStream_t st)
     }
     const dim3 grid(sk ? g.sk_wgs : g.mtiles * g.ntiles);
     if (g.rows == 192) launch_gemm_hl_rows<3>(p, sk, grid, st);
+    else if (g.rows == 320) launch_gemm_hl_rows<5>(p, false, grid, st);
     else launch_gemm_hl_rows<4>(p, sk, grid, st);
     return dcn::check_launch();
 }
@@ -615,7 +717,7 @@ static bool hl_supported(const dcn_conv_desc* c, int dgrad) {
     const int64_t K = (int64_t)c->kh * c->kw * cs;
     if ((cs % HLK) != 0 || (dgrad && c->ldc != c->cout) || (cd % 4) != 0 || M >= ((int64_t)1 << 30)) return false;
     if (dgrad && (c->hin != c->hout || c->win != c->wout)) return false;       // (stride-1 "same" convolutions)
-    if (!dgrad && c->group_rows > 0 && (c->group_rows % 256) != 0 && (c->group_rows % 192) != 0) return false;
+    if (!dgrad && c->group_rows > 0 && (c->group_rows % 256) != 0 && (c->group_rows % 192) != 0 && (c->group_rows % 320) != 0) return false;
     const int64_t src_bytes = (int64_t)c->n * (dgrad ? c->hout * c->wout : c->hin * c->win) * cs * 4;
     const int64_t w_bytes = (int64_t)cd * K * 4;
     return src_bytes <= ((int64_t)1 << 31) - 1 && w_bytes <= ((int64_t)1 << 31) - 1;
@@ -634,6 +736,9 @@ extern "C" int dcn_conv_hl_eligible(const dcn_conv_desc* c, int dgrad) {
     // costs about what it saves unless the K loop is long: the fp32-operand kernel's 256 x 128 tiles quantise better there
     // (measured: ResNet50-8s layer-3 3x3 at 1280 x 960 -5 %, its 1x1 1024 -> 256 -20 %; layer4.0.conv1 of ResNet34-8s at
     // N = 8 -3 %; the 512 -> 512 layer-4 convolutions, K = 4608, +7 %)
+    // (a launch that 320-row tiles cover in at most one round is none of these cases)
+    const HlShape chosen = hl_shape((int)M, cd, (int)K, dgrad ? 0 : c->group_rows, c->kh * c->kw);
+    if (chosen.rows == 320 && chosen.mtiles * chosen.ntiles <= 256 && chosen.mtiles * chosen.ntiles >= 120) return 1;
     const double rounds = (double)dcn::ceil_div64(M, 256) * dcn::ceil_div(cd, 256) / 256.0;
     if (rounds > 1.0 && rounds < 1.5 && K < 4096) return 0;
     // fewer than ~120 tiles leave more than half of the 256 CUs idle (no stream-K below one round): config 1 (two images,
@@ -644,20 +749,20 @@ extern "C" int dcn_conv_hl_eligible(const dcn_conv_desc* c, int dgrad) {
 
 extern "C" int dcn_conv_num_mtiles_hl(const dcn_conv_desc* c) {
     if (!valid_desc_hl(c)) return DCN_E_INVALID;
-    return hl_shape(c->n * c->hout * c->wout, c->cout, c->kh * c->kw * c->cin, c->group_rows).mtiles;
+    return hl_shape(c->n * c->hout * c->wout, c->cout, c->kh * c->kw * c->cin, c->group_rows, c->kh * c->kw).mtiles;
 }
 
 // Rows per tile the launch of this convolution will use (256 or 192): the granularity of its batch-norm partial statistics.
 extern "C" int dcn_conv_tile_rows_hl(const dcn_conv_desc* c, int dgrad) {
     if (!valid_desc_hl(c)) return DCN_E_INVALID;
-    if (dgrad) return hl_shape(c->n * c->hin * c->win, c->cin, c->kh * c->kw * c->ldc, 0).rows;
-    return hl_shape(c->n * c->hout * c->wout, c->cout, c->kh * c->kw * c->cin, c->group_rows).rows;
+    if (dgrad) return hl_shape(c->n * c->hin * c->win, c->cin, c->kh * c->kw * c->ldc, 0, c->kh * c->kw).rows;
+    return hl_shape(c->n * c->hout * c->wout, c->cout, c->kh * c->kw * c->cin, c->group_rows, c->kh * c->kw).rows;
 }
 
 extern "C" size_t dcn_conv_gemm_workspace_hl(const dcn_conv_desc* c, int dgrad) {
     if (!valid_desc_hl(c)) return 0;
-    if (dgrad) return hl_shape(c->n * c->hin * c->win, c->cin, c->kh * c->kw * c->ldc, 0).ws_bytes;
-    return hl_shape(c->n * c->hout * c->wout, c->cout, c->kh * c->kw * c->cin, c->group_rows).ws_bytes;
+    if (dgrad) return hl_shape(c->n * c->hin * c->win, c->cin, c->kh * c->kw * c->ldc, 0, c->kh * c->kw).ws_bytes;
+    return hl_shape(c->n * c->hout * c->wout, c->cout, c->kh * c->kw * c->cin, c->group_rows, c->kh * c->kw).ws_bytes;
 }
 
 extern "C" int dcn_split_act_hl32(const float* src, const float* absmax, void* dst, int64_t rows, int channels, void* stream) {

@@ -22,8 +22,8 @@
 //   DCN_GEMM_HL             0: the wide layers stay on the fp32-operand gather-GEMM (conv_f16_kernels.hip) instead of the
 //                           pre-split (hl32) LDS-DMA kernel (conv_hl_kernels.hip); 2: every convolution that kernel supports
 //                           takes it, whatever its size (tests)
-//   DCN_GEMM_HL_ROWS        192 / 256: tile height of the hl32 gather-GEMM (default 0: whichever quantises better on the 256 CUs,
-//                           hl_shape in conv_hl_kernels.hip)
+//   DCN_GEMM_HL_ROWS        192 / 256 / 320: tile height of the hl32 gather-GEMM (default 0: whichever quantises better on the
+//                           256 CUs, hl_shape in conv_hl_kernels.hip); -320: as decided, but never 320 (the round-3 choice)
 //   DCN_WGRAD_HL            0: the wide layers' weight gradients stay on the fp32-operand kernel (conv_f16_kernels.hip) instead of
 //                           the pre-split (hl32) LDS-DMA kernel (wgrad_hl_kernels.hip); 2: every supported convolution (tests)
 //   DCN_HL_PRODUCERS        0: hl32 activation / gradient images are made by stand-alone split passes instead of by the

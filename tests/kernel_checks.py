@@ -229,7 +229,7 @@ def check_conv_hl(L, dev, n, h, w, cin, cout, k, dil, set_env=None, sk=None, sca
     if sk is not None:
         env["DCN_GEMM_SK"] = sk
     if rows is not None:
-        env["DCN_GEMM_HL_ROWS"] = rows      # tile height 256 / 192 (conv_hl_kernels.hip: two different software pipelines)
+        env["DCN_GEMM_HL_ROWS"] = rows      # tile height 256 / 192 / 320 (conv_hl_kernels.hip: three software pipelines)
     if env:
         set_env(**env)
     d = L.ConvDesc(n, h, w, cin, h, w, cout, k, k, 1, pad, dil, cout, 0)
@@ -262,8 +262,8 @@ def check_conv_hl(L, dev, n, h, w, cin, cout, k, dil, set_env=None, sk=None, sca
     # ---- forward
     mt = lib.dcn_conv_num_mtiles_hl(ctypes.byref(d))
     tr = lib.dcn_conv_tile_rows_hl(ctypes.byref(d), 0)
-    assert tr in (192, 256) and (rows is None or tr == int(rows)) and mt == (M + tr - 1) // tr
-    assert lib.dcn_conv_tile_rows_hl(ctypes.byref(d), 1) in ((192, 256) if rows is None else (int(rows),))
+    assert tr in (192, 256, 320) and (rows is None or tr == int(rows)) and mt == (M + tr - 1) // tr
+    assert lib.dcn_conv_tile_rows_hl(ctypes.byref(d), 1) in ((192, 256, 320) if rows is None else (int(rows),))
     nws = max(lib.dcn_conv_gemm_workspace_hl(ctypes.byref(d), 0), lib.dcn_conv_gemm_workspace_hl(ctypes.byref(d), 1))
     if sk is not None and str(sk) != "0":
         assert nws > 8, "stream-K is not exercised by this shape"

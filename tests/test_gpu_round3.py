@@ -37,10 +37,12 @@ HL_LAYERS = [
 ]
 
 
-@pytest.mark.parametrize("rows", ["256", "192"])   # (tile height: two software pipelines, conv_hl_kernels.hip)
+@pytest.mark.parametrize("rows", ["256", "192", "320"])   # (tile height: three software pipelines, conv_hl_kernels.hip)
 @pytest.mark.parametrize("case", HL_SMALL + HL_LAYERS, ids=[str(c) for c in HL_SMALL + HL_LAYERS])
 def test_conv_hl32_lds_dma_gather_gemm(L, case, rows, dcn_env):
     n, h, w, cin, cout, k, dil, sk, sx = case
+    if rows == "320" and sk not in (None, "0"):
+        pytest.skip("320-row tiles run data-parallel launches only (hl_shape)")
     for rep in range(2):   # (again on the workspace the previous launch left behind; another seed, other data)
         res = kernel_checks.check_conv_hl(L, "cuda", n, h, w, cin, cout, k, dil, set_env=dcn_env, sk=sk, scale_x=sx,
                                           seed=len(str(case)) + rep, rows=rows)

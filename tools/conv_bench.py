@@ -96,7 +96,10 @@ def main():
             amax = dy.abs().max().reshape(1)
             wsf = torch.empty(max(lib.dcn_conv_gemm_workspace_f16(ctypes.byref(d), 0), 4) // 4, device=dev)
             wsd = torch.empty(max(lib.dcn_conv_gemm_workspace_f16(ctypes.byref(d), 1), 4) // 4, device=dev)
-            part = torch.empty(lib.dcn_conv_num_mtiles_f16(ctypes.byref(d)), 3, cout, device=dev)
+            # (sized for whichever kernel writes more rows of batch-norm partial sums: the hl32 kernel's 192-row tiles make
+            # more M tiles than the 256-row ones of the fp32-operand kernel -- 50 against 38 at two images)
+            part = torch.empty(max(lib.dcn_conv_num_mtiles_f16(ctypes.byref(d)), lib.dcn_conv_num_mtiles_hl(ctypes.byref(d)),
+                                   (n * hout * wout + 31) // 32), 3, cout, device=dev)
         calls = {
             "fwd": lambda: lib.dcn_conv_forward(ctypes.byref(d), _lib.ptr(x), _lib.ptr(w), None, _lib.ptr(y), _lib.ptr(part), _lib.ptr(wsf), st),
             "dgrad": lambda: lib.dcn_conv_dgrad(ctypes.byref(d), _lib.ptr(dy), _lib.ptr(wt), None, _lib.ptr(dx), _lib.ptr(wsd), st),
