@@ -689,7 +689,7 @@ def main():
 
     def summarize(job_, sec, steps_, extra=None):
         d = {"value": 2 * job_.B * world * steps_ / sec, "unit": "images/s", "ms_per_step": 1e3 * sec / steps_, "steps": steps_,
-             "pairs_per_gpu": job_.B, "global_pairs": job_.B * world}
+             "pairs_per_gpu": job_.B, "global_pairs": job_.B * world, "host_enqueue_ms_per_step": getattr(job_, "host_enqueue_ms", None)}
         d.update(extra or {})
         return d
 

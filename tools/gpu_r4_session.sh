@@ -49,6 +49,9 @@ PY
     convn8)    timeout 400 python tools/conv_bench.py --mode hl --n 8 --x-direct --reps 20 --relu-x 2>&1 | grep -v "Warn\|amdgpu.ids" | cut -c1-170 | tee gpurun_out/${tag}_conv_per_layer_n8.txt
                for r in ${HL_ROWS_LIST:-}; do echo "--- DCN_GEMM_HL_ROWS=$r" | tee -a gpurun_out/${tag}_conv_per_layer_n8.txt
                  timeout 300 env DCN_GEMM_HL_ROWS=$r python tools/conv_bench.py --mode hl --n 8 --kinds fwd,dgrad --only "layer4\|layer3" --reps 20 --relu-x 2>&1 | grep -v "Warn\|amdgpu.ids" | cut -c1-170 | tee -a gpurun_out/${tag}_conv_per_layer_n8.txt; done ;;
+    tests320)  timeout 900 python -m pytest tests/test_gpu_round3.py tests/test_gpu_round4.py -m gpu -q -p no:cacheprovider -k "320 or identical or profile" > gpurun_out/${tag}_pytest_320.log 2>&1; tail -6 gpurun_out/${tag}_pytest_320.log | cut -c1-300 ;;
+    c1sep)     # config 1, two-call pattern, on its own (the in-process variant of the default line measured 35 ms/step, host-bound)
+               timeout 300 python bench.py --workload config1 --separate-forwards --no-variants --cpu-baseline-steps 0 --profile-steps 0 --steps 30 --warmup 8 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('config1 separate alone: %.1f images/s  %.3f ms/step  host %.2f' % (d['value'], d['ms_per_step'], d['host_enqueue_ms_per_step']))" ;;
     *) echo "unknown step $s" ;;
   esac
 done
