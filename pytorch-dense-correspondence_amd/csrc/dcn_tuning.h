@@ -36,6 +36,8 @@
 //                           whose input the convolution has just written front to back; 2: the backward apply pass, whose two
 //                           inputs the reduce pass has just read front to back) -- what was touched last is then read first
 //                           and is still in the 256 MB Infinity Cache when the tensors do not fit it whole.  Same results bit for bit.
+//   DCN_BN_REDUCE_WIDE      16 / 32 / 64 / 128: channel quads per workgroup of the batch-norm backward reduction at most (16 = 64
+//                           channels: 256-byte pieces of a row per tensor; 128 = whole rows of 512 channels, but 8x fewer workgroups)
 #pragma once
 
 namespace dcn {
@@ -61,6 +63,7 @@ struct Tuning {
     int hl_producers = 1;        // hl32 images written by the producing batch-norm passes (0: stand-alone split passes)
     int hl_only_mid = 1;         // mid-block activations whose two readers (next conv, its wgrad) take the hl32 image: no fp32 copy (0: keep it)
     int stem_pool_fused = 1;     // the stem's batch norm + ReLU applied inside the max-pool pass (0: an apply pass of its own)
+    int bn_reduce_wide = 16;     // see DCN_BN_REDUCE_WIDE above
     int bn_reverse = 0;          // see DCN_BN_REVERSE above
     int wgrad_roles = 1;         // wide tile: wavefronts 0-3 stage the activations, 4-7 the gradient (0: copy spread over all 8)
 };

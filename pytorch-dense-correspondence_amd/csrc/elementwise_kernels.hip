@@ -252,18 +252,22 @@ __device__ __forceinline__ float4 load_dy(const float* __restrict__ dy, const fl
 // partial[chunk][C][4] = ( sum g , sum g * xhat , max |g| , max |xhat| ) over the chunk's rows, xhat = (x - mean) * invstd
 // (the four statistics of a channel are one float4: the finalize kernel reads them with a single load).
 // (The two maxima bound |dx| per channel without another pass or any atomics in the big kernels: bn_bwd_finalize.)
-// work-item (c4 = tid & 15, rl = tid >> 4): 16 channel quads x 16 row lanes; grid = (C/64 groups, chunks).
+// work-item (c4 = tid % CQ, rl = tid / CQ): CQ channel quads x 256 / CQ row lanes; grid = (C / (4 CQ) groups, chunks).
+// CQ = 16 (64 channels per workgroup) is the general shape; the wider ones (round 4) make a workgroup read WHOLE rows of up
+// to 512 channels -- one contiguous stream per tensor instead of 256-byte pieces strided by the row pitch.
+template <int CQ>
 __global__ void __launch_bounds__(256)
 bn_bwd_reduce_kernel(const float* __restrict__ dy, const float* dy2, const float* __restrict__ relu_out,
                      const unsigned char* __restrict__ relu_mask, const float* __restrict__ x,
                      const float* __restrict__ mean, const float* __restrict__ invstd, int C, int64_t rows_per_group,
                      int chunks_per_group, int gstride, int rows_per_chunk, float* __restrict__ partial) {
-    __shared__ float4 s_g[16][16];
-    __shared__ float4 s_gx[16][16];
-    __shared__ float4 s_mg[16][16];
-    __shared__ float4 s_mx[16][16];
-    const int c4 = threadIdx.x & 15, rl = threadIdx.x >> 4;
-    const int c = blockIdx.x * 64 + c4 * 4;
+    constexpr int RL = 256 / CQ;
+    __shared__ float4 s_g[RL][CQ];
+    __shared__ float4 s_gx[RL][CQ];
+    __shared__ float4 s_mg[RL][CQ];
+    __shared__ float4 s_mx[RL][CQ];
+    const int c4 = threadIdx.x % CQ, rl = threadIdx.x / CQ;
+    const int c = blockIdx.x * (4 * CQ) + c4 * 4;
     float4 ag = make_float4(0.f, 0.f, 0.f, 0.f), agx = ag, mg = ag, mx = ag;
     if (c < C) {
         const int g = (int)blockIdx.y / chunks_per_group;            // chunks never straddle a group boundary
@@ -273,7 +277,7 @@ bn_bwd_reduce_kernel(const float* __restrict__ dy, const float* dy2, const float
         int64_t r1 = r0 + rows_per_chunk;
         if (r1 > (g + 1) * rows_per_group) r1 = (g + 1) * rows_per_group;
 #pragma unroll 4   // (8 loads in flight per work-item instead of 2: 27 -> 23 us per launch)
-        for (int64_t r = r0 + rl; r < r1; r += 16) {
+        for (int64_t r = r0 + rl; r < r1; r += RL) {
             const int64_t o = r * C + c;
             const float4 g = relu_masked(load_dy(dy, dy2, o >> 2), relu_out, relu_mask, o >> 2);
             const float4 v = *reinterpret_cast<const float4*>(x + o);
@@ -293,7 +297,7 @@ bn_bwd_reduce_kernel(const float* __restrict__ dy, const float* dy2, const float
     s_mx[rl][c4] = mx;
     __syncthreads();
     if (rl == 0 && c < C) {
-        for (int i = 1; i < 16; ++i) {
+        for (int i = 1; i < RL; ++i) {
             const float4 a = s_g[i][c4], b = s_gx[i][c4], m1 = s_mg[i][c4], m2 = s_mx[i][c4];
             ag.x += a.x; ag.y += a.y; ag.z += a.z; ag.w += a.w;
             agx.x += b.x; agx.y += b.y; agx.z += b.z; agx.w += b.w;
@@ -772,8 +776,16 @@ void launch_bn_bwd(const float* dy, const float* relu_out, const unsigned char* 
         chunks = bn_bwd_chunks(rpg);   // per group
         const int rpc = (int)ceil_div64(rpg, chunks);
         ObservedLaunch obs(DCN_PROF_BN_BWD_REDUCE, (double)rows * C * in_bytes, st);
-        hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(ceil_div(C, 64), chunks * groups), dim3(256), 0, st, dy, dy2, relu_out,
-                           relu_mask, x, mean, invstd, C, rpg, chunks, 4 * C, rpc, partial);
+        const int cap = tuning().bn_reduce_wide;   // DCN_BN_REDUCE_WIDE: 16 / 32 / 64 / 128 channel quads per workgroup at most
+        const int cq = ((C % 512) == 0 && cap >= 128) ? 128 : (((C % 256) == 0 && cap >= 64) ? 64 : (((C % 128) == 0 && cap >= 32) ? 32 : 16));
+#define DCN_BN_RED(CQ)                                                                                                        \
+        hipLaunchKernelGGL(bn_bwd_reduce_kernel<CQ>, dim3(ceil_div(C, 4 * CQ), chunks * groups), dim3(256), 0, st, dy, dy2, relu_out, \
+                           relu_mask, x, mean, invstd, C, rpg, chunks, 4 * C, rpc, partial)
+        if (cq == 128) DCN_BN_RED(128);
+        else if (cq == 64) DCN_BN_RED(64);
+        else if (cq == 32) DCN_BN_RED(32);
+        else DCN_BN_RED(16);
+#undef DCN_BN_RED
     }
     {
         ObservedLaunch obs(DCN_PROF_BN_FINALIZE, 16.0 * (double)chunks * groups * C, st);

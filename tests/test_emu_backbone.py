@@ -607,3 +607,22 @@ def test_bn_passes_walked_back_to_front_are_bit_identical(dcn_env, conv_mode):
         assert torch.equal(p.grad, p2.grad), k
     for (k, b), b2 in zip(m.named_buffers(), m2.buffers()):
         assert torch.equal(b, b2), k
+
+
+@pytest.mark.parametrize("cap", [32, 128])
+def test_bn_backward_reduction_with_wide_workgroups(cap, dcn_env, conv_mode):
+    """DCN_BN_REDUCE_WIDE: workgroups of the batch-norm backward reduction that cover 128 ... 512 channels of a row instead of
+    64 -- another partition of the same sums: gradients equal to round-off of the default partition."""
+    if conv_mode != "f16x3":
+        pytest.skip("the pass does not depend on the convolution arithmetic")
+    m, _ = _pair("Resnet18_8s", 3, 64)     # 64 / 128 / 256 / 512 channels
+    m2 = copy.deepcopy(m)
+    g = torch.Generator().manual_seed(2)
+    x = torch.randn(1, 3, 32, 32, generator=g)
+    gy = torch.randn(1, 3, 32, 32, generator=g)
+    for net, c in ((m, 16), (m2, cap)):
+        dcn_env(DCN_BN_REDUCE_WIDE=c)
+        net.train()
+        (net(x) * gy).sum().backward()
+    for (k, p), p2 in zip(m.named_parameters(), m2.parameters()):
+        assert rel_err(p2.grad, p.grad) < 2e-5, (k, rel_err(p2.grad, p.grad))
