@@ -18,6 +18,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -454,6 +455,28 @@ colsum_kernel(const float* __restrict__ m, int64_t rows, int ld, float* __restri
     if (threadIdx.x == 0) out[blockIdx.x] = (float)a;
 }
 
+// ONE low-priority side stream per device for the whole process, shared by every plan (a plan is only ever in one backward
+// call at a time, and the call joins the side stream before it returns, so the stream's FIFO order is all the ordering two
+// plans need).  A stream per plan -- rounds 1-3 -- maps onto the runtime's few hardware queues round-robin: the side stream of
+// the fourth plan of a process landed on the hardware queue of the caller's stream, whose wgrad kernels and cross-stream waits
+// then serialised with the main chain (seen as 2.4x slower steps, host-bound, for whichever workload came fourth:
+// profiles/r4c_debug_c1sep.txt; the 52 ... 63 images/s "run to run" spread of config 5 as an in-process bench variant was this).
+hipStream_t shared_side_stream() {
+    static std::mutex mu;
+    static std::vector<std::pair<int, hipStream_t>> streams;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+    std::lock_guard<std::mutex> lock(mu);
+    for (const auto& e : streams)
+        if (e.first == dev) return e.second;
+    int lo_prio = 0, hi_prio = 0;
+    if (hipDeviceGetStreamPriorityRange(&lo_prio, &hi_prio) != hipSuccess) lo_prio = 0;
+    hipStream_t st = nullptr;
+    if (hipStreamCreateWithPriority(&st, hipStreamNonBlocking, lo_prio) != hipSuccess) return nullptr;
+    streams.emplace_back(dev, st);
+    return st;
+}
+
 #define DCN_TRY(expr)                    \
     do {                                 \
         const int rc__ = (expr);         \
@@ -715,7 +738,7 @@ extern "C" void dcn_plan_destroy(dcn_plan* plan) {
     for (hipEvent_t e : plan->ev_bucket)
         if (e) hipEventDestroy(e);
     if (plan->ev_bucket_side) hipEventDestroy(plan->ev_bucket_side);
-    if (plan->side) hipStreamDestroy(plan->side);
+    // (plan->side is the process-wide side stream of its device -- shared_side_stream -- and is not the plan's to destroy)
     delete plan;
 }
 extern "C" int dcn_plan_set_conv_mode(dcn_plan* plan, int mode) {
@@ -1040,7 +1063,9 @@ int backward_impl(dcn_plan* plan, const float* grad_descriptors, const float* gr
         bool ok = dcn::tuning().backward_overlap != 0;
         int lo_prio = 0, hi_prio = 0;
         if (ok && hipDeviceGetStreamPriorityRange(&lo_prio, &hi_prio) != hipSuccess) lo_prio = 0;
-        ok = ok && hipStreamCreateWithPriority(&p.side, hipStreamNonBlocking, lo_prio) == hipSuccess;
+        (void)lo_prio;
+        p.side = ok ? shared_side_stream() : nullptr;
+        ok = ok && p.side != nullptr;
         for (hipEvent_t* ev : {&p.ev_dq[0], &p.ev_dq[1], &p.ev_wg[0], &p.ev_wg[1], &p.ev_join})
             ok = ok && hipEventCreateWithFlags(ev, hipEventDisableTiming) == hipSuccess;
         p.side_state = ok ? 1 : -1;

@@ -63,7 +63,7 @@ struct Tuning {
     int hl_producers = 1;        // hl32 images written by the producing batch-norm passes (0: stand-alone split passes)
     int hl_only_mid = 1;         // mid-block activations whose two readers (next conv, its wgrad) take the hl32 image: no fp32 copy (0: keep it)
     int stem_pool_fused = 1;     // the stem's batch norm + ReLU applied inside the max-pool pass (0: an apply pass of its own)
-    int bn_reduce_wide = 16;     // see DCN_BN_REDUCE_WIDE above
+    int bn_reduce_wide = 32;     // see DCN_BN_REDUCE_WIDE above (32: +0.2 % on the step, 128: -1 %, profiles/r4c_ab_bn_reduce_wide.txt)
     int bn_reverse = 0;          // see DCN_BN_REVERSE above
     int wgrad_roles = 1;         // wide tile: wavefronts 0-3 stage the activations, 4-7 the gradient (0: copy spread over all 8)
 };

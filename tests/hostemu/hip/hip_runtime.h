@@ -54,6 +54,7 @@ inline hipError_t hipEventDestroy(hipEvent_t e) { delete e; return hipSuccess; }
 #define hipEventDisableTiming 2
 inline hipError_t hipEventCreateWithFlags(hipEvent_t* e, unsigned) { *e = new hipemu_event{0.0}; return hipSuccess; }
 inline hipError_t hipDeviceGetStreamPriorityRange(int* lo, int* hi) { *lo = 0; *hi = 0; return hipSuccess; }
+inline hipError_t hipGetDevice(int* d) { *d = 0; return hipSuccess; }
 inline hipError_t hipStreamCreateWithPriority(hipStream_t* s, unsigned, int) { *s = (hipStream_t)new int(0); return hipSuccess; }
 inline hipError_t hipStreamDestroy(hipStream_t s) { delete (int*)s; return hipSuccess; }
 inline hipError_t hipStreamWaitEvent(hipStream_t, hipEvent_t, unsigned) { return hipSuccess; }
