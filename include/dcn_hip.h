@@ -134,6 +134,25 @@ int dcn_contrastive_loss_backward(const float* desc_a, const float* desc_b, int 
                                   const int32_t* hard_neg, const float* grad_loss, const float* pair_grad,
                                   float* grad_a, float* grad_b, void* stream);
 
+/* The same forward / backward pair with the backward's gathers traded for coalesced streams (round 4): the forward also
+ * writes, per pixel pair, the difference vector a - b and the factor s with  d loss / d a = coef(list, image pair) * s * (a - b)
+ * into pair_records (dcn_loss_saved_floats(total pairs, d) floats: [total][d] differences, then [total] factors); the backward
+ * reads those records -- no descriptor is gathered a second time -- and scatter-adds the same values, bit for bit, as
+ * dcn_contrastive_loss_backward.  prefilled != 0: the caller has already zero-filled grad_a / grad_b (dcn_fill_bytes on another
+ * stream, overlapped with the forward kernels); the call then only accumulates. */
+size_t dcn_loss_saved_floats(int64_t total_pairs, int d);
+int dcn_contrastive_loss_forward_save(const float* desc_a, const float* desc_b, int num_pairs, int64_t hw, int d,
+                                      const int64_t* idx_a, const int64_t* idx_b, const int64_t* offsets_host,
+                                      const int64_t* offsets_dev, const dcn_loss_config* cfg, float* terms, float* sums,
+                                      int32_t* hard_neg, float* loss, float* per_term, int32_t* status, void* workspace,
+                                      float* pair_records, void* stream);
+int dcn_contrastive_loss_backward_saved(int num_pairs, int64_t hw, int d, const int64_t* idx_a, const int64_t* idx_b,
+                                        const int64_t* offsets_host, const int64_t* offsets_dev, const dcn_loss_config* cfg,
+                                        const int32_t* hard_neg, const float* grad_loss, const float* pair_records,
+                                        int prefilled, float* grad_a, float* grad_b, void* stream);
+/* Stream-ordered fill of n bytes (n % 4 == 0) with a byte value, as a kernel (an ordinary node under hipGraph capture). */
+int dcn_fill_bytes(void* p, int byte_value, size_t n, void* stream);
+
 /* Triplet variant (pixelwise_contrastive_loss.py:104-129, loss_composer.py:145-166):
  *   loss = 1/n * sum_i sum_k max(0, (a_k - m_k)^2 - (a_k - q_k)^2 + alpha),   a = A[non_a[i]], m = B[match_b[i / (n / n_match)]],
  *   q = B[non_b[i]]  -- hinge per descriptor component, exactly as the reference computes it.  n % n_match == 0.

@@ -38,6 +38,8 @@
 //                           and is still in the 256 MB Infinity Cache when the tensors do not fit it whole.  Same results bit for bit.
 //   DCN_BN_REDUCE_WIDE      16 / 32 / 64 / 128: channel quads per workgroup of the batch-norm backward reduction at most (16 = 64
 //                           channels: 256-byte pieces of a row per tensor; 128 = whole rows of 512 channels, but 8x fewer workgroups)
+//   DCN_BN_NT               bit mask: non-temporal loads of tensors a batch-norm pass reads for the last time (1: the conv output in
+//                           the forward apply pass, 2: dy and the conv output in the backward apply pass)
 #pragma once
 
 namespace dcn {
@@ -64,6 +66,7 @@ struct Tuning {
     int hl_only_mid = 1;         // mid-block activations whose two readers (next conv, its wgrad) take the hl32 image: no fp32 copy (0: keep it)
     int stem_pool_fused = 1;     // the stem's batch norm + ReLU applied inside the max-pool pass (0: an apply pass of its own)
     int bn_reduce_wide = 32;     // see DCN_BN_REDUCE_WIDE above (32: +0.2 % on the step, 128: -1 %, profiles/r4c_ab_bn_reduce_wide.txt)
+    int bn_nt = 0;               // see DCN_BN_NT above
     int bn_reverse = 0;          // see DCN_BN_REVERSE above
     int wgrad_roles = 1;         // wide tile: wavefronts 0-3 stage the activations, 4-7 the gradient (0: copy spread over all 8)
 };

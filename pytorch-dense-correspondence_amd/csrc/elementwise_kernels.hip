@@ -179,12 +179,21 @@ bn_finalize_kernel(const float* __restrict__ partial, int tiles, int groups, int
     }
 }
 
+// float4 load that will not be needed again soon (DCN_BN_NT: streamed past the caches instead of displacing what the next
+// kernel is about to read)
+__device__ __forceinline__ float4 ld4(const float* p, int64_t i4, bool nt) {
+    typedef float f4v __attribute__((ext_vector_type(4)));
+    const f4v* q = reinterpret_cast<const f4v*>(p) + i4;
+    const f4v v = nt ? __builtin_nontemporal_load(q) : *q;
+    return make_float4(v[0], v[1], v[2], v[3]);
+}
+
 // y = [relu]( x*s1 + b1 + (res ? (s2 ? res*s2 + b2 : res) : 0) )
 __global__ void __launch_bounds__(256)
 bn_apply_kernel(const float* __restrict__ x, const float* __restrict__ s1, const float* __restrict__ b1,
                 const float* __restrict__ res, const float* __restrict__ s2, const float* __restrict__ b2, int relu,
                 float* __restrict__ y, unsigned char* __restrict__ relu_mask, int c4n, int64_t total4, int64_t group4,
-                int gstride, dcnsplit::u32x2* __restrict__ hl, const float* __restrict__ hl_absmax, int rev) {
+                int gstride, dcnsplit::u32x2* __restrict__ hl, const float* __restrict__ hl_absmax, int rev, int nt) {
     // hl (optional, c4n % 8 == 0): y also as the "hl32" image the pre-split convolution kernel reads (conv_hl_kernels.hip) --
     // per 32-channel chunk one 128-byte line [hi x32 | lo x32] fp16 of s y, s = the power of two chosen from *hl_absmax (the
     // bound of max |y| that bn_finalize_kernel stored before this pass): the consumer's operand split costs 4 B / element
@@ -193,7 +202,7 @@ bn_apply_kernel(const float* __restrict__ x, const float* __restrict__ s1, const
     for (int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x; j < total4; j += (int64_t)gridDim.x * 256) {
         const int64_t i = rev ? total4 - 1 - j : j;   // (rev: back to front, DCN_BN_REVERSE)
         const int c = (int)(i % c4n) * 4 + (i >= group4 ? gstride : 0);   // (at most two groups: second group's statistics)
-        const float4 v = reinterpret_cast<const float4*>(x)[i];
+        const float4 v = ld4(x, i, nt != 0);
         const float4 s = *reinterpret_cast<const float4*>(s1 + c);
         const float4 b = *reinterpret_cast<const float4*>(b1 + c);
         float4 o = make_float4(v.x * s.x + b.x, v.y * s.y + b.y, v.z * s.z + b.z, v.w * s.w + b.w);
@@ -422,7 +431,7 @@ bn_bwd_apply_blocked_kernel(const float* __restrict__ dy, const float* dy2, cons
                             const float* __restrict__ k2, const float* __restrict__ k3, float* __restrict__ dx,
                             float* g_out, dcnsplit::u32x4* __restrict__ dq, const float* __restrict__ absmax,
                             int c4n, int64_t rows, int64_t rows_per_group, int gstride, int kstride,
-                            dcnsplit::u32x2* __restrict__ hl, int rev) {
+                            dcnsplit::u32x2* __restrict__ hl, int rev, int nt) {
     // hl (optional, c4n % 8 == 0): dx as the hl32 image the pre-split dgrad reads (same scale as dq); dx itself may then be
     // null -- nobody else reads the fp32 tensor
     const float s = dcnsplit::pow2_scale(*absmax);
@@ -444,8 +453,13 @@ bn_bwd_apply_blocked_kernel(const float* __restrict__ dy, const float* dy2, cons
             const int64_t m = q * 4 + r;
             if (m < rows) {
                 const int64_t e = m * c4n + cq;
-                const float4 g = relu_masked(load_dy(dy, dy2, e), relu_out, relu_mask, e);
-                const float4 v = reinterpret_cast<const float4*>(x)[e];
+                float4 g0 = ld4(dy, e, nt != 0);
+                if (dy2) {
+                    const float4 h = reinterpret_cast<const float4*>(dy2)[e];
+                    g0.x += h.x; g0.y += h.y; g0.z += h.z; g0.w += h.w;
+                }
+                const float4 g = relu_masked(g0, relu_out, relu_mask, e);
+                const float4 v = ld4(x, e, nt != 0);
                 o[r][0] = a.x * (g.x - b.x - (v.x - mu.x) * is.x * d.x);
                 o[r][1] = a.y * (g.y - b.y - (v.y - mu.y) * is.y * d.y);
                 o[r][2] = a.z * (g.z - b.z - (v.z - mu.z) * is.z * d.z);
@@ -752,7 +766,7 @@ void launch_bn_apply(const float* x, const float* stats1, const float* res, cons
                                                              (relu_mask ? 0.25 : 0.0)), st);
     hipLaunchKernelGGL(bn_apply_kernel, dim3(blocks_for(total4, kGridCap)), dim3(256), 0, st, x, stats1, stats1 + C, res,
                        stats2, stats2 ? stats2 + C : nullptr, relu, y, relu_mask, C / 4, total4, total4 / groups, 4 * C,
-                       (dcnsplit::u32x2*)hl_out, hl_absmax, tuning().bn_reverse & 1);
+                       (dcnsplit::u32x2*)hl_out, hl_absmax, tuning().bn_reverse & 1, tuning().bn_nt & 1);
 }
 int bn_bwd_chunks(int64_t rows_per_group) {
     // enough row chunks that even a 64-channel layer launches >= ~1000 workgroups (HBM-bound pass: fill all 256 CUs)
@@ -801,7 +815,7 @@ void launch_bn_bwd(const float* dy, const float* relu_out, const unsigned char* 
                            dy, dy2, relu_out, relu_mask, x, mean, invstd, (const float*)k123, (const float*)(k123 + C),
                            (const float*)(k123 + 2 * C), (hl_dx && (C % 32) == 0 && !keep_dx) ? nullptr : dx, g_out,
                            (dcnsplit::u32x4*)dq, (const float*)absmax, C / 4, rows, rpg, 4 * C, 3 * C,
-                           (C % 32) == 0 ? (dcnsplit::u32x2*)hl_dx : nullptr, (tuning().bn_reverse >> 1) & 1);
+                           (C % 32) == 0 ? (dcnsplit::u32x2*)hl_dx : nullptr, (tuning().bn_reverse >> 1) & 1, (tuning().bn_nt >> 1) & 1);
         return;
     }
     ObservedLaunch obs(DCN_PROF_BN_BWD_APPLY, (double)rows * C * (in_bytes + 4.0 + (g_out ? 4.0 : 0.0)), st);

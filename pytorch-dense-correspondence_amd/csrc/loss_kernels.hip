@@ -49,7 +49,12 @@ __global__ void __launch_bounds__(kThreads)
 loss_fwd_kernel(const float* __restrict__ A, const float* __restrict__ B, int64_t hw, int D,
                 const int64_t* __restrict__ idx_a, const int64_t* __restrict__ idx_b,
                 const int64_t* __restrict__ offsets, dcn_loss_config cfg, double* __restrict__ part_sum,
-                int* __restrict__ part_cnt, float* __restrict__ per_term, int* __restrict__ part_oob) {
+                int* __restrict__ part_cnt, float* __restrict__ per_term, int* __restrict__ part_oob,
+                float* __restrict__ rec_d, float* __restrict__ rec_s) {
+    // rec_d [total][D], rec_s [total] (optional, together): per pixel pair the difference vector a - b and the factor s with
+    //     d loss / d a = coef(list, image pair) * s * (a - b)      (= - d loss / d b)
+    // -- everything of the pair's gradient that does not depend on the hard-negative counts of the whole image pair.  The
+    // backward pass (loss_bwd_saved_kernel) then reads these coalesced records instead of gathering both descriptors again.
     // part_oob[workgroup]: 1 if the workgroup met an index outside [0, hw) -- OR-ed into the status word by the finalize
     // kernel (no cleared status word needed in front of this launch)
     __shared__ double s_sum[kThreads / dcn::kWave];
@@ -87,35 +92,49 @@ loss_fwd_kernel(const float* __restrict__ A, const float* __restrict__ B, int64_
                 const float* a = Ap + ia * D;
                 const float* b = Bp + ib * D;
                 if (SINGLE) {
-                    if (sub < D) { const float df = a[sub] - b[sub]; s = df * df; }
+                    if (sub < D) {
+                        const float df = a[sub] - b[sub];
+                        s = df * df;
+                        if (rec_d) rec_d[(beg + j) * D + sub] = df;
+                    }
                 } else {
-                    for (int c = sub; c < D; c += LP) { const float df = a[c] - b[c]; s = fmaf(df, df, s); }
+                    for (int c = sub; c < D; c += LP) {
+                        const float df = a[c] - b[c];
+                        s = fmaf(df, df, s);
+                        if (rec_d) rec_d[(beg + j) * D + c] = df;
+                    }
                 }
             }
             const float d2 = group_sum<LP>(s);
-            float term = 0.f;
+            float term = 0.f, sfac = 0.f;
             if (ok) {
                 if (t == DCN_LIST_MATCH) {
                     term = d2;
                     acc += sub == 0 ? term : 0.f;
+                    sfac = 2.f;
                 } else {
-                    if (cfg.invert[t] == 2) {   // legacy hinge on the SQUARED distance, not squared again (pcl.py:399-404)
-                        term = fmaxf(M - d2, 0.f);
-                    } else {
-                        const float dist = sqrtf(d2);
-                        const float h = fmaxf(cfg.invert[t] ? dist - M : M - dist, 0.f);
-                        term = h * h;
-                    }
-                    cnt += (sub == 0 && term != 0.f) ? 1 : 0;
                     float w = 1.f;
                     if (per > 0) {
                         const int64_t mi = j / per;
                         w = mi < mlen ? pixel_weight(idx_b[mbeg + mi], ib, cfg.image_width, cfg.m_pixel) : 0.f;
                     }
+                    if (cfg.invert[t] == 2) {   // legacy hinge on the SQUARED distance, not squared again (pcl.py:399-404)
+                        term = fmaxf(M - d2, 0.f);
+                        sfac = (M - d2 > 0.f) ? -2.f : 0.f;
+                    } else {
+                        const float dist = sqrtf(d2);
+                        const float hinge = cfg.invert[t] ? dist - M : M - dist;
+                        const float h = fmaxf(hinge, 0.f);
+                        term = h * h;
+                        // (the expressions of loss_bwd_kernel: same bits; d||x||/dx := 0 at x = 0 like torch)
+                        if (hinge > 0.f && dist > 0.f) sfac = (cfg.invert[t] ? 2.f : -2.f) * hinge / dist * w;
+                    }
+                    cnt += (sub == 0 && term != 0.f) ? 1 : 0;
                     acc += sub == 0 ? term * w : 0.f;
                 }
             }
             if (per_term && live && sub == 0) per_term[beg + j] = term;
+            if (rec_s && live && sub == 0) rec_s[beg + j] = sfac;
         }
         sum = (double)acc;
     }
@@ -379,6 +398,55 @@ loss_bwd_kernel(const float* __restrict__ A, const float* __restrict__ B, int64_
     }
 }
 
+// Backward from the records the forward pass saved (loss_fwd_kernel: rec_d, rec_s): per pixel pair two int64 indices, the
+// factor and the D-float difference -- coalesced streams -- then the same run of D fp32 atomics per descriptor as above.  No
+// descriptor is gathered again.  grid = (chunks, 4*num_pairs).
+template <int LP, bool SINGLE>
+__global__ void __launch_bounds__(kThreads)
+loss_bwd_saved_kernel(int64_t hw, int D, int num_pairs, const int64_t* __restrict__ idx_a, const int64_t* __restrict__ idx_b,
+                      const int64_t* __restrict__ offsets, dcn_loss_config cfg, const int* __restrict__ hard_neg,
+                      const float* __restrict__ grad_loss, const float* __restrict__ rec_d, const float* __restrict__ rec_s,
+                      float* __restrict__ gA, float* __restrict__ gB) {
+    constexpr int GROUPS = kThreads / LP, PPB = GROUPS * kItems;
+    const int seg = blockIdx.y, p = seg >> 2, t = seg & 3;
+    const int64_t beg = offsets[seg], len = offsets[seg + 1] - beg;
+    const int64_t chunk0 = (int64_t)blockIdx.x * PPB;
+    if (chunk0 >= len) return;
+    const int grp = threadIdx.x / LP, sub = threadIdx.x % LP;
+    int64_t lens[4];
+    int h[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { lens[k] = offsets[4 * p + k + 1] - offsets[4 * p + k]; h[k] = hard_neg[4 * p + k]; }
+    const PairScales sc = pair_scales(cfg, h, lens);
+    float coef = t == DCN_LIST_MATCH ? sc.match_coef : (t == DCN_LIST_BLIND ? sc.blind_coef : sc.nonmatch_coef);
+    if (coef == 0.f) return;
+    coef *= grad_loss[0] / (float)num_pairs;
+    float* gAp = gA + (int64_t)p * hw * D;
+    float* gBp = gB + (int64_t)p * hw * D;
+#pragma unroll
+    for (int it = 0; it < kItems; ++it) {
+        const int64_t j = chunk0 + (int64_t)it * GROUPS + grp;
+        if (j >= len) continue;
+        const float sf = rec_s[beg + j];
+        if (sf == 0.f) continue;            // skipped / out-of-range pair, flat hinge, zero distance
+        const int64_t ia = idx_a[beg + j], ib = idx_b[beg + j];
+        const float g = sf * coef;          // (loss_bwd_kernel's g: factor x coefficient)
+        if (SINGLE) {
+            if (sub < D) {
+                const float v = g * rec_d[(beg + j) * D + sub];
+                unsafeAtomicAdd(gAp + ia * D + sub, v);
+                unsafeAtomicAdd(gBp + ib * D + sub, -v);
+            }
+        } else {
+            for (int c = sub; c < D; c += LP) {
+                const float v = g * rec_d[(beg + j) * D + c];
+                unsafeAtomicAdd(gAp + ia * D + c, v);
+                unsafeAtomicAdd(gBp + ib * D + c, -v);
+            }
+        }
+    }
+}
+
 // workgroups per list for descriptor dimension d (d <= 0: the worst case over all d, for workspace sizing)
 int chunks_for(int64_t max_list_len, int d) {
     const int ppb = pairs_per_block(d > 0 ? lanes_per_pair(d) : 32);
@@ -500,11 +568,42 @@ extern "C" size_t dcn_loss_workspace_bytes(int num_pairs, int64_t max_list_len) 
     return n * sizeof(double) + (size_t)num_pairs * sizeof(double) + 2 * n * sizeof(int) + (size_t)num_pairs * sizeof(int) + 64;
 }
 
+namespace {
+int loss_forward_impl(const float* desc_a, const float* desc_b, int num_pairs, int64_t hw, int d, const int64_t* idx_a,
+                      const int64_t* idx_b, const int64_t* offsets_host, const int64_t* offsets_dev, const dcn_loss_config* cfg,
+                      float* terms, float* sums, int32_t* hard_neg, float* loss, float* per_term, int32_t* status,
+                      void* workspace, float* rec_d, float* rec_s, void* stream);
+}  // namespace
+
 extern "C" int dcn_contrastive_loss_forward(const float* desc_a, const float* desc_b, int num_pairs, int64_t hw, int d,
                                             const int64_t* idx_a, const int64_t* idx_b, const int64_t* offsets_host,
                                             const int64_t* offsets_dev, const dcn_loss_config* cfg, float* terms,
                                             float* sums, int32_t* hard_neg, float* loss, float* per_term,
                                             int32_t* status, void* workspace, void* stream) {
+    return loss_forward_impl(desc_a, desc_b, num_pairs, hw, d, idx_a, idx_b, offsets_host, offsets_dev, cfg, terms, sums, hard_neg,
+                             loss, per_term, status, workspace, nullptr, nullptr, stream);
+}
+
+extern "C" size_t dcn_loss_saved_floats(int64_t total_pairs, int d) {
+    return total_pairs < 1 || d < 1 ? 0 : (size_t)total_pairs * ((size_t)d + 1);
+}
+
+extern "C" int dcn_contrastive_loss_forward_save(const float* desc_a, const float* desc_b, int num_pairs, int64_t hw, int d,
+                                                 const int64_t* idx_a, const int64_t* idx_b, const int64_t* offsets_host,
+                                                 const int64_t* offsets_dev, const dcn_loss_config* cfg, float* terms,
+                                                 float* sums, int32_t* hard_neg, float* loss, float* per_term,
+                                                 int32_t* status, void* workspace, float* pair_records, void* stream) {
+    if (!pair_records || !offsets_host || num_pairs < 1 || d < 1) return DCN_E_INVALID;
+    const int64_t total = offsets_host[4 * num_pairs];
+    return loss_forward_impl(desc_a, desc_b, num_pairs, hw, d, idx_a, idx_b, offsets_host, offsets_dev, cfg, terms, sums, hard_neg,
+                             loss, per_term, status, workspace, pair_records, pair_records + (size_t)total * d, stream);
+}
+
+namespace {
+int loss_forward_impl(const float* desc_a, const float* desc_b, int num_pairs, int64_t hw, int d, const int64_t* idx_a,
+                      const int64_t* idx_b, const int64_t* offsets_host, const int64_t* offsets_dev, const dcn_loss_config* cfg,
+                      float* terms, float* sums, int32_t* hard_neg, float* loss, float* per_term, int32_t* status,
+                      void* workspace, float* rec_d, float* rec_s, void* stream) {
     if (!desc_a || !desc_b || !offsets_host || !offsets_dev || !cfg || !terms || !sums || !hard_neg || !loss ||
         !status || !workspace || num_pairs < 1 || hw < 1 || d < 1)
         return DCN_E_INVALID;
@@ -522,7 +621,7 @@ extern "C" int dcn_contrastive_loss_forward(const float* desc_a, const float* de
     const dim3 grid(chunks, 4 * num_pairs), block(kThreads);
 #define DCN_LAUNCH_FWD(LP, SINGLE)                                                                                       \
     hipLaunchKernelGGL((loss_fwd_kernel<LP, SINGLE>), grid, block, 0, st, desc_a, desc_b, hw, d, idx_a, idx_b, offsets_dev, \
-                       *cfg, part_sum, part_cnt, per_term, part_oob)
+                       *cfg, part_sum, part_cnt, per_term, part_oob, rec_d, rec_s)
     switch (lanes_per_pair(d)) {
         case 4: DCN_LAUNCH_FWD(4, true); break;
         case 8: DCN_LAUNCH_FWD(8, true); break;
@@ -544,6 +643,7 @@ extern "C" int dcn_contrastive_loss_forward(const float* desc_a, const float* de
     }
     return dcn::check_launch();
 }
+}  // namespace
 
 extern "C" int dcn_contrastive_loss_backward(const float* desc_a, const float* desc_b, int num_pairs, int64_t hw, int d,
                                              const int64_t* idx_a, const int64_t* idx_b, const int64_t* offsets_host,
@@ -580,4 +680,54 @@ extern "C" int dcn_contrastive_loss_backward(const float* desc_a, const float* d
     }
 #undef DCN_LAUNCH_BWD
     return dcn::check_launch();
+}
+
+// Backward from the forward pass's pair records (dcn_contrastive_loss_forward_save).  prefilled != 0: grad_a / grad_b have
+// already been zero-filled by the caller (e.g. on another stream while the forward kernels ran: dcn_fill_bytes) -- the call
+// then only accumulates; otherwise it zero-fills them first, like dcn_contrastive_loss_backward.
+extern "C" int dcn_contrastive_loss_backward_saved(int num_pairs, int64_t hw, int d, const int64_t* idx_a, const int64_t* idx_b,
+                                                   const int64_t* offsets_host, const int64_t* offsets_dev,
+                                                   const dcn_loss_config* cfg, const int32_t* hard_neg, const float* grad_loss,
+                                                   const float* pair_records, int prefilled, float* grad_a, float* grad_b,
+                                                   void* stream) {
+    if (!offsets_host || !offsets_dev || !cfg || !hard_neg || !grad_loss || !pair_records || !grad_a || !grad_b || num_pairs < 1 ||
+        hw < 1 || d < 1)
+        return DCN_E_INVALID;
+    hipStream_t st = (hipStream_t)stream;
+    const size_t bytes = (size_t)num_pairs * (size_t)hw * (size_t)d * sizeof(float);
+    if (!prefilled) {
+        if ((char*)grad_b == (char*)grad_a + bytes) {
+            if (dcn::fill_bytes_async(grad_a, 0, 2 * bytes, st) != DCN_OK) return DCN_E_LAUNCH;
+        } else {
+            if (dcn::fill_bytes_async(grad_a, 0, bytes, st) != DCN_OK) return DCN_E_LAUNCH;
+            if (dcn::fill_bytes_async(grad_b, 0, bytes, st) != DCN_OK) return DCN_E_LAUNCH;
+        }
+    }
+    const int64_t ml = max_len(offsets_host, num_pairs);
+    if (ml == 0) return DCN_OK;
+    if (!idx_a || !idx_b) return DCN_E_INVALID;
+    const int64_t total = offsets_host[4 * num_pairs];
+    const float* rec_d = pair_records;
+    const float* rec_s = pair_records + (size_t)total * d;
+    const dim3 grid(chunks_for(ml, d), 4 * num_pairs), block(kThreads);
+#define DCN_LAUNCH_BWDS(LP, SINGLE)                                                                                          \
+    hipLaunchKernelGGL((loss_bwd_saved_kernel<LP, SINGLE>), grid, block, 0, st, hw, d, num_pairs, idx_a, idx_b, offsets_dev, *cfg, \
+                       (const int*)hard_neg, grad_loss, rec_d, rec_s, grad_a, grad_b)
+    switch (lanes_per_pair(d)) {
+        case 4: DCN_LAUNCH_BWDS(4, true); break;
+        case 8: DCN_LAUNCH_BWDS(8, true); break;
+        case 16: DCN_LAUNCH_BWDS(16, true); break;
+        default:
+            if (d <= 32) DCN_LAUNCH_BWDS(32, true);
+            else DCN_LAUNCH_BWDS(32, false);
+            break;
+    }
+#undef DCN_LAUNCH_BWDS
+    return dcn::check_launch();
+}
+
+// Stream-ordered fill of n bytes (n % 4 == 0) with a byte value, as a kernel (an ordinary node under hipGraph capture).
+extern "C" int dcn_fill_bytes(void* p, int byte_value, size_t n, void* stream) {
+    if (!p && n) return DCN_E_INVALID;
+    return dcn::fill_bytes_async(p, byte_value, n, (hipStream_t)stream);
 }

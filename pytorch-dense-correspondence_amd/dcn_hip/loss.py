@@ -89,7 +89,19 @@ def make_config(margins, image_width, match_loss_weight=1.0, non_match_loss_weig
     return cfg
 
 
-def _run_forward(desc_a, desc_b, lists, cfg, want_per_term):
+SAVE_PAIR_RECORDS = True   # forward keeps per-pair (difference, factor) records, backward reads them instead of gathering again
+PREFILL_GRADIENTS = True   # the dense gradient maps are zero-filled on a side stream while the forward kernels run
+_fill_streams = {}
+
+
+def _fill_stream(dev):
+    st = _fill_streams.get(dev)
+    if st is None:
+        st = _fill_streams[dev] = torch.cuda.Stream(device=dev)
+    return st
+
+
+def _run_forward(desc_a, desc_b, lists, cfg, want_per_term, records=None):
     lib = _lib.get()
     _lib.require_device(desc_a, desc_b, lists.idx_a, lists.idx_b)
     P, HW, D = desc_a.shape
@@ -110,11 +122,18 @@ def _run_forward(desc_a, desc_b, lists, cfg, want_per_term):
     status = torch.empty(1, dtype=torch.int32, device=dev)
     per_term = torch.empty(max(lists.total, 1), **f32) if want_per_term else None
     ws = torch.empty(lib.dcn_loss_workspace_bytes(P, lists.max_len), dtype=torch.uint8, device=dev)
-    rc = lib.dcn_contrastive_loss_forward(
-        _lib.ptr(desc_a), _lib.ptr(desc_b), P, HW, D, _lib.ptr(lists.idx_a), _lib.ptr(lists.idx_b),
-        ctypes.cast(lists._off_c, ctypes.c_void_p), _lib.ptr(lists.offsets_dev), ctypes.byref(cfg),
-        _lib.ptr(terms), _lib.ptr(sums), _lib.ptr(hard), _lib.ptr(loss), _lib.ptr(per_term), _lib.ptr(status),
-        _lib.ptr(ws), _lib.stream_ptr())
+    if records is not None:
+        rc = lib.dcn_contrastive_loss_forward_save(
+            _lib.ptr(desc_a), _lib.ptr(desc_b), P, HW, D, _lib.ptr(lists.idx_a), _lib.ptr(lists.idx_b),
+            ctypes.cast(lists._off_c, ctypes.c_void_p), _lib.ptr(lists.offsets_dev), ctypes.byref(cfg),
+            _lib.ptr(terms), _lib.ptr(sums), _lib.ptr(hard), _lib.ptr(loss), _lib.ptr(per_term), _lib.ptr(status),
+            _lib.ptr(ws), _lib.ptr(records), _lib.stream_ptr())
+    else:
+        rc = lib.dcn_contrastive_loss_forward(
+            _lib.ptr(desc_a), _lib.ptr(desc_b), P, HW, D, _lib.ptr(lists.idx_a), _lib.ptr(lists.idx_b),
+            ctypes.cast(lists._off_c, ctypes.c_void_p), _lib.ptr(lists.offsets_dev), ctypes.byref(cfg),
+            _lib.ptr(terms), _lib.ptr(sums), _lib.ptr(hard), _lib.ptr(loss), _lib.ptr(per_term), _lib.ptr(status),
+            _lib.ptr(ws), _lib.stream_ptr())
     _lib.check(rc, "dcn_contrastive_loss_forward")
     return desc_a, desc_b, loss, terms, sums, hard, status, per_term
 
@@ -122,9 +141,35 @@ def _run_forward(desc_a, desc_b, lists, cfg, want_per_term):
 class _ContrastiveLossFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, desc_a, desc_b, lists, cfg, want_per_term):
+        lib = _lib.get()
+        wants_grad = bool(ctx.needs_input_grad[0] or ctx.needs_input_grad[1])
+        records = None
+        ctx.grads, ctx.grads_ready = None, None
+        if wants_grad and SAVE_PAIR_RECORDS and lists.total > 0:
+            records = torch.empty(lib.dcn_loss_saved_floats(lists.total, int(desc_a.shape[2])), dtype=torch.float32,
+                                  device=desc_a.device)
+        if wants_grad and PREFILL_GRADIENTS and records is not None:
+            # the two dense gradient maps of the backward pass, zero-filled NOW on a side stream: the fill (1.26 GB at
+            # BASELINE configs[2]'s sizes) streams at HBM speed next to the latency-bound gather of the forward kernels
+            # instead of in front of the backward scatter
+            g2 = torch.empty((2,) + tuple(desc_a.shape), dtype=torch.float32, device=desc_a.device)
+            if g2.is_cuda:
+                cur, side = torch.cuda.current_stream(g2.device), _fill_stream(g2.device)
+                side.wait_stream(cur)     # (the allocator may hand out memory whose last use is still queued on `cur`)
+                _lib.check(lib.dcn_fill_bytes(_lib.ptr(g2), 0, g2.numel() * 4, ctypes.c_void_p(side.cuda_stream)), "dcn_fill_bytes")
+                g2.record_stream(side)
+                ctx.grads_ready = side.record_event()
+            else:
+                _lib.check(lib.dcn_fill_bytes(_lib.ptr(g2), 0, g2.numel() * 4, None), "dcn_fill_bytes")
+            ctx.grads = g2
         desc_a, desc_b, loss, terms, sums, hard, status, per_term = _run_forward(desc_a, desc_b, lists, cfg,
-                                                                                 want_per_term)
-        ctx.save_for_backward(desc_a, desc_b, sums, hard)
+                                                                                 want_per_term, records)
+        ctx.records = records
+        if records is not None:
+            ctx.save_for_backward(sums, hard)       # (the descriptor maps themselves are not needed again)
+            ctx.shape = tuple(desc_a.shape)
+        else:
+            ctx.save_for_backward(desc_a, desc_b, sums, hard)
         ctx.lists = lists
         ctx.cfg = cfg
         if want_per_term:
@@ -136,8 +181,26 @@ class _ContrastiveLossFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, grad_loss, *unused):
         lib = _lib.get()
-        desc_a, desc_b, sums, hard = ctx.saved_tensors
         lists, cfg = ctx.lists, ctx.cfg
+        if ctx.records is not None:
+            sums, hard = ctx.saved_tensors
+            P, HW, D = ctx.shape
+            g2, prefilled = ctx.grads, 0
+            ctx.grads = None                      # (a second backward through the same graph fills its own maps)
+            if g2 is not None:
+                prefilled = 1
+                if ctx.grads_ready is not None:
+                    torch.cuda.current_stream(g2.device).wait_event(ctx.grads_ready)
+            else:
+                g2 = torch.empty((2, P, HW, D), dtype=torch.float32, device=hard.device)
+            gl = grad_loss.reshape(1).to(torch.float32).contiguous()
+            rc = lib.dcn_contrastive_loss_backward_saved(
+                P, HW, D, _lib.ptr(lists.idx_a), _lib.ptr(lists.idx_b), ctypes.cast(lists._off_c, ctypes.c_void_p),
+                _lib.ptr(lists.offsets_dev), ctypes.byref(cfg), _lib.ptr(hard), _lib.ptr(gl), _lib.ptr(ctx.records), prefilled,
+                _lib.ptr(g2[0]), _lib.ptr(g2[1]), _lib.stream_ptr())
+            _lib.check(rc, "dcn_contrastive_loss_backward_saved")
+            return g2[0], g2[1], None, None, None
+        desc_a, desc_b, sums, hard = ctx.saved_tensors
         P, HW, D = desc_a.shape
         g2 = torch.empty((2,) + tuple(desc_a.shape), dtype=desc_a.dtype, device=desc_a.device)   # one allocation: the kernel side
         ga, gb = g2[0], g2[1]                                                                     # zero-fills both maps in one launch

@@ -595,7 +595,7 @@ def test_bn_passes_walked_back_to_front_are_bit_identical(dcn_env, conv_mode):
     gy = torch.randn(1, 3, 64, 64, generator=g)
     outs = []
     for net, rev in ((m, 0), (m2, 3)):
-        dcn_env(DCN_BN_REVERSE=rev)
+        dcn_env(DCN_BN_REVERSE=rev, DCN_BN_NT=rev)   # (and DCN_BN_NT: non-temporal loads of the last-use tensors)
         net.train()
         ya, yb = net.forward_pair(xa, xb)
         y1 = net(xa)

@@ -249,3 +249,63 @@ def test_triplet_kernel_shapes_vs_oracle(D, mult):
         res.append((l.item(), A.grad, B.grad))
     assert abs(res[0][0] - res[1][0]) <= 1e-6 * abs(res[1][0])
     assert rel_err(res[0][1], res[1][1]) < 1e-5 and rel_err(res[0][2], res[1][2]) < 1e-5
+
+
+@pytest.mark.parametrize("path", GOLDENS, ids=[os.path.basename(p)[9:-4] for p in GOLDENS])
+def test_record_based_backward_equals_the_gathering_backward(path):
+    """Round 4: the forward pass keeps per-pair (difference, factor) records and the backward pass reads them instead of
+    gathering both descriptors again; the gradient maps are zero-filled ahead of time.  Every scattered value is the one the
+    gathering backward pass computes (same expressions); the maps agree to the order of the atomic accumulation, on every
+    reference golden (pixel-distance weights, inverted / legacy hinges, empty lists, D = 3 ... 16) and after a second backward
+    pass through the same graph."""
+    from dcn_hip import loss as K
+    from dense_correspondence.loss_functions import loss_composer
+    from dense_correspondence.loss_functions.pixelwise_contrastive_loss import PixelwiseContrastiveLoss
+    z, cfg = load_golden_loss(path)
+    grads = {}
+    for mode in (False, True):
+        K.SAVE_PAIR_RECORDS = K.PREFILL_GRADIENTS = mode
+        try:
+            A = torch.tensor(z["A"], requires_grad=True)
+            B = torch.tensor(z["B"], requires_grad=True)
+            pcl = PixelwiseContrastiveLoss([int(z["H"]), int(z["W"])], cfg)
+            out = loss_composer.get_loss(pcl, torch.tensor([int(z["match_type"])]), A, B, *lists_from_golden(z))
+            out[0].backward(retain_graph=True)
+            first = (A.grad.clone(), B.grad.clone())
+            A.grad = None; B.grad = None
+            out[0].backward()
+            # (duplicate pixel indices accumulate with atomics: the order -- and the last bit -- may differ from pass to pass)
+            assert rel_err(A.grad, first[0]) < 1e-6 and rel_err(B.grad, first[1]) < 1e-6
+            grads[mode] = first + (out[0].detach().clone(),)
+        finally:
+            K.SAVE_PAIR_RECORDS = K.PREFILL_GRADIENTS = True
+    assert torch.equal(grads[False][2], grads[True][2])
+    assert rel_err(grads[True][0], grads[False][0]) < 1e-6 and rel_err(grads[True][1], grads[False][1]) < 1e-6
+
+
+def test_record_based_backward_large_descriptors_and_no_grad_path():
+    """D > 32 (lane groups loop over the components) through the record path; a forward pass without gradient keeps no records."""
+    from dcn_hip import loss as K
+    g = torch.Generator().manual_seed(8)
+    P, HW, D = 2, 60, 40
+    lists = []
+    for _ in range(P):
+        lists.append(tuple(torch.randint(0, HW, (n,), generator=g) for n in (17, 17, 9, 9, 30, 30)) + (torch.tensor([-1]), torch.tensor([-1])))
+    pl = K.PairLists.from_lists(lists, "cpu", hw=HW)
+    cfg = K.make_config([0.0, 0.5, 0.7, 0.5], 10)
+    res = {}
+    for mode in (False, True):
+        K.SAVE_PAIR_RECORDS = K.PREFILL_GRADIENTS = mode
+        try:
+            A = (torch.rand(P, HW, D, generator=torch.Generator().manual_seed(1)) * 0.2).requires_grad_(True)
+            B = (torch.rand(P, HW, D, generator=torch.Generator().manual_seed(2)) * 0.2).requires_grad_(True)
+            loss = K.contrastive_loss(A, B, pl, cfg)[0]
+            loss.backward()
+            res[mode] = (loss.detach().clone(), A.grad.clone(), B.grad.clone())
+        finally:
+            K.SAVE_PAIR_RECORDS = K.PREFILL_GRADIENTS = True
+    assert torch.equal(res[False][0], res[True][0])
+    assert rel_err(res[True][1], res[False][1]) < 1e-6 and rel_err(res[True][2], res[False][2]) < 1e-6
+    with torch.no_grad():
+        out = K.contrastive_loss(A.detach(), B.detach(), pl, cfg)
+    assert torch.equal(out[0], res[True][0]) and not out[0].requires_grad
