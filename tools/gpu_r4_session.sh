@@ -56,6 +56,10 @@ PY
     dbg5)      timeout 600 python tools/debug_c1sep.py config5 2>&1 | grep -v "Warn\|amdgpu.ids" | tee gpurun_out/${tag}_debug_config5.txt ;;
     testsloss) timeout 900 python -m pytest tests/test_gpu_parity.py tests/test_gpu_round2.py -m gpu -q -p no:cacheprovider -k "loss or triplet or step" > gpurun_out/${tag}_pytest_loss.log 2>&1; tail -6 gpurun_out/${tag}_pytest_loss.log | cut -c1-300 ;;
     ab4)       timeout 900 python tools/ab_env.py ${AB4_ARGS} 2>&1 | grep "^ab \|^#" | tee -a gpurun_out/${tag}_ab4.txt ;;
+    lossb)     timeout 300 python tools/loss_bench.py --config 3 2>&1 | grep "^loss call" | tee gpurun_out/${tag}_loss_bench.txt
+               timeout 300 python tools/loss_bench.py --config 2 --reps 50 2>&1 | grep "^loss call" | tee -a gpurun_out/${tag}_loss_bench.txt
+               for m in 00 10; do (cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/${tag}_lossprof_$m -- python $GRAFT_REPO_ROOT/tools/loss_bench.py --config 3 --modes $m > /dev/null 2>&1)
+                 python tools/stats_summary.py gpurun_out/${tag}_lossprof_$m "loss call at config-3 sizes, records/prefill = $m" 2>&1 | grep -i "loss\|fill\|kernel |" | head -8 | cut -c1-150 | tee -a gpurun_out/${tag}_loss_bench.txt; done ;;
     *) echo "unknown step $s" ;;
   esac
 done
