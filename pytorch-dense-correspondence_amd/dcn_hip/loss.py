@@ -89,8 +89,13 @@ def make_config(margins, image_width, match_loss_weight=1.0, non_match_loss_weig
     return cfg
 
 
+# Measured on the MI355X at BASELINE configs[2]'s list sizes (profiles/r4e_loss_bench.txt): the backward pass is bound by the
+# fp32 atomics of its scatter (7 M descriptor-sized runs in ~420 us), not by its gathers -- records alone: call 912 -> 885 us
+# (backward kernel 462 -> 418 us, forward 259 -> 279 us); the early zero-fill competes with the forward gather for HBM and
+# buys nothing (897 us alone, 910 us with records) while its two cross-stream waits cost ~13 us on a 41-us call at configs[1]'s
+# sizes: off by default.
 SAVE_PAIR_RECORDS = True   # forward keeps per-pair (difference, factor) records, backward reads them instead of gathering again
-PREFILL_GRADIENTS = True   # the dense gradient maps are zero-filled on a side stream while the forward kernels run
+PREFILL_GRADIENTS = False  # the dense gradient maps zero-filled on a side stream while the forward kernels run
 _fill_streams = {}
 
 
