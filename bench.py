@@ -365,8 +365,9 @@ def main():
                     help="convolution arithmetic (include/dcn_hip.h): split-fp16 on the fp16 MFMA pipe with fp32-level "
                          "accuracy (default), or fp32 MFMA")
     ap.add_argument("--hip-graph", action="store_true",
-                    help="replay forward + loss + backward (~600 launches) from one captured hipGraph instead of launching "
-                         "them every step; measured: no gain -- the step is kernel-bound, the host stays ahead of the GPU")
+                    help="replay forward + loss + backward (~350 launches) from one captured hipGraph instead of launching "
+                         "them every step; measured: no gain at B = 4 and 4 %% SLOWER at B = 1 (profiles/r4a_config1_graph_separate_ab.txt) "
+                         "-- the step is kernel-bound, the host stays ahead of the GPU")
     ap.add_argument("--separate-forwards", action="store_true",
                     help="forward(img_a) and forward(img_b) as two engine calls (default: one grouped call with identical results)")
     ap.add_argument("--torch-adam", action="store_true", help="optimizer.step() through torch.optim.Adam instead of dcn_adam_step")
@@ -490,8 +491,8 @@ def main():
             # one fp32-accurate multiply-add = 3 fp16 MFMA products (hi*hi + hi*lo + lo*hi): the ceiling for
             # ALGORITHMIC flops is a third of the fp16 pipe's dense peak
             peak, kern = F16X3_PEAK_TFLOPS, ("gather-GEMM convolution, forward + dgrad (3x v_mfma_f32_32x32x16_f16 per product): "
-                                             "conv_gemm_hl_kernel on the wide layers (pre-split hl32 operands by LDS-DMA, 256 x 256 or "
-                                             "192 x 256 tiles), conv_gemm_f16_kernel on the others")
+                                             "conv_gemm_hl_kernel on the wide layers (pre-split hl32 operands by LDS-DMA, 320 x 256, 256 x 256 or "
+                                             "192 x 256 tiles by quantisation on the 256 CUs), conv_gemm_f16_kernel on the others")
             peak_note = "fp16 MFMA dense peak %.1f / 3 products per fp32-accurate MAC (fp32 MFMA peak: %.1f)" % (
                 F16_MFMA_PEAK_TFLOPS, FP32_MFMA_PEAK_TFLOPS)
         # HBM-side traffic of the dominant kernel cannot be measured from inside the process (PMC counters need
@@ -499,7 +500,7 @@ def main():
         # MI355X_MICROARCH.md's HBM section), attached only when workload / arithmetic / call pattern match -- the
         # field name says so: it was not measured in this run
         traffic, traffic_src, traffic_hl = None, None, None
-        for name in ("r3_hbm_counters.json", "r2m_hbm_counters.json", "r2_hbm_counters.json", "r1g_hbm_counters.json"):
+        for name in ("r4_hbm_counters.json", "r3_hbm_counters.json", "r2m_hbm_counters.json", "r2_hbm_counters.json", "r1g_hbm_counters.json"):
             try:
                 rec = json.load(open(os.path.join(ROOT, "profiles", name)))
                 if (rec["workload"] == args.workload and rec["conv_mode"] == conv_mode and not args.batch and job_ is job and

@@ -160,6 +160,9 @@ def run_config_against_fixture(config, pair_call=False):
     return out
 
 
+_ORACLE_TRAJECTORIES = {}   # the two CPU oracle runs depend on the problem only, not on the product variant: made once per process
+
+
 def run_trajectory(dcn, oracle, B, H, W, steps, device, pairs=(400, 200, 200), decay_every=5, decay=0.9, lr=1.0e-4,
                    separate_forwards=True, fc_scale=1.0, seed=1):
     """`steps` iterations of the reference's training loop (training.py:325-346: zero_grad, forward x2, loss, backward,
@@ -195,22 +198,45 @@ def run_trajectory(dcn, oracle, B, H, W, steps, device, pairs=(400, 200, 200), d
             for net in (dcn.fcn, oracle):
                 trunk = getattr(net, [n for n, _ in net.named_children()][0])
                 trunk.get_parameter("fc.weight").mul_(fc_scale)
-    o64 = copy.deepcopy(oracle).double()
-    dcn.train(); oracle.train(); o64.train()
-    opt_o = torch.optim.Adam(oracle.parameters(), lr=lr, weight_decay=1e-4)
-    opt_6 = torch.optim.Adam(o64.parameters(), lr=lr, weight_decay=1e-4)
+    # ---- the two oracle trajectories (cached: identical for every product variant of the same problem)
+    key = (tuple(sorted((k, tuple(v.shape), float(v.double().sum())) for k, v in oracle.state_dict().items()))[:6], B, H, W, steps,
+           pairs, decay_every, decay, lr, fc_scale, seed)
+    if key not in _ORACLE_TRAJECTORIES:
+        o32, o64 = copy.deepcopy(oracle), copy.deepcopy(oracle).double()
+        o32.train(); o64.train()
+        opt_o = torch.optim.Adam(o32.parameters(), lr=lr, weight_decay=1e-4)
+        opt_6 = torch.optim.Adam(o64.parameters(), lr=lr, weight_decay=1e-4)
+        lo, l6, h_o = [], [], []
+        for it in range(1, steps + 1):
+            for opt in (opt_o, opt_6):
+                if it % decay_every == 0:
+                    for g in opt.param_groups:
+                        g["lr"] = g["lr"] * decay
+            loss_o, _, da_o, db_o = ostep.train_step(o32, opt_o, img_a, img_b, lists, synth.LOSS_CONFIG)
+            l6.append(float(ostep.train_step(o64, opt_6, img_a.double(), img_b.double(), lists, synth.LOSS_CONFIG)[0].item()))
+            lo.append(float(loss_o.item()))
+            row = []
+            for b in range(B):   # the float32 oracle's own hard-negative counts, from the descriptor maps its step produced
+                pa, pb = ostep.process_network_output(da_o[b:b + 1], 1), ostep.process_network_output(db_o[b:b + 1], 1)
+                row.append(sum(ostep.PixelwiseContrastiveLoss.non_match_descriptor_loss(
+                    pa, pb, lists[b][n + "_non_matches_a"], lists[b][n + "_non_matches_b"], M=synth.LOSS_CONFIG["M_" + n])[1]
+                    for n in ("masked", "background")))
+            h_o.append(row)
+        with torch.no_grad():
+            o32.eval(); o64.eval()
+            _ORACLE_TRAJECTORIES[key] = (lo, l6, h_o, o32(img_a).double(), o64(img_a.double()))
+    lo, l6, h_o, y3, y6 = _ORACLE_TRAJECTORIES[key]
+    # ---- the product
+    dcn.train()
     opt_p = Adam(dcn.parameters(), lr=lr, weight_decay=1e-4)
     pcl = PixelwiseContrastiveLoss(image_shape=dcn.image_shape, config=synth.LOSS_CONFIG)
     xa, xb = img_a.to(device), img_b.to(device)
     pl = PairLists.from_lists([tuple(L[k] for k in KEYS) for L in lists], device, hw=H * W)
-    lp, lo, l6, slack = [], [], [], []
+    lp, slack = [], []
     for it in range(1, steps + 1):
-        for opt in (opt_o, opt_6, opt_p):
-            if it % decay_every == 0:
-                for g in opt.param_groups:
-                    g["lr"] = g["lr"] * decay
-        loss_o, _, da_o, db_o = ostep.train_step(oracle, opt_o, img_a, img_b, lists, synth.LOSS_CONFIG)
-        loss_6 = ostep.train_step(o64, opt_6, img_a.double(), img_b.double(), lists, synth.LOSS_CONFIG)[0]
+        if it % decay_every == 0:
+            for g in opt_p.param_groups:
+                g["lr"] = g["lr"] * decay
         opt_p.zero_grad()
         if separate_forwards:
             ya, yb = dcn.forward(xa), dcn.forward(xb)
@@ -220,24 +246,16 @@ def run_trajectory(dcn, oracle, B, H, W, steps, device, pairs=(400, 200, 200), d
         loss_p.backward()
         opt_p.step()
         lp.append(float(loss_p.item()))
-        lo.append(float(loss_o.item()))
-        l6.append(float(loss_6.item()))
         hp = hard_p.cpu()
         s_it = 0.0
-        for b in range(B):   # the float32 oracle's own counts, from the descriptor maps its step produced
-            pa, pb = ostep.process_network_output(da_o[b:b + 1], 1), ostep.process_network_output(db_o[b:b + 1], 1)
-            h_o = sum(ostep.PixelwiseContrastiveLoss.non_match_descriptor_loss(
-                pa, pb, lists[b][n + "_non_matches_a"], lists[b][n + "_non_matches_b"], M=synth.LOSS_CONFIG["M_" + n])[1]
-                for n in ("masked", "background"))
+        for b in range(B):
             h_p = int(hp[b, 1]) + int(hp[b, 2])
-            s_it = max(s_it, abs(h_p - h_o) / max(min(h_p, h_o), 1))
+            s_it = max(s_it, abs(h_p - h_o[it - 1][b]) / max(min(h_p, h_o[it - 1][b]), 1))
         slack.append(s_it)
     with torch.no_grad():
-        dcn.eval(); oracle.eval(); o64.eval()
+        dcn.eval()
         yp = dcn.forward(xa).cpu().double()
-        y3 = oracle(img_a).double()
-        y6 = o64(img_a.double())
-        dcn.train(); oracle.train()
+        dcn.train()
     centre = lambda y: y - y.mean(dim=(0, 2, 3), keepdim=True)
     yp, y3, y6 = centre(yp), centre(y3), centre(y6)
     rel = lambda a, b: [abs(x - y) / abs(y) for x, y in zip(a, b)]
