@@ -445,13 +445,22 @@ act_status_kernel(const float* __restrict__ actmax, int n, int* __restrict__ sta
     if (threadIdx.x == 0 && bad) atomicOr(status, 1);
 }
 
-// column sums of a [rows][ld] matrix (fc bias gradient): one workgroup per column, fixed-order reduction
-__global__ void __launch_bounds__(256)
+// column sums of a [rows][ld] matrix (fc bias gradient): one workgroup per column, fixed-order reduction.  1024 work-items
+// with four independent partial sums each: the D (= 3) workgroups of this launch are latency-bound -- 150 dependent
+// iterations per work-item measured 45 us at 38 400 rows (profiles/r3f_kernel_stats.txt), 10 iterations of 4 loads do not
+__global__ void __launch_bounds__(1024)
 colsum_kernel(const float* __restrict__ m, int64_t rows, int ld, float* __restrict__ out) {
-    __shared__ double s[4];
-    double a = 0.0;
-    for (int64_t r = threadIdx.x; r < rows; r += 256) a += (double)m[r * ld + blockIdx.x];
-    a = dcn::block_sum<256>(a, s);
+    __shared__ double s[16];
+    double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+    int64_t r = threadIdx.x;
+    for (; r + 3 * 1024 < rows; r += 4 * 1024) {
+        a0 += (double)m[r * ld + blockIdx.x];
+        a1 += (double)m[(r + 1024) * ld + blockIdx.x];
+        a2 += (double)m[(r + 2048) * ld + blockIdx.x];
+        a3 += (double)m[(r + 3072) * ld + blockIdx.x];
+    }
+    for (; r < rows; r += 1024) a0 += (double)m[r * ld + blockIdx.x];
+    const double a = dcn::block_sum<1024>((a0 + a1) + (a2 + a3), s);
     if (threadIdx.x == 0) out[blockIdx.x] = (float)a;
 }
 
@@ -1228,7 +1237,7 @@ int backward_impl(dcn_plan* plan, const float* grad_descriptors, const float* gr
     const float* feat = R.S(p.blocks.back().out);
     DCN_TRY(wgrad(fc, feat, glow, grads[fc.w]));
     DCN_TRY(R.other([&] {
-        hipLaunchKernelGGL(colsum_kernel, dim3(p.D), dim3(256), 0, st, (const float*)glow, (int64_t)N * p.hl * p.wl, p.Dp,
+        hipLaunchKernelGGL(colsum_kernel, dim3(p.D), dim3(1024), 0, st, (const float*)glow, (int64_t)N * p.hl * p.wl, p.Dp,
                            grads[fc.b]);
         return dcn::check_launch();
     }));
