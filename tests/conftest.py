@@ -12,7 +12,16 @@ for p in (ROOT, PKG):
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
-    config.addinivalue_line("markers", "slow: long-running CPU test")
+    config.addinivalue_line("markers", "slow: exhaustive sweep, skipped unless DCN_RUN_SLOW=1 (keeps the default GPU suite inside its time limit)")
+
+
+def pytest_collection_modifyitems(config, items):
+    if os.environ.get("DCN_RUN_SLOW") == "1":
+        return
+    skip = pytest.mark.skip(reason="exhaustive sweep: set DCN_RUN_SLOW=1 to run it")
+    for item in items:
+        if "slow" in item.keywords:
+            item.add_marker(skip)
 
 
 @pytest.fixture(scope="session")

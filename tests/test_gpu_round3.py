@@ -106,10 +106,11 @@ def test_wgrad_hl32_transposing_lds_reads(L, case, dcn_env):
 
 @pytest.mark.parametrize("env", [
     dict(DCN_GEMM_HL=0, DCN_WGRAD_HL=0),                          # round-2 kernels everywhere
-    dict(DCN_GEMM_HL=1, DCN_WGRAD_HL=1, DCN_HL_PRODUCERS=0),      # hl32 kernels, operand images by stand-alone split passes
+    pytest.param(dict(DCN_GEMM_HL=1, DCN_WGRAD_HL=1, DCN_HL_PRODUCERS=0), marks=pytest.mark.slow),   # hl32 kernels, operand images by stand-alone split passes
     dict(DCN_GEMM_HL=2, DCN_WGRAD_HL=2),                          # every supported convolution (narrow layers included)
-    dict(DCN_GEMM_HL=2, DCN_GEMM_HL_ROWS=192),                    # ... all of them on 192-row tiles
-], ids=["hl-off", "split-passes", "forced-everywhere", "forced-192"])
+    pytest.param(dict(DCN_GEMM_HL=2, DCN_GEMM_HL_ROWS=192), marks=pytest.mark.slow),   # ... all of them on 192-row tiles
+    pytest.param(dict(DCN_GEMM_HL_ROWS=-320), marks=pytest.mark.slow),                 # the round-3 tile choice (never 320 rows)
+], ids=["hl-off", "split-passes", "forced-everywhere", "forced-192", "no-320"])
 def test_headline_step_vs_fixture_under_hl32_switches(L, env, dcn_env):
     """The headline workload (config 2, forward_pair) against its float32 / float64 oracle fixture with the hl32 path switched
     off, fed by stand-alone split passes, and forced onto every supported layer (also with 192-row tiles only): same tolerances as the default
