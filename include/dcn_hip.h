@@ -47,7 +47,7 @@ const char* dcn_version(void);
 /* The DCN_* environment overrides -- the full list with their meaning is the header comment of csrc/dcn_tuning.h:
  * DCN_CONV_MODE, DCN_BACKWARD_OVERLAP, DCN_GEMM_TILE_M, DCN_STEM8, DCN_GEMM_SK, DCN_GEMM_SK_MIN_GAIN,
  * DCN_GEMM_UNI, DCN_GEMM_SK_FIXUP, DCN_BN_BWD_FUSED, DCN_DEFER_RESIDUAL_ADD, DCN_WGRAD_TILE, DCN_WGRAD_DEEP, DCN_WGRAD_ROLES,
- * DCN_WGRAD_SPLITS, DCN_GEMM_HL, DCN_GEMM_HL_ROWS, DCN_WGRAD_HL, DCN_HL_PRODUCERS, DCN_HL_ONLY_MID, DCN_STEM_POOL_FUSED -- are read ONCE, at the first call that needs them -- never on the
+ * DCN_WGRAD_SPLITS, DCN_GEMM_HL, DCN_GEMM_HL_ROWS, DCN_WGRAD_HL, DCN_HL_PRODUCERS, DCN_HL_ONLY_MID, DCN_STEM_POOL_FUSED, DCN_BN_REVERSE, DCN_BN_NT, DCN_BN_REDUCE_WIDE -- are read ONCE, at the first call that needs them -- never on the
  * launch path.  dcn_reload_env re-reads them (tests / tuning scripts that change a variable in-process); not to be called
  * while another thread is inside the library. */
 void dcn_reload_env(void);
@@ -375,7 +375,7 @@ int dcn_split_weights_checked_f16(int n, const float* const* w, const float* con
  * summation order).  dcn_conv_hl_eligible: 1 when the descriptor qualifies (forward: dgrad = 0). */
 int dcn_conv_hl_eligible(const dcn_conv_desc* c, int dgrad);
 int dcn_conv_num_mtiles_hl(const dcn_conv_desc* c);
-/* rows per tile of the launch (256, or 192 where that fills the 256 CUs better; DCN_GEMM_HL_ROWS forces one) */
+/* rows per tile of the launch (256, or 192 / 320 where that fills the 256 CUs better; DCN_GEMM_HL_ROWS forces one) */
 int dcn_conv_tile_rows_hl(const dcn_conv_desc* c, int dgrad);
 size_t dcn_conv_gemm_workspace_hl(const dcn_conv_desc* c, int dgrad);
 /* fp32 [rows][channels] (channels % 32 == 0) -> hl32, scaled by the power of two chosen from *absmax (NULL: 1) */
