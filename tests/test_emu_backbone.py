@@ -514,7 +514,7 @@ def test_backward_refuses_an_arena_whose_forward_decisions_no_longer_hold(dcn_en
     from dcn_hip import backbone as _bb
     m, _ = _pair("Resnet18_8s", 3, 32)
     g = torch.Generator().manual_seed(4)
-    x = torch.randn(1, 3, 16, 256, generator=g)
+    x = torch.randn(1, 3, 16, 128, generator=g)
     m.train()
     try:
         dcn_env(DCN_GEMM_HL=2, DCN_WGRAD_HL=2, DCN_HL_ONLY_MID=1)
@@ -522,12 +522,11 @@ def test_backward_refuses_an_arena_whose_forward_decisions_no_longer_hold(dcn_en
         y = m(x)                                   # mid activations of the qualifying blocks: hl32 image only
         dcn_env(DCN_GEMM_HL=2, DCN_WGRAD_HL=0)     # their weight gradients would now read the fp32 tensors
         with pytest.raises(RuntimeError, match="DCN_E_INVALID"):
-            y.sum().backward()
+            y.sum().backward(retain_graph=True)
         dcn_env(DCN_GEMM_HL=2, DCN_WGRAD_HL=2, DCN_HL_ONLY_MID=1)
-        y = m(x)
         _bb.set_conv_mode("fp32")                  # another arithmetic than the one that filled the arena
         with pytest.raises(RuntimeError, match="DCN_E_INVALID"):
-            y.sum().backward()
+            y.sum().backward(retain_graph=True)
         _bb.set_conv_mode("f16x3")
         m.zero_grad()
         y.sum().backward()                         # the arena is still differentiable under the switches it was made with
@@ -609,13 +608,13 @@ def test_bn_passes_walked_back_to_front_are_bit_identical(dcn_env, conv_mode):
         assert torch.equal(b, b2), k
 
 
-@pytest.mark.parametrize("cap", [32, 128])
+@pytest.mark.parametrize("cap", [128])
 def test_bn_backward_reduction_with_wide_workgroups(cap, dcn_env, conv_mode):
     """DCN_BN_REDUCE_WIDE: workgroups of the batch-norm backward reduction that cover 128 ... 512 channels of a row instead of
     64 -- another partition of the same sums: gradients equal to round-off of the default partition."""
     if conv_mode != "f16x3":
         pytest.skip("the pass does not depend on the convolution arithmetic")
-    m, _ = _pair("Resnet18_8s", 3, 64)     # 64 / 128 / 256 / 512 channels
+    m, _ = _pair("Resnet18_8s", 3, 64)     # 64 / 128 / 256 / 512 channels: workgroups of 64 (stem: one group), 32, 64 and 128 quads
     m2 = copy.deepcopy(m)
     g = torch.Generator().manual_seed(2)
     x = torch.randn(1, 3, 32, 32, generator=g)
