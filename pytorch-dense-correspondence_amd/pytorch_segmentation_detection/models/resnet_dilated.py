@@ -143,9 +143,54 @@ class _DilatedResnet8s(nn.Module):
         if self.training:
             torch._foreach_add_(tracked, int(groups))
         owner = getattr(self, "_flat_grad_owner", None)   # dcn_hip.distributed.FlatGradients, if one manages the gradients
+        self._check_previous_status()
         self._last_plan = plan
-        return _bb.backbone_forward(x, plan, params, running, self.training, normalize, self.bn_momentum, self.bn_eps,
-                                    grad_sink=owner.flat if owner is not None else None, grad_owner=owner, image_b=x_b)
+        out = _bb.backbone_forward(x, plan, params, running, self.training, normalize, self.bn_momentum, self.bn_eps,
+                                   grad_sink=owner.flat if owner is not None else None, grad_owner=owner, image_b=x_b)
+        self._watch_status(plan)
+        return out
+
+    # The status word of a forward call (last_forward_status) is looked at WITHOUT a synchronisation: it is copied to pinned
+    # host memory behind the call and read at the start of a later call, once the copy has completed.  A convolution weight
+    # outside the range of its fp16 image (bit 1: |w| >= 1023 with the fixed weight scale 64 -- a checkpoint of another
+    # training recipe could hold one) makes the split-fp16 products of that layer wrong: the training path must not go on
+    # silently, so the NEXT call raises.  A non-finite activation (bit 0) is what the reference would propagate as NaN too: warned once.
+    def _watch_status(self, plan):
+        rng = getattr(plan, "last_activation_range", None)
+        if rng is None or getattr(self, "_pending_status", None) is not None:
+            return
+        status = rng[1]
+        if not status.is_cuda:
+            self._pending_status = (status, None)
+            return
+        if torch.cuda.is_current_stream_capturing():
+            return
+        host = getattr(self, "_status_host", None)
+        if host is None:
+            host = self._status_host = torch.zeros(1, dtype=torch.int32).pin_memory()
+        host.copy_(status, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        self._pending_status = (host, ev)
+
+    def _check_previous_status(self):
+        pend = getattr(self, "_pending_status", None)
+        if pend is None:
+            return
+        host, ev = pend
+        if ev is not None and (torch.cuda.is_current_stream_capturing() or not ev.query()):
+            return                      # (not there yet: looked at again at the next call)
+        self._pending_status = None
+        st = int(host[0])
+        if st & 2:
+            raise FloatingPointError(
+                "%s: a convolution weight of the previous forward call was outside the range of its fp16 image (|w| >= 1023 with "
+                "the fixed weight scale of the split-fp16 arithmetic, or NaN): that call's results are not fp32-accurate.  Use "
+                "dcn_hip.backbone.set_conv_mode('fp32') for such weights." % type(self).__name__)
+        if (st & 1) and not getattr(self, "_warned_nonfinite", False):
+            self._warned_nonfinite = True
+            warnings.warn("%s: a non-finite activation (inf / NaN) in a forward call -- the descriptors of that call are NaN, "
+                          "as they would be in the reference" % type(self).__name__)
 
     def last_forward_status(self):
         """(abs-max of every convolution input, status word) of the most recent forward call, as device tensors (reading

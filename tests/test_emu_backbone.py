@@ -496,6 +496,10 @@ def test_status_word_flags_nan_input_and_out_of_range_weights(conv_mode):
     assert int(m.last_forward_status()[1]) & 2
     with torch.no_grad():
         m.resnet18_8s.get_parameter("layer2.0.conv1.weight")[3, 2, 1, 1] = 900.0            # inside the range again
+    # the training path does not go on silently: the status word of a call is read (without a synchronisation) at the start
+    # of a later call, which raises
+    with pytest.raises(FloatingPointError, match="outside the range of its fp16 image"):
+        m(x)
     m(x)
     assert not (int(m.last_forward_status()[1]) & 2)
     # a NaN batch-norm parameter: the statistics path reports it through the bound

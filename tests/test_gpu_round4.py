@@ -81,3 +81,28 @@ def test_profile_categories_on_hardware(L):
         rate = b / (ms * 1e-3) / 1e12
         print(k, "%.2f TB/s over %d launches" % (rate, n))
         assert 0.3 < rate < 8.0, (k, rate)
+
+
+def test_out_of_range_weight_stops_the_training_path(L):
+    """Split-fp16 arithmetic: a convolution weight outside the range of its fp16 image (|w| >= 1023 at the fixed weight scale)
+    only raises a status bit inside the call (no synchronisation on the hot path) -- the status word is copied to pinned host
+    memory behind the call and a LATER forward call raises, so a training loop cannot go on silently."""
+    from dcn_hip import backbone
+    backbone.set_conv_mode("f16x3")
+    try:
+        dcn, _ = pc.build_dcn("Resnet34_8s", 3, 64, 96)
+        x = torch.randn(1, 3, 64, 96).cuda()
+        dcn.train()
+        dcn.forward(x)
+        with torch.no_grad():
+            dcn.fcn.resnet34_8s.get_parameter("layer2.0.conv1.weight")[3, 2, 1, 1] = 2000.0
+        dcn.forward(x)                       # sets the bit; returns normally
+        torch.cuda.synchronize()
+        dcn.forward(x)                       # (reads the status of the clean first call, watches this one)
+        torch.cuda.synchronize()
+        with pytest.raises(FloatingPointError, match="outside the range of its fp16 image"):
+            dcn.forward(x)
+            torch.cuda.synchronize()
+            dcn.forward(x)
+    finally:
+        backbone.set_conv_mode(None)
