@@ -89,6 +89,9 @@ struct dcn_plan {
     int hl = 0, wl = 0, feat_c = 0;
     // saved arena offsets (floats)
     size_t s_in4 = 0, s_stem_y = 0, s_pool = 0, s_argmax = 0, s_low = 0, s_actmax = 0, saved_floats = 0;
+    // the backward pass's (channel-transposed) weight images, written by the FORWARD call on the side stream (round 4):
+    // fp16 hi / lo planes and hl32 images, laid out like w_wh / w_wl / w_whl
+    size_t s_wht = 0, s_wlt = 0, s_whlt = 0;
     int n_act = 0;    // activation tensors that feed a convolution: s_actmax[n_act] abs-max scalars + one status word behind them
     // workspace offsets (floats)
     size_t w_buf[6] = {0, 0, 0, 0, 0, 0}, w_wt = 0, w_slab = 0, w_part = 0, w_k123 = 0, w_wstem = 0, w_dwstem = 0,
@@ -111,12 +114,15 @@ struct dcn_plan {
         int conv_mode = 0;
         std::vector<unsigned char> mid_hl_only;   // per convolution: its INPUT activation exists as the saved hl32 image only
         std::vector<unsigned char> hl_x_written;  // per convolution: the saved hl32 image of its input was written
+        bool wt_saved = false;                    // the backward pass's weight images are in the saved arena (s_wht / s_wlt / s_whlt)
+        std::vector<unsigned char> hl_t_written;  // ... per convolution: its transposed hl32 image among them
     };
     std::vector<FwdRecord> fwd_records;           // newest last; a handful at most (one per forward call awaiting its backward)
     // backward pass, split-fp16 mode: the weight-gradient GEMMs run on a second, low-priority stream next to the
     // dgrad -> BN-backward chain of the following layer (created on first use; DCN_BACKWARD_OVERLAP=0 disables)
     hipStream_t side = nullptr;
     hipEvent_t ev_dq[2] = {nullptr, nullptr}, ev_wg[2] = {nullptr, nullptr}, ev_join = nullptr;
+    hipEvent_t ev_ws[2] = {nullptr, nullptr};   // forward: weight images on the side stream (fork after the stem's padding, join before layer 1)
     int side_state = 0;   // 0: not tried, 1: ready, -1: unavailable
     // gradient buckets (data-parallel training): bucket k = parameters [bucket_first[k], bucket_first[k - 1]) in
     // state-dict order (bucket 0 ends at the last parameter); backward finishes them in the order 0, 1, ... and records
@@ -401,6 +407,8 @@ int build_plan(dcn_plan& p) {
         }
         p.w_wh = alloc((halves + 1) / 2);
         p.w_wl = alloc((halves + 1) / 2);
+        p.s_wht = B.alloc_saved((halves + 1) / 2);
+        p.s_wlt = B.alloc_saved((halves + 1) / 2);
     }
     {   // hl32 weight images (conv_hl_kernels.hip) of the convolutions whose forward or dgrad may take that path (the image of
         // the forward pass and the one of the backward pass share the slot), and ONE transient hl32 activation / gradient image
@@ -415,6 +423,7 @@ int build_plan(dcn_plan& p) {
             max_img = std::max(max_img, std::max((size_t)c.d.n * c.d.hin * c.d.win * c.d.cin, (size_t)c.d.n * c.d.hout * c.d.wout * c.d.ldc));
         }
         p.w_whl = alloc(fl);
+        p.s_whlt = B.alloc_saved(fl);
         p.w_hl = alloc(max_img);    // image of a block's input / output (forward), of a batch-norm backward's dx (backward)
         p.w_hl2 = alloc(max_img);   // image of a block's mid activation
     }
@@ -427,6 +436,7 @@ int build_plan(dcn_plan& p) {
         p.w_dq2 = alloc(max_dq);   // second image: wgrad of layer k reads one while BN backward of layer k - 1 writes the other
     }
     p.ws_floats = ws;
+    p.saved_floats = B.saved;   // (the saved copies of the backward weight images were added behind the activations)
     return DCN_OK;
 }
 
@@ -484,6 +494,19 @@ hipStream_t shared_side_stream() {
     if (hipStreamCreateWithPriority(&st, hipStreamNonBlocking, lo_prio) != hipSuccess) return nullptr;
     streams.emplace_back(dev, st);
     return st;
+}
+
+// the plan's handle on the side stream + the events that order it against the caller's stream (created on first use)
+bool ensure_side(dcn_plan& p) {
+    if (p.side_state == 0) {
+        bool ok = dcn::tuning().backward_overlap != 0;
+        p.side = ok ? shared_side_stream() : nullptr;
+        ok = ok && p.side != nullptr;
+        for (hipEvent_t* ev : {&p.ev_dq[0], &p.ev_dq[1], &p.ev_wg[0], &p.ev_wg[1], &p.ev_join, &p.ev_ws[0], &p.ev_ws[1]})
+            ok = ok && hipEventCreateWithFlags(ev, hipEventDisableTiming) == hipSuccess;
+        p.side_state = ok ? 1 : -1;
+    }
+    return p.side_state == 1;
 }
 
 #define DCN_TRY(expr)                    \
@@ -602,7 +625,14 @@ struct Run {
         });
     }
 
-    void* wimg(size_t plane, const ConvL& c) const { return (void*)((_Float16*)Wk(plane) + c.wsplit); }
+    // weight images: in the workspace, or (backward pass, images saved by the forward call) wherever the overrides point
+    float* wh_over = nullptr;
+    float* wl_over = nullptr;
+    float* whl_over = nullptr;
+    void* wimg(size_t plane, const ConvL& c) const {
+        float* base = plane == p.w_wh ? (wh_over ? wh_over : Wk(p.w_wh)) : (wl_over ? wl_over : Wk(p.w_wl));
+        return (void*)((_Float16*)base + c.wsplit);
+    }
 
     // the saved hl32 copy of activation y (channels C, absmax slot act) by a stand-alone pass, when the apply pass that produced
     // y did not write it (DCN_HL_PRODUCERS=0)
@@ -614,7 +644,7 @@ struct Run {
     bool use_hl(const ConvL& c, int dgrad) const {
         return p.conv_mode == DCN_CONV_F16X3 && c.hl_any && dcn_conv_hl_eligible(&c.d, dgrad) != 0;
     }
-    void* whl(const ConvL& c) const { return (void*)Wk(p.w_whl + c.whl); }
+    void* whl(const ConvL& c) const { return (void*)((whl_over ? whl_over : Wk(p.w_whl)) + c.whl); }
     float* hlbuf(int k) const { return Wk(k == 0 ? p.w_hl : p.w_hl2); }
     // buffer k will hold the hl32 image of the activation `y` (written by the bn_apply pass that is about to produce y), if a
     // convolution that reads y takes the hl32 path; returns the buffer or null
@@ -742,7 +772,7 @@ extern "C" int dcn_plan_create_grouped(const char* arch, int base_width, int n, 
 extern "C" void dcn_plan_destroy(dcn_plan* plan) {
     if (!plan) return;
     for (hipEvent_t e : plan->prof_ev) hipEventDestroy(e);
-    for (hipEvent_t e : {plan->ev_dq[0], plan->ev_dq[1], plan->ev_wg[0], plan->ev_wg[1], plan->ev_join})
+    for (hipEvent_t e : {plan->ev_dq[0], plan->ev_dq[1], plan->ev_wg[0], plan->ev_wg[1], plan->ev_join, plan->ev_ws[0], plan->ev_ws[1]})
         if (e) hipEventDestroy(e);
     for (hipEvent_t e : plan->ev_bucket)
         if (e) hipEventDestroy(e);
@@ -906,12 +936,39 @@ int forward_impl(dcn_plan* plan, const float* image, const float* image_b, const
             DCN_TRY(R.conv_fused(last, cur, res, 1, R.S(blk.out), blk.act_out));
         }
     } else {
-    if (p.conv_mode == DCN_CONV_F16X3) {
-        DCN_TRY(R.split_all_weights(false, R.Wk(p.w_wstem)));
-        DCN_TRY(R.split_hl_weights(false));
+    const bool stem8 = p.conv_mode == DCN_CONV_F16X3 && dcn::tuning().stem8 != 0 && dcn::tuning().gemm_uni != 0 && stem.d.win >= 8 &&
+                       stem.d.kh == 7 && stem.d.cin == 4 && (int64_t)stem.d.n * stem.d.hin * stem.d.win * 16 <= ((int64_t)1 << 31);
+    // Weight images on the side stream (round 4, training, split-fp16, stem on its own image): the batched splits of ALL layers'
+    // weights -- the forward images AND the channel-transposed ones of this call's backward pass, the latter into the saved arena
+    // -- run next to the input layout pass, the stem convolution, its batch norm and the max pool instead of in front of them
+    // (and in front of the backward pass): ~0.2 ms per step off the critical path.  Fork: after the stem's weight padding
+    // (the forward image of the stem is part of the batch); join: before the first block.  Not while launches are being timed
+    // one by one, not inside a hipGraph capture.
+    bool hoist = training && f16_mode && stem8 && !p.prof_on && dcn::tuning().wsplit_overlap != 0 && ensure_side(p);
+    if (hoist) {
+        hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+        if (hipStreamIsCapturing(st, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) hoist = false;
     }
-    if (p.conv_mode == DCN_CONV_F16X3 && dcn::tuning().stem8 != 0 && dcn::tuning().gemm_uni != 0 && stem.d.win >= 8 && stem.d.kh == 7 &&
-        stem.d.cin == 4 && (int64_t)stem.d.n * stem.d.hin * stem.d.win * 16 <= ((int64_t)1 << 31)) {
+    if (p.conv_mode == DCN_CONV_F16X3) {
+        if (hoist) {
+            Run Rs{p, params, (float*)saved, (float*)workspace, p.side};
+            bool ok = hipEventRecord(p.ev_ws[0], st) == hipSuccess && hipStreamWaitEvent(p.side, p.ev_ws[0], 0) == hipSuccess;
+            if (!ok) return DCN_E_LAUNCH;
+            DCN_TRY(Rs.split_all_weights(false, Rs.Wk(p.w_wstem)));
+            DCN_TRY(Rs.split_hl_weights(false));
+            Rs.wh_over = Rs.S(p.s_wht); Rs.wl_over = Rs.S(p.s_wlt); Rs.whl_over = Rs.S(p.s_whlt);
+            DCN_TRY(Rs.split_all_weights(true, nullptr));
+            DCN_TRY(Rs.split_hl_weights(true));
+            rec.wt_saved = true;
+            rec.hl_t_written.assign(p.convs.size(), 0);
+            for (const ConvL& c : p.convs) rec.hl_t_written[c.idx] = Rs.use_hl(c, 1) ? 1 : 0;
+            if (hipEventRecord(p.ev_ws[1], p.side) != hipSuccess) return DCN_E_LAUNCH;
+        } else {
+            DCN_TRY(R.split_all_weights(false, R.Wk(p.w_wstem)));
+            DCN_TRY(R.split_hl_weights(false));
+        }
+    }
+    if (stem8) {
         _Float16* hi = (_Float16*)R.Wk(p.w_stem8);
         DCN_TRY(R.other([&] { return dcn_split_stem_weights_f16(R.Wk(p.w_wstem), hi, hi + (size_t)p.base * 224, p.base, kWeightScale, st); }));
         R.stem8 = true;
@@ -932,6 +989,7 @@ int forward_impl(dcn_plan* plan, const float* image, const float* image_b, const
                                     stem.d.wout, hp, wp, b.C, st);
         }
     }
+    if (hoist && hipStreamWaitEvent(st, p.ev_ws[1], 0) != hipSuccess) return DCN_E_LAUNCH;   // join: the weight images are there
     if (training && f16_mode && p.blocks[0].has_hl_in) {   // (the first block's input is the max-pool output: no apply pass writes it)
         const BlockL& b0 = p.blocks[0];
         R.hl_saved.emplace_back(R.S(b0.in), R.S(b0.hl_in));
@@ -1068,18 +1126,7 @@ int backward_impl(dcn_plan* plan, const float* grad_descriptors, const float* gr
     // so it runs on the plan's side stream while the main stream goes on with dgrad(k) -> BN backward(k - 1) -> ...; the
     // gradient's pixel-blocked image alternates between two buffers and events order writer and reader of each.
     bool overlap = f16 && !p.prof_on;
-    if (overlap && p.side_state == 0) {
-        bool ok = dcn::tuning().backward_overlap != 0;
-        int lo_prio = 0, hi_prio = 0;
-        if (ok && hipDeviceGetStreamPriorityRange(&lo_prio, &hi_prio) != hipSuccess) lo_prio = 0;
-        (void)lo_prio;
-        p.side = ok ? shared_side_stream() : nullptr;
-        ok = ok && p.side != nullptr;
-        for (hipEvent_t* ev : {&p.ev_dq[0], &p.ev_dq[1], &p.ev_wg[0], &p.ev_wg[1], &p.ev_join})
-            ok = ok && hipEventCreateWithFlags(ev, hipEventDisableTiming) == hipSuccess;
-        p.side_state = ok ? 1 : -1;
-    }
-    overlap = overlap && p.side_state == 1;
+    overlap = overlap && ensure_side(p);
     if (p.bucket_state == 0) {   // events behind dcn_plan_stream_wait_grad_bucket
         bool ok = true;
         p.ev_bucket.assign(p.bucket_first.size(), nullptr);
@@ -1212,8 +1259,18 @@ int backward_impl(dcn_plan* plan, const float* grad_descriptors, const float* gr
         });
     };
     if (f16) {
-        DCN_TRY(R.split_all_weights(true, nullptr));
-        DCN_TRY(R.split_hl_weights(true));
+        // the forward call of this arena already made this pass's weight images (dcn_plan::FwdRecord::wt_saved) -- unless a
+        // convolution that takes the hl32 dgrad NOW was not among them (the tuning changed in between): then they are made here
+        bool have = rec.wt_saved;
+        if (have)
+            for (const ConvL& c : p.convs)
+                if (R.use_hl(c, 1) && !rec.hl_t_written[c.idx]) have = false;
+        if (have) {
+            R.wh_over = R.S(p.s_wht); R.wl_over = R.S(p.s_wlt); R.whl_over = R.S(p.s_whlt);
+        } else {
+            DCN_TRY(R.split_all_weights(true, nullptr));
+            DCN_TRY(R.split_hl_weights(true));
+        }
     }
     // split-fp16 mode: every gradient tensor that feeds a convolution records its abs-max (pre-scale selection)
     if (f16) DCN_TRY(R.other([&] { return dcn::fill_bytes_async(amax, 0, p.convs.size() * sizeof(float), st); }));

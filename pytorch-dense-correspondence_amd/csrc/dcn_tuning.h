@@ -40,6 +40,8 @@
 //                           channels: 256-byte pieces of a row per tensor; 128 = whole rows of 512 channels, but 8x fewer workgroups)
 //   DCN_BN_NT               bit mask: non-temporal loads of tensors a batch-norm pass reads for the last time (1: the conv output in
 //                           the forward apply pass, 2: dy and the conv output in the backward apply pass)
+//   DCN_WSPLIT_OVERLAP      0: the per-call weight images are made on the caller's stream in front of the forward / backward pass
+//                           (default 1: all of them on the side stream during the stem of the forward pass)
 #pragma once
 
 namespace dcn {
@@ -66,6 +68,7 @@ struct Tuning {
     int hl_only_mid = 1;         // mid-block activations whose two readers (next conv, its wgrad) take the hl32 image: no fp32 copy (0: keep it)
     int stem_pool_fused = 1;     // the stem's batch norm + ReLU applied inside the max-pool pass (0: an apply pass of its own)
     int bn_reduce_wide = 32;     // see DCN_BN_REDUCE_WIDE above (32: +0.2 % on the step, 128: -1 %, profiles/r4c_ab_bn_reduce_wide.txt)
+    int wsplit_overlap = 1;      // see DCN_WSPLIT_OVERLAP above
     int bn_nt = 0;               // see DCN_BN_NT above
     int bn_reverse = 0;          // see DCN_BN_REVERSE above
     int wgrad_roles = 1;         // wide tile: wavefronts 0-3 stage the activations, 4-7 the gradient (0: copy spread over all 8)

@@ -42,6 +42,7 @@ void read_env(Tuning& t) {
     if (const char* e = getenv("DCN_HL_PRODUCERS")) t.hl_producers = atoi(e) != 0;
     if (const char* e = getenv("DCN_BN_REVERSE")) t.bn_reverse = atoi(e);
     if (const char* e = getenv("DCN_BN_NT")) t.bn_nt = atoi(e);
+    if (const char* e = getenv("DCN_WSPLIT_OVERLAP")) t.wsplit_overlap = atoi(e) != 0;
     if (const char* e = getenv("DCN_BN_REDUCE_WIDE")) t.bn_reduce_wide = atoi(e);
 }
 

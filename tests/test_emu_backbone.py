@@ -629,3 +629,31 @@ def test_bn_backward_reduction_with_wide_workgroups(cap, dcn_env, conv_mode):
         (net(x) * gy).sum().backward()
     for (k, p), p2 in zip(m.named_parameters(), m2.parameters()):
         assert rel_err(p2.grad, p.grad) < 2e-5, (k, rel_err(p2.grad, p.grad))
+
+
+def test_weight_images_made_on_the_side_stream_are_the_same_images(dcn_env, conv_mode):
+    """DCN_WSPLIT_OVERLAP: the forward call makes all weight images -- its own and the channel-transposed ones of its backward
+    pass, the latter into the saved arena -- on the side stream during the stem; the backward pass then makes none.  Same bits
+    as the images made on the caller's stream in front of each pass (NaN-poisoned arenas: nothing is read before it is written)."""
+    if conv_mode != "f16x3":
+        pytest.skip("weight images belong to the split-fp16 arithmetic")
+    from dcn_hip import backbone as _bb
+    m, _ = _pair("Resnet18_8s", 3, 8)
+    m2 = copy.deepcopy(m)
+    g = torch.Generator().manual_seed(12)
+    x = torch.randn(2, 3, 32, 40, generator=g)
+    gy = torch.randn(2, 3, 32, 40, generator=g)
+    _bb.POISON_ARENAS = True
+    try:
+        outs = []
+        for net, on in ((m, 1), (m2, 0)):
+            dcn_env(DCN_WSPLIT_OVERLAP=on)
+            net.train()
+            y = net(x)
+            (y * gy).sum().backward()
+            outs.append(y.detach())
+    finally:
+        _bb.POISON_ARENAS = False
+    assert bool(torch.isfinite(outs[0]).all()) and torch.equal(outs[0], outs[1])
+    for (k, p), p2 in zip(m.named_parameters(), m2.parameters()):
+        assert bool(torch.isfinite(p.grad).all()) and torch.equal(p.grad, p2.grad), k

@@ -107,3 +107,40 @@ def test_out_of_range_weight_stops_the_training_path(L):
                 torch.cuda.synchronize()
     finally:
         backbone.set_conv_mode(None)
+
+
+def test_weight_images_made_on_the_side_stream_full_size(L, dcn_env):
+    """Config-2 shapes, forward_pair, NaN-poisoned arenas: with the weight images of forward AND backward made on the side stream
+    during the stem (DCN_WSPLIT_OVERLAP, default) descriptors and all gradients equal, bit for bit, those of the run that makes
+    them on the caller's stream in front of each pass -- three times in a row (a missing cross-stream dependency would show up
+    as a layer that read its weight image before it was written)."""
+    import copy
+    from dcn_hip import backbone
+    from pytorch_segmentation_detection.models import resnet_dilated as prod
+    backbone.set_conv_mode("f16x3")
+    try:
+        torch.manual_seed(3)
+        m = prod.Resnet34_8s(num_classes=3).cuda()
+        m2 = copy.deepcopy(m)
+        g = torch.Generator().manual_seed(5)
+        xa, xb = torch.randn(4, 3, 480, 640, generator=g).cuda(), torch.randn(4, 3, 480, 640, generator=g).cuda()
+        gy = torch.randn(4, 3, 480, 640, generator=g).cuda()
+        backbone.POISON_ARENAS = True
+        res = []
+        for net, on in ((m, 1), (m2, 0)):
+            dcn_env(DCN_WSPLIT_OVERLAP=on)
+            net.train()
+            for rep in range(3):
+                net.zero_grad()
+                ya, yb = net.forward_pair(xa, xb)
+                ((ya * gy).sum() + (yb * gy).sum()).backward()
+            torch.cuda.synchronize()
+            res.append((ya.detach().clone(), [p.grad.clone() for p in net.parameters()]))
+    finally:
+        backbone.POISON_ARENAS = False
+        backbone.set_conv_mode(None)
+        backbone._PLANS.clear()
+        torch.cuda.empty_cache()
+    assert bool(torch.isfinite(res[0][0]).all()) and torch.equal(res[0][0], res[1][0])
+    for (k, _), g1, g2 in zip(m.named_parameters(), res[0][1], res[1][1]):
+        assert bool(torch.isfinite(g1).all()) and torch.equal(g1, g2), k
