@@ -63,6 +63,7 @@ PY
     tests34)   timeout 1200 python -m pytest tests/test_gpu_round3.py tests/test_gpu_round4.py tests/test_gpu_round2.py -m gpu -q -p no:cacheprovider --durations=8 > gpurun_out/${tag}_pytest_34.log 2>&1; tail -16 gpurun_out/${tag}_pytest_34.log | cut -c1-200 ;;
     report)    timeout 900 python tools/parity_report.py --json gpurun_out/${tag}_parity_report.json > gpurun_out/${tag}_parity_report.log 2>&1; tail -14 gpurun_out/${tag}_parity_report.log | cut -c1-400 ;;
     sustained) timeout 300 python bench.py --steps 300 --warmup 10 --no-variants --cpu-baseline-steps 0 --profile-steps 0 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('300 consecutive steps: %.1f images/s  %.3f ms/step  final loss %.5f' % (d['value'], d['ms_per_step'], d['config']['final_loss']))" | tee gpurun_out/${tag}_sustained.txt ;;
+    tests4b)   timeout 900 python -m pytest tests/test_gpu_round4.py -m gpu -q -p no:cacheprovider --durations=5 > gpurun_out/${tag}_pytest_r4b.log 2>&1; tail -14 gpurun_out/${tag}_pytest_r4b.log | cut -c1-200 ;;
     *) echo "unknown step $s" ;;
   esac
 done
