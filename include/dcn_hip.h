@@ -378,6 +378,11 @@ int dcn_conv_num_mtiles_hl(const dcn_conv_desc* c);
 /* rows per tile of the launch (256, or 192 / 320 where that fills the 256 CUs better; DCN_GEMM_HL_ROWS forces one) */
 int dcn_conv_tile_rows_hl(const dcn_conv_desc* c, int dgrad);
 size_t dcn_conv_gemm_workspace_hl(const dcn_conv_desc* c, int dgrad);
+/* the tile the launch of this convolution takes under the tuning of the moment: info[0..5] = rows (256 / 192 / 320: the big
+ * tiles; 160: the small-tile kernel of csrc/conv_hlx_kernels.hip -- round 5: the reference's batch_size 1,
+ * training.yaml:14, and its two separate forward calls, training.py:329-333), columns, K groups inside the workgroup,
+ * workgroups per tile along K, M tiles, N tiles.  Returns 0, or DCN_E_UNSUPPORTED when no tile height fits. */
+int dcn_conv_hl_shape_info(const dcn_conv_desc* c, int dgrad, int* info6);
 /* fp32 [rows][channels] (channels % 32 == 0) -> hl32, scaled by the power of two chosen from *absmax (NULL: 1) */
 int dcn_split_act_hl32(const float* src, const float* absmax, void* dst, int64_t rows, int channels, void* stream);
 /* n weight tensors w[i] = [cout][taps][cin] -> out[i] = hl32 [cout][taps*cin/32][hi|lo], or (transposed) the dgrad image

@@ -56,6 +56,7 @@
 #include <atomic>
 #include <type_traits>
 
+#include "conv_hlx.h"
 #include "conv_shared.h"
 #include "dcn_tuning.h"
 #include "f16_split.h"
@@ -573,6 +574,8 @@ struct HlShape {
     int rows, mtiles, ntiles, nk, sk_wgs, sk_units, sk_dp;
     bool sk;
     size_t ws_bytes, sk_count_off;
+    bool ok = true;   // false: no tile height divides the rows of a statistics group (the caller takes another kernel)
+    HlxShape x;       // rows == 160: the launch goes to the small-tile kernel (conv_hlx_kernels.hip) with this shape
 };
 HlShape hl_shape_rows(int M, int cd, int K, int rows) {
     HlShape g;
@@ -621,12 +624,16 @@ HlShape hl_shape_rows(int M, int cd, int K, int rows) {
 // shapes (profiles/r3q_hl_rows_per_layer.txt): 256 -> 256 3x3, 150 / 200 tiles: 160 -> 139 us; 512 -> 512 3x3, 300 / 400
 // tiles, both stream-K'd: 491 -> 450 us.  group_rows: rows per statistics group of the forward epilogue (0: none) -- a
 // group is made of whole tiles.
-// taps: filter taps of the convolution (the 320-row kernel keeps one validity bit per tap in a 32-bit word)
-HlShape hl_shape(int M, int cd, int K, int group_rows, int taps) {
-    const HlShape g4 = hl_shape_rows(M, cd, K, 256);
-    const int force = dcn::tuning().gemm_hl_rows;
+// taps: filter taps of the convolution (the 320-row kernel keeps one validity bit per tap in a 32-bit word); cs: source channels.
+// Round 5: the small tiles of conv_hlx_kernels.hip (160 x 256, 160 x 128 with two K groups, K split over workgroups) compete
+// in the same model -- cost x stages of a workgroup, so that a K split counts -- and win where the big tiles leave CUs idle.
+HlShape hl_shape(int M, int cd, int K, int group_rows, int taps, int cs) {
+    HlShape g4 = hl_shape_rows(M, cd, K, 256);
+    const dcn::Tuning& tune = dcn::tuning();
+    const int force = tune.gemm_hl_rows;
     const bool ok3 = group_rows <= 0 || (group_rows % 192) == 0, ok4 = group_rows <= 0 || (group_rows % 256) == 0;
-    const bool ok5 = (group_rows <= 0 || (group_rows % 320) == 0) && taps <= 32;
+    const bool ok5 = (group_rows <= 0 || (group_rows % 320) == 0) && taps <= 32 && force != -320;
+    g4.ok = ok4;
     // 320-row tiles (round 4) run data-parallel only: they are for the launches they fit in whole rounds (38 400 x 512 outputs
     // = 240 tiles = ONE round without any stream-K partial)
     auto shape5 = [&]() {
@@ -634,24 +641,39 @@ HlShape hl_shape(int M, int cd, int K, int group_rows, int taps) {
         g5.sk = false; g5.sk_wgs = 0; g5.sk_units = 0; g5.sk_dp = 0; g5.ws_bytes = 0; g5.sk_count_off = 0;
         return g5;
     };
-    if (force == 320 && ok5) return shape5();
-    if ((!ok3 && !ok5) || force == 256) return g4;
     auto cost = [](const HlShape& g) {
         const double rounds = g.mtiles * g.ntiles / 256.0;
         const double per_row = g.rows == 192 ? 1.08 : 1.0, fixup = g.rows == 192 ? 30.0 : 50.0;
         return (g.sk ? rounds + fixup / g.nk : (double)(int)(rounds + 0.999999)) * g.rows * per_row;
     };
-    if (force == 192 && ok3) return hl_shape_rows(M, cd, K, 192);
     HlShape best = g4;
     double best_cost = ok4 ? cost(g4) : 1e300;
+    if (force == 320 || force == 192 || force == 256) {   // a forced height: that one or nothing (never a tile that straddles groups)
+        if (force == 320) { best = shape5(); best.ok = ok5; }
+        else if (force == 192) { best = hl_shape_rows(M, cd, K, 192); best.ok = ok3; }
+        return best;
+    }
     if (ok3) {
         const HlShape g3 = hl_shape_rows(M, cd, K, 192);
         if (cost(g3) < 0.97 * best_cost) { best = g3; best_cost = cost(g3); }
     }
-    if (ok5 && dcn::tuning().gemm_hl_rows != -320) {   // (DCN_GEMM_HL_ROWS=-320: never 320 -- the round-3 choice, for A/B runs)
+    if (ok5) {   // (DCN_GEMM_HL_ROWS=-320: never 320 -- the round-3 choice, for A/B runs)
         const HlShape g5 = shape5();
         if (cost(g5) < 0.97 * best_cost) { best = g5; best_cost = cost(g5); }
     }
+    best.ok = best_cost < 1e299;
+    const HlxShape x = hlx_shape(M, cd, K, group_rows, taps, cs);
+    const bool x_forced = force == 160 || tune.gemm_hlx_kg > 0 || tune.gemm_hlx_splits > 0;
+    if (x.ok && (x_forced || !best.ok || x.cost < 0.97 * best_cost * best.nk)) {
+        HlShape gx = best;
+        gx.rows = kHlxRows; gx.mtiles = x.mtiles; gx.ntiles = x.ntiles; gx.nk = x.nk;
+        gx.sk = false; gx.sk_wgs = 0; gx.sk_units = 0; gx.sk_dp = 0;
+        gx.ws_bytes = x.ws_bytes; gx.sk_count_off = x.cnt_off;
+        gx.ok = true;
+        gx.x = x;
+        return gx;
+    }
+    if (force == 160) best.ok = false;
     return best;
 }
 
@@ -682,7 +704,16 @@ int launch_gemm_hl(GemmConv& p, int group_rows, void* workspace, hipStream_t st)
     p.div_w = make_fastdiv(p.wd);
     p.div_cs = make_fastdiv(p.cs);
     p.div_kw = make_fastdiv(p.kw);
-    const HlShape g = hl_shape(p.M, p.cd, p.K, group_rows, p.kh * p.kw);
+    const HlShape g = hl_shape(p.M, p.cd, p.K, group_rows, p.kh * p.kw, p.cs);
+    if (!g.ok) return DCN_E_UNSUPPORTED;
+    if (g.rows == kHlxRows) {
+        if (g.x.splits > 1 && !workspace) {   // no scratch (the tuning changed after the plan was sized): the same tiles, unsplit
+            HlxShape x1 = g.x;
+            x1.splits = 1; x1.ws_bytes = 0; x1.cnt_off = 0;
+            return launch_gemm_hlx(p, x1, nullptr, st);
+        }
+        return launch_gemm_hlx(p, g.x, workspace, st);
+    }
     const bool sk = g.sk && workspace != nullptr;
     p.mtiles = g.mtiles;
     p.ntiles = g.ntiles;
@@ -707,8 +738,13 @@ int launch_gemm_hl(GemmConv& p, int group_rows, void* workspace, hipStream_t st)
 
 }  // namespace
 
+static HlShape hl_shape_of(const dcn_conv_desc* c, int dgrad) {
+    if (dgrad) return hl_shape(c->n * c->hin * c->win, c->cin, c->kh * c->kw * c->ldc, 0, c->kh * c->kw, c->ldc);
+    return hl_shape(c->n * c->hout * c->wout, c->cout, c->kh * c->kw * c->cin, c->group_rows, c->kh * c->kw, c->cin);
+}
+
 // What the kernel can compute at all: whole 32-channel source chunks, stride 1, tensors addressable through 2 GiB buffer
-// resources, statistics groups made of whole 256- or 192-row tiles.
+// resources, statistics groups made of whole tiles of the height the tuning of the moment selects.
 static bool hl_supported(const dcn_conv_desc* c, int dgrad) {
     if (!valid_desc_hl(c)) return false;
     if (c->stride != 1 || (c->ldc % 4) != 0) return false;
@@ -717,10 +753,10 @@ static bool hl_supported(const dcn_conv_desc* c, int dgrad) {
     const int64_t K = (int64_t)c->kh * c->kw * cs;
     if ((cs % HLK) != 0 || (dgrad && c->ldc != c->cout) || (cd % 4) != 0 || M >= ((int64_t)1 << 30)) return false;
     if (dgrad && (c->hin != c->hout || c->win != c->wout)) return false;       // (stride-1 "same" convolutions)
-    if (!dgrad && c->group_rows > 0 && (c->group_rows % 256) != 0 && (c->group_rows % 192) != 0 && (c->group_rows % 320) != 0) return false;
     const int64_t src_bytes = (int64_t)c->n * (dgrad ? c->hout * c->wout : c->hin * c->win) * cs * 4;
     const int64_t w_bytes = (int64_t)cd * K * 4;
-    return src_bytes <= ((int64_t)1 << 31) - 1 && w_bytes <= ((int64_t)1 << 31) - 1;
+    if (!(src_bytes <= ((int64_t)1 << 31) - 1 && w_bytes <= ((int64_t)1 << 31) - 1)) return false;
+    return hl_shape_of(c, dgrad).ok;   // (false: every tile height the tuning allows would straddle two statistics groups)
 }
 
 // Which convolutions the engine sends down the hl32 path: supported, and wide / deep / tall enough for the 256 x 256 tile
@@ -731,13 +767,17 @@ extern "C" int dcn_conv_hl_eligible(const dcn_conv_desc* c, int dgrad) {
     const int cs = dgrad ? c->ldc : c->cin, cd = dgrad ? c->cin : c->cout;
     const int64_t M = (int64_t)c->n * (dgrad ? c->hin * c->win : c->hout * c->wout);
     const int64_t K = (int64_t)c->kh * c->kw * cs;
-    if (!(cd >= 256 && K >= 512 && M >= 4096)) return 0;
+    if (!(cd >= 128 && K >= 512 && M >= 4096)) return 0;
+    const HlShape chosen = hl_shape_of(c, dgrad);
+    // the small tiles (round 5): chosen by the cost model where the big ones leave CUs idle -- sub-round launches (B = 1, the
+    // two-call pattern), layer 3 at 8 images; 128-channel destinations only when asked for (DCN_GEMM_HLX_NARROW)
+    if (chosen.rows == kHlxRows) return (cd >= 256 || dcn::tuning().gemm_hlx_narrow != 0) ? 1 : 0;
+    if (cd < 256) return 0;
     // between one and one and a half rounds of tiles the second round leaves most of the chip idle, and splitting its tiles
     // costs about what it saves unless the K loop is long: the fp32-operand kernel's 256 x 128 tiles quantise better there
     // (measured: ResNet50-8s layer-3 3x3 at 1280 x 960 -5 %, its 1x1 1024 -> 256 -20 %; layer4.0.conv1 of ResNet34-8s at
     // N = 8 -3 %; the 512 -> 512 layer-4 convolutions, K = 4608, +7 %)
     // (a launch that 320-row tiles cover in at most one round is none of these cases)
-    const HlShape chosen = hl_shape((int)M, cd, (int)K, dgrad ? 0 : c->group_rows, c->kh * c->kw);
     if (chosen.rows == 320 && chosen.mtiles * chosen.ntiles <= 256 && chosen.mtiles * chosen.ntiles >= 120) return 1;
     const double rounds = (double)dcn::ceil_div64(M, 256) * dcn::ceil_div(cd, 256) / 256.0;
     if (rounds > 1.0 && rounds < 1.5 && K < 4096) return 0;
@@ -749,20 +789,28 @@ extern "C" int dcn_conv_hl_eligible(const dcn_conv_desc* c, int dgrad) {
 
 extern "C" int dcn_conv_num_mtiles_hl(const dcn_conv_desc* c) {
     if (!valid_desc_hl(c)) return DCN_E_INVALID;
-    return hl_shape(c->n * c->hout * c->wout, c->cout, c->kh * c->kw * c->cin, c->group_rows, c->kh * c->kw).mtiles;
+    return hl_shape_of(c, 0).mtiles;
 }
 
-// Rows per tile the launch of this convolution will use (256 or 192): the granularity of its batch-norm partial statistics.
+// Rows per tile the launch of this convolution will use (256, 192, 320 or 160): the granularity of its batch-norm partial statistics.
 extern "C" int dcn_conv_tile_rows_hl(const dcn_conv_desc* c, int dgrad) {
     if (!valid_desc_hl(c)) return DCN_E_INVALID;
-    if (dgrad) return hl_shape(c->n * c->hin * c->win, c->cin, c->kh * c->kw * c->ldc, 0, c->kh * c->kw).rows;
-    return hl_shape(c->n * c->hout * c->wout, c->cout, c->kh * c->kw * c->cin, c->group_rows, c->kh * c->kw).rows;
+    return hl_shape_of(c, dgrad).rows;
 }
 
 extern "C" size_t dcn_conv_gemm_workspace_hl(const dcn_conv_desc* c, int dgrad) {
     if (!valid_desc_hl(c)) return 0;
-    if (dgrad) return hl_shape(c->n * c->hin * c->win, c->cin, c->kh * c->kw * c->ldc, 0, c->kh * c->kw).ws_bytes;
-    return hl_shape(c->n * c->hout * c->wout, c->cout, c->kh * c->kw * c->cin, c->group_rows, c->kh * c->kw).ws_bytes;
+    return hl_shape_of(c, dgrad).ws_bytes;
+}
+
+extern "C" int dcn_conv_hl_shape_info(const dcn_conv_desc* c, int dgrad, int* info6) {
+    if (!valid_desc_hl(c) || !info6) return DCN_E_INVALID;
+    if (!hl_supported(c, dgrad)) return DCN_E_UNSUPPORTED;
+    const HlShape g = hl_shape_of(c, dgrad);
+    const bool x = g.rows == kHlxRows;
+    info6[0] = g.rows; info6[1] = x ? g.x.bn : 256; info6[2] = x ? g.x.kg : 1; info6[3] = x ? g.x.splits : 1;
+    info6[4] = g.mtiles; info6[5] = g.ntiles;
+    return DCN_OK;
 }
 
 extern "C" int dcn_split_act_hl32(const float* src, const float* absmax, void* dst, int64_t rows, int channels, void* stream) {

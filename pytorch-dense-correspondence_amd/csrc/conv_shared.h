@@ -63,6 +63,9 @@ struct GemmConv {
     unsigned src_bytes, w_bytes;   // extents of src and of each weight image (buffer-resource bounds; 0: tensor too large)
     int hs, ws, cs, hd, wd, cd, kh, kw, stride, sshift, pad, dil, ldc, M, K, transposed, mtiles, ntiles, sk_units, sk_dp, relu;
     FastDiv div_hw, div_w, div_cs, div_kw, div_nt, div_nk;
+    // small-tile hl32 kernel (conv_hlx_kernels.hip): workgroups per tile along K (contiguous stage ranges), tiles per launch
+    int ksplit = 0;
+    FastDiv div_tiles = {0u, 0u, 1};
 };
 
 // bijective XCD-aware remap: consecutive logical tiles (sharing an M tile) land on the same XCD / L2

@@ -24,6 +24,12 @@
 //                           takes it, whatever its size (tests)
 //   DCN_GEMM_HL_ROWS        192 / 256 / 320: tile height of the hl32 gather-GEMM (default 0: whichever quantises better on the
 //                           256 CUs, hl_shape in conv_hl_kernels.hip); -320: as decided, but never 320 (the round-3 choice)
+//   DCN_GEMM_HLX            0: never the small-tile variants of the hl32 gather-GEMM (conv_hlx_kernels.hip: 160 x 256 / 160 x 128
+//                           tiles, K split over workgroups); "kg" or "kg,splits": force the K groups per workgroup (1 | 2) and
+//                           the workgroups per tile along K wherever the kernel applies (0 = as decided)
+//   DCN_GEMM_HLX_NARROW     1: destinations of 128 channels take the 160 x 128 tile too (default: >= 256 channels only)
+//   DCN_HLX_COST            "e1,e2,split": cost-model constants of hlx_shape (per-stage cost factor of the 160 x 256 and of the
+//                           160 x 128 tile relative to a 256-row tile of conv_hl_kernels.hip; stages one parked partial costs)
 //   DCN_WGRAD_HL            0: the wide layers' weight gradients stay on the fp32-operand kernel (conv_f16_kernels.hip) instead of
 //                           the pre-split (hl32) LDS-DMA kernel (wgrad_hl_kernels.hip); 2: every supported convolution (tests)
 //   DCN_HL_PRODUCERS        0: hl32 activation / gradient images are made by stand-alone split passes instead of by the
@@ -63,6 +69,11 @@ struct Tuning {
     int wgrad_deep = 4;
     int gemm_hl = 1;             // wide layers on the pre-split (hl32) LDS-DMA gather-GEMM
     int gemm_hl_rows = 0;        // hl32 gather-GEMM tile height: 0 = by tile quantisation, 192 / 256 = forced
+    int gemm_hlx = 1;            // small-tile variants of the hl32 gather-GEMM where hl_shape's cost model picks them
+    int gemm_hlx_kg = 0;         // forced K groups per workgroup (0: as decided)
+    int gemm_hlx_splits = 0;     // forced workgroups per tile along K (0: as decided)
+    int gemm_hlx_narrow = 0;     // 128-channel destinations on the 160 x 128 tile
+    double hlx_cost1 = 1.10, hlx_cost2 = 1.22, hlx_split_cost = 10.0;
     int wgrad_hl = 1;            // wide layers' weight gradients on the pre-split (hl32) LDS-DMA kernel
     int hl_producers = 1;        // hl32 images written by the producing batch-norm passes (0: stand-alone split passes)
     int hl_only_mid = 1;         // mid-block activations whose two readers (next conv, its wgrad) take the hl32 image: no fp32 copy (0: keep it)

@@ -1,5 +1,6 @@
 // Environment overrides, read once (dcn_tuning.h).
 #include <atomic>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <mutex>
@@ -36,6 +37,17 @@ void read_env(Tuning& t) {
     if (const char* e = getenv("DCN_WGRAD_SPLITS")) t.wgrad_splits = atoi(e);
     if (const char* e = getenv("DCN_GEMM_HL")) t.gemm_hl = atoi(e);
     if (const char* e = getenv("DCN_GEMM_HL_ROWS")) t.gemm_hl_rows = atoi(e);
+    if (const char* e = getenv("DCN_GEMM_HLX")) {
+        int a = 0, b = 0;
+        const int n = sscanf(e, "%d,%d", &a, &b);
+        if (n >= 1 && a == 0) t.gemm_hlx = 0;
+        else if (n >= 1) { t.gemm_hlx = 1; t.gemm_hlx_kg = (a == 1 || a == 2) ? a : 0; t.gemm_hlx_splits = (n >= 2 && b > 0) ? b : 0; }
+    }
+    if (const char* e = getenv("DCN_GEMM_HLX_NARROW")) t.gemm_hlx_narrow = atoi(e) != 0;
+    if (const char* e = getenv("DCN_HLX_COST")) {
+        double a = 0, b = 0, c = 0;
+        if (sscanf(e, "%lf,%lf,%lf", &a, &b, &c) == 3 && a > 0 && b > 0 && c >= 0) { t.hlx_cost1 = a; t.hlx_cost2 = b; t.hlx_split_cost = c; }
+    }
     if (const char* e = getenv("DCN_HL_ONLY_MID")) t.hl_only_mid = atoi(e);
     if (const char* e = getenv("DCN_STEM_POOL_FUSED")) t.stem_pool_fused = atoi(e);
     if (const char* e = getenv("DCN_WGRAD_HL")) t.wgrad_hl = atoi(e);

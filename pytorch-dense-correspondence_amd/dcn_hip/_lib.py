@@ -157,6 +157,7 @@ SYMBOLS = {
     "dcn_conv_num_mtiles_hl": (c_int, [ctypes.POINTER(ConvDesc)]),
     "dcn_conv_tile_rows_hl": (c_int, [ctypes.POINTER(ConvDesc), c_int]),
     "dcn_conv_gemm_workspace_hl": (c_size_t, [ctypes.POINTER(ConvDesc), c_int]),
+    "dcn_conv_hl_shape_info": (c_int, [ctypes.POINTER(ConvDesc), c_int, ctypes.POINTER(c_int)]),
     "dcn_split_act_hl32": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_void_p]),
     "dcn_split_weights_hl32": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_float,
                                        c_void_p]),

@@ -346,6 +346,30 @@ static inline hipemu_f32x16 hipemu_mfma_32x32x16f16(hipemu_h8 a, hipemu_h8 b, hi
     wave_barrier();
     return c;
 }
+// v_mfma_f32_16x16x32_f16: lane (i = l & 15, q = l >> 4) holds A[i][8q..8q+7] and B[8q..8q+7][i]; C/D: col = l & 15,
+// row = 4 (l >> 4) + reg; fp32 accumulate.
+static inline hipemu_f32x4 hipemu_mfma_16x16x32f16(hipemu_h8 a, hipemu_h8 b, hipemu_f32x4 c, int, int, int) {
+    using namespace ::hipemu;
+    WaveState& ws = my_wave();
+    int l = lane_id();
+    memcpy(ws.wide_a[l], &a, 16);
+    memcpy(ws.wide_b[l], &b, 16);
+    wave_barrier();
+    int col = l & 15;
+    for (int r = 0; r < 4; ++r) {
+        int row = 4 * (l >> 4) + r;
+        float acc = c[r];
+        for (int q = 0; q < 4; ++q) {
+            _Float16 av[8], bv[8];
+            memcpy(av, ws.wide_a[row + 16 * q], 16);
+            memcpy(bv, ws.wide_b[col + 16 * q], 16);
+            for (int k = 0; k < 8; ++k) acc += (float)av[k] * (float)bv[k];
+        }
+        c[r] = acc;
+    }
+    wave_barrier();
+    return c;
+}
 // raw buffer resources (stride 0): loads whose byte offset (voffset; the scalar offset is NOT range-checked, as on the
 // hardware) reaches past num_records return zeros
 struct hipemu_buffer_rsrc { const char* base; unsigned num_records; };
@@ -379,6 +403,7 @@ static inline void hipemu_raw_buffer_store_b128(hipemu_u32x4 v, hipemu_buffer_rs
 #define __builtin_amdgcn_raw_buffer_load_b128 hipemu_raw_buffer_load_b128
 #define __builtin_amdgcn_raw_buffer_load_b64 hipemu_raw_buffer_load_b64
 #define __builtin_amdgcn_mfma_f32_32x32x16_f16 hipemu_mfma_32x32x16f16
+#define __builtin_amdgcn_mfma_f32_16x16x32_f16 hipemu_mfma_16x16x32f16
 #define __builtin_amdgcn_mfma_f32_32x32x2f32 hipemu_mfma_32x32x2f32
 #define __builtin_amdgcn_mfma_f32_16x16x4f32 hipemu_mfma_16x16x4f32
 // ---- LDS-DMA + counted waits + raw barrier (conv_hl_kernels.hip)

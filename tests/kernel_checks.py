@@ -213,7 +213,7 @@ def hl32_decode(img, rows, C):
     return h[:, :, 0, :].reshape(rows, C), h[:, :, 1, :].reshape(rows, C)
 
 
-def check_conv_hl(L, dev, n, h, w, cin, cout, k, dil, set_env=None, sk=None, scale_x=1.0, seed=0, rows=None):
+def check_conv_hl(L, dev, n, h, w, cin, cout, k, dil, set_env=None, sk=None, scale_x=1.0, seed=0, rows=None, hlx=None):
     """The pre-split (hl32) LDS-DMA gather-GEMM, forward and dgrad, against F.conv2d / its autograd in float64 and against
     the fp32-operand split-fp16 kernel; the operand split, the weight images and the batch-norm partial sums on the way."""
     lib = L.get()
@@ -230,6 +230,8 @@ def check_conv_hl(L, dev, n, h, w, cin, cout, k, dil, set_env=None, sk=None, sca
         env["DCN_GEMM_SK"] = sk
     if rows is not None:
         env["DCN_GEMM_HL_ROWS"] = rows      # tile height 256 / 192 / 320 (conv_hl_kernels.hip: three software pipelines)
+    if hlx is not None:
+        env["DCN_GEMM_HLX"] = hlx           # "kg,splits" of the small-tile kernel (conv_hlx_kernels.hip), 160-row tiles
     if env:
         set_env(**env)
     d = L.ConvDesc(n, h, w, cin, h, w, cout, k, k, 1, pad, dil, cout, 0)
@@ -262,11 +264,12 @@ def check_conv_hl(L, dev, n, h, w, cin, cout, k, dil, set_env=None, sk=None, sca
     # ---- forward
     mt = lib.dcn_conv_num_mtiles_hl(ctypes.byref(d))
     tr = lib.dcn_conv_tile_rows_hl(ctypes.byref(d), 0)
-    assert tr in (192, 256, 320) and (rows is None or tr == int(rows)) and mt == (M + tr - 1) // tr
-    assert lib.dcn_conv_tile_rows_hl(ctypes.byref(d), 1) in ((192, 256, 320) if rows is None else (int(rows),))
+    assert tr in (160, 192, 256, 320) and (rows is None or tr == int(rows)) and mt == (M + tr - 1) // tr
+    assert hlx is None or tr == 160
+    assert lib.dcn_conv_tile_rows_hl(ctypes.byref(d), 1) in ((160, 192, 256, 320) if rows is None else (int(rows),))
     nws = max(lib.dcn_conv_gemm_workspace_hl(ctypes.byref(d), 0), lib.dcn_conv_gemm_workspace_hl(ctypes.byref(d), 1))
-    if sk is not None and str(sk) != "0":
-        assert nws > 8, "stream-K is not exercised by this shape"
+    if (sk is not None and str(sk) != "0") or (hlx is not None and "," in str(hlx) and int(str(hlx).split(",")[1]) > 1):
+        assert nws > 8, "stream-K / the K split is not exercised by this shape"
     ws = garbage(nws, dev, seed + 3)
     out = torch.full((n, h, w, cout), float("nan"), device=dev)
     part = torch.full((mt, 3, cout), float("nan"), device=dev)

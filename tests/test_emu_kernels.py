@@ -478,6 +478,30 @@ def test_conv_hl32_lds_dma_gather_gemm(L, case, dma, rows, dcn_env, monkeypatch)
                                 rows=rows)
 
 
+HLX_CASES = [
+    # n, h, w, cin, cout, k, dil, "kg,splits" forced, x scale
+    (1, 12, 20, 32, 40, 3, 2, "1,1", 1.0),     # 160 x 256 tile: two ragged M tiles (240 rows), ragged channels, one chunk per tap
+    (2, 16, 24, 64, 288, 3, 1, "1,1", 1.0),    # 5 x 2 tiles, second N tile ragged, chunk groups of 2
+    (2, 16, 24, 64, 288, 3, 1, "1,3", 1e4),    # ... K split over 3 workgroups per tile: partials completed in-launch, fixed order
+    (2, 16, 24, 64, 288, 3, 1, "2,1", 1.0),    # 160 x 128 tile, two K groups added through LDS; 3 N tiles (third ragged)
+    (1, 20, 20, 128, 256, 1, 1, "2,2", 1.0),   # 1x1: ONE tap, chunk groups of 4 = two stages of the K-group kernel, split in two
+    (1, 9, 30, 64, 256, 3, 4, "2,3", 1e-6),    # dilation 4 with halos wider than the border, tiny operands, 3 splits of 3 stages
+    (1, 10, 30, 32, 64, 1, 1, "1,1", 1.0),     # K = 32: ONE stage
+    (1, 10, 30, 64, 64, 1, 1, "2,1", 1.0),     # K = 64: ONE stage of the K-group kernel
+]
+
+
+@pytest.mark.parametrize("dma", ["late", "early"])
+@pytest.mark.parametrize("case", HLX_CASES, ids=[str(c) for c in HLX_CASES])
+def test_conv_hlx_small_tiles(L, case, dma, dcn_env, monkeypatch):
+    """conv_hlx_kernels.hip on the host (160 x 256 and 160 x 128 tiles of 16 x 16 x 32 MFMAs, K groups inside the workgroup, K
+    split over workgroups): same checks as the big tiles, LDS-DMA landing as late and as early as the hardware allows."""
+    import kernel_checks
+    monkeypatch.setenv("HIPEMU_LDS_DMA", dma)
+    n, h, w, cin, cout, k, dil, hlx, sx = case
+    kernel_checks.check_conv_hl(L, "cpu", n, h, w, cin, cout, k, dil, set_env=dcn_env, scale_x=sx, seed=len(str(case)), hlx=hlx)
+
+
 WGRAD_HL_CASES = [
     # n, h, w, cin, cout, k, dil, forced splits
     (1, 3, 40, 32, 64, 3, 1, None),      # one ragged tile (64 of 256 output channels, K = 288 of 2 x 256), 120 pixels = 4 stages

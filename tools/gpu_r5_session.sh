@@ -1,0 +1,24 @@
+#!/bin/bash
+# Round-5 GPU-box sessions (run through gpurun from the repo root): bash tools/gpu_r5_session.sh <tag> [steps...]
+# Steps of its own first; anything else is handed to tools/gpu_r4_session.sh (bench, prof, pmc, tests, smoke, ab, convn2, convn8 ...).
+tag=${1:-r5}; shift
+steps=${*:-tests5 sweep}
+mkdir -p gpurun_out
+export TMPDIR=/tmp
+for s in $steps; do
+  echo "=== $s $(date +%T)"
+  case $s in
+    tests5)    timeout 900 python -m pytest tests/test_gpu_round5.py -m gpu -q -x -p no:cacheprovider --durations=5 > gpurun_out/${tag}_pytest_r5.log 2>&1; tail -12 gpurun_out/${tag}_pytest_r5.log | cut -c1-300 ;;
+    sweep)     timeout 600 python tools/hlx_sweep.py --n ${SWEEP_N:-1,2,4,8} ${SWEEP_ARGS:-} 2>&1 | grep -v "Warn\|amdgpu.ids" | cut -c1-250 | tee gpurun_out/${tag}_hlx_sweep.txt ;;
+    sweepnarrow) timeout 300 python tools/hlx_sweep.py --n 2,4,8 --narrow --only layer2 --variants default,old,2:1,2:2,2:3 2>&1 | grep -v "Warn\|amdgpu.ids" | cut -c1-250 | tee gpurun_out/${tag}_hlx_sweep_narrow.txt ;;
+    crashn2)   # which launch of the forced-hl N = 2 table faults (profiles/r4a_conv_per_layer_n2.txt ended in a memory access fault)
+               for kind in fwd dgrad wgrad; do echo "--- layer4.0 $kind, DCN_GEMM_HL=2 DCN_WGRAD_HL=2 DCN_GEMM_HLX=0, N = 2" | tee -a gpurun_out/${tag}_crashn2.txt
+                 timeout 120 env DCN_GEMM_HL=2 DCN_WGRAD_HL=2 DCN_GEMM_HLX=0 python tools/conv_bench.py --mode hl --n 2 --only "layer4.0" --kinds $kind --reps 5 2>&1 | grep -v "Warn\|amdgpu.ids" | cut -c1-200 | tail -4 | tee -a gpurun_out/${tag}_crashn2.txt; done ;;
+    wgradn2)   # weight gradients at two images: fp32-operand kernel vs the hl32 kernel without its M >= 16384 gate
+               for hl in 1 2; do echo "--- DCN_WGRAD_HL=$hl, N = ${WG_N:-2}" | tee -a gpurun_out/${tag}_wgrad_n2.txt
+                 timeout 200 env DCN_WGRAD_HL=$hl python tools/conv_bench.py --mode hl --n ${WG_N:-2} --only "layer" --kinds wgrad --x-direct --reps 20 2>&1 | grep -v "Warn\|amdgpu.ids" | grep "layer3\|layer4" | cut -c1-200 | tee -a gpurun_out/${tag}_wgrad_n2.txt; done ;;
+    *)         bash tools/gpu_r4_session.sh $tag $s ;;
+  esac
+done
+find gpurun_out -name "*.db" -size +20M -delete 2>/dev/null
+echo "=== r5 done $(date +%T)"
