@@ -771,7 +771,9 @@ extern "C" int dcn_conv_hl_eligible(const dcn_conv_desc* c, int dgrad) {
     const HlShape chosen = hl_shape_of(c, dgrad);
     // the small tiles (round 5): chosen by the cost model where the big ones leave CUs idle -- sub-round launches (B = 1, the
     // two-call pattern), layer 3 at 8 images; 128-channel destinations only when asked for (DCN_GEMM_HLX_NARROW)
-    if (chosen.rows == kHlxRows) return (cd >= 256 || dcn::tuning().gemm_hlx_narrow != 0) ? 1 : 0;
+    // (128-channel destinations fed by >= 256 source channels -- the dgrad of layer3.0.conv1: 35-66 us against 53-97 on the
+    // fp32-operand kernel at 1-8 images, profiles/r5a_hlx_sweep.txt -- take it too: the gradient image exists anyway)
+    if (chosen.rows == kHlxRows) return (cd >= 256 || cs >= 256 || dcn::tuning().gemm_hlx_narrow != 0) ? 1 : 0;
     if (cd < 256) return 0;
     // between one and one and a half rounds of tiles the second round leaves most of the chip idle, and splitting its tiles
     // costs about what it saves unless the K loop is long: the fp32-operand kernel's 256 x 128 tiles quantise better there

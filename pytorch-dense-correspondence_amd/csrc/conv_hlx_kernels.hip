@@ -26,6 +26,9 @@
 // ds_read_b128 lane groups of gfx950 as well (rows 0-3 / 12-15 of one octet with rows 4-11 of the next: 16 distinct
 // (row parity, slot) pairs).
 #include <algorithm>
+#include <mutex>
+#include <type_traits>
+#include <unordered_map>
 
 #include "conv_hlx.h"
 #include "dcn_tuning.h"
@@ -248,27 +251,40 @@ conv_gemm_hlx_kernel(GemmConv p) {
 #pragma unroll
         for (int j = 0; j < XTN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
     auto bar = [&]() { __builtin_amdgcn_sched_barrier(0); __builtin_amdgcn_s_barrier(); __builtin_amdgcn_sched_barrier(0); };
-    auto compute = [&](int buf) {
-        const unsigned char* cbase = lds + buf * kStage + kg * kChunk;
-        h8 fa[XTM][2], fb[XTN][2];
+    // compute slot of a stage in two parts (rows 0-47 of the wavefront's block with the B fragments, rows 48-79), so that the
+    // LDS-DMA issue of the next stage can sit in front of the first part (wavefronts 0-3) or between the parts (wavefronts
+    // 4-7): wavefronts w and w + 4 share a SIMD, and with every wavefront released by the same barrier an unstaggered loop
+    // has BOTH of them issuing their 7-9 DMA pieces (~100 issue cycles each) while the matrix pipe idles.
+    h8 fa[XTM][2], fb[XTN][2];
+    auto load_b = [&](const unsigned char* cbase) {
 #pragma unroll
         for (int tn = 0; tn < XTN; ++tn)
 #pragma unroll
             for (int pl = 0; pl < 2; ++pl) fb[tn][pl] = *reinterpret_cast<const h8*>(cbase + b_row + tn * 2048 + foff[pl]);
+    };
+    auto load_a = [&](const unsigned char* cbase, auto t0, auto t1) {
 #pragma unroll
-        for (int tm = 0; tm < XTM; ++tm)
+        for (int tm = decltype(t0)::value; tm < decltype(t1)::value; ++tm)
 #pragma unroll
             for (int pl = 0; pl < 2; ++pl) fa[tm][pl] = *reinterpret_cast<const h8*>(cbase + a_row + tm * 2048 + foff[pl]);
-        // product type outermost (the small cross terms before hi x hi), 20 independent accumulators in between
+    };
+    // product type outermost (the small cross terms before hi x hi), the part's independent accumulators in between
+    auto mm = [&](auto t0, auto t1) {
+        __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int pt = 0; pt < 3; ++pt)
 #pragma unroll
-            for (int tm = 0; tm < XTM; ++tm)
+            for (int tm = decltype(t0)::value; tm < decltype(t1)::value; ++tm)
 #pragma unroll
                 for (int tn = 0; tn < XTN; ++tn)
                     acc[tm][tn] = __builtin_amdgcn_mfma_f32_16x16x32_f16(pt == 0 ? fa[tm][1] : fa[tm][0],
                                                                          pt == 1 ? fb[tn][1] : fb[tn][0], acc[tm][tn], 0, 0, 0);
+        __builtin_amdgcn_s_setprio(0);
     };
+    using I0 = std::integral_constant<int, 0>;
+    using I3 = std::integral_constant<int, 3>;
+    using I5 = std::integral_constant<int, XTM>;
+    const bool late_issue = p.hlx_stagger != 0 && wv >= 4;
 
     if (ss0 < ss1) {   // (wave-uniform; a split without stages contributes zeros)
         issue(0);
@@ -277,12 +293,24 @@ conv_gemm_hlx_kernel(GemmConv p) {
         for (int ss = ss0; ss < ss1; ++ss) {
             DCN_WAIT_VMCNT(0);
             bar();
-            if (ss + 1 < ss1) {
+            const bool more = ss + 1 < ss1;
+            const unsigned char* cbase = lds + buf * kStage + kg * kChunk;
+            if (more && !late_issue) {
                 issue(buf ^ 1);
                 advance();
             }
             __builtin_amdgcn_sched_barrier(0);
-            compute(buf);
+            load_b(cbase);
+            load_a(cbase, I0{}, I3{});
+            mm(I0{}, I3{});
+            __builtin_amdgcn_sched_barrier(0);
+            if (more && late_issue) {
+                issue(buf ^ 1);
+                advance();
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            load_a(cbase, I3{}, I5{});
+            mm(I3{}, I5{});
             buf ^= 1;
         }
     }
@@ -359,19 +387,33 @@ conv_gemm_hlx_kernel(GemmConv p) {
         const int last = *s_last;
         __syncthreads();                               // (s_last has been read by everyone: the epilogue reuses the array)
         if (!last) return;
+        // sum over the splits in the order 0 .. S - 1, this workgroup's own share from its registers (the same bits it parked)
+        f32x4 own[XTM][TNE];
 #pragma unroll
         for (int tm = 0; tm < XTM; ++tm)
 #pragma unroll
-            for (int tn = 0; tn < TNE; ++tn) out[tm][tn] = f32x4{0.f, 0.f, 0.f, 0.f};
+            for (int tn = 0; tn < TNE; ++tn) { own[tm][tn] = out[tm][tn]; out[tm][tn] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+        constexpr int kBatch = 10;   // 16-byte loads issued back to back (device-coherent round trips)
+        static_assert((XTM * TNE) % kBatch == 0, "whole batches");
         for (int g = 0; g < S; ++g) {
+            if (g == split) {
+#pragma unroll
+                for (int tm = 0; tm < XTM; ++tm)
+#pragma unroll
+                    for (int tn = 0; tn < TNE; ++tn) out[tm][tn] += own[tm][tn];
+                continue;
+            }
             const int so = (tile * S + g) * kSlotBytes;
-            u32x4 t[XTM * TNE];
 #pragma unroll
-            for (int j = 0; j < XTM * TNE; ++j) t[j] = __builtin_amdgcn_raw_buffer_load_b128(rs_p, lane_off + j * 1024, so, kSc1);
-            __builtin_amdgcn_sched_barrier(0);
+            for (int b0 = 0; b0 < XTM * TNE; b0 += kBatch) {
+                u32x4 t[kBatch];
 #pragma unroll
-            for (int j = 0; j < XTM * TNE; ++j) out[j / TNE][j % TNE] += __builtin_bit_cast(f32x4, t[j]);
-            __builtin_amdgcn_sched_barrier(0);
+                for (int j = 0; j < kBatch; ++j) t[j] = __builtin_amdgcn_raw_buffer_load_b128(rs_p, lane_off + (b0 + j) * 1024, so, kSc1);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int j = 0; j < kBatch; ++j) out[(b0 + j) / TNE][(b0 + j) % TNE] += __builtin_bit_cast(f32x4, t[j]);
+                __builtin_amdgcn_sched_barrier(0);
+            }
         }
         if (tid == 0) atomicExch(p.sk_count + tile, 0ull);
     }
@@ -412,7 +454,8 @@ HlxShape hlx_shape(int M, int cd, int K, int group_rows, int taps, int cs) {
             const double eff = kg == 1 ? tune.hlx_cost1 : tune.hlx_cost2;
             const double per_stage = XR * (bn / 256.0) * eff;
             const double stages = (double)nk / s;   // (chunks per workgroup; a KG = 2 stage is two of them on half the columns)
-            const double fix = s > 1 ? tune.hlx_split_cost * XR * (bn / 256.0) * (1.0 + 0.5 * s) : 0.0;
+            // (calibrated on profiles/r5a_hlx_sweep.txt: 12-21 us per split launch, growing slowly with the tile width and s)
+            const double fix = s > 1 ? tune.hlx_split_cost * XR * (0.5 + 0.5 * bn / 256.0) * (1.0 + 0.1 * s) : 0.0;
             const double cost = rounds * (stages * per_stage + fix);
             if (cost < best_cost) {
                 best_cost = cost;
@@ -425,6 +468,33 @@ HlxShape hlx_shape(int M, int cd, int K, int group_rows, int taps, int cs) {
         }
     }
     return best;
+}
+
+// Arrival words of the K splits.  They must be clean (no word that carries the id of the launch about to start) -- the
+// stream-K scratch of the caller is shared with other launches' partial tiles and would have to be cleared by a fill launch
+// in front of every split launch (~4 us of dependent-launch latency on a 40-us kernel).  Instead: one small buffer per
+// (device, stream), owned by the library, zeroed once; launches of a stream are ordered, the last arriver of a tile leaves
+// its word zero, and the id tag makes whatever an aborted launch left behind count as zero.  Not available while the stream
+// is being captured into a graph (no allocation then), for more tiles than the buffer holds, or with DCN_HLX_COUNTERS=0:
+// the launch then uses the words behind the partials in the caller's scratch, cleared by a fill launch.
+constexpr int kPoolWords = 8192;
+unsigned long long* pooled_counters(hipStream_t st, int tiles) {
+    if (tiles > kPoolWords || dcn::tuning().hlx_counters == 0) return nullptr;
+    static std::mutex mu;
+    static std::unordered_map<unsigned long long, unsigned long long*> pool;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+    const unsigned long long key = ((unsigned long long)(uintptr_t)st << 8) ^ (unsigned long long)(dev & 0xff);
+    std::lock_guard<std::mutex> lock(mu);
+    auto it = pool.find(key);
+    if (it != pool.end()) return it->second;
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(st, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) return nullptr;
+    void* ptr = nullptr;
+    if (hipMalloc(&ptr, kPoolWords * sizeof(unsigned long long)) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    if (hipMemset(ptr, 0, kPoolWords * sizeof(unsigned long long)) != hipSuccess) { (void)hipFree(ptr); (void)hipGetLastError(); return nullptr; }
+    pool[key] = (unsigned long long*)ptr;
+    return (unsigned long long*)ptr;
 }
 
 int launch_gemm_hlx(GemmConv& p, const HlxShape& g, void* workspace, hipStream_t st) {
@@ -440,16 +510,19 @@ int launch_gemm_hlx(GemmConv& p, const HlxShape& g, void* workspace, hipStream_t
     p.div_nk = make_fastdiv(g.nk);
     p.div_tiles = make_fastdiv(g.mtiles * g.ntiles);
     p.ksplit = g.splits;
+    p.hlx_stagger = dcn::tuning().hlx_stagger;
     p.sk_units = 0; p.sk_dp = 0;
     p.sk_partial = nullptr; p.sk_count = nullptr; p.sk_bytes = 0u;
     if (g.splits > 1) {
         p.sk_partial = (float*)workspace;
-        p.sk_count = (unsigned long long*)((char*)workspace + g.cnt_off);
         p.sk_bytes = (unsigned)g.cnt_off;
         p.sk_id = next_sk_launch_id();
-        // (arrival words cleared in front of every launch: they share the scratch with other launches' partials, launch_gemm_f16)
-        if (dcn::fill_bytes_async(p.sk_count, 0, (size_t)g.mtiles * g.ntiles * sizeof(unsigned long long), st) != DCN_OK)
-            return DCN_E_LAUNCH;
+        p.sk_count = pooled_counters(st, g.mtiles * g.ntiles);
+        if (!p.sk_count) {
+            p.sk_count = (unsigned long long*)((char*)workspace + g.cnt_off);
+            if (dcn::fill_bytes_async(p.sk_count, 0, (size_t)g.mtiles * g.ntiles * sizeof(unsigned long long), st) != DCN_OK)
+                return DCN_E_LAUNCH;
+        }
     }
     const dim3 grid(g.mtiles * g.ntiles * g.splits), block(512);
     if (g.kg == 1) {

@@ -316,9 +316,12 @@ int wgrad_hl_splits(const dcn_conv_desc* c, int* stages_per_split) {
 extern "C" int dcn_conv_wgrad_hl_eligible(const dcn_conv_desc* c) {
     if (!wgrad_hl_supported(c) || dcn::tuning().wgrad_hl == 0) return 0;
     if (dcn::tuning().wgrad_hl == 2) return 1;   // (tests: every supported convolution)
-    // (M >= 16384: at two images, M = 9600, the pixel splits are 30-40 stages long and the kernel loses 0.5 % on the step,
-    // profiles/r3l_config1_ab.txt)
-    return ((c->cout % 256) == 0 && c->kh * c->kw * c->cin >= 1024 && (int64_t)c->n * c->hout * c->wout >= 16384) ? 1 : 0;
+    // (round 3 asked for M >= 16384: at two images the step lost 0.5 % -- with the main stream's GEMMs on 38-76 tiles the
+    // fp32-operand kernel's launches ran for free on the idle CUs.  Round 5: the small-tile forward / dgrad kernel fills the
+    // chip at that size too, the weight gradients are then paid in full, and per launch this kernel is the faster one at two
+    // images already -- layer 4 137 vs 187 us, layer 3 52 vs 61 us, profiles/r5a_wgrad_n2.txt)
+    const int64_t min_m = dcn::tuning().wgrad_hl_min_m > 0 ? dcn::tuning().wgrad_hl_min_m : 8192;
+    return ((c->cout % 256) == 0 && c->kh * c->kw * c->cin >= 1024 && (int64_t)c->n * c->hout * c->wout >= min_m) ? 1 : 0;
 }
 
 extern "C" size_t dcn_conv_wgrad_workspace_hl(const dcn_conv_desc* c) {

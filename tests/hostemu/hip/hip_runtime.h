@@ -46,6 +46,9 @@ inline hipError_t hipMemsetAsync(void* p, int v, size_t n, hipStream_t) { memset
 enum hipMemcpyKind { hipMemcpyHostToHost, hipMemcpyHostToDevice, hipMemcpyDeviceToHost, hipMemcpyDeviceToDevice, hipMemcpyDefault };
 inline hipError_t hipMemcpyAsync(void* d, const void* s, size_t n, hipMemcpyKind, hipStream_t) { memmove(d, s, n); return hipSuccess; }
 inline hipError_t hipStreamSynchronize(hipStream_t) { return hipSuccess; }
+inline hipError_t hipMalloc(void** p, size_t n) { *p = malloc(n); return *p ? hipSuccess : hipErrorInvalidValue; }
+inline hipError_t hipFree(void* p) { free(p); return hipSuccess; }
+inline hipError_t hipMemset(void* p, int v, size_t n) { memset(p, v, n); return hipSuccess; }
 typedef struct hipemu_event { double t; }* hipEvent_t;
 inline hipError_t hipEventCreate(hipEvent_t* e) { *e = new hipemu_event{0.0}; return hipSuccess; }
 inline hipError_t hipEventDestroy(hipEvent_t e) { delete e; return hipSuccess; }
@@ -267,6 +270,20 @@ static inline unsigned long long atomicExch(unsigned long long* p, unsigned long
     return __atomic_exchange_n(p, v, __ATOMIC_SEQ_CST);
 }
 #define __builtin_amdgcn_fence(order, scope) __atomic_thread_fence(__ATOMIC_SEQ_CST)
+// agent-scope relaxed atomic loads / stores (the cooperative batch-norm launches: statistics exchanged between workgroups)
+#define __HIP_MEMORY_SCOPE_AGENT 4
+static inline unsigned long long hipemu_atomic_load(const unsigned long long* p) { return __atomic_load_n(p, __ATOMIC_SEQ_CST); }
+static inline float hipemu_atomic_load(const float* p) {
+    uint32_t u = __atomic_load_n(reinterpret_cast<const uint32_t*>(p), __ATOMIC_SEQ_CST);
+    float f; memcpy(&f, &u, 4); return f;
+}
+static inline void hipemu_atomic_store(float* p, float v) {
+    uint32_t u; memcpy(&u, &v, 4);
+    __atomic_store_n(reinterpret_cast<uint32_t*>(p), u, __ATOMIC_SEQ_CST);
+}
+#define __hip_atomic_load(p, order, scope) hipemu_atomic_load(p)
+#define __hip_atomic_store(p, v, order, scope) hipemu_atomic_store(p, v)
+#define __builtin_amdgcn_s_sleep(n) std::this_thread::yield()
 static inline unsigned __float_as_uint(float f) { unsigned u; memcpy(&u, &f, 4); return u; }
 static inline float __uint_as_float(unsigned u) { float f; memcpy(&f, &u, 4); return f; }
 #define unsafeAtomicAdd atomicAdd

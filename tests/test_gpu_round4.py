@@ -74,10 +74,12 @@ def test_profile_categories_on_hardware(L):
     plan.profile_begin()
     dcn.fcn(x).sum().backward()
     prof = plan.profile_end()
-    assert prof["conv_gemm"][1] == 37 + 36 and prof["conv_wgrad"][1] == 37 and prof["bn_finalize"][1] == 72
+    # (round 5: the finalize of a batch norm runs inside the apply pass that consumes it -- what is left as launches of its own:
+    #  the stem's and the three downsample branches' of the forward pass)
+    assert prof["conv_gemm"][1] == 37 + 36 and prof["conv_wgrad"][1] == 37 and prof["bn_finalize"][1] == 4
     for k, (ms, n, work) in prof.items():
         if k == "conv_gemm_hl":
-            continue   # (two images: the wide layers stay on the fp32-operand kernel, dcn_conv_hl_eligible)
+            continue   # (a sub-count of conv_gemm)
         assert n > 0 and ms > 0, k
     for k in ("bn_apply", "bn_bwd_reduce", "bn_bwd_apply"):
         ms, n, b = prof[k]
