@@ -343,9 +343,7 @@ int build_plan(dcn_plan& p) {
         }
     }
     p.n_act = n_act;
-    // abs-max of every convolution input (kept for wgrad) + status word; behind them (8-byte aligned, cleared by the same fill at
-    // the start of a forward call) the two words of the cooperative batch-norm launches (elementwise_kernels.hip coop_finalize)
-    p.s_actmax = B.alloc_saved((((size_t)n_act + 2) & ~(size_t)1) + 4);
+    p.s_actmax = B.alloc_saved((size_t)n_act + 1);        // abs-max of every convolution input (kept for wgrad) + status word
     p.saved_floats = B.saved;
     {   // gradient buckets, in the order backward completes them: fc + layer4 | layer3 | layer2 + layer1 + stem
         int first_block[4], b0 = 0;
@@ -433,8 +431,7 @@ int build_plan(dcn_plan& p) {
         p.w_hl = alloc(max_img);    // image of a block's input / output (forward), of a batch-norm backward's dx (backward)
         p.w_hl2 = alloc(max_img);   // image of a block's mid activation
     }
-    // abs-max of the gradient w.r.t. each convolution's output; behind them the backward pass's two cooperative-launch words
-    p.w_amax = alloc(((p.convs.size() + 1) & ~(size_t)1) + 4);
+    p.w_amax = alloc(p.convs.size());   // abs-max of the gradient w.r.t. each convolution's output
     {   // pixel-blocked split (fp16 hi | lo) copy of one gradient tensor: wgrad's dy operand, written by the BN backward pass
         size_t max_dq = 0;
         for (const ConvL& c : p.convs)
@@ -589,9 +586,6 @@ struct Run {
     float* S(size_t off) const { return saved + off; }
     // abs-max scalar of activation slot `a` (split-fp16 mode only: null otherwise, i.e. "no pre-scale")
     float* A(int a) const { return (p.conv_mode == DCN_CONV_F16X3 && a >= 0) ? saved + p.s_actmax + a : nullptr; }
-    // the words of the cooperative batch-norm launches of a forward / backward call (see dcn_plan_create_grouped)
-    unsigned long long* fwd_sync() const { return (unsigned long long*)(saved + p.s_actmax + (((size_t)p.n_act + 2) & ~(size_t)1)); }
-    unsigned long long* bwd_sync() const { return (unsigned long long*)(ws + p.w_amax + ((p.convs.size() + 1) & ~(size_t)1)); }
     // ReLU mask bytes of the post-ReLU activation at saved-arena offset `off`
     unsigned char* M(size_t off) const {
         for (const auto& m : p.relu_masks)
@@ -741,24 +735,8 @@ struct Run {
 
     // conv + BN statistics -> scale/shift in the saved arena.  out_act: abs-max slot of the tensor the apply pass will
     // produce from this batch norm (its bound is computed here, from the statistics); res_act: slot of the residual added there
-    // defer: the finalize is left to the apply pass that consumes the statistics (take_pending; a cooperative launch does it
-    // inside itself, elementwise_kernels.hip) -- the partial sums stay in w_part until then: no other convolution in between
-    struct PendingFin { const float* stats = nullptr; dcn::BnFinalize f{}; int C = 0; } pend;
-    int flush_pending() {
-        if (!pend.stats) return DCN_OK;
-        const dcn::BnFinalize& f = pend.f;
-        dcn::launch_bn_finalize(f.partial, f.tiles_per_group, p.groups, pend.C, f.count_per_group, f.gamma, f.beta, f.rmean, f.rvar,
-                                f.momentum, f.eps, 1, const_cast<float*>(pend.stats), f.out_bound, f.res_bound, st);
-        pend.stats = nullptr;
-        return DCN_OK;
-    }
-    const dcn::BnFinalize* take_pending(const float* stats) {
-        if (pend.stats && pend.stats == stats) { pend.stats = nullptr; return &pend.f; }
-        return nullptr;
-    }
     int conv_bn(const ConvL& c, const float* in, const float* w, float* const* bn_running, float momentum, float eps,
-                int training, int out_act, int res_act = -1, bool defer = false) {
-        DCN_TRY(flush_pending());   // (never two outstanding: they share w_part)
+                int training, int out_act, int res_act = -1) {
         float* part = training ? Wk(p.w_part) : nullptr;
         DCN_TRY(conv_fwd(c, in, w, nullptr, S(c.x), part));
         const BnL& b = p.bns[c.bn];
@@ -768,13 +746,6 @@ struct Run {
         if (!training && (!rm || !rv)) return DCN_E_INVALID;
         // (M tiles of the launch just made: asked again, the tile shape follows the tuning table of the moment)
         const int mtiles = fwd_mtiles(c);
-        if (defer && training && dcn::bn_coop_enabled()) {
-            pend.stats = stats;
-            pend.C = b.C;
-            pend.f = dcn::BnFinalize{part, mtiles / p.groups, (double)(b.rows / p.groups), P(b.g), P(b.b), rm, rv, momentum, eps,
-                                     A(out_act), A(res_act)};
-            return DCN_OK;
-        }
         dcn::launch_bn_finalize(part, mtiles / p.groups, p.groups, b.C, (double)(b.rows / p.groups), P(b.g),
                                 P(b.b), rm, rv, momentum, eps, training, stats, training ? A(out_act) : nullptr,
                                 training ? A(res_act) : nullptr, st);
@@ -917,7 +888,7 @@ int forward_impl(dcn_plan* plan, const float* image, const float* image_b, const
     const int N = p.N;
 
     // abs-max slots of the activation tensors (+ the status word behind them)
-    DCN_TRY(R.other([&] { return dcn::fill_bytes_async(R.S(p.s_actmax), 0, ((((size_t)p.n_act + 2) & ~(size_t)1) + 4) * sizeof(float), st); }));
+    DCN_TRY(R.other([&] { return dcn::fill_bytes_async(R.S(p.s_actmax), 0, ((size_t)p.n_act + 1) * sizeof(float), st); }));
     // stem: NCHW(3) -> NHWC(4), weight [w][7][7][3] -> [w][7][7][4]
     const ConvL& stem = p.convs[p.stem];
     if (image_b) {
@@ -1040,7 +1011,7 @@ int forward_impl(dcn_plan* plan, const float* image, const float* image_b, const
         for (int i = 0; i < blk.nconv; ++i) {
             const ConvL& c = p.convs[blk.conv[i]];
             if (i + 1 < blk.nconv) {
-                DCN_TRY(R.conv_bn(c, cur, R.P(c.w), bn_running, momentum, eps, training, blk.act_mid[i], -1, true));
+                DCN_TRY(R.conv_bn(c, cur, R.P(c.w), bn_running, momentum, eps, training, blk.act_mid[i]));
                 const BnL& b = p.bns[c.bn];
                 const float* s = R.S(b.stats);
                 float* slot = (training && f16_mode && blk.has_hl_mid[i]) ? R.S(blk.hl_mid[i]) : nullptr;
@@ -1051,16 +1022,13 @@ int forward_impl(dcn_plan* plan, const float* image, const float* image_b, const
                 const bool hl_only = hl && slot && hl == (void*)slot && (b.C % 32) == 0 && dcn::tuning().hl_only_mid != 0 &&
                                      R.use_hl(nxt, 0) && R.use_wgrad_hl(nxt);
                 rec.mid_hl_only[nxt.idx] = hl_only ? 1 : 0;
-                {
-                    const dcn::BnFinalize* fin = R.take_pending(s);
-                    dcn::launch_bn_apply(R.S(c.x), s, nullptr, nullptr, 1, hl_only ? nullptr : R.S(blk.mid[i]), R.M(blk.mid[i]), b.C,
-                                         b.rows, p.groups, st, hl, R.A(blk.act_mid[i]), fin, fin ? R.fwd_sync() : nullptr);
-                }
+                dcn::launch_bn_apply(R.S(c.x), s, nullptr, nullptr, 1, hl_only ? nullptr : R.S(blk.mid[i]), R.M(blk.mid[i]), b.C,
+                                     b.rows, p.groups, st, hl, R.A(blk.act_mid[i]));
                 DCN_TRY(R.ensure_saved_hl(R.S(blk.mid[i]), slot, b.rows, b.C, blk.act_mid[i]));
                 cur = R.S(blk.mid[i]);
             } else {
                 DCN_TRY(R.conv_bn(c, cur, R.P(c.w), bn_running, momentum, eps, training, blk.act_out,
-                                  blk.down >= 0 ? blk.act_down : blk.act_in, true));
+                                  blk.down >= 0 ? blk.act_down : blk.act_in));
             }
         }
         const ConvL& last = p.convs[blk.conv[blk.nconv - 1]];
@@ -1072,19 +1040,17 @@ int forward_impl(dcn_plan* plan, const float* image, const float* image_b, const
         void* hl = (training && nb) ? R.hl_image_for(R.S(blk.out), 0, &p.convs[nb->conv[0]], nb->down >= 0 ? &p.convs[nb->down] : nullptr,
                                                      slot)
                                     : nullptr;
-        const dcn::BnFinalize* fin = R.take_pending(sl);   // (the downsample branch's statistics were finalized by a launch of their own)
         if (blk.down >= 0) {
             const ConvL& dc = p.convs[blk.down];
             const float* sd = R.S(p.bns[dc.bn].stats);
             dcn::launch_bn_apply(R.S(last.x), sl, R.S(dc.x), sd, 1, R.S(blk.out), R.M(blk.out), bl.C, bl.rows, p.groups, st, hl,
-                                 R.A(blk.act_out), fin, fin ? R.fwd_sync() : nullptr);
+                                 R.A(blk.act_out));
         } else {
             dcn::launch_bn_apply(R.S(last.x), sl, in, nullptr, 1, R.S(blk.out), R.M(blk.out), bl.C, bl.rows, p.groups, st, hl,
-                                 R.A(blk.act_out), fin, fin ? R.fwd_sync() : nullptr);
+                                 R.A(blk.act_out));
         }
         DCN_TRY(R.ensure_saved_hl(R.S(blk.out), slot, bl.rows, bl.C, blk.act_out));
     }
-    DCN_TRY(R.flush_pending());   // (nothing is left: every deferred finalize was taken by its apply pass)
     }   // !fused_eval
     // scoring layer (1x1 conv + bias) into the padded low-resolution map, then bilinear upsample
     const ConvL& fc = p.convs[p.fc];
@@ -1215,7 +1181,7 @@ int backward_impl(dcn_plan* plan, const float* grad_descriptors, const float* gr
         dcn::launch_bn_bwd(dy, relu_out, mask, R.S(c.x), s, R.P(b.g), b.C, b.rows, p.groups, part, grads[b.g],
                            grads[b.b], k123, dx, g_out, f16 ? amax + c.idx : nullptr,
                            (f16 && !hl_w) ? (void*)dqbuf[cur] : nullptr, st, tiles, dy2,
-                           (hl_d || hl_w) ? (void*)hlimg[cur] : nullptr, hl_d ? 0 : 1, R.bwd_sync());
+                           (hl_d || hl_w) ? (void*)hlimg[cur] : nullptr, hl_d ? 0 : 1);
         if (overlap) RT(hipEventRecord(p.ev_dq[cur], st));
         ++n_bn;
         dq_of = (f16 && !hl_w) ? dx : nullptr;   // the pixel-blocked split copy of this dx now sits in dqbuf[cur]
@@ -1311,8 +1277,7 @@ int backward_impl(dcn_plan* plan, const float* grad_descriptors, const float* gr
         }
     }
     // split-fp16 mode: every gradient tensor that feeds a convolution records its abs-max (pre-scale selection)
-    // (and the two words of the cooperative batch-norm launches behind them: both arithmetics)
-    DCN_TRY(R.other([&] { return dcn::fill_bytes_async(amax, 0, (((p.convs.size() + 1) & ~(size_t)1) + 4) * sizeof(float), st); }));
+    if (f16) DCN_TRY(R.other([&] { return dcn::fill_bytes_async(amax, 0, p.convs.size() * sizeof(float), st); }));
 
     // ---- upsample + scoring layer
     float* glow = R.Wk(p.w_glow);

@@ -454,8 +454,9 @@ HlxShape hlx_shape(int M, int cd, int K, int group_rows, int taps, int cs) {
             const double eff = kg == 1 ? tune.hlx_cost1 : tune.hlx_cost2;
             const double per_stage = XR * (bn / 256.0) * eff;
             const double stages = (double)nk / s;   // (chunks per workgroup; a KG = 2 stage is two of them on half the columns)
-            // (calibrated on profiles/r5a_hlx_sweep.txt: 12-21 us per split launch, growing slowly with the tile width and s)
-            const double fix = s > 1 ? tune.hlx_split_cost * XR * (0.5 + 0.5 * bn / 256.0) * (1.0 + 0.1 * s) : 0.0;
+            // (calibrated on profiles/r5a_hlx_sweep.txt / r5b_hlx_sweep.txt: 10-14 us per split launch of the 160 x 128 tile, twice
+            // that with the 160 KB partials of the 160 x 256 one, growing slowly with s)
+            const double fix = s > 1 ? tune.hlx_split_cost * XR * 0.75 * (bn / 128.0) * (1.0 + 0.1 * s) : 0.0;
             const double cost = rounds * (stages * per_stage + fix);
             if (cost < best_cost) {
                 best_cost = cost;

@@ -36,9 +36,7 @@
 //                           (default 1: wavefronts 4-7 between the two parts of theirs -- the partner on the SIMD computes meanwhile)
 //   DCN_HLX_COUNTERS        0: the arrival words of the small-tile kernel's K splits live in the caller's scratch and are cleared by
 //                           a fill launch in front of every split launch (default 1: a library-owned clean buffer per stream)
-//   DCN_BN_COOP             0: the per-channel batch-norm finalize kernels are launches of their own in front of the apply passes
-//                           (default 1: done by the apply pass's first workgroups, elementwise_kernels.hip coop_finalize)
-//   DCN_WGRAD_HL_MIN_M      output pixels from which the weight gradients of the wide layers take the hl32 kernel (default 8192)
+//   DCN_WGRAD_HL_MIN_M      output pixels from which the weight gradients of the wide layers take the hl32 kernel (default 4096)
 //   DCN_HL_PRODUCERS        0: hl32 activation / gradient images are made by stand-alone split passes instead of by the
 //                           batch-norm apply kernels that produce the tensors
 //   DCN_STEM_POOL_FUSED     0: the stem's batch norm + ReLU as an apply pass of its own in front of the max pool (default 1: applied
@@ -80,10 +78,9 @@ struct Tuning {
     int gemm_hlx_kg = 0;         // forced K groups per workgroup (0: as decided)
     int gemm_hlx_splits = 0;     // forced workgroups per tile along K (0: as decided)
     int gemm_hlx_narrow = 0;     // 128-channel destinations on the 160 x 128 tile
-    double hlx_cost1 = 1.32, hlx_cost2 = 1.53, hlx_split_cost = 14.0;   // (profiles/r5a_hlx_sweep.txt)
+    double hlx_cost1 = 1.32, hlx_cost2 = 1.42, hlx_split_cost = 14.0;   // (profiles/r5a_hlx_sweep.txt, r5b_hlx_sweep.txt)
     int hlx_stagger = 1;         // see DCN_HLX_STAGGER
     int hlx_counters = 1;        // see DCN_HLX_COUNTERS
-    int bn_coop = 1;             // see DCN_BN_COOP
     int wgrad_hl_min_m = 0;      // 0: the default of dcn_conv_wgrad_hl_eligible
     int wgrad_hl = 1;            // wide layers' weight gradients on the pre-split (hl32) LDS-DMA kernel
     int hl_producers = 1;        // hl32 images written by the producing batch-norm passes (0: stand-alone split passes)

@@ -53,7 +53,6 @@ void read_env(Tuning& t) {
     if (const char* e = getenv("DCN_WGRAD_HL")) t.wgrad_hl = atoi(e);
     if (const char* e = getenv("DCN_HLX_STAGGER")) t.hlx_stagger = atoi(e) != 0;
     if (const char* e = getenv("DCN_HLX_COUNTERS")) t.hlx_counters = atoi(e) != 0;
-    if (const char* e = getenv("DCN_BN_COOP")) t.bn_coop = atoi(e) != 0;
     if (const char* e = getenv("DCN_WGRAD_HL_MIN_M")) t.wgrad_hl_min_m = atoi(e);
     if (const char* e = getenv("DCN_HL_PRODUCERS")) t.hl_producers = atoi(e) != 0;
     if (const char* e = getenv("DCN_BN_REVERSE")) t.bn_reverse = atoi(e);

@@ -42,19 +42,9 @@ void launch_bn_finalize(const float* partial, int tiles_per_group, int groups, i
 // relu_mask (optional, with relu): one byte per float4 of y, bit j = y[4i + j] > 0 (read back by launch_bn_bwd)
 // hl_out (optional, with hl_absmax; C % 32 == 0): y also as the hl32 image of conv_hl_kernels.hip, scaled by the power of two
 // chosen from *hl_absmax (the bound launch_bn_finalize stored for y)
-// fin (optional, training): the statistics behind stats1 have NOT been finalized yet -- they are made from fin->partial by this
-// call: inside the apply launch itself when coop_words (two 8-byte words of device memory that only such launches of this
-// stream ever write, zero or left by an earlier one) is given and DCN_BN_COOP allows (see coop_finalize in the .hip: the apply
-// pass's first workgroups do the finalize, nothing is launched in front), otherwise by a finalize launch in front of it
-struct BnFinalize {
-    const float* partial; int tiles_per_group; double count_per_group;
-    const float* gamma; const float* beta; float* rmean; float* rvar; float momentum, eps;
-    float* out_bound; const float* res_bound;
-};
 void launch_bn_apply(const float* x, const float* stats1, const float* res, const float* stats2, int relu, float* y,
                      unsigned char* relu_mask, int C, int64_t rows, int groups, hipStream_t st, void* hl_out = nullptr,
-                     const float* hl_absmax = nullptr, const BnFinalize* fin = nullptr, unsigned long long* coop_words = nullptr);
-bool bn_coop_enabled();
+                     const float* hl_absmax = nullptr);
 int bn_bwd_chunks(int64_t rows_per_group);
 // partial: groups*bn_bwd_chunks(rows/groups)*4*C floats, k123: groups*3*C floats.  g_out (nullable) receives the
 // relu-masked dy.  absmax (optional): raised to an upper bound of max |dx|
@@ -66,8 +56,7 @@ void launch_bn_bwd(const float* dy, const float* relu_out, const unsigned char* 
                    int reduced_tiles_per_group = 0,                          // pixel-blocked split-fp16 tensor (f16_split.h)
                    const float* dy2 = nullptr,    // dy2 (optional): the upstream gradient is dy + dy2 (residual branch's share)
                    void* hl_dx = nullptr,         // hl_dx (optional, with dq; C % 32 == 0): dx also as the hl32 image the pre-split
-                   int keep_dx = 0,               // dgrad reads; the fp32 dx is then NOT written unless keep_dx
-                   unsigned long long* coop_words = nullptr);   // the finalize inside the apply launch (see launch_bn_apply)
+                   int keep_dx = 0);              // dgrad reads; the fp32 dx is then NOT written unless keep_dx
 // reduced_tiles_per_group > 0: `partial` already holds that many rows per group of per-tile sums, written by the epilogue
 // of the dgrad that produced dy (GemmConv::bnb_partial) -- the reduce pass is skipped; dy is then already ReLU-masked
 // (pass relu_out = relu_mask = nullptr)

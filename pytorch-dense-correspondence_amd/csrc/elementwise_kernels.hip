@@ -8,8 +8,6 @@
 //   max pool 3x3/2 pad 1 (first maximum in window scan order wins, like ATen's CPU kernel)
 //   bilinear upsample, align_corners=True  == F.upsample_bilinear (called from Resnet34_8s.forward [NOT IN TREE])
 //   optional per-pixel L2 normalisation of the descriptor (dense_correspondence_network.py:256-259)
-#include <atomic>
-
 #include "dcn_tuning.h"
 #include "elementwise_kernels.h"
 #include "f16_split.h"
@@ -109,73 +107,8 @@ __device__ __forceinline__ float part_tree_max(float v) {
     return v;
 }
 
-// ---- finalize INSIDE the apply pass (round 5).  The per-channel finalize kernels are ~10 us of dependent-launch latency each,
-// 72 per training step (4 % of a config-2 step, 7 % at the reference's batch size of 1): the apply pass that consumes the
-// statistics does the finalize itself, cooperatively -- its first workgroups claim the finalize units (4 channels each, the
-// work split of the stand-alone kernel, same arithmetic and order: bit-identical statistics) through a ticket word, write the
-// results THROUGH to memory (agent-scope stores: the per-XCD L2s are not coherent with one another) and count themselves
-// done; every workgroup then waits for the done count (only workgroups that are RUNNING ever hold a ticket, so the wait
-// cannot depend on a workgroup that has not been dispatched), reads the statistics of its own channel quad past its L2
-// (agent-scope loads, once, into registers) and streams.  Both words carry the launch id in their upper half: whatever
-// another launch left there counts as zero, nothing needs clearing between launches.
-__device__ __forceinline__ unsigned long long coop_load(const unsigned long long* w) {
-    return __hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-__device__ __forceinline__ float coop_loadf(const float* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ float4 coop_load4(const float* p) {
-    return make_float4(coop_loadf(p), coop_loadf(p + 1), coop_loadf(p + 2), coop_loadf(p + 3));
-}
-template <bool COOP> __device__ __forceinline__ void stat_store(float* p, float v) {
-    if (COOP) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    else *p = v;
-}
-__device__ __forceinline__ unsigned coop_count(const unsigned long long* w, unsigned id) {
-    const unsigned long long v = coop_load(w);
-    return (unsigned)(v >> 32) == id ? (unsigned)(v & 0xffffffffull) : 0u;
-}
-// (launch id << 32) | count  +=  1; returns the count before the add
-__device__ __forceinline__ unsigned coop_ticket(unsigned long long* w, unsigned id) {
-    unsigned long long old = coop_load(w);
-    for (;;) {
-        const bool mine = (unsigned)(old >> 32) == id;
-        const unsigned long long nv = mine ? old + 1ull : (((unsigned long long)id << 32) | 1ull);
-        const unsigned long long seen = atomicCAS(w, old, nv);
-        if (seen == old) return mine ? (unsigned)(old & 0xffffffffull) : 0u;
-        old = seen;
-    }
-}
-// words[0]: tickets, words[1]: units done.  `unit(u)` is executed by the whole workgroup (256 work-items) and ends with
-// its result stores issued.
-template <class Unit>
-__device__ __forceinline__ void coop_finalize(unsigned long long* words, unsigned id, int units, Unit&& unit) {
-    __shared__ int s_ticket;
-    for (;;) {
-        if (threadIdx.x == 0) {
-            // look before the atomic: the workgroups dispatched after the last unit was claimed only read
-            s_ticket = coop_count(words, id) >= (unsigned)units ? units : (int)coop_ticket(words, id);
-        }
-        __syncthreads();
-        const int t = s_ticket;
-        __syncthreads();
-        if (t >= units) break;
-        unit(t);
-        DCN_WAIT_VMCNT(0);   // this work-item's write-through stores and atomics have completed
-        __syncthreads();
-        if (threadIdx.x == 0) coop_ticket(words + 1, id);
-    }
-    if (threadIdx.x == 0) {
-        long spins = 0;
-        while (coop_count(words + 1, id) < (unsigned)units) {
-            __builtin_amdgcn_s_sleep(1);
-            if (++spins > (1L << 27)) __builtin_trap();   // (seconds: a protocol error must not hang the GPU)
-        }
-    }
-    __syncthreads();
-}
-
-// one finalize unit = channels 4 cq .. 4 cq + 3, by the whole workgroup (see the header comment above)
-template <bool COOP>
-__device__ __forceinline__ void bn_finalize_unit(int cq, const float* __restrict__ partial, int tiles, int groups, int C, double count,
+__global__ void __launch_bounds__(256)
+bn_finalize_kernel(const float* __restrict__ partial, int tiles, int groups, int C, double count,
                    const float* __restrict__ gamma, const float* __restrict__ beta, float* __restrict__ running_mean,
                    float* __restrict__ running_var, float momentum, float eps, int training, float* __restrict__ scale,
                    float* __restrict__ shift, float* __restrict__ save_mean, float* __restrict__ save_invstd, int gstride,
@@ -185,7 +118,7 @@ __device__ __forceinline__ void bn_finalize_unit(int cq, const float* __restrict
     __shared__ float s_mx[4][4];
     __shared__ float s_bound[4];
     const int cl = threadIdx.x & 3, part = threadIdx.x >> 2, wv = threadIdx.x >> 6;
-    const int c = cq * 4 + cl;
+    const int c = blockIdx.x * 4 + cl;
     float bound = 0.f;
     for (int g = 0; g < groups; ++g) {
         double a = 0.0, b = 0.0;
@@ -224,8 +157,8 @@ __device__ __forceinline__ void bn_finalize_unit(int cq, const float* __restrict
         const float invstd = (float)(1.0 / sqrt(var + (double)eps));
         const float sc = gamma[c] * invstd;
         const float sh = beta[c] - (float)mean * sc;
-        stat_store<COOP>(scale + g * gstride + c, sc);
-        stat_store<COOP>(shift + g * gstride + c, sh);
+        scale[g * gstride + c] = sc;
+        shift[g * gstride + c] = sh;
         if (save_mean) { save_mean[g * gstride + c] = (float)mean; save_invstd[g * gstride + c] = invstd; }
         mx = fmaxf(fmaxf(s_mx[0][cl], s_mx[1][cl]), fmaxf(s_mx[2][cl], s_mx[3][cl]));
         // (fmaxf drops a NaN: a non-finite statistic -- NaN sums from NaN activations, a NaN / inf parameter -- is reported as an
@@ -243,27 +176,8 @@ __device__ __forceinline__ void bn_finalize_unit(int cq, const float* __restrict
             if (m > 0.f && bits > __atomic_load_n(reinterpret_cast<unsigned*>(out_bound), __ATOMIC_RELAXED))
                 atomicMax(reinterpret_cast<unsigned*>(out_bound), bits);
         }
-        __syncthreads();   // (s_bound: the next unit of a cooperative launch writes it again)
     }
 }
-
-struct BnFinArgs {   // arguments of bn_finalize_unit, by value (the cooperative apply kernel carries them along)
-    const float* partial; int tiles, groups, C; double count;
-    const float* gamma; const float* beta; float* running_mean; float* running_var; float momentum, eps; int training;
-    float* stats; float* out_bound; const float* res_bound;
-};
-
-__global__ void __launch_bounds__(256)
-bn_finalize_kernel(BnFinArgs f) {
-    bn_finalize_unit<false>((int)blockIdx.x, f.partial, f.tiles, f.groups, f.C, f.count, f.gamma, f.beta, f.running_mean, f.running_var,
-                            f.momentum, f.eps, f.training, f.stats, f.stats + f.C, f.stats + 2 * f.C, f.stats + 3 * f.C, 4 * f.C,
-                            f.out_bound, f.res_bound);
-}
-
-struct BnCoop {   // words == nullptr: not a cooperative launch
-    unsigned long long* words;
-    unsigned id;
-};
 
 // float4 load that will not be needed again soon (DCN_BN_NT: streamed past the caches instead of displacing what the next
 // kernel is about to read)
@@ -275,40 +189,22 @@ __device__ __forceinline__ float4 ld4(const float* p, int64_t i4, bool nt) {
 }
 
 // y = [relu]( x*s1 + b1 + (res ? (s2 ? res*s2 + b2 : res) : 0) )
-// COOP: the statistics (s1, b1) and *hl_absmax are made by THIS launch first (coop_finalize above, arguments `fin`); a
-// work-item's channel quad is the same in every iteration (the launcher makes the grid stride a multiple of c4n), so its
-// scale / shift are read once, past the L2.
-template <bool COOP>
 __global__ void __launch_bounds__(256)
 bn_apply_kernel(const float* __restrict__ x, const float* __restrict__ s1, const float* __restrict__ b1,
                 const float* __restrict__ res, const float* __restrict__ s2, const float* __restrict__ b2, int relu,
                 float* __restrict__ y, unsigned char* __restrict__ relu_mask, int c4n, int64_t total4, int64_t group4,
-                int gstride, dcnsplit::u32x2* __restrict__ hl, const float* __restrict__ hl_absmax, int rev, int nt,
-                BnFinArgs fin, BnCoop coop) {
-    float4 cs[2], cb[2];
-    if (COOP) {
-        coop_finalize(coop.words, coop.id, (fin.C + 3) / 4, [&](int u) {
-            bn_finalize_unit<true>(u, fin.partial, fin.tiles, fin.groups, fin.C, fin.count, fin.gamma, fin.beta, fin.running_mean,
-                                   fin.running_var, fin.momentum, fin.eps, fin.training, fin.stats, fin.stats + fin.C,
-                                   fin.stats + 2 * fin.C, fin.stats + 3 * fin.C, 4 * fin.C, fin.out_bound, fin.res_bound);
-        });
-        const int64_t j0 = (int64_t)blockIdx.x * 256 + threadIdx.x;
-        const int c0 = (int)((rev ? total4 - 1 - j0 : j0) % c4n) * 4;
-        cs[0] = coop_load4(s1 + c0); cb[0] = coop_load4(b1 + c0);
-        const bool two = group4 < total4;
-        cs[1] = two ? coop_load4(s1 + c0 + gstride) : cs[0]; cb[1] = two ? coop_load4(b1 + c0 + gstride) : cb[0];
-    }
+                int gstride, dcnsplit::u32x2* __restrict__ hl, const float* __restrict__ hl_absmax, int rev, int nt) {
     // hl (optional, c4n % 8 == 0): y also as the "hl32" image the pre-split convolution kernel reads (conv_hl_kernels.hip) --
     // per 32-channel chunk one 128-byte line [hi x32 | lo x32] fp16 of s y, s = the power of two chosen from *hl_absmax (the
     // bound of max |y| that bn_finalize_kernel stored before this pass): the consumer's operand split costs 4 B / element
     // of extra stores here instead of a pass of its own
-    const float hs = hl ? dcnsplit::pow2_scale(COOP ? coop_loadf(hl_absmax) : *hl_absmax) : 1.f;
+    const float hs = hl ? dcnsplit::pow2_scale(*hl_absmax) : 1.f;
     for (int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x; j < total4; j += (int64_t)gridDim.x * 256) {
         const int64_t i = rev ? total4 - 1 - j : j;   // (rev: back to front, DCN_BN_REVERSE)
         const int c = (int)(i % c4n) * 4 + (i >= group4 ? gstride : 0);   // (at most two groups: second group's statistics)
         const float4 v = ld4(x, i, nt != 0);
-        const float4 s = COOP ? cs[i >= group4 ? 1 : 0] : *reinterpret_cast<const float4*>(s1 + c);
-        const float4 b = COOP ? cb[i >= group4 ? 1 : 0] : *reinterpret_cast<const float4*>(b1 + c);
+        const float4 s = *reinterpret_cast<const float4*>(s1 + c);
+        const float4 b = *reinterpret_cast<const float4*>(b1 + c);
         float4 o = make_float4(v.x * s.x + b.x, v.y * s.y + b.y, v.z * s.z + b.z, v.w * s.w + b.w);
         if (res) {
             float4 r = reinterpret_cast<const float4*>(res)[i];
@@ -429,8 +325,8 @@ bn_bwd_reduce_kernel(const float* __restrict__ dy, const float* dy2, const float
 //   dx = k1 * (g - k2 - xhat * k3),  k1 = gamma*invstd, k2 = sum_g / M, k3 = sum_gx / M
 // and, when absmax is given, raises absmax[0] to  max_c |k1| (max|g| + |k2| + max|xhat| |k3|)  >=  max |dx|  (the
 // pre-scale of the split-fp16 convolutions only needs an upper bound within a small factor of the true abs-max).
-template <bool COOP>
-__device__ __forceinline__ void bn_bwd_finalize_unit(int cq, const float* __restrict__ partial, int chunks, int groups, int C, double count,
+__global__ void __launch_bounds__(256)
+bn_bwd_finalize_kernel(const float* __restrict__ partial, int chunks, int groups, int C, double count,
                        const float* __restrict__ gamma, const float* __restrict__ invstd, int gstride,
                        float* __restrict__ dgamma, float* __restrict__ dbeta, float* __restrict__ k123,
                        float* __restrict__ absmax) {
@@ -441,7 +337,7 @@ __device__ __forceinline__ void bn_bwd_finalize_unit(int cq, const float* __rest
     __shared__ float s_mg[4][4];
     __shared__ float s_mx[4][4];
     const int cl = threadIdx.x & 3, part = threadIdx.x >> 2, wv = threadIdx.x >> 6;
-    const int c = cq * 4 + cl;
+    const int c = blockIdx.x * 4 + cl;
     const bool lead = threadIdx.x < 4 && c < C;
     double tot_a = 0.0, tot_b = 0.0;
     float bound = 0.f;
@@ -472,9 +368,9 @@ __device__ __forceinline__ void bn_bwd_finalize_unit(int cq, const float* __rest
             mx = fmaxf(fmaxf(s_mx[0][cl], s_mx[1][cl]), fmaxf(s_mx[2][cl], s_mx[3][cl]));
             const float c1 = gamma[c] * invstd[g * gstride + c], c2 = (float)(a / count), c3 = (float)(b / count);
             float* k = k123 + (int64_t)g * 3 * C;
-            stat_store<COOP>(k + c, c1);
-            stat_store<COOP>(k + C + c, c2);
-            stat_store<COOP>(k + 2 * C + c, c3);
+            k[c] = c1;
+            k[C + c] = c2;
+            k[2 * C + c] = c3;
             tot_a += a;
             tot_b += b;
             bound = fmaxf(bound, fabsf(c1) * (mg + fabsf(c2) + mx * fabsf(c3)));
@@ -493,53 +389,16 @@ __device__ __forceinline__ void bn_bwd_finalize_unit(int cq, const float* __rest
                 atomicMax(reinterpret_cast<unsigned*>(absmax), bits);
         }
     }
-    __syncthreads();   // (the LDS sums: the next unit of a cooperative launch writes them again)
-}
-
-struct BnBwdFinArgs {
-    const float* partial; int chunks, groups, C; double count;
-    const float* gamma; const float* invstd; int gstride;
-    float* dgamma; float* dbeta; float* k123; float* absmax;
-};
-
-__global__ void __launch_bounds__(256)
-bn_bwd_finalize_kernel(BnBwdFinArgs f) {
-    bn_bwd_finalize_unit<false>((int)blockIdx.x, f.partial, f.chunks, f.groups, f.C, f.count, f.gamma, f.invstd, f.gstride, f.dgamma,
-                                f.dbeta, f.k123, f.absmax);
-}
-
-// the backward apply passes' side of a cooperative launch: finalize, then this work-item's (k1, k2, k3) per group, read once
-// past the L2 (its channel quad `c0` is the same in every iteration)
-__device__ __forceinline__ void bn_bwd_coop_prologue(const BnBwdFinArgs& f, const BnCoop& coop, int c0, bool two, int kstride,
-                                                     float4 (&ka)[2], float4 (&kb)[2], float4 (&kd)[2]) {
-    coop_finalize(coop.words, coop.id, (f.C + 3) / 4, [&](int u) {
-        bn_bwd_finalize_unit<true>(u, f.partial, f.chunks, f.groups, f.C, f.count, f.gamma, f.invstd, f.gstride, f.dgamma, f.dbeta,
-                                   f.k123, f.absmax);
-    });
-    const float* k1 = f.k123;
-    const float* k2 = f.k123 + f.C;
-    const float* k3 = f.k123 + 2 * f.C;
-    ka[0] = coop_load4(k1 + c0); kb[0] = coop_load4(k2 + c0); kd[0] = coop_load4(k3 + c0);
-    ka[1] = two ? coop_load4(k1 + c0 + kstride) : ka[0];
-    kb[1] = two ? coop_load4(k2 + c0 + kstride) : kb[0];
-    kd[1] = two ? coop_load4(k3 + c0 + kstride) : kd[0];
 }
 
 // dx = k1*(g - k2 - (x-mean)*invstd*k3); optionally also writes g (the relu-masked upstream gradient) for the
 // residual branch.
-template <bool COOP>
 __global__ void __launch_bounds__(256)
 bn_bwd_apply_kernel(const float* __restrict__ dy, const float* dy2, const float* __restrict__ relu_out,
                     const unsigned char* __restrict__ relu_mask, const float* __restrict__ x,
                     const float* __restrict__ mean, const float* __restrict__ invstd, const float* __restrict__ k1,
                     const float* __restrict__ k2, const float* __restrict__ k3, float* __restrict__ dx,
-                    float* g_out, int c4n, int64_t total4, int64_t group4, int gstride, int kstride, int rev,
-                    BnBwdFinArgs fin, BnCoop coop) {
-    float4 ka[2], kb[2], kd[2];
-    if (COOP) {
-        const int64_t j0 = (int64_t)blockIdx.x * 256 + threadIdx.x;
-        bn_bwd_coop_prologue(fin, coop, (int)((rev ? total4 - 1 - j0 : j0) % c4n) * 4, group4 < total4, kstride, ka, kb, kd);
-    }
+                    float* g_out, int c4n, int64_t total4, int64_t group4, int gstride, int kstride, int rev) {
     for (int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x; j < total4; j += (int64_t)gridDim.x * 256) {
         const int64_t i = rev ? total4 - 1 - j : j;
         const int c0 = (int)(i % c4n) * 4;
@@ -549,9 +408,9 @@ bn_bwd_apply_kernel(const float* __restrict__ dy, const float* dy2, const float*
         const float4 v = reinterpret_cast<const float4*>(x)[i];
         const float4 mu = *reinterpret_cast<const float4*>(mean + c);
         const float4 is = *reinterpret_cast<const float4*>(invstd + c);
-        const float4 a = COOP ? ka[second ? 1 : 0] : *reinterpret_cast<const float4*>(k1 + ck);
-        const float4 b = COOP ? kb[second ? 1 : 0] : *reinterpret_cast<const float4*>(k2 + ck);
-        const float4 d = COOP ? kd[second ? 1 : 0] : *reinterpret_cast<const float4*>(k3 + ck);
+        const float4 a = *reinterpret_cast<const float4*>(k1 + ck);
+        const float4 b = *reinterpret_cast<const float4*>(k2 + ck);
+        const float4 d = *reinterpret_cast<const float4*>(k3 + ck);
         float4 o;
         o.x = a.x * (g.x - b.x - (v.x - mu.x) * is.x * d.x);
         o.y = a.y * (g.y - b.y - (v.y - mu.y) * is.y * d.y);
@@ -565,7 +424,6 @@ bn_bwd_apply_kernel(const float* __restrict__ dy, const float* dy2, const float*
 // The same pass for the split-fp16 convolution mode: one work-item per (pixel quad, channel quad) so that it can ALSO emit
 // dx as the pixel-blocked split tensor wgrad consumes (f16_split.h), scaled by the power of two chosen from the bound the
 // finalize kernel has just stored in *absmax -- no separate split pass over dx.  rows_per_group % 4 == 0 when grouped.
-template <bool COOP>
 __global__ void __launch_bounds__(256)
 bn_bwd_apply_blocked_kernel(const float* __restrict__ dy, const float* dy2, const float* __restrict__ relu_out,
                             const unsigned char* __restrict__ relu_mask, const float* __restrict__ x,
@@ -573,16 +431,11 @@ bn_bwd_apply_blocked_kernel(const float* __restrict__ dy, const float* dy2, cons
                             const float* __restrict__ k2, const float* __restrict__ k3, float* __restrict__ dx,
                             float* g_out, dcnsplit::u32x4* __restrict__ dq, const float* __restrict__ absmax,
                             int c4n, int64_t rows, int64_t rows_per_group, int gstride, int kstride,
-                            dcnsplit::u32x2* __restrict__ hl, int rev, int nt, BnBwdFinArgs fin, BnCoop coop) {
+                            dcnsplit::u32x2* __restrict__ hl, int rev, int nt) {
     // hl (optional, c4n % 8 == 0): dx as the hl32 image the pre-split dgrad reads (same scale as dq); dx itself may then be
     // null -- nobody else reads the fp32 tensor
+    const float s = dcnsplit::pow2_scale(*absmax);
     const int64_t total = ((rows + 3) >> 2) * c4n;
-    float4 ka[2], kb[2], kd[2];
-    if (COOP) {
-        const int64_t j0 = (int64_t)blockIdx.x * 256 + threadIdx.x;
-        bn_bwd_coop_prologue(fin, coop, (int)((rev ? total - 1 - j0 : j0) % c4n) * 4, rows_per_group < rows, kstride, ka, kb, kd);
-    }
-    const float s = dcnsplit::pow2_scale(COOP ? coop_loadf(absmax) : *absmax);
     for (int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x; j < total; j += (int64_t)gridDim.x * 256) {
         const int64_t i = rev ? total - 1 - j : j;
         const int64_t q = i / c4n;
@@ -591,9 +444,9 @@ bn_bwd_apply_blocked_kernel(const float* __restrict__ dy, const float* dy2, cons
         const int c = cq * 4 + (second ? gstride : 0), ck = cq * 4 + (second ? kstride : 0);
         const float4 mu = *reinterpret_cast<const float4*>(mean + c);
         const float4 is = *reinterpret_cast<const float4*>(invstd + c);
-        const float4 a = COOP ? ka[second ? 1 : 0] : *reinterpret_cast<const float4*>(k1 + ck);
-        const float4 b = COOP ? kb[second ? 1 : 0] : *reinterpret_cast<const float4*>(k2 + ck);
-        const float4 d = COOP ? kd[second ? 1 : 0] : *reinterpret_cast<const float4*>(k3 + ck);
+        const float4 a = *reinterpret_cast<const float4*>(k1 + ck);
+        const float4 b = *reinterpret_cast<const float4*>(k2 + ck);
+        const float4 d = *reinterpret_cast<const float4*>(k3 + ck);
         float o[4][4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
@@ -899,57 +752,21 @@ void launch_bn_finalize(const float* partial, int tiles_per_group, int groups, i
                         const float* gamma, const float* beta, float* rmean, float* rvar, float momentum, float eps,
                         int training, float* stats, float* out_bound, const float* res_bound, hipStream_t st) {
     ObservedLaunch obs(DCN_PROF_BN_FINALIZE, training ? 12.0 * (double)tiles_per_group * groups * C : 0.0, st);
-    const BnFinArgs f{partial, tiles_per_group, groups, C, count_per_group, gamma, beta, rmean, rvar, momentum, eps, training,
-                      stats, out_bound, res_bound};
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3(ceil_div(C, 4)), dim3(256), 0, st, f);
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3(ceil_div(C, 4)), dim3(256), 0, st, partial, tiles_per_group, groups, C,
+                       count_per_group, gamma, beta, rmean, rvar, momentum, eps, training, stats, stats + C, stats + 2 * C,
+                       stats + 3 * C, 4 * C, out_bound, res_bound);
 }
-// grid of a cooperative apply launch: the grid stride (256 x workgroups) must be a multiple of the channel quads per row, so
-// that a work-item keeps its channel quad (it reads its statistics once); 0: this channel count cannot (separate finalize)
-static unsigned coop_grid(int64_t n, int c4n) {
-    unsigned g = blocks_for(n, kGridCap);
-    if (c4n <= 256) return (256 % c4n) == 0 ? g : 0u;
-    if ((c4n % 256) != 0) return 0u;
-    const unsigned m = (unsigned)(c4n / 256);
-    g = g / m * m;
-    return g;   // (0 when the tensor is smaller than one stride)
-}
-unsigned next_coop_id() {
-    static std::atomic<unsigned> next_id{1u};
-    unsigned id;
-    do { id = next_id.fetch_add(1u, std::memory_order_relaxed); } while (id == 0u);
-    return id;
-}
-bool bn_coop_enabled() { return tuning().bn_coop != 0; }
 void launch_bn_apply(const float* x, const float* stats1, const float* res, const float* stats2, int relu, float* y,
                      unsigned char* relu_mask, int C, int64_t rows, int groups, hipStream_t st, void* hl_out,
-                     const float* hl_absmax, const BnFinalize* fin, unsigned long long* coop_words) {
+                     const float* hl_absmax) {
     const int64_t total4 = rows * (C / 4);
     if ((C % 32) != 0 || !hl_absmax) hl_out = nullptr;
-    BnFinArgs f{};
-    unsigned grid = blocks_for(total4, kGridCap);
-    bool coop = false;
-    if (fin) {   // the statistics behind stats1 are still to be made from fin->partial: here (cooperative launch) or in front
-        f = BnFinArgs{fin->partial, fin->tiles_per_group, groups, C, fin->count_per_group, fin->gamma, fin->beta, fin->rmean,
-                      fin->rvar, fin->momentum, fin->eps, 1, const_cast<float*>(stats1), fin->out_bound, fin->res_bound};
-        const unsigned cg = (coop_words && bn_coop_enabled() && groups <= 2) ? coop_grid(total4, C / 4) : 0u;
-        if (cg > 0) { coop = true; grid = cg; }
-        else launch_bn_finalize(fin->partial, fin->tiles_per_group, groups, C, fin->count_per_group, fin->gamma, fin->beta, fin->rmean,
-                                fin->rvar, fin->momentum, fin->eps, 1, const_cast<float*>(stats1), fin->out_bound, fin->res_bound, st);
-    }
     // bytes per element: x (+ the residual) in; y, the hl32 image (the size of y) and a quarter byte of ReLU mask out
     ObservedLaunch obs(DCN_PROF_BN_APPLY, (double)rows * C * (4.0 + (res ? 4.0 : 0.0) + (y ? 4.0 : 0.0) + (hl_out ? 4.0 : 0.0) +
-                                                             (relu_mask ? 0.25 : 0.0)) +
-                                              (coop ? 12.0 * (double)f.tiles * groups * C : 0.0), st);
-    if (coop) {
-        const BnCoop cw{coop_words, next_coop_id()};
-        hipLaunchKernelGGL(bn_apply_kernel<true>, dim3(grid), dim3(256), 0, st, x, stats1, stats1 + C, res,
-                           stats2, stats2 ? stats2 + C : nullptr, relu, y, relu_mask, C / 4, total4, total4 / groups, 4 * C,
-                           (dcnsplit::u32x2*)hl_out, hl_absmax, tuning().bn_reverse & 1, tuning().bn_nt & 1, f, cw);
-    } else {
-        hipLaunchKernelGGL(bn_apply_kernel<false>, dim3(grid), dim3(256), 0, st, x, stats1, stats1 + C, res,
-                           stats2, stats2 ? stats2 + C : nullptr, relu, y, relu_mask, C / 4, total4, total4 / groups, 4 * C,
-                           (dcnsplit::u32x2*)hl_out, hl_absmax, tuning().bn_reverse & 1, tuning().bn_nt & 1, f, BnCoop{nullptr, 0u});
-    }
+                                                             (relu_mask ? 0.25 : 0.0)), st);
+    hipLaunchKernelGGL(bn_apply_kernel, dim3(blocks_for(total4, kGridCap)), dim3(256), 0, st, x, stats1, stats1 + C, res,
+                       stats2, stats2 ? stats2 + C : nullptr, relu, y, relu_mask, C / 4, total4, total4 / groups, 4 * C,
+                       (dcnsplit::u32x2*)hl_out, hl_absmax, tuning().bn_reverse & 1, tuning().bn_nt & 1);
 }
 int bn_bwd_chunks(int64_t rows_per_group) {
     // enough row chunks that even a 64-channel layer launches >= ~1000 workgroups (HBM-bound pass: fill all 256 CUs)
@@ -966,7 +783,7 @@ void launch_bn_bwd(const float* dy, const float* relu_out, const unsigned char* 
                    const float* gamma, int C,
                    int64_t rows, int groups, float* partial, float* dgamma, float* dbeta, float* k123, float* dx,
                    float* g_out, float* absmax, void* dq, hipStream_t st, int reduced_tiles_per_group, const float* dy2,
-                   void* hl_dx, int keep_dx, unsigned long long* coop_words) {
+                   void* hl_dx, int keep_dx) {
     const int64_t rpg = rows / groups;
     const float* mean = stats + 2 * C;
     const float* invstd = stats + 3 * C;
@@ -988,42 +805,27 @@ void launch_bn_bwd(const float* dy, const float* relu_out, const unsigned char* 
         else DCN_BN_RED(16);
 #undef DCN_BN_RED
     }
-    const int64_t total4 = rows * (C / 4);
-    const bool blocked = (dq || (hl_dx && (C % 32) == 0)) && absmax;
-    const int64_t items = blocked ? ((rows + 3) / 4) * (C / 4) : total4;
-    const BnBwdFinArgs f{(const float*)partial, chunks, groups, C, (double)rpg, gamma, invstd, 4 * C, dgamma, dbeta, k123, absmax};
-    unsigned grid = blocks_for(items, kGridCap);
-    // the finalize between the two streaming passes: inside the apply pass (cooperative launch, see coop_finalize) or a launch
-    const unsigned cg = (coop_words && bn_coop_enabled() && groups <= 2) ? coop_grid(items, C / 4) : 0u;
-    const bool coop = cg > 0;
-    if (coop) grid = cg;
-    else {
+    {
         ObservedLaunch obs(DCN_PROF_BN_FINALIZE, 16.0 * (double)chunks * groups * C, st);
-        hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(ceil_div(C, 4)), dim3(256), 0, st, f);
+        hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(ceil_div(C, 4)), dim3(256), 0, st, (const float*)partial, chunks,
+                           groups, C, (double)rpg, gamma, invstd, 4 * C, dgamma, dbeta, k123, absmax);
     }
-    const BnCoop cw{coop ? coop_words : nullptr, coop ? next_coop_id() : 0u};
-    const double fin_bytes = coop ? 16.0 * (double)chunks * groups * C : 0.0;
-    if (blocked) {
+    const int64_t total4 = rows * (C / 4);
+    if ((dq || (hl_dx && (C % 32) == 0)) && absmax) {
         const bool hl = hl_dx && (C % 32) == 0;
         ObservedLaunch obs(DCN_PROF_BN_BWD_APPLY, (double)rows * C * (in_bytes + ((hl && !keep_dx) ? 0.0 : 4.0) + (g_out ? 4.0 : 0.0) +
-                                                                      (dq ? 4.0 : 0.0) + (hl ? 4.0 : 0.0)) + fin_bytes, st);
-#define DCN_BN_BLK(COOP)                                                                                                      \
-        hipLaunchKernelGGL(bn_bwd_apply_blocked_kernel<COOP>, dim3(grid), dim3(256), 0, st,                                       \
-                           dy, dy2, relu_out, relu_mask, x, mean, invstd, (const float*)k123, (const float*)(k123 + C),         \
-                           (const float*)(k123 + 2 * C), (hl_dx && (C % 32) == 0 && !keep_dx) ? nullptr : dx, g_out,            \
-                           (dcnsplit::u32x4*)dq, (const float*)absmax, C / 4, rows, rpg, 4 * C, 3 * C,                         \
-                           (C % 32) == 0 ? (dcnsplit::u32x2*)hl_dx : nullptr, (tuning().bn_reverse >> 1) & 1, (tuning().bn_nt >> 1) & 1, f, cw)
-        if (coop) DCN_BN_BLK(true); else DCN_BN_BLK(false);
-#undef DCN_BN_BLK
+                                                                      (dq ? 4.0 : 0.0) + (hl ? 4.0 : 0.0)), st);
+        hipLaunchKernelGGL(bn_bwd_apply_blocked_kernel, dim3(blocks_for(((rows + 3) / 4) * (C / 4), kGridCap)), dim3(256), 0, st,
+                           dy, dy2, relu_out, relu_mask, x, mean, invstd, (const float*)k123, (const float*)(k123 + C),
+                           (const float*)(k123 + 2 * C), (hl_dx && (C % 32) == 0 && !keep_dx) ? nullptr : dx, g_out,
+                           (dcnsplit::u32x4*)dq, (const float*)absmax, C / 4, rows, rpg, 4 * C, 3 * C,
+                           (C % 32) == 0 ? (dcnsplit::u32x2*)hl_dx : nullptr, (tuning().bn_reverse >> 1) & 1, (tuning().bn_nt >> 1) & 1);
         return;
     }
-    ObservedLaunch obs(DCN_PROF_BN_BWD_APPLY, (double)rows * C * (in_bytes + 4.0 + (g_out ? 4.0 : 0.0)) + fin_bytes, st);
-#define DCN_BN_APP(COOP)                                                                                                      \
-    hipLaunchKernelGGL(bn_bwd_apply_kernel<COOP>, dim3(grid), dim3(256), 0, st, dy, dy2, relu_out, relu_mask,                     \
-                       x, mean, invstd, (const float*)k123, (const float*)(k123 + C), (const float*)(k123 + 2 * C), dx, g_out,  \
-                       C / 4, total4, total4 / groups, 4 * C, 3 * C, (tuning().bn_reverse >> 1) & 1, f, cw)
-    if (coop) DCN_BN_APP(true); else DCN_BN_APP(false);
-#undef DCN_BN_APP
+    ObservedLaunch obs(DCN_PROF_BN_BWD_APPLY, (double)rows * C * (in_bytes + 4.0 + (g_out ? 4.0 : 0.0)), st);
+    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(blocks_for(total4, kGridCap)), dim3(256), 0, st, dy, dy2, relu_out, relu_mask,
+                       x, mean, invstd, (const float*)k123, (const float*)(k123 + C), (const float*)(k123 + 2 * C), dx, g_out,
+                       C / 4, total4, total4 / groups, 4 * C, 3 * C, (tuning().bn_reverse >> 1) & 1);
 }
 void launch_add(const float* a, const float* b, float* out, int64_t n, hipStream_t st) {
     ObservedLaunch obs(DCN_PROF_OTHER, 12.0 * (double)n, st);

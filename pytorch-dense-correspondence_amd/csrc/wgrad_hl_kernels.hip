@@ -319,8 +319,9 @@ extern "C" int dcn_conv_wgrad_hl_eligible(const dcn_conv_desc* c) {
     // (round 3 asked for M >= 16384: at two images the step lost 0.5 % -- with the main stream's GEMMs on 38-76 tiles the
     // fp32-operand kernel's launches ran for free on the idle CUs.  Round 5: the small-tile forward / dgrad kernel fills the
     // chip at that size too, the weight gradients are then paid in full, and per launch this kernel is the faster one at two
-    // images already -- layer 4 137 vs 187 us, layer 3 52 vs 61 us, profiles/r5a_wgrad_n2.txt)
-    const int64_t min_m = dcn::tuning().wgrad_hl_min_m > 0 ? dcn::tuning().wgrad_hl_min_m : 8192;
+    // images already -- layer 4 137 vs 187 us, layer 3 52 vs 61 us, profiles/r5a_wgrad_n2.txt -- and at one: 82 vs 113 us,
+    // 39 vs 41 us, profiles/r5b_wgrad_n1.txt)
+    const int64_t min_m = dcn::tuning().wgrad_hl_min_m > 0 ? dcn::tuning().wgrad_hl_min_m : 4096;
     return ((c->cout % 256) == 0 && c->kh * c->kw * c->cin >= 1024 && (int64_t)c->n * c->hout * c->wout >= min_m) ? 1 : 0;
 }
 

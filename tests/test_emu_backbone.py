@@ -539,34 +539,6 @@ def test_backward_refuses_an_arena_whose_forward_decisions_no_longer_hold(dcn_en
         _bb._PLANS.clear()
 
 
-@pytest.mark.parametrize("arch,bw,shape,pair", [("Resnet50_8s", 8, (2, 32, 40), False), ("Resnet18_8s", 8, (1, 64, 64), True)])
-def test_cooperative_bn_finalize_is_bit_identical(arch, bw, shape, pair, dcn_env, conv_mode):
-    """DCN_BN_COOP: the batch-norm finalize done by the first workgroups of the apply pass that consumes the statistics (ticket
-    word, write-through statistics, done count: elementwise_kernels.hip) against the stand-alone finalize launches -- the same
-    arithmetic in the same order: descriptors, gradients and running statistics bit for bit, one batch and a grouped pair."""
-    N, H, W = shape
-    g = torch.Generator().manual_seed(21)
-    xa, xb = torch.randn(N, 3, H, W, generator=g), torch.randn(N, 3, H, W, generator=g)
-    gy = torch.randn(N, 3, H, W, generator=g)
-    res = []
-    for coop in (1, 0):
-        dcn_env(DCN_BN_COOP=coop)
-        m, _ = _pair(arch, 3, bw)
-        m.train()
-        if pair:
-            ya, yb = m.forward_pair(xa, xb)
-            ((ya * gy).sum() + (yb * gy).sum() * 0.5).backward()
-            out = [ya.detach().clone(), yb.detach().clone()]
-        else:
-            y = m(xa)
-            (y * gy).sum().backward()
-            out = [y.detach().clone()]
-        res.append(out + [p.grad.clone() for p in m.parameters()] + [b.clone() for b in m.buffers()])
-    assert len(res[0]) == len(res[1])
-    for a, b in zip(*res):
-        assert torch.equal(a, b)
-
-
 def test_many_forward_calls_outstanding_before_one_backward(conv_mode):
     """Ten separate training-mode forward calls of one plan, losses summed, ONE backward(): every arena is differentiated
     (the engine used to keep the decisions of the newest 8 forward calls only and refused the older arenas)."""
@@ -582,14 +554,10 @@ def test_many_forward_calls_outstanding_before_one_backward(conv_mode):
         assert rel_err(p.grad, po.grad) < 2e-4, (k, rel_err(p.grad, po.grad))
 
 
-@pytest.mark.parametrize("coop", [1, 0])
-def test_profile_reports_every_engine_launch_by_category(conv_mode, coop, dcn_env):
+def test_profile_reports_every_engine_launch_by_category(conv_mode):
     """dcn_plan_profile_end_all: between begin and end every launch of the engine is bracketed and attributed to a category
-    with its algorithmic work (FLOPs for the matrix-core categories, HBM bytes for the streaming passes).  coop: the
-    per-channel finalize of a batch norm done by the first workgroups of the apply pass that consumes it (round 5) -- the
-    finalize launches that remain are the stem's and the three downsample branches' of the forward pass."""
+    with its algorithmic work (FLOPs for the matrix-core categories, HBM bytes for the streaming passes)."""
     from dcn_hip import backbone as _bb
-    dcn_env(DCN_BN_COOP=coop)
     arch, bw, (N, H, W), D = "Resnet18_8s", 8, (2, 32, 40), 3
     m, _ = _pair(arch, D, bw)
     m.train()
@@ -600,7 +568,7 @@ def test_profile_reports_every_engine_launch_by_category(conv_mode, coop, dcn_en
     prof = plan.profile_end()
     assert set(prof) == set(_bb.Plan.PROFILE_CATEGORIES)
     n_bn, n_conv = len(plan.bn_names), len(plan.bn_names) + 1            # every convolution but the scoring layer has a batch norm
-    assert prof["bn_finalize"][1] == (1 + 3 if coop else 2 * n_bn)        # (coop off: forward + backward finalize per batch norm)
+    assert prof["bn_finalize"][1] == 2 * n_bn                             # forward + backward finalize per batch norm
     assert prof["bn_bwd_reduce"][1] == n_bn and prof["bn_bwd_apply"][1] == n_bn
     # one apply pass per batch norm, except the stem's (applied inside the max pool) and the three downsample branches'
     # (folded into their block's last pass)

@@ -59,7 +59,12 @@ def test_forward_pair_takes_two_base_pointers_and_separate_gradients(L):
     (za * ga).sum().backward()
     for (k, p), p2 in zip(dcn.named_parameters(), dcn2.parameters()):
         d = float((p.grad - p2.grad).norm() / p2.grad.norm().clamp_min(1e-20))
-        assert d < 2e-2, (k, d)        # (ReLU masks may differ where a pre-activation is within round-off of zero: as in the full-size test)
+        # fc.weight has no ReLU between it and the loss: the two call patterns must agree to round-off there (round 5: was 2e-2
+        # like the rest).  Everywhere else ONE ReLU element whose pre-activation lies within the two patterns' forward
+        # difference (other tile shapes, other summation order) of zero flips its mask: at 8 x 16 pixels per channel that is
+        # ~4e-3 of the layer's gradient per flip, up to 1e-2 accumulated below layer 4 -- measured with the float64 oracle itself
+        # (weights perturbed by 1e-6: __graft_entry__.smoke has the numbers), not an arithmetic error
+        assert d < (1e-4 if k.endswith("fc.weight") else 2e-2), (k, d)
 
 
 def test_profile_categories_on_hardware(L):
@@ -74,9 +79,7 @@ def test_profile_categories_on_hardware(L):
     plan.profile_begin()
     dcn.fcn(x).sum().backward()
     prof = plan.profile_end()
-    # (round 5: the finalize of a batch norm runs inside the apply pass that consumes it -- what is left as launches of its own:
-    #  the stem's and the three downsample branches' of the forward pass)
-    assert prof["conv_gemm"][1] == 37 + 36 and prof["conv_wgrad"][1] == 37 and prof["bn_finalize"][1] == 4
+    assert prof["conv_gemm"][1] == 37 + 36 and prof["conv_wgrad"][1] == 37 and prof["bn_finalize"][1] == 72
     for k, (ms, n, work) in prof.items():
         if k == "conv_gemm_hl":
             continue   # (a sub-count of conv_gemm)
