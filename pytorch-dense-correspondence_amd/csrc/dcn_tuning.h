@@ -25,8 +25,9 @@
 //   DCN_GEMM_HL_ROWS        192 / 256 / 320: tile height of the hl32 gather-GEMM (default 0: whichever quantises better on the
 //                           256 CUs, hl_shape in conv_hl_kernels.hip); -320: as decided, but never 320 (the round-3 choice)
 //   DCN_GEMM_HLX            0: never the small-tile variants of the hl32 gather-GEMM (conv_hlx_kernels.hip: 160 x 256 / 160 x 128
-//                           tiles, K split over workgroups); "kg" or "kg,splits": force the K groups per workgroup (1 | 2) and
-//                           the workgroups per tile along K wherever the kernel applies (0 = as decided)
+//                           tiles, K split over workgroups); 1: where hl_shape's cost model picks them (default); "kg,splits":
+//                           force the K groups per workgroup (1 | 2) and the workgroups per tile along K wherever the kernel
+//                           applies (0 = as decided)
 //   DCN_GEMM_HLX_NARROW     1: destinations of 128 channels take the 160 x 128 tile too (default: >= 256 channels only)
 //   DCN_HLX_COST            "e1,e2,split": cost-model constants of hlx_shape (per-stage cost factor of the 160 x 256 and of the
 //                           160 x 128 tile relative to a 256-row tile of conv_hl_kernels.hip; stages one parked partial costs)

@@ -37,11 +37,17 @@ void read_env(Tuning& t) {
     if (const char* e = getenv("DCN_WGRAD_SPLITS")) t.wgrad_splits = atoi(e);
     if (const char* e = getenv("DCN_GEMM_HL")) t.gemm_hl = atoi(e);
     if (const char* e = getenv("DCN_GEMM_HL_ROWS")) t.gemm_hl_rows = atoi(e);
-    if (const char* e = getenv("DCN_GEMM_HLX")) {
+    if (const char* e = getenv("DCN_GEMM_HLX")) {   // "0" / "1": off / on (as decided); "kg,splits": forced (0 = as decided)
         int a = 0, b = 0;
-        const int n = sscanf(e, "%d,%d", &a, &b);
-        if (n >= 1 && a == 0) t.gemm_hlx = 0;
-        else if (n >= 1) { t.gemm_hlx = 1; t.gemm_hlx_kg = (a == 1 || a == 2) ? a : 0; t.gemm_hlx_splits = (n >= 2 && b > 0) ? b : 0; }
+        if (strchr(e, ',')) {
+            if (sscanf(e, "%d,%d", &a, &b) == 2) {
+                t.gemm_hlx = 1;
+                t.gemm_hlx_kg = (a == 1 || a == 2) ? a : 0;
+                t.gemm_hlx_splits = b > 0 ? b : 0;
+            }
+        } else {
+            t.gemm_hlx = atoi(e) != 0;
+        }
     }
     if (const char* e = getenv("DCN_GEMM_HLX_NARROW")) t.gemm_hlx_narrow = atoi(e) != 0;
     if (const char* e = getenv("DCN_HLX_COST")) {

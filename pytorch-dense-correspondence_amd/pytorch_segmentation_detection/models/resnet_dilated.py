@@ -118,14 +118,49 @@ class _DilatedResnet8s(nn.Module):
             fcb.zero_()
         return loaded
 
+    def __getstate__(self):
+        # per-process handles (a CUDA event, pinned host memory, the owner table of _tables): not part of the module's state --
+        # copy.deepcopy / pickle of the whole module work after a forward call too
+        d = dict(self.__dict__)
+        for k in ("_pending_status", "_status_host", "_table_cache", "_last_plan"):
+            d.pop(k, None)
+        return d
+
     def _tables(self):
+        """(parameters, running statistics, num_batches_tracked) in the engine's order.  Walking the module tree by dotted name
+        (110 get_parameter + 36 get_submodule calls) cost 1.5 - 2 ms of host time per forward call -- at the reference's batch
+        size of 1 with its two forward calls per step the HOST was the bottleneck (round 5: host 10.9 of 12.2 ms) -- so the
+        owners are resolved once and every call only checks that each slot still holds the tensor it held (a parameter or buffer
+        re-registered, replaced by .to() under overwrite_module_params_on_conversion, or deleted rebuilds the table)."""
+        tab = self.__dict__.get("_table_cache")
+        if tab is not None:
+            ok = True
+            for owner, name, t in tab[0]:
+                if owner._parameters.get(name) is not t:
+                    ok = False
+                    break
+            if ok:
+                for owner, name, t in tab[1]:
+                    if owner._buffers.get(name) is not t:
+                        ok = False
+                        break
+            if ok:
+                return tab[2], tab[3], tab[4]
         trunk = getattr(self, self.attr)
-        params = [trunk.get_parameter(n) for n in self._param_names]
-        running, tracked = [], []
+        slots_p, slots_b, params, running, tracked = [], [], [], [], []
+        for n in self._param_names:
+            owner_name, _, leaf = n.rpartition(".")
+            owner = trunk.get_submodule(owner_name) if owner_name else trunk
+            t = owner._parameters[leaf]
+            slots_p.append((owner, leaf, t))
+            params.append(t)
         for n in self._bn_names:
             node = trunk.get_submodule(n)
+            for leaf in ("running_mean", "running_var", "num_batches_tracked"):
+                slots_b.append((node, leaf, node._buffers[leaf]))
             running += [node.running_mean, node.running_var]
             tracked.append(node.num_batches_tracked)
+        self.__dict__["_table_cache"] = (slots_p, slots_b, params, running, tracked)
         return params, running, tracked
 
     def forward(self, x, normalize=False, groups=1, x_b=None):
@@ -139,11 +174,11 @@ class _DilatedResnet8s(nn.Module):
                 raise ValueError("x_b needs groups=2 and the shape of x")
             n = 2 * n
         plan = _bb.get_plan(self.arch, self.base_width, int(n), int(h), int(w), self.num_classes, int(groups))
+        self._check_previous_status()   # (may raise for an EARLIER call: before this call changes any state)
         params, running, tracked = self._tables()
         if self.training:
             torch._foreach_add_(tracked, int(groups))
         owner = getattr(self, "_flat_grad_owner", None)   # dcn_hip.distributed.FlatGradients, if one manages the gradients
-        self._check_previous_status()
         self._last_plan = plan
         out = _bb.backbone_forward(x, plan, params, running, self.training, normalize, self.bn_momentum, self.bn_eps,
                                    grad_sink=owner.flat if owner is not None else None, grad_owner=owner, image_b=x_b)

@@ -102,6 +102,10 @@ void run_grid(dim3 grid, dim3 block, const std::function<void()>& body) {
     const long nblocks = (long)grid.x * grid.y * grid.z;
     const int nthreads = (int)(block.x * block.y * block.z);
     if (nblocks <= 0 || nthreads <= 0) return;
+    // HIPEMU_NOEXEC=1: launches return at once -- what is left of a call is the HOST side of the engine (plan logic, tile
+    // selection, launch bookkeeping): tools/host_overhead.py times it on a machine without a GPU
+    static const bool noexec = [] { const char* e = getenv("HIPEMU_NOEXEC"); return e && atoi(e) != 0; }();
+    if (noexec) return;
     int nworkers = (int)std::thread::hardware_concurrency();
     if (const char* e = getenv("HIPEMU_THREADS")) nworkers = atoi(e);
     if (nworkers < 1) nworkers = 1;

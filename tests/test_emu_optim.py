@@ -121,3 +121,56 @@ def test_adam_rejects_what_it_does_not_implement():
     s.grad = torch.zeros(8, 4)
     with pytest.raises(ValueError):
         Adam([s]).step()
+
+
+def test_adam_fast_path_and_its_invalidation():
+    """The steady-state path of Adam.step() (round 5: the pointer tables of the previous call, after checking that no
+    parameter, gradient buffer or state tensor moved) against torch.optim.Adam: gradients written IN PLACE into the same buffers
+    (the fast path), then a gradient tensor replaced, a missing gradient, a changed learning rate and a loaded state dict --
+    each must fall back to the general path and stay on torch's trajectory."""
+    from dcn_hip.optim import Adam
+    ours, ref = _params(3), _params(3)
+    o = Adam(ours, lr=2e-3, weight_decay=1e-4)
+    r = torch.optim.Adam(ref, lr=2e-3, weight_decay=1e-4, foreach=False)
+    _set_grads(ours, 1)
+    _set_grads(ref, 1)
+    taken = []
+    orig = o._fast_step
+    o._fast_step = lambda *a: taken.append(orig(*a)) or taken[-1]
+
+    def inplace_grads(seed):
+        g = torch.Generator().manual_seed(seed)
+        for p, q in zip(ours, ref):
+            v = torch.randn(p.shape, generator=g)
+            p.grad.copy_(v)
+            q.grad.copy_(v)
+    for it in range(4):          # steps 2-4 reuse the buffers: fast path
+        if it:
+            inplace_grads(10 + it)
+        o.step(); r.step()
+    assert taken == [False, True, True, True]
+    ours[2].grad = ours[2].grad.clone()          # a new gradient tensor for one parameter
+    o.step(); r.step()
+    assert taken[-1] is False
+    inplace_grads(30)
+    o.step(); r.step()
+    assert taken[-1] is True
+    for gr in o.param_groups + r.param_groups:   # adjust_learning_rate: read from the group every call
+        gr["lr"] *= 0.5
+    inplace_grads(31)
+    o.step(); r.step()
+    assert taken[-1] is True
+    o.load_state_dict(copy.deepcopy(o.state_dict()))   # new state tensors
+    inplace_grads(32)
+    o.step(); r.step()
+    assert taken[-1] is False
+    g5 = ours[5].grad
+    ours[5].grad, ref[5].grad = None, None       # a parameter without a gradient is skipped (its step does not advance)
+    o.step(); r.step()
+    assert taken[-1] is False
+    ours[5].grad, ref[5].grad = g5, g5.clone()
+    o.step(); r.step()                           # steps now differ between parameters: general path, two launches
+    assert taken[-1] is False
+    for a, b in zip(ours, ref):
+        assert _max_rel(a, b) < 3e-6
+        assert float(o.state[a]["step"]) == float(r.state[b]["step"])

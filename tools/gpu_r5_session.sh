@@ -17,6 +17,8 @@ for s in $steps; do
     wgradn2)   # weight gradients at two images: fp32-operand kernel vs the hl32 kernel without its M >= 16384 gate
                for hl in 1 2; do echo "--- DCN_WGRAD_HL=$hl, N = ${WG_N:-2}" | tee -a gpurun_out/${tag}_wgrad_n2.txt
                  timeout 200 env DCN_WGRAD_HL=$hl python tools/conv_bench.py --mode hl --n ${WG_N:-2} --only "layer" --kinds wgrad --x-direct --reps 20 2>&1 | grep -v "Warn\|amdgpu.ids" | grep "layer3\|layer4" | cut -c1-200 | tee -a gpurun_out/${tag}_wgrad_n2.txt; done ;;
+    convn)     # per-layer table through the C ABI at N = ${CONV_N:-2} images, the kernels the library picks by default
+               timeout 400 python tools/conv_bench.py --mode hl --n ${CONV_N:-2} --x-direct --reps 30 --relu-x 2>&1 | grep -v "Warn\|amdgpu.ids" | cut -c1-170 | tee gpurun_out/${tag}_conv_per_layer_n${CONV_N:-2}.txt ;;
     *)         bash tools/gpu_r4_session.sh $tag $s ;;
   esac
 done
