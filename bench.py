@@ -348,6 +348,18 @@ class Job(object):
             t = torch.tensor([elapsed], dtype=torch.float64, device=self.dev)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             elapsed = float(t.item())
+        # (outside the timed region) the same enqueue against an IDLE GPU, one step at a time with a synchronisation in
+        # between: the launch queue never fills, so this is the host's own cost of a step -- Python, bindings, the engine's
+        # C++ and the HIP runtime's launch path -- without the back-pressure that host_enqueue_ms includes when the GPU is
+        # the slower side.  Two steps; the smaller one.
+        idle = []
+        for it in range(2):
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            self.step(first_it + warmup + steps + it)
+            idle.append(1e3 * (time.perf_counter() - t1))
+        torch.cuda.synchronize()
+        self.host_enqueue_idle_ms = min(idle)
         return elapsed, loss
 
 
@@ -597,6 +609,7 @@ def main():
         ksum = eng_ms + opt_ms + loss_ms
         return {"ms_per_step": ms_per_step_, "kernel_ms_sum": ksum, "engine_kernel_ms": eng_ms, "engine_launches_per_step": eng_n,
                 "loss_call_ms": loss_ms, "optimizer_ms": opt_ms, "host_enqueue_ms_per_step": job_.host_enqueue_ms,
+                "host_enqueue_idle_gpu_ms_per_step": getattr(job_, "host_enqueue_idle_ms", None),
                 "engine_ms_by_category": {k: v[0] / args.profile_steps for k, v in prof.items()},
                 "engine_launches_by_category": {k: v[1] / args.profile_steps for k, v in prof.items()},
                 "note": "kernel_ms_sum = engine launches one by one (serial schedule, HIP events around each) + loss forward/backward "
@@ -778,6 +791,7 @@ def main():
                "value": images_per_step * args.steps / elapsed, "unit": "images/s", "n_gpus": world,
                "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
                "scaling": "weak", "vs_baseline": None, "host_enqueue_ms_per_step": host_enqueue_ms,
+               "host_enqueue_idle_gpu_ms_per_step": getattr(job, "host_enqueue_idle_ms", None),
                "host_enqueue_ms_per_rank": host_enqueue_per_rank, "host_usable_cpus": usable_cpus(),
                "dtype": "f32 (f16x3 products)" if args.conv_mode == "f16x3" else "f32", "data": "synthetic",
                "arithmetic": ("fp32 tensors and accumulation; convolution products as 3 fp16 MFMAs on exact hi/lo operand "

@@ -371,7 +371,8 @@ int dcn_split_weights_checked_f16(int n, const float* const* w, const float* con
  * every stride-1 convolution with >= 256 destination channels and source channels % 32 == 0 (layers 3-4 of the backbone behind
  * network.py:255 / training.py:345).  Operands are "hl32" tensors -- per 32-channel chunk one 128-byte line
  * [hi x32 | lo x32] fp16, the byte size of the fp32 tensor -- so that the GEMM loop is LDS-DMA + MFMA only (256 x 256 tiles,
- * two wavefront groups one phase apart).  Results equal dcn_conv_forward_f16 / dcn_conv_dgrad_f16 (same products, other
+ * two wavefront groups one phase apart; round 5: 160 x 256 / 160 x 128 tiles with a K split for the launches the big tiles do
+ * not fill the chip with -- B = 1, training.yaml:14 -- from 128 destination channels on: csrc/conv_hlx_kernels.hip).  Results equal dcn_conv_forward_f16 / dcn_conv_dgrad_f16 (same products, other
  * summation order).  dcn_conv_hl_eligible: 1 when the descriptor qualifies (forward: dgrad = 0). */
 int dcn_conv_hl_eligible(const dcn_conv_desc* c, int dgrad);
 int dcn_conv_num_mtiles_hl(const dcn_conv_desc* c);

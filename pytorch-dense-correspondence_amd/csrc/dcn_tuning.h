@@ -28,7 +28,8 @@
 //                           tiles, K split over workgroups); 1: where hl_shape's cost model picks them (default); "kg,splits":
 //                           force the K groups per workgroup (1 | 2) and the workgroups per tile along K wherever the kernel
 //                           applies (0 = as decided)
-//   DCN_GEMM_HLX_NARROW     1: destinations of 128 channels take the 160 x 128 tile too (default: >= 256 channels only)
+//   DCN_GEMM_HLX_NARROW     0: only destinations of >= 256 channels (or fed by >= 256) take the small tiles (default 1: the 128-channel
+//                           layers too -- layer 2: +1.5 % on a config-1 step, profiles/r5d_ab_config1.txt)
 //   DCN_HLX_COST            "e1,e2,split": cost-model constants of hlx_shape (per-stage cost factor of the 160 x 256 and of the
 //                           160 x 128 tile relative to a 256-row tile of conv_hl_kernels.hip; stages one parked partial costs)
 //   DCN_WGRAD_HL            0: the wide layers' weight gradients stay on the fp32-operand kernel (conv_f16_kernels.hip) instead of
@@ -78,7 +79,7 @@ struct Tuning {
     int gemm_hlx = 1;            // small-tile variants of the hl32 gather-GEMM where hl_shape's cost model picks them
     int gemm_hlx_kg = 0;         // forced K groups per workgroup (0: as decided)
     int gemm_hlx_splits = 0;     // forced workgroups per tile along K (0: as decided)
-    int gemm_hlx_narrow = 0;     // 128-channel destinations on the 160 x 128 tile
+    int gemm_hlx_narrow = 1;     // 128-channel destinations on the 160 x 128 tile
     double hlx_cost1 = 1.32, hlx_cost2 = 1.42, hlx_split_cost = 14.0;   // (profiles/r5a_hlx_sweep.txt, r5b_hlx_sweep.txt)
     int hlx_stagger = 1;         // see DCN_HLX_STAGGER
     int hlx_counters = 1;        // see DCN_HLX_COUNTERS
