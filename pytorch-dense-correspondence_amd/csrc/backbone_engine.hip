@@ -953,11 +953,22 @@ int forward_impl(dcn_plan* plan, const float* image, const float* image_b, const
         hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
         if (hipStreamIsCapturing(st, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) hoist = false;
     }
+    // an error return between fork and join must not leave side-stream kernels writing into arenas the caller is about to free:
+    // the guard makes the caller's stream wait for whatever the side stream has been given
+    struct ForkGuard {
+        dcn_plan& p;
+        hipStream_t st;
+        bool armed = false;
+        ~ForkGuard() {
+            if (armed && hipEventRecord(p.ev_ws[1], p.side) == hipSuccess) (void)hipStreamWaitEvent(st, p.ev_ws[1], 0);
+        }
+    } fork_guard{p, st};
     if (p.conv_mode == DCN_CONV_F16X3) {
         if (hoist) {
             Run Rs{p, params, (float*)saved, (float*)workspace, p.side};
             bool ok = hipEventRecord(p.ev_ws[0], st) == hipSuccess && hipStreamWaitEvent(p.side, p.ev_ws[0], 0) == hipSuccess;
             if (!ok) return DCN_E_LAUNCH;
+            fork_guard.armed = true;
             DCN_TRY(Rs.split_all_weights(false, Rs.Wk(p.w_wstem)));
             DCN_TRY(Rs.split_hl_weights(false));
             Rs.wh_over = Rs.S(p.s_wht); Rs.wl_over = Rs.S(p.s_wlt); Rs.whl_over = Rs.S(p.s_whlt);
@@ -994,6 +1005,7 @@ int forward_impl(dcn_plan* plan, const float* image, const float* image_b, const
         }
     }
     if (hoist && hipStreamWaitEvent(st, p.ev_ws[1], 0) != hipSuccess) return DCN_E_LAUNCH;   // join: the weight images are there
+    fork_guard.armed = false;
     if (training && f16_mode && p.blocks[0].has_hl_in) {   // (the first block's input is the max-pool output: no apply pass writes it)
         const BlockL& b0 = p.blocks[0];
         R.hl_saved.emplace_back(R.S(b0.in), R.S(b0.hl_in));
