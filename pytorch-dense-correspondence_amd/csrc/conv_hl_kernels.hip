@@ -234,55 +234,55 @@ __device__ __forceinline__ void gemm_segment_hl(const GemmConv& p, unsigned char
         }
     };
 
-    // ---- fragments: lane (fi = lane & 31, fh = lane >> 5) holds 8 consecutive k (k-octet 2 ks + fh) of row fi of a 32-row tile
-    const int fi = lane & 31, fh = lane >> 5, swz = (fi >> 1) & 7;
-    int foff[2][2];   // [plane][ks]: byte offset of the lane's slot inside its row (plane 0 = hi, 1 = lo)
+    // ---- fragments (round 5: v_mfma_f32_16x16x32_f16 tiles -- the same two-group schedule sustains 10-15 % more on that shape,
+    // tools/hl_gemm_probe3.hip / profiles/r5g_hl_probe3.txt: half the accumulator-register traffic per FLOP under the power
+    // limit; the LDS image, the DMA schedule and the NUMBER of fragment reads are unchanged): lane (fr = lane & 15,
+    // fq = lane >> 4) holds k-octet fq of the stage's 32 k of row fr of a 16-row block; plane 0 = hi, 1 = lo.  The source-side
+    // XOR swizzle (slot ^ ((row >> 1) & 7)) is conflict-free for the ds_read_b128 lane groups of this layout too (rows 0-3 /
+    // 12-15 of one octet with rows 4-11 of the next: 16 distinct (row parity, slot) pairs).
+    const int fr = lane & 15, fq = lane >> 4, swz = (fr >> 1) & 7;
+    int foff[2];   // [plane]: byte offset of the lane's slot inside its 16-row block
 #pragma unroll
-    for (int pl = 0; pl < 2; ++pl)
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) foff[pl][ks] = ((pl * 4 + ks * 2 + fh) ^ swz) * 16;
-    const int a_row = (grp * GR + fi) * 128, b_row = kAB + (wn * 64 + fi) * 128;
+    for (int pl = 0; pl < 2; ++pl) foff[pl] = fr * 128 + ((pl * 4 + fq) ^ swz) * 16;
+    const int a_row = (grp * GR) * 128, b_row = kAB + (wn * 64) * 128;
 
-    f32x16 acc[MT][2];   // [tm][tn]: rows GR g + 32 tm, columns 64 wn + 32 tn  (the common epilogue's map; MT = 4: tm = 2 i + t)
+    f32x4_t acc[2 * MT][4];   // [row block of 16][column block of 16]: rows GR g + 16 tb, columns 64 wn + 16 cb
 #pragma unroll
-    for (int i = 0; i < MT; ++i)
+    for (int i = 0; i < 2 * MT; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
     using T = std::true_type;
     using F = std::false_type;
     // raw s_barrier: no fence, LDS-DMA stays in flight across it
     auto bar = [&]() { __builtin_amdgcn_sched_barrier(0); __builtin_amdgcn_s_barrier(); __builtin_amdgcn_sched_barrier(0); };
   if constexpr (MT == 4) {
-    h8 fa[2][2][2], fb[2][2];   // A: [t][ks][plane], B: [ks][plane]
+    h8 fa[4][2], fb[2][2];   // A: [row block of the quadrant's 64 rows][plane], B: [column block of its 32 columns][plane]
     auto read_a = [&](int buf, int i) {
         const unsigned char* st = lds + buf * kHlStage + a_row + i * 8192;
 #pragma unroll
-        for (int t = 0; t < 2; ++t)
+        for (int rb = 0; rb < 4; ++rb)
 #pragma unroll
-            for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-                for (int pl = 0; pl < 2; ++pl) fa[t][ks][pl] = *reinterpret_cast<const h8*>(st + t * 4096 + foff[pl][ks]);
+            for (int pl = 0; pl < 2; ++pl) fa[rb][pl] = *reinterpret_cast<const h8*>(st + rb * 2048 + foff[pl]);
     };
     auto read_b = [&](int buf, int j) {
         const unsigned char* st = lds + buf * kHlStage + b_row + j * 4096;
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks)
+        for (int cb = 0; cb < 2; ++cb)
 #pragma unroll
-            for (int pl = 0; pl < 2; ++pl) fb[ks][pl] = *reinterpret_cast<const h8*>(st + foff[pl][ks]);
+            for (int pl = 0; pl < 2; ++pl) fb[cb][pl] = *reinterpret_cast<const h8*>(st + cb * 2048 + foff[pl]);
     };
-    // product-type outermost, the two accumulators of the quadrant alternating; the small cross terms before hi * hi
+    // product-type outermost, the eight accumulators of the quadrant in between; the small cross terms before hi * hi
     auto mfma_quadrant = [&](int i, int j) {
         __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int pt = 0; pt < 3; ++pt)
 #pragma unroll
-            for (int ks = 0; ks < 2; ++ks)
+            for (int rb = 0; rb < 4; ++rb)
 #pragma unroll
-                for (int t = 0; t < 2; ++t)
-                    acc[2 * i + t][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(pt == 0 ? fa[t][ks][1] : fa[t][ks][0],
-                                                                              pt == 1 ? fb[ks][1] : fb[ks][0], acc[2 * i + t][j], 0, 0, 0);
+                for (int cb = 0; cb < 2; ++cb)
+                    acc[4 * i + rb][2 * j + cb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(pt == 0 ? fa[rb][1] : fa[rb][0],
+                                                                                         pt == 1 ? fb[cb][1] : fb[cb][0],
+                                                                                         acc[4 * i + rb][2 * j + cb], 0, 0, 0);
         __builtin_amdgcn_s_setprio(0);
     };
     // one phase of stage s (LDS buffer s & 1).  MORE: stage s + 1 exists -- issue its half-tile p and leave two half-tiles
@@ -330,33 +330,31 @@ __device__ __forceinline__ void gemm_segment_hl(const GemmConv& p, unsigned char
     phase(F{}, buf, 2);
     phase(F{}, buf, 3);
   } else {
-    h8 fa[2][2], fb[2][2][2];   // A: [ks][plane] of the phase's row block, B: [j][ks][plane] of the stage
+    h8 fa[2][2], fb[4][2];   // A: [16-row block][plane] of the phase's 32-row block, B: [column block of 16][plane] of the stage
     auto read_a = [&](int buf, int tm) {
         const unsigned char* st = lds + buf * kHlStage + a_row + tm * 4096;
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks)
+        for (int rb = 0; rb < 2; ++rb)
 #pragma unroll
-            for (int pl = 0; pl < 2; ++pl) fa[ks][pl] = *reinterpret_cast<const h8*>(st + foff[pl][ks]);
+            for (int pl = 0; pl < 2; ++pl) fa[rb][pl] = *reinterpret_cast<const h8*>(st + rb * 2048 + foff[pl]);
     };
     auto read_b = [&](int buf) {
         const unsigned char* st = lds + buf * kHlStage + b_row;
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int cb = 0; cb < 4; ++cb)
 #pragma unroll
-            for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-                for (int pl = 0; pl < 2; ++pl) fb[j][ks][pl] = *reinterpret_cast<const h8*>(st + j * 4096 + foff[pl][ks]);
+            for (int pl = 0; pl < 2; ++pl) fb[cb][pl] = *reinterpret_cast<const h8*>(st + cb * 2048 + foff[pl]);
     };
     auto mfma_block = [&](int tm) {
         __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int pt = 0; pt < 3; ++pt)
 #pragma unroll
-            for (int ks = 0; ks < 2; ++ks)
+            for (int rb = 0; rb < 2; ++rb)
 #pragma unroll
-                for (int j = 0; j < 2; ++j)
-                    acc[tm][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(pt == 0 ? fa[ks][1] : fa[ks][0],
-                                                                        pt == 1 ? fb[j][ks][1] : fb[j][ks][0], acc[tm][j], 0, 0, 0);
+                for (int cb = 0; cb < 4; ++cb)
+                    acc[2 * tm + rb][cb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(pt == 0 ? fa[rb][1] : fa[rb][0],
+                                                                                  pt == 1 ? fb[cb][1] : fb[cb][0], acc[2 * tm + rb][cb], 0, 0, 0);
         __builtin_amdgcn_s_setprio(0);
     };
     // one phase of stage s (LDS buffer s & 1).  AHEAD: how many later stages of the segment exist (2 = at least two).
@@ -467,34 +465,25 @@ __device__ __forceinline__ void gemm_segment_hl(const GemmConv& p, unsigned char
     const float sa = p.a_absmax ? pow2_scale(*p.a_absmax) : 1.f;   // (the scale the producer of the hl32 image applied)
     const float inv = p.b_inv_scale / sa;
 #pragma unroll
-    for (int tm = 0; tm < MT; ++tm)
+    for (int tb = 0; tb < 2 * MT; ++tb)
 #pragma unroll
-        for (int tn = 0; tn < 2; ++tn)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[tm][tn][r] *= inv;
+        for (int cb = 0; cb < 4; ++cb) acc[tb][cb] *= inv;
     if (k0 == 0 && k1 == nk) {
-        gemm_epilogue<2, MT, 2, 16, 4>(p, acc, mt, nt, reinterpret_cast<float*>(lds));
+        gemm_epilogue16<2 * MT, 4, BM, 256>(p, acc, mt, nt, grp, grp * GR, wn * 64, reinterpret_cast<float*>(lds));
         return;
     }
     // ---- stream-K partial: parked device-coherently, completed by the last contributor inside the launch
-    // (conv_f16_kernels.hip, gemm_segment_f16: same protocol and slot layout [wavefront][tm][tn][r / 4][lane][r % 4])
-    constexpr int TM = MT, TN = 2;
+    // (conv_f16_kernels.hip, gemm_segment_f16: same protocol; slot layout [wavefront][row block][column block][lane] float4)
+    constexpr int TM = MT;
     const __amdgpu_buffer_rsrc_t rs_p = __builtin_amdgcn_make_buffer_rsrc(p.sk_partial, 0, (int)p.sk_bytes, 0x00020000);
     constexpr int kSc1 = 16;
-    const int lane_off = (wv * (TM * TN * 16 * 64) + lane * 4) * 4;
+    constexpr int kPieces = 2 * MT * 4;   // float4 pieces per lane
+    const int lane_off = (wv * (kPieces * 64) + lane) * 16;
     {
         const int so = (int)((slot - p.sk_partial) * 4);
 #pragma unroll
-        for (int tm = 0; tm < TM; ++tm)
-#pragma unroll
-            for (int tn = 0; tn < TN; ++tn)
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const float4 v = make_float4(acc[tm][tn][4 * q], acc[tm][tn][4 * q + 1], acc[tm][tn][4 * q + 2],
-                                                 acc[tm][tn][4 * q + 3]);
-                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rs_p,
-                                                           lane_off + ((tm * TN + tn) * 4 + q) * 1024, so, kSc1);
-                }
+        for (int pc = 0; pc < kPieces; ++pc)
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, acc[pc >> 2][pc & 3]), rs_p, lane_off + pc * 1024, so, kSc1);
     }
     const int rel = tile - p.sk_dp;
     const int ua = rel * nk, ub = ua + nk - 1;
@@ -506,14 +495,12 @@ __device__ __forceinline__ void gemm_segment_hl(const GemmConv& p, unsigned char
     __syncthreads();
     if (*s_last) {
 #pragma unroll
-        for (int tm = 0; tm < TM; ++tm)
+        for (int tb = 0; tb < 2 * MT; ++tb)
 #pragma unroll
-            for (int tn = 0; tn < TN; ++tn)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc[tm][tn][r] = 0.f;
+            for (int cb = 0; cb < 4; ++cb) acc[tb][cb] = f32x4_t{0.f, 0.f, 0.f, 0.f};
         // (each contributor's partial in batches of 16 (12) loads of 16 B issued back to back, then added: left to itself the
         // compiler waits for every 4 loads -- device-coherent round trips on the critical path of the launch)
-        constexpr int kPieces = TM * TN * 4, kBatch = TM == 4 ? 16 : (TM == 3 ? 12 : 10);
+        constexpr int kBatch = TM == 4 ? 16 : (TM == 3 ? 12 : 10);
         static_assert(kPieces % kBatch == 0, "whole batches");
         for (int g = ga; g <= gb; ++g) {               // fixed order, own partial included: deterministic
             const int first_tile = (g * p.sk_units) / nk;
@@ -525,17 +512,12 @@ __device__ __forceinline__ void gemm_segment_hl(const GemmConv& p, unsigned char
                 for (int j = 0; j < kBatch; ++j) t[j] = __builtin_amdgcn_raw_buffer_load_b128(rs_p, lane_off + (b0 + j) * 1024, so, kSc1);
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int j = 0; j < kBatch; ++j) {
-                    const int pc = b0 + j, blk = pc >> 2, q = pc & 3;
-                    const float4 v = __builtin_bit_cast(float4, t[j]);
-                    acc[blk / TN][blk % TN][4 * q] += v.x; acc[blk / TN][blk % TN][4 * q + 1] += v.y;
-                    acc[blk / TN][blk % TN][4 * q + 2] += v.z; acc[blk / TN][blk % TN][4 * q + 3] += v.w;
-                }
+                for (int j = 0; j < kBatch; ++j) acc[(b0 + j) >> 2][(b0 + j) & 3] += __builtin_bit_cast(f32x4_t, t[j]);
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
         __syncthreads();                               // (s_last has been read by everyone: the epilogue reuses the array)
-        gemm_epilogue<2, MT, 2, 16, 4>(p, acc, mt, nt, reinterpret_cast<float*>(lds));
+        gemm_epilogue16<2 * MT, 4, BM, 256>(p, acc, mt, nt, grp, grp * GR, wn * 64, reinterpret_cast<float*>(lds));
         if (tid == 0) atomicExch(p.sk_count + rel, 0ull);
     }
 }

@@ -40,7 +40,7 @@ using namespace dcnconv;
 using namespace dcnsplit;
 
 typedef __attribute__((address_space(3))) void* hlx_lds_ptr;
-typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef f32x4_t f32x4;
 
 constexpr int kOob = (int)0x80000000;   // voffset that fails the bounds check of any buffer <= 2 GiB: LDS receives zeros
 constexpr int XR = 160;                 // rows per tile
@@ -59,68 +59,6 @@ template <int KG> struct Hlx {
 // (a NON-template function: inside a template this builtin breaks the host-side kernel stub with this compiler)
 __device__ __forceinline__ void glds16x(__amdgpu_buffer_rsrc_t rs, void* lds_dst, int voffset, int soffset) {
     __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (hlx_lds_ptr)lds_dst, 16, voffset, soffset, 0, 0);
-}
-
-// Epilogue of one wavefront's 80 x (16 TNE) block: rows rb .. rb + 79, columns cb .. of the tile (mt, nt).
-// C/D map of the 16 x 16 tiles: column = lane & 15, row = 4 (lane >> 4) + register.  + bias, + residual gradient, per-M-tile
-// batch-norm partial statistics (sum, sum of squares, max |x| of the accumulators; fixed order) like gemm_epilogue.
-template <int BN, int TNE>
-__device__ __forceinline__ void hlx_epilogue(const GemmConv& p, f32x4 (&out)[XTM][TNE], int mt, int nt, int wm, int cb, float* red) {
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int fc = lane & 15, fq = lane >> 4;
-    const int m0 = mt * XR + wm * 80, n0 = nt * BN;
-    float csum[TNE], csq[TNE], cmax[TNE];
-#pragma unroll
-    for (int tn = 0; tn < TNE; ++tn) {
-        csum[tn] = 0.f; csq[tn] = 0.f; cmax[tn] = 0.f;
-        const int col = n0 + cb + tn * 16 + fc;
-        const bool cok = col < p.cd;
-        const float bv = (p.bias && cok) ? p.bias[col] : 0.f;
-#pragma unroll
-        for (int tm = 0; tm < XTM; ++tm) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int row = m0 + tm * 16 + 4 * fq + r;
-                const float a = out[tm][tn][r];
-                if (cok && row < p.M) {
-                    const int64_t o = (int64_t)row * p.ldc + col;
-                    float v = a + bv;
-                    if (p.add) v += p.add[o];
-                    p.dst[o] = v;
-                }
-                csum[tn] += a;
-                csq[tn] = fmaf(a, a, csq[tn]);
-                cmax[tn] = fmaxf(cmax[tn], fabsf(a));
-            }
-        }
-    }
-    if (p.bn_partial) {
-        // rows >= M and columns >= cd are exactly zero in the accumulators (zero-filled fragments): no masking needed
-#pragma unroll
-        for (int tn = 0; tn < TNE; ++tn) {
-            csum[tn] += __shfl_xor(csum[tn], 16, 64);
-            csq[tn] += __shfl_xor(csq[tn], 16, 64);
-            cmax[tn] = fmaxf(cmax[tn], __shfl_xor(cmax[tn], 16, 64));
-            csum[tn] += __shfl_xor(csum[tn], 32, 64);
-            csq[tn] += __shfl_xor(csq[tn], 32, 64);
-            cmax[tn] = fmaxf(cmax[tn], __shfl_xor(cmax[tn], 32, 64));
-            if (fq == 0) {
-                const int cl = cb + tn * 16 + fc;
-                red[(wm * 3 + 0) * BN + cl] = csum[tn];
-                red[(wm * 3 + 1) * BN + cl] = csq[tn];
-                red[(wm * 3 + 2) * BN + cl] = cmax[tn];
-            }
-        }
-        __syncthreads();
-        if (tid < BN && n0 + tid < p.cd) {   // the two row halves in fixed order
-            const float s = red[0 * BN + tid] + red[3 * BN + tid];
-            const float q = red[1 * BN + tid] + red[4 * BN + tid];
-            const float mx = fmaxf(red[2 * BN + tid], red[5 * BN + tid]);
-            p.bn_partial[((int64_t)mt * 3 + 0) * p.cd + n0 + tid] = s;
-            p.bn_partial[((int64_t)mt * 3 + 1) * p.cd + n0 + tid] = q;
-            p.bn_partial[((int64_t)mt * 3 + 2) * p.cd + n0 + tid] = mx;
-        }
-    }
 }
 
 // TR: dgrad (the gather runs over the output gradient with mirrored taps).
@@ -417,7 +355,7 @@ conv_gemm_hlx_kernel(GemmConv p) {
         }
         if (tid == 0) atomicExch(p.sk_count + tile, 0ull);
     }
-    hlx_epilogue<BN, TNE>(p, out, mt, nt, wm, cb, scratch);
+    gemm_epilogue16<XTM, TNE, XR, BN>(p, out, mt, nt, wm, wm * 80, cb, scratch);
 }
 
 }  // namespace

@@ -244,6 +244,73 @@ __device__ __forceinline__ void gemm_epilogue(const GemmConv& p, f32x16 (&acc)[T
 }
 
 
+// The same epilogue for accumulators made of 16 x 16 tiles (v_mfma_f32_16x16x32_f16: column = lane & 15, row = 4 (lane >> 4) +
+// register) -- the hl32 kernels since round 5 (tools/hl_gemm_probe3.hip: that shape sustains 10-15 % more than 32 x 32 x 16
+// in the same schedule -- half the accumulator-register traffic per FLOP under the power limit).  One wavefront's block:
+// TM16 x TN16 tiles at tile-relative row `row0` / column `col0` of the BM x BN workgroup tile (mt, nt); the workgroup has TWO
+// wavefronts along M (`wm` = 0 / 1: the fixed order of the statistics).  + bias, + residual gradient, per-M-tile batch-norm
+// partial statistics (sum, sum of squares, max |x| of the accumulators).  `red`: >= 6 BN floats of LDS, free to use.
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+template <int TM16, int TN16, int BM, int BN>
+__device__ __forceinline__ void gemm_epilogue16(const GemmConv& p, f32x4_t (&out)[TM16][TN16], int mt, int nt, int wm, int row0, int col0,
+                                                float* red) {
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int fc = lane & 15, fq = lane >> 4;
+    const int m0 = mt * BM + row0, n0 = nt * BN;
+    float csum[TN16], csq[TN16], cmax[TN16];
+#pragma unroll
+    for (int tn = 0; tn < TN16; ++tn) {
+        csum[tn] = 0.f; csq[tn] = 0.f; cmax[tn] = 0.f;
+        const int col = n0 + col0 + tn * 16 + fc;
+        const bool cok = col < p.cd;
+        const float bv = (p.bias && cok) ? p.bias[col] : 0.f;
+#pragma unroll
+        for (int tm = 0; tm < TM16; ++tm) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = m0 + tm * 16 + 4 * fq + r;
+                const float a = out[tm][tn][r];
+                if (cok && row < p.M) {
+                    const int64_t o = (int64_t)row * p.ldc + col;
+                    float v = a + bv;
+                    if (p.add) v += p.add[o];
+                    p.dst[o] = v;
+                }
+                csum[tn] += a;
+                csq[tn] = fmaf(a, a, csq[tn]);
+                cmax[tn] = fmaxf(cmax[tn], fabsf(a));
+            }
+        }
+    }
+    if (p.bn_partial) {
+        // rows >= M and columns >= cd are exactly zero in the accumulators (zero-filled fragments): no masking needed
+#pragma unroll
+        for (int tn = 0; tn < TN16; ++tn) {
+            csum[tn] += __shfl_xor(csum[tn], 16, 64);
+            csq[tn] += __shfl_xor(csq[tn], 16, 64);
+            cmax[tn] = fmaxf(cmax[tn], __shfl_xor(cmax[tn], 16, 64));
+            csum[tn] += __shfl_xor(csum[tn], 32, 64);
+            csq[tn] += __shfl_xor(csq[tn], 32, 64);
+            cmax[tn] = fmaxf(cmax[tn], __shfl_xor(cmax[tn], 32, 64));
+            if (fq == 0) {
+                const int cl = col0 + tn * 16 + fc;
+                red[(wm * 3 + 0) * BN + cl] = csum[tn];
+                red[(wm * 3 + 1) * BN + cl] = csq[tn];
+                red[(wm * 3 + 2) * BN + cl] = cmax[tn];
+            }
+        }
+        __syncthreads();
+        if (tid < BN && n0 + tid < p.cd) {   // the two row halves in fixed order
+            const float s = red[0 * BN + tid] + red[3 * BN + tid];
+            const float q = red[1 * BN + tid] + red[4 * BN + tid];
+            const float mx = fmaxf(red[2 * BN + tid], red[5 * BN + tid]);
+            p.bn_partial[((int64_t)mt * 3 + 0) * p.cd + n0 + tid] = s;
+            p.bn_partial[((int64_t)mt * 3 + 1) * p.cd + n0 + tid] = q;
+            p.bn_partial[((int64_t)mt * 3 + 2) * p.cd + n0 + tid] = mx;
+        }
+    }
+}
+
 // dw[i] = sum over splits of slab[s][i] in fixed order (defined in conv_kernels.hip)
 void launch_wgrad_reduce(const float* slabs, float* dw, int64_t n4, int splits, hipStream_t st);
 
