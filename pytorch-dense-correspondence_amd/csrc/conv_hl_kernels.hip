@@ -273,7 +273,7 @@ __device__ __forceinline__ void gemm_segment_hl(const GemmConv& p, unsigned char
     };
     // product-type outermost, the eight accumulators of the quadrant in between; the small cross terms before hi * hi
     auto mfma_quadrant = [&](int i, int j) {
-        __builtin_amdgcn_s_setprio(1);
+        if (p.hl_setprio) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int pt = 0; pt < 3; ++pt)
 #pragma unroll
@@ -283,7 +283,7 @@ __device__ __forceinline__ void gemm_segment_hl(const GemmConv& p, unsigned char
                     acc[4 * i + rb][2 * j + cb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(pt == 0 ? fa[rb][1] : fa[rb][0],
                                                                                          pt == 1 ? fb[cb][1] : fb[cb][0],
                                                                                          acc[4 * i + rb][2 * j + cb], 0, 0, 0);
-        __builtin_amdgcn_s_setprio(0);
+        if (p.hl_setprio) __builtin_amdgcn_s_setprio(0);
     };
     // one phase of stage s (LDS buffer s & 1).  MORE: stage s + 1 exists -- issue its half-tile p and leave two half-tiles
     // in flight; otherwise drain what the next phases read.
@@ -346,7 +346,7 @@ __device__ __forceinline__ void gemm_segment_hl(const GemmConv& p, unsigned char
             for (int pl = 0; pl < 2; ++pl) fb[cb][pl] = *reinterpret_cast<const h8*>(st + cb * 2048 + foff[pl]);
     };
     auto mfma_block = [&](int tm) {
-        __builtin_amdgcn_s_setprio(1);
+        if (p.hl_setprio) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int pt = 0; pt < 3; ++pt)
 #pragma unroll
@@ -355,7 +355,7 @@ __device__ __forceinline__ void gemm_segment_hl(const GemmConv& p, unsigned char
                 for (int cb = 0; cb < 4; ++cb)
                     acc[2 * tm + rb][cb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(pt == 0 ? fa[rb][1] : fa[rb][0],
                                                                                   pt == 1 ? fb[cb][1] : fb[cb][0], acc[2 * tm + rb][cb], 0, 0, 0);
-        __builtin_amdgcn_s_setprio(0);
+        if (p.hl_setprio) __builtin_amdgcn_s_setprio(0);
     };
     // one phase of stage s (LDS buffer s & 1).  AHEAD: how many later stages of the segment exist (2 = at least two).
     auto phase = [&](auto ahead_tag, int buf, int ph) {
@@ -688,6 +688,7 @@ int launch_gemm_hl(GemmConv& p, int group_rows, void* workspace, hipStream_t st)
     p.div_kw = make_fastdiv(p.kw);
     const HlShape g = hl_shape(p.M, p.cd, p.K, group_rows, p.kh * p.kw, p.cs);
     if (!g.ok) return DCN_E_UNSUPPORTED;
+    p.hl_setprio = dcn::tuning().hl_setprio;
     if (g.rows == kHlxRows) {
         if (g.x.splits > 1 && !workspace) {   // no scratch (the tuning changed after the plan was sized): the same tiles, unsplit
             HlxShape x1 = g.x;

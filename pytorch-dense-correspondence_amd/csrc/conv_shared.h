@@ -65,6 +65,7 @@ struct GemmConv {
     FastDiv div_hw, div_w, div_cs, div_kw, div_nt, div_nk;
     // small-tile hl32 kernel (conv_hlx_kernels.hip): workgroups per tile along K (contiguous stage ranges), tiles per launch
     int ksplit = 0;
+    int hl_setprio = 1;    // s_setprio 1 around the MFMA bursts of the big-tile hl32 kernel (DCN_HL_SETPRIO)
     int hlx_stagger = 1;   // wavefronts 4-7 issue the next stage's LDS-DMA between the two parts of their compute slot (0: in front)
     FastDiv div_tiles = {0u, 0u, 1};
 };

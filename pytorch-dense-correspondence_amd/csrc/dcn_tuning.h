@@ -34,6 +34,7 @@
 //                           160 x 128 tile relative to a 256-row tile of conv_hl_kernels.hip; stages one parked partial costs)
 //   DCN_WGRAD_HL            0: the wide layers' weight gradients stay on the fp32-operand kernel (conv_f16_kernels.hip) instead of
 //                           the pre-split (hl32) LDS-DMA kernel (wgrad_hl_kernels.hip); 2: every supported convolution (tests)
+//   DCN_HL_SETPRIO          0: no s_setprio around the MFMA bursts of the big-tile hl32 kernels (conv_hl_kernels.hip, wgrad_hl_kernels.hip)
 //   DCN_HLX_STAGGER         0: every wavefront of the small-tile kernel issues the next stage's LDS-DMA in front of its compute slot
 //                           (default 1: wavefronts 4-7 between the two parts of theirs -- the partner on the SIMD computes meanwhile)
 //   DCN_HLX_COUNTERS        0: the arrival words of the small-tile kernel's K splits live in the caller's scratch and are cleared by
@@ -81,6 +82,7 @@ struct Tuning {
     int gemm_hlx_splits = 0;     // forced workgroups per tile along K (0: as decided)
     int gemm_hlx_narrow = 1;     // 128-channel destinations on the 160 x 128 tile
     double hlx_cost1 = 1.32, hlx_cost2 = 1.42, hlx_split_cost = 14.0;   // (profiles/r5a_hlx_sweep.txt, r5b_hlx_sweep.txt)
+    int hl_setprio = 1;          // see DCN_HL_SETPRIO
     int hlx_stagger = 1;         // see DCN_HLX_STAGGER
     int hlx_counters = 1;        // see DCN_HLX_COUNTERS
     int wgrad_hl_min_m = 0;      // 0: the default of dcn_conv_wgrad_hl_eligible

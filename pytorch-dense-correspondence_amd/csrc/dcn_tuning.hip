@@ -57,6 +57,7 @@ void read_env(Tuning& t) {
     if (const char* e = getenv("DCN_HL_ONLY_MID")) t.hl_only_mid = atoi(e);
     if (const char* e = getenv("DCN_STEM_POOL_FUSED")) t.stem_pool_fused = atoi(e);
     if (const char* e = getenv("DCN_WGRAD_HL")) t.wgrad_hl = atoi(e);
+    if (const char* e = getenv("DCN_HL_SETPRIO")) t.hl_setprio = atoi(e) != 0;
     if (const char* e = getenv("DCN_HLX_STAGGER")) t.hlx_stagger = atoi(e) != 0;
     if (const char* e = getenv("DCN_HLX_COUNTERS")) t.hlx_counters = atoi(e) != 0;
     if (const char* e = getenv("DCN_WGRAD_HL_MIN_M")) t.wgrad_hl_min_m = atoi(e);

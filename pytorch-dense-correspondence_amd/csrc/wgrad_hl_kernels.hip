@@ -13,8 +13,13 @@
 //     8-byte runs S[s][0..3]; lane i receives S[4 j + (i >> 2)][i & 3], j = 0..3): a group that supplies pixel rows
 //     k0 + (s >> 2) and channels 4 (s & 3) .. + 3 hands lane i the four pixels k0 .. k0 + 3 of channel i -- two reads make
 //     the 8-k operand of one lane.
-// The 64-byte slots of a pixel's 512 bytes are XOR-swizzled with (pixel & 3) on the source side of the DMA, so that the four
-// pixel rows a 32-lane access touches fall into the four quarters of the 64 banks (row pitch 512 B = 0 mod 256 otherwise).
+// Round 5: v_mfma_f32_16x16x32_f16 tiles (the two-group schedule sustains 10-15 % more on that shape: tools/hl_gemm_probe3.hip) --
+// lane (channel fr = lane & 15, k-octet fq = lane >> 4) holds the pixels 8 fq .. 8 fq + 7 of the 32-pixel stage: lane group fq reads
+// the pixel rows 8 fq + (s >> 2) (+ 4 for the second read), ONE 16-channel block per read.  A 32-lane access then touches EIGHT
+// pixel rows (8 fq' + 0..3, fq' = two consecutive groups) x 32 bytes: the 32-byte units of a pixel's 512 bytes are XOR-swizzled
+// with key(pixel) = (pixel & 3) | ((pixel >> 3) & 1) << 2 on the source side of the DMA, so that those eight rows fall into the
+// eight 32-byte groups of the 64 banks (row pitch 512 B = 0 mod 256 otherwise).  (Rounds 3-4: 32 x 32 x 16 tiles, 64-byte slots
+// swizzled with pixel & 3 -- four rows x two channel halves per access.)
 // Half-tiles in the order the phases first need them, as in the forward kernel: H0 = A_0, H1 = B_0, H2 = B_1, H3 = A_1 with
 //     A_i = the dy channels {128 g + 64 i + [0, 64)} (g = 0, 1: local chunk a = 2 g + t),  B_j = the x columns
 //     {64 wn + 32 j + [0, 32)} (wn = 0..3: local chunk b = wn)
@@ -55,7 +60,7 @@ struct WgradHl {
     const float* x_absmax;
     const float* d_absmax;
     unsigned x_bytes, d_bytes;
-    int hin, win, cin, cout, kh, kw, pad, dil, ldo, M, K, splits, stages_per_split, ntiles_n, ntiles_k, cpt;
+    int hin, win, cin, cout, kh, kw, pad, dil, ldo, M, K, splits, stages_per_split, ntiles_n, ntiles_k, cpt, setprio;
     FastDiv div_hw, div_w, div_cpt, div_kw;
 };
 
@@ -78,18 +83,21 @@ conv_wgrad_hl_kernel(WgradHl p) {
     const __amdgpu_buffer_rsrc_t rs_d = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.dh), 0, (int)p.d_bytes, 0x00020000);
 
     // ---- LDS-DMA pieces of this lane.  Piece e (0, 1) of every half-tile covers stage pixels 4 wv + 2 e + {0, 1}: lanes
-    // 0-31 the first, 32-63 the second; lane l fills PHYSICAL 16-byte slot l & 31 of its pixel's 512 bytes = logical 64-byte
-    // slot ((l & 31) >> 2) ^ (pixel & 3) -> (local chunk = slot >> 1, plane = slot & 1), 16-byte quarter l & 3.
+    // 0-31 the first, 32-63 the second; lane l fills PHYSICAL 16-byte slot l & 31 of its pixel's 512 bytes = 16-byte half
+    // (l & 1) of physical 32-byte unit (l & 31) >> 1 = logical unit ((l & 31) >> 1) ^ key(pixel) -> (64-byte slot = unit >> 1 ->
+    // local chunk = slot >> 1, plane = slot & 1; 16-channel block = unit & 1).
     const int lp = lane >> 5, p16 = lane & 31;
     const int ldo4 = p.ldo * 4, cin4 = p.cin * 4;
     int kp[2];                    // pixel index inside the stage
-    int cA[2][2], cB[2][2];       // [i | j][e]: byte offset inside the source pixel (chunk line + plane + quarter), or -1: no such chunk
+    int cA[2][2], cB[2][2];       // [i | j][e]: byte offset inside the source pixel (chunk line + plane + 16-byte piece), or -1: no such chunk
     int tdy[2][2], tdx[2][2];     // [j][e]: filter-tap offset (input pixel = output pixel + this) of the lane's x chunk
 #pragma unroll
     for (int e = 0; e < 2; ++e) {
         kp[e] = 4 * wv + 2 * e + lp;
-        const int slot = (p16 >> 2) ^ (kp[e] & 3);
-        const int lc = slot >> 1, pl = slot & 1, q16 = p16 & 3;
+        const int key = (kp[e] & 3) | (((kp[e] >> 3) & 1) << 2);
+        const int unit = (p16 >> 1) ^ key;
+        const int slot = unit >> 1;
+        const int lc = slot >> 1, pl = slot & 1, q16 = 2 * (unit & 1) + (p16 & 1);
 #pragma unroll
         for (int i = 0; i < 2; ++i) {   // A_i: local chunk lc = 2 g' + t  <->  tile chunk 4 g' + 2 i + t
             const int chunk = n0 / 32 + 4 * (lc >> 1) + 2 * i + (lc & 1);
@@ -161,27 +169,26 @@ conv_wgrad_hl_kernel(WgradHl p) {
         }
     };
 
-    // ---- fragments: lane (group gq = lane >> 4, s = lane & 15) supplies pixel row 16 ks + 8 (gq >> 1) + 4 h + (s >> 2),
-    // channels 16 (gq & 1) + 4 (s & 3) .. + 3 of a 32-channel tile and receives the pixels 16 ks + 8 fh + 4 h .. + 3 of channel
-    // lane & 31 (fh = lane >> 5 = gq >> 1): element 4 h + .. of the lane's 8-k MFMA operand
+    // ---- fragments: lane (group gq = lane >> 4, s = lane & 15) supplies pixel row 8 gq + 4 h + (s >> 2), channels
+    // 4 (s & 3) .. + 3 of a 16-channel block and receives the pixels 8 gq + 4 h .. + 3 of channel lane & 15: element 4 h + .. of
+    // the lane's 8-k MFMA operand (k-octet gq of the stage's 32 pixels)
     const int gq = lane >> 4, s16 = lane & 15, rq = s16 >> 2;
-    const int fi = lane & 31, fh = lane >> 5;
-    const int rowc = (8 * (gq >> 1) + rq) * 512 + (16 * (gq & 1) + 4 * (s16 & 3)) * 2;
-    int offA[2][2], offB[2];   // [t][plane], [plane]: lane constants (physical slot = logical ^ (pixel & 3), pixel & 3 = rq)
+    const int fkey = rq | ((gq & 1) << 2);                 // key(pixel) of the lane's pixel rows (both reads: + 4 leaves it)
+    const int prow = (8 * gq + rq) * 512 + (s16 & 3) * 8;
+    int offA[4][2], offB[2][2];   // [16-channel block of the quadrant's 64 / 32][plane]: lane constants
 #pragma unroll
     for (int pl = 0; pl < 2; ++pl) {
 #pragma unroll
-        for (int t = 0; t < 2; ++t) offA[t][pl] = rowc + ((2 * (2 * grp + t) + pl) ^ rq) * 64;
-        offB[pl] = rowc + ((2 * wn + pl) ^ rq) * 64;
+        for (int rb = 0; rb < 4; ++rb) offA[rb][pl] = prow + ((2 * (2 * (2 * grp + (rb >> 1)) + pl) + (rb & 1)) ^ fkey) * 32;
+#pragma unroll
+        for (int cb = 0; cb < 2; ++cb) offB[cb][pl] = prow + ((2 * (2 * wn + pl) + cb) ^ fkey) * 32;
     }
-    f32x16 acc[4][2];
+    f32x4_t acc[8][4];   // [16-row block of the wavefront's 128 dy channels][16-column block of its 64 K columns]
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < 8; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-    h8 fa[2][2][2], fb[2][2];   // A: [t][ks][plane], B: [ks][plane]
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    h8 fa[4][2], fb[2][2];   // A: [block][plane], B: [block][plane]
     auto frag = [&](const unsigned char* q) {
         const s4v lo = lds_tr4(q), hi = lds_tr4(q + 4 * 512);
         typedef short s8v __attribute__((ext_vector_type(8)));
@@ -191,30 +198,29 @@ conv_wgrad_hl_kernel(WgradHl p) {
     auto read_a = [&](int buf, int i) {
         const unsigned char* st = lds + buf * kStage + (i ? 16384 : 0);
 #pragma unroll
-        for (int t = 0; t < 2; ++t)
+        for (int rb = 0; rb < 4; ++rb)
 #pragma unroll
-            for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-                for (int pl = 0; pl < 2; ++pl) fa[t][ks][pl] = frag(st + ks * (16 * 512) + offA[t][pl]);
+            for (int pl = 0; pl < 2; ++pl) fa[rb][pl] = frag(st + offA[rb][pl]);
     };
     auto read_b = [&](int buf, int j) {
         const unsigned char* st = lds + buf * kStage + (j ? 49152 : 32768);
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks)
+        for (int cb = 0; cb < 2; ++cb)
 #pragma unroll
-            for (int pl = 0; pl < 2; ++pl) fb[ks][pl] = frag(st + ks * (16 * 512) + offB[pl]);
+            for (int pl = 0; pl < 2; ++pl) fb[cb][pl] = frag(st + offB[cb][pl]);
     };
     auto mfma_quadrant = [&](int i, int j) {
-        __builtin_amdgcn_s_setprio(1);
+        if (p.setprio) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int pt = 0; pt < 3; ++pt)
 #pragma unroll
-            for (int ks = 0; ks < 2; ++ks)
+            for (int rb = 0; rb < 4; ++rb)
 #pragma unroll
-                for (int t = 0; t < 2; ++t)
-                    acc[2 * i + t][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(pt == 0 ? fa[t][ks][1] : fa[t][ks][0],
-                                                                              pt == 1 ? fb[ks][1] : fb[ks][0], acc[2 * i + t][j], 0, 0, 0);
-        __builtin_amdgcn_s_setprio(0);
+                for (int cb = 0; cb < 2; ++cb)
+                    acc[4 * i + rb][2 * j + cb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(pt == 0 ? fa[rb][1] : fa[rb][0],
+                                                                                         pt == 1 ? fb[cb][1] : fb[cb][0],
+                                                                                         acc[4 * i + rb][2 * j + cb], 0, 0, 0);
+        if (p.setprio) __builtin_amdgcn_s_setprio(0);
     };
     auto bar = [&]() { __builtin_amdgcn_sched_barrier(0); __builtin_amdgcn_s_barrier(); __builtin_amdgcn_sched_barrier(0); };
     auto phase = [&](auto more_tag, int buf, int ph) {
@@ -264,18 +270,19 @@ conv_wgrad_hl_kernel(WgradHl p) {
         phase(F{}, buf, 3);
         if (grp == 0) bar();
     }
-    // C fragment: row (r) <-> output channel n, column (lane & 31) <-> K column: 128-byte coalesced rows
+    // C fragment of a 16 x 16 tile: row 4 (lane >> 4) + r <-> output channel n, column lane & 15 <-> K column: 64-byte row pieces
     const float inv = 1.f / ((p.d_absmax ? pow2_scale(*p.d_absmax) : 1.f) * (p.x_absmax ? pow2_scale(*p.x_absmax) : 1.f));
     float* out = p.slab + (int64_t)split * p.cout * p.K;
+    const int fc = lane & 15, fq4 = 4 * (lane >> 4);
 #pragma unroll
-    for (int tm = 0; tm < 4; ++tm)
+    for (int tb = 0; tb < 8; ++tb)
 #pragma unroll
-        for (int tn = 0; tn < 2; ++tn) {
-            const int kc = kc0 + wn * 64 + tn * 32 + fi;
+        for (int cb = 0; cb < 4; ++cb) {
+            const int kc = kc0 + wn * 64 + cb * 16 + fc;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int n = n0 + grp * 128 + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh;
-                if (n < p.cout && kc < p.K) out[(int64_t)n * p.K + kc] = acc[tm][tn][r] * inv;
+            for (int r = 0; r < 4; ++r) {
+                const int n = n0 + grp * 128 + tb * 16 + fq4 + r;
+                if (n < p.cout && kc < p.K) out[(int64_t)n * p.K + kc] = acc[tb][cb][r] * inv;
             }
         }
 }
@@ -346,6 +353,7 @@ extern "C" int dcn_conv_wgrad_hl(const dcn_conv_desc* c, const void* x_hl, const
     p.hin = c->hin; p.win = c->win; p.cin = c->cin; p.cout = c->cout; p.kh = c->kh; p.kw = c->kw; p.pad = c->pad; p.dil = c->dil;
     p.ldo = c->ldc; p.M = c->n * c->hout * c->wout; p.K = c->kh * c->kw * c->cin; p.cpt = c->cin / 32;
     p.splits = wgrad_hl_splits(c, &p.stages_per_split);
+    p.setprio = dcn::tuning().hl_setprio;
     p.ntiles_n = dcn::ceil_div(c->cout, 256); p.ntiles_k = dcn::ceil_div(p.K, 256);
     p.div_hw = make_fastdiv(c->hout * c->wout); p.div_w = make_fastdiv(c->wout);
     p.div_cpt = make_fastdiv(p.cpt); p.div_kw = make_fastdiv(c->kw);

@@ -19,6 +19,10 @@ for s in $steps; do
                  timeout 200 env DCN_WGRAD_HL=$hl python tools/conv_bench.py --mode hl --n ${WG_N:-2} --only "layer" --kinds wgrad --x-direct --reps 20 2>&1 | grep -v "Warn\|amdgpu.ids" | grep "layer3\|layer4" | cut -c1-200 | tee -a gpurun_out/${tag}_wgrad_n2.txt; done ;;
     convn)     # per-layer table through the C ABI at N = ${CONV_N:-2} images, the kernels the library picks by default
                timeout 400 python tools/conv_bench.py --mode hl --n ${CONV_N:-2} --x-direct --reps 30 --relu-x 2>&1 | grep -v "Warn\|amdgpu.ids" | cut -c1-170 | tee gpurun_out/${tag}_conv_per_layer_n${CONV_N:-2}.txt ;;
+    sq)        # SQ counters of the hl32 kernels at N = 8 (two --pmc passes, each with --kernel-trace only)
+               i=0; for pass in "SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES GRBM_GUI_ACTIVE SQ_WAIT_INST_ANY SQ_WAIT_ANY" "SQ_WAVE_CYCLES SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT"; do i=$((i+1))
+                 (cd /tmp && timeout 300 rocprofv3 --kernel-trace --pmc $pass --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/${tag}_sq_$i -- python $GRAFT_REPO_ROOT/tools/conv_bench.py --mode hl --n 8 --kinds fwd,dgrad,wgrad --x-direct --no-split --only "3x3 d" --reps 5 --relu-x > $GRAFT_REPO_ROOT/gpurun_out/${tag}_sq_$i.log 2>&1); done
+               python tools/sq_summary.py gpurun_out/${tag}_hl_sq_counters.txt "rocprofv3 --kernel-trace --pmc <two passes> -- python tools/conv_bench.py --mode hl --n 8 --kinds fwd,dgrad,wgrad --x-direct --no-split --only '3x3 d' --reps 5 --relu-x" gpurun_out/${tag}_sq_1 gpurun_out/${tag}_sq_2; cat gpurun_out/${tag}_hl_sq_counters.txt | cut -c1-120 ;;
     *)         bash tools/gpu_r4_session.sh $tag $s ;;
   esac
 done
