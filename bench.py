@@ -502,9 +502,11 @@ def main():
         else:
             # one fp32-accurate multiply-add = 3 fp16 MFMA products (hi*hi + hi*lo + lo*hi): the ceiling for
             # ALGORITHMIC flops is a third of the fp16 pipe's dense peak
-            peak, kern = F16X3_PEAK_TFLOPS, ("gather-GEMM convolution, forward + dgrad (3x v_mfma_f32_32x32x16_f16 per product): "
-                                             "conv_gemm_hl_kernel on the wide layers (pre-split hl32 operands by LDS-DMA, 320 x 256, 256 x 256 or "
-                                             "192 x 256 tiles by quantisation on the 256 CUs), conv_gemm_f16_kernel on the others")
+            peak, kern = F16X3_PEAK_TFLOPS, ("gather-GEMM convolution, forward + dgrad (3 fp16 MFMAs per product: v_mfma_f32_16x16x32_f16 in the hl32 "
+                                             "kernels, v_mfma_f32_32x32x16_f16 in the fp32-operand ones): conv_gemm_hl_kernel on the wide layers "
+                                             "(pre-split hl32 operands by LDS-DMA, 320 x 256, 256 x 256 or 192 x 256 tiles by quantisation on the 256 CUs), "
+                                             "conv_gemm_hlx_kernel (160 x 256 / 160 x 128 tiles, K split) where those leave CUs idle, "
+                                             "conv_gemm_f16_kernel on the others")
             peak_note = "fp16 MFMA dense peak %.1f / 3 products per fp32-accurate MAC (fp32 MFMA peak: %.1f)" % (
                 F16_MFMA_PEAK_TFLOPS, FP32_MFMA_PEAK_TFLOPS)
         # HBM-side traffic of the dominant kernel cannot be measured from inside the process (PMC counters need
@@ -512,7 +514,7 @@ def main():
         # MI355X_MICROARCH.md's HBM section), attached only when workload / arithmetic / call pattern match -- the
         # field name says so: it was not measured in this run
         traffic, traffic_src, traffic_hl = None, None, None
-        for name in ("r4_hbm_counters.json", "r3_hbm_counters.json", "r2m_hbm_counters.json", "r2_hbm_counters.json", "r1g_hbm_counters.json"):
+        for name in ("r5_hbm_counters.json", "r4_hbm_counters.json", "r3_hbm_counters.json", "r2m_hbm_counters.json", "r2_hbm_counters.json", "r1g_hbm_counters.json"):
             try:
                 rec = json.load(open(os.path.join(ROOT, "profiles", name)))
                 if (rec["workload"] == args.workload and rec["conv_mode"] == conv_mode and not args.batch and job_ is job and

@@ -432,6 +432,10 @@ int main(int argc, char** argv) {
         {"ping-pong, DMA before reads, no setprio", 32u, PPV(2)},
         {"ping-pong + setprio, 16x16x32 MFMA tiles", 64u, PPV(9)},
         {"ping-pong, 16x16x32 MFMA tiles, no setprio", 128u, PPV(8)},
+        {"16x16x32, setprio, no lgkmcnt(0) before the barrier", 256u, PPV(13)},
+        {"16x16x32, no setprio, no lgkmcnt(0) before the barrier", 512u, PPV(12)},
+        {"16x16x32, setprio, DMA before reads", 1024u, PPV(11)},
+        {"16x16x32, no setprio, DMA before reads, no lgkmcnt(0)", 2048u, PPV(14)},
     };
     (void)lds;
     for (int round = 0; round < rounds; ++round)
