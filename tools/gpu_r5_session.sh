@@ -23,6 +23,12 @@ for s in $steps; do
                i=0; for pass in "SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES GRBM_GUI_ACTIVE SQ_WAIT_INST_ANY SQ_WAIT_ANY" "SQ_WAVE_CYCLES SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT"; do i=$((i+1))
                  (cd /tmp && timeout 300 rocprofv3 --kernel-trace --pmc $pass --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/${tag}_sq_$i -- python $GRAFT_REPO_ROOT/tools/conv_bench.py --mode hl --n 8 --kinds fwd,dgrad,wgrad --x-direct --no-split --only "3x3 d" --reps 5 --relu-x > $GRAFT_REPO_ROOT/gpurun_out/${tag}_sq_$i.log 2>&1); done
                python tools/sq_summary.py gpurun_out/${tag}_hl_sq_counters.txt "rocprofv3 --kernel-trace --pmc <two passes> -- python tools/conv_bench.py --mode hl --n 8 --kinds fwd,dgrad,wgrad --x-direct --no-split --only '3x3 d' --reps 5 --relu-x" gpurun_out/${tag}_sq_1 gpurun_out/${tag}_sq_2; cat gpurun_out/${tag}_hl_sq_counters.txt | cut -c1-120 ;;
+    fp32all)   # the exact-fp32 MFMA arithmetic beside every split-fp16 row of the results table
+               for w in config1 config2 config3 config4 config5; do for sep in "" "--separate-forwards"; do
+                 [ -n "$sep" ] && [ "$w" != "config1" ] && [ "$w" != "config2" ] && continue
+                 timeout 300 python bench.py --workload $w $sep --conv-mode fp32 --no-variants --cpu-baseline-steps 0 --profile-steps 0 --steps 10 --warmup 3 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('fp32 mode %s %s: %.1f images/s  %.2f ms/step' % ('$w', '$sep' or 'pair', d['value'], d['ms_per_step']))" | tee -a gpurun_out/${tag}_fp32_mode.txt; done; done ;;
+    dist1)     # the RCCL path with ONE rank (nobody to talk to: what the collective machinery costs a step)
+               timeout 300 python bench.py --force-dist --no-variants --cpu-baseline-steps 0 --profile-steps 0 --steps 20 --warmup 5 2>/dev/null | tail -1 > gpurun_out/${tag}_bench_force_dist_1rank.json; python -c "import json; d=json.loads(open('gpurun_out/${tag}_bench_force_dist_1rank.json').read()); print('force-dist, 1 rank: %.1f images/s  %.2f ms/step  %s' % (d['value'], d['ms_per_step'], {k: d.get(k) for k in ('allreduce_ms','communication') if k in d}))" ;;
     *)         bash tools/gpu_r4_session.sh $tag $s ;;
   esac
 done
