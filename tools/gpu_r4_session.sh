@@ -52,8 +52,8 @@ PY
     tests320)  timeout 900 python -m pytest tests/test_gpu_round3.py tests/test_gpu_round4.py -m gpu -q -p no:cacheprovider -k "320 or identical or profile" > gpurun_out/${tag}_pytest_320.log 2>&1; tail -6 gpurun_out/${tag}_pytest_320.log | cut -c1-300 ;;
     c1sep)     # config 1, two-call pattern, on its own (the in-process variant of the default line measured 35 ms/step, host-bound)
                timeout 300 python bench.py --workload config1 --separate-forwards --no-variants --cpu-baseline-steps 0 --profile-steps 0 --steps 30 --warmup 8 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('config1 separate alone: %.1f images/s  %.3f ms/step  host %.2f' % (d['value'], d['ms_per_step'], d['host_enqueue_ms_per_step']))" ;;
-    dbg)       timeout 600 python tools/debug_c1sep.py 2>&1 | grep -v "Warn\|amdgpu.ids" | tee gpurun_out/${tag}_debug_c1sep.txt ;;
-    dbg5)      timeout 600 python tools/debug_c1sep.py config5 2>&1 | grep -v "Warn\|amdgpu.ids" | tee gpurun_out/${tag}_debug_config5.txt ;;
+    dbg)       timeout 600 python tools/debug/debug_c1sep.py 2>&1 | grep -v "Warn\|amdgpu.ids" | tee gpurun_out/${tag}_debug_c1sep.txt ;;
+    dbg5)      timeout 600 python tools/debug/debug_c1sep.py config5 2>&1 | grep -v "Warn\|amdgpu.ids" | tee gpurun_out/${tag}_debug_config5.txt ;;
     testsloss) timeout 900 python -m pytest tests/test_gpu_parity.py tests/test_gpu_round2.py -m gpu -q -p no:cacheprovider -k "loss or triplet or step" > gpurun_out/${tag}_pytest_loss.log 2>&1; tail -6 gpurun_out/${tag}_pytest_loss.log | cut -c1-300 ;;
     ab4)       timeout 900 python tools/ab_env.py ${AB4_ARGS} 2>&1 | grep "^ab \|^#" | tee -a gpurun_out/${tag}_ab4.txt ;;
     lossb)     timeout 300 python tools/loss_bench.py --config 3 2>&1 | grep "^loss call" | tee gpurun_out/${tag}_loss_bench.txt
