@@ -222,9 +222,49 @@ conv_gemm_hlx_kernel(GemmConv p) {
     using I0 = std::integral_constant<int, 0>;
     using I3 = std::integral_constant<int, 3>;
     using I5 = std::integral_constant<int, XTM>;
-    const bool late_issue = p.hlx_stagger != 0 && wv >= 4;
+    const bool late_issue = p.hlx_stagger == 1 && wv >= 4;
+    const int grp = wv >> 2;   // wavefronts w and w + 4 share a SIMD: group 0 = wavefronts 0-3, group 1 = 4-7
 
-    if (ss0 < ss1) {   // (wave-uniform; a split without stages contributes zeros)
+    if (ss0 < ss1 && p.hlx_stagger == 2) {
+        // Two wavefront groups ONE SLOT APART (the idea of the big tiles' schedule with one phase per stage): a stage is a LOAD
+        // slot (all 18 fragment reads of the wavefront's 80 x 64 block) and a COMPUTE slot (its 60 MFMAs), a barrier behind each;
+        // group 1 runs one slot behind group 0, so on every SIMD one wavefront computes while the other one loads.  Both groups
+        // issue the LDS-DMA pieces of stage s + 1 in the SAME slot -- group 0 in LOAD(s), group 1 at the start of COMPUTE(s - 1)
+        // -- and wait for them at the end of the next one: two slots to land.  WAR: the buffer of stage s + 1 held stage s - 1,
+        // last read in group 1's LOAD(s - 1), the slot before.  RAW: stage s + 1 is first read in group 0's LOAD(s + 1), behind
+        // the barrier that closes the slot both groups' waits sit in.
+        issue(0);
+        advance();
+        DCN_WAIT_VMCNT(0);
+        bar();
+        if (grp == 1) {   // (group 1's extra slot, next to group 0's LOAD(ss0))
+            if (ss0 + 1 < ss1) { issue(1); advance(); }
+            bar();
+        }
+        int buf = 0;
+        for (int ss = ss0; ss < ss1; ++ss) {
+            const unsigned char* cbase = lds + buf * kStage + kg * kChunk;
+            load_b(cbase);
+            load_a(cbase, I0{}, I5{});
+            __builtin_amdgcn_sched_barrier(0);
+            if (grp == 0) {
+                if (ss + 1 < ss1) { issue(buf ^ 1); advance(); }
+            } else {
+                DCN_WAIT_VMCNT(0);        // stage ss + 1 (issued one slot ago)
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            DCN_WAIT_LGKMCNT0();
+            bar();
+            if (grp == 1 && ss + 2 < ss1) { issue(buf); advance(); }   // stage ss + 2 into the buffer just read
+            __builtin_amdgcn_sched_barrier(0);
+            mm(I0{}, I5{});
+            __builtin_amdgcn_sched_barrier(0);
+            if (grp == 0) DCN_WAIT_VMCNT(0);   // stage ss + 1 (issued in this stage's LOAD slot)
+            bar();
+            buf ^= 1;
+        }
+        if (grp == 0) bar();
+    } else if (ss0 < ss1) {   // (wave-uniform; a split without stages contributes zeros)
         issue(0);
         advance();
         int buf = 0;

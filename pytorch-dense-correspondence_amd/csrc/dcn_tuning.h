@@ -35,8 +35,9 @@
 //   DCN_WGRAD_HL            0: the wide layers' weight gradients stay on the fp32-operand kernel (conv_f16_kernels.hip) instead of
 //                           the pre-split (hl32) LDS-DMA kernel (wgrad_hl_kernels.hip); 2: every supported convolution (tests)
 //   DCN_HL_SETPRIO          0: no s_setprio around the MFMA bursts of the big-tile hl32 kernels (conv_hl_kernels.hip, wgrad_hl_kernels.hip)
-//   DCN_HLX_STAGGER         0: every wavefront of the small-tile kernel issues the next stage's LDS-DMA in front of its compute slot
-//                           (default 1: wavefronts 4-7 between the two parts of theirs -- the partner on the SIMD computes meanwhile)
+//   DCN_HLX_STAGGER         schedule of the small-tile kernel.  0: every wavefront issues the next stage's LDS-DMA in front of its
+//                           compute slot; 1: wavefronts 4-7 between the two parts of theirs (the partner on the SIMD computes
+//                           meanwhile); 2: two wavefront groups one slot apart (LOAD slot | barrier | COMPUTE slot | barrier)
 //   DCN_HLX_COUNTERS        0: the arrival words of the small-tile kernel's K splits live in the caller's scratch and are cleared by
 //                           a fill launch in front of every split launch (default 1: a library-owned clean buffer per stream)
 //   DCN_WGRAD_HL_MIN_M      output pixels from which the weight gradients of the wide layers take the hl32 kernel (default 4096)

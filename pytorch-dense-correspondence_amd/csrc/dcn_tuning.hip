@@ -58,7 +58,7 @@ void read_env(Tuning& t) {
     if (const char* e = getenv("DCN_STEM_POOL_FUSED")) t.stem_pool_fused = atoi(e);
     if (const char* e = getenv("DCN_WGRAD_HL")) t.wgrad_hl = atoi(e);
     if (const char* e = getenv("DCN_HL_SETPRIO")) t.hl_setprio = atoi(e) != 0;
-    if (const char* e = getenv("DCN_HLX_STAGGER")) t.hlx_stagger = atoi(e) != 0;
+    if (const char* e = getenv("DCN_HLX_STAGGER")) { const int v = atoi(e); t.hlx_stagger = (v >= 0 && v <= 2) ? v : 1; }
     if (const char* e = getenv("DCN_HLX_COUNTERS")) t.hlx_counters = atoi(e) != 0;
     if (const char* e = getenv("DCN_WGRAD_HL_MIN_M")) t.wgrad_hl_min_m = atoi(e);
     if (const char* e = getenv("DCN_HL_PRODUCERS")) t.hl_producers = atoi(e) != 0;
