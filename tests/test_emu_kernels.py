@@ -502,15 +502,17 @@ def test_conv_hlx_small_tiles(L, case, dma, dcn_env, monkeypatch):
     kernel_checks.check_conv_hl(L, "cpu", n, h, w, cin, cout, k, dil, set_env=dcn_env, scale_x=sx, seed=len(str(case)), hlx=hlx)
 
 
-@pytest.mark.parametrize("switch", ["DCN_HLX_STAGGER", "DCN_HLX_COUNTERS"])
-@pytest.mark.parametrize("case", [HLX_CASES[2], HLX_CASES[5]], ids=str)
-def test_conv_hlx_schedule_and_counter_switches(L, case, switch, dcn_env, monkeypatch):
-    """The two switches of the small-tile kernel: every wavefront issuing its LDS-DMA in front of the compute slot (instead of
-    wavefronts 4-7 between its two parts), and the K splits' arrival words in the caller's scratch behind a fill launch
-    (instead of the library's clean per-stream buffer)."""
+@pytest.mark.parametrize("switch", ["DCN_HLX_STAGGER=0", "DCN_HLX_STAGGER=2", "DCN_HLX_COUNTERS=0"])
+@pytest.mark.parametrize("dma", ["late", "early"])
+@pytest.mark.parametrize("case", [HLX_CASES[2], HLX_CASES[5], HLX_CASES[7]], ids=str)
+def test_conv_hlx_schedule_and_counter_switches(L, case, switch, dma, dcn_env, monkeypatch):
+    """The switches of the small-tile kernel: every wavefront issuing its LDS-DMA in front of the compute slot (instead of
+    wavefronts 4-7 between its two parts); two wavefront groups one slot apart (LOAD slot | barrier | COMPUTE slot | barrier --
+    its own RAW / WAR argument, hence both DMA landing modes); the K splits' arrival words in the caller's scratch behind a fill
+    launch (instead of the library's clean per-stream buffer)."""
     import kernel_checks
-    monkeypatch.setenv("HIPEMU_LDS_DMA", "late")
-    monkeypatch.setenv(switch, "0")
+    monkeypatch.setenv("HIPEMU_LDS_DMA", dma)
+    monkeypatch.setenv(*switch.split("="))
     n, h, w, cin, cout, k, dil, hlx, sx = case
     kernel_checks.check_conv_hl(L, "cpu", n, h, w, cin, cout, k, dil, set_env=dcn_env, scale_x=sx, seed=len(str(case)), hlx=hlx)
 
