@@ -221,6 +221,7 @@ gemm_hl_pp_kernel(const _Float16* __restrict__ A, const _Float16* __restrict__ B
                     for (int cb = 0; cb < 2; ++cb) acc16[i][j][rb][cb] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
     h8 ga[4][2], gb[2][2];      // A: [rb][plane], B: [cb][plane]
+    h8 gb2[2][2];               // (VAR & 16) the second column half's B fragments, kept for the whole stage
     const int fr = lane & 15, fq = lane >> 4, swz16 = (fr >> 1) & 7;
     int goff[2];
 #pragma unroll
@@ -309,6 +310,64 @@ gemm_hl_pp_kernel(const _Float16* __restrict__ A, const _Float16* __restrict__ B
     using T = std::true_type;
     using F = std::false_type;
 
+    if constexpr ((VAR & 16) != 0) {
+        // TWO quadrants per slot (48 MFMAs = 768 matrix-pipe cycles): slot 0 = quadrants (0,0) (0,1), slot 1 = (1,1) (1,0); the B
+        // fragments of both column halves are read in slot 0 and kept.  LOAD(s,0) issues H0 H1 H2 of stage s + 1, LOAD(s,1) its H3;
+        // end of LOAD(s,0): H3(s) landed = all but the 6 youngest pieces; end of LOAD(s,1): H0 H1 H2 (s + 1) = all but 2.
+        auto read_b2 = [&](int buf) {
+            const unsigned char* st = lds + buf * kStageBytes + b_row16 + 16384;
+#pragma unroll
+            for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+                for (int pl = 0; pl < 2; ++pl) gb2[cb][pl] = *reinterpret_cast<const h8*>(st + cb * 2048 + goff[pl]);
+        };
+        auto mfma_pair = [&](int i) {
+            if (VAR & 1) __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int pt = 0; pt < 3; ++pt)
+#pragma unroll
+                for (int rb = 0; rb < 4; ++rb)
+#pragma unroll
+                    for (int cb = 0; cb < 2; ++cb) {
+                        acc16[i][0][rb][cb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(pt == 0 ? ga[rb][1] : ga[rb][0], pt == 1 ? gb[cb][1] : gb[cb][0], acc16[i][0][rb][cb], 0, 0, 0);
+                        acc16[i][1][rb][cb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(pt == 0 ? ga[rb][1] : ga[rb][0], pt == 1 ? gb2[cb][1] : gb2[cb][0], acc16[i][1][rb][cb], 0, 0, 0);
+                    }
+            if (VAR & 1) __builtin_amdgcn_s_setprio(0);
+        };
+        auto slot = [&](auto more_tag, int s, int p) {
+            constexpr bool MORE = decltype(more_tag)::value;
+            const int buf = s & 1;
+            if (p == 0) { read_b(buf, 0); read_b2(buf); __builtin_amdgcn_sched_barrier(0); read_a(buf, 0); }
+            else read_a(buf, 1);
+            __builtin_amdgcn_sched_barrier(0);
+            if (MORE) {
+                if (p == 0) { issue_half(s + 1, buf ^ 1, 0); issue_half(s + 1, buf ^ 1, 1); issue_half(s + 1, buf ^ 1, 2); }
+                else issue_half(s + 1, buf ^ 1, 3);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            if (MORE) { if (p == 0) PP_WAIT_VM(6); else PP_WAIT_VM(2); }
+            else if (p == 0) PP_WAIT_VM(0);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            bar();
+            mfma_pair(p);
+            bar();
+        };
+        issue_half(0, 0, 0);
+        issue_half(0, 0, 1);
+        issue_half(0, 0, 2);
+        issue_half(0, 0, 3);
+        __builtin_amdgcn_sched_barrier(0);
+        PP_WAIT_VM(2);
+        bar();
+        if (grp == 1) bar();
+        for (int s = 0; s + 1 < nk; ++s) {
+            slot(T{}, s, 0);
+            slot(T{}, s, 1);
+        }
+        slot(F{}, nk - 1, 0);
+        slot(F{}, nk - 1, 1);
+        if (grp == 0) bar();
+    } else {
     issue_half(0, 0, 0);
     issue_half(0, 0, 1);
     issue_half(0, 0, 2);
@@ -328,6 +387,7 @@ gemm_hl_pp_kernel(const _Float16* __restrict__ A, const _Float16* __restrict__ B
     phase(F{}, nk - 1, 2);
     phase(F{}, nk - 1, 3);
     if (grp == 0) bar();
+    }
 #undef PP_WAIT_VM
     if (M16) {
 #pragma unroll
@@ -436,6 +496,8 @@ int main(int argc, char** argv) {
         {"16x16x32, no setprio, no lgkmcnt(0) before the barrier", 512u, PPV(12)},
         {"16x16x32, setprio, DMA before reads", 1024u, PPV(11)},
         {"16x16x32, no setprio, DMA before reads, no lgkmcnt(0)", 2048u, PPV(14)},
+        {"16x16x32, setprio, TWO quadrants per slot (48 MFMAs)", 4096u, PPV(25)},
+        {"16x16x32, no setprio, TWO quadrants per slot (48 MFMAs)", 8192u, PPV(24)},
     };
     (void)lds;
     for (int round = 0; round < rounds; ++round)
