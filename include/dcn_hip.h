@@ -398,8 +398,13 @@ int dcn_conv_dgrad_hl(const dcn_conv_desc* c, const void* dout_hl, const void* w
 /* Weight gradient on hl32 operands (csrc/wgrad_hl_kernels.hip; the wgrad of training.py:345 for the same wide layers): x_hl /
  * dout_hl are the hl32 images of the convolution's input and of the output gradient (scaled by the powers of two chosen from
  * *x_absmax / *dout_absmax).  256 x 256 tiles, pixel-major tiles by LDS-DMA, k-major fragments by transposing LDS reads.
- * Same result as dcn_conv_wgrad_f16 (same products, other summation order); bit-reproducible. */
+ * Same result as dcn_conv_wgrad_f16 (same products, other summation order); bit-reproducible.
+ * Round 5: the narrow 3 x 3 layers (64 / 128 input channels, stride 1, dilation 1: ResNet layers 1 and 2) take a second kernel behind
+ * the same entry points -- 64 output channels x nine taps x all input channels per workgroup, three row windows of x per
+ * 32-pixel stage (conv_wgrad_hlr_kernel).  dcn_conv_wgrad_hl_kind: which kernel dcn_conv_wgrad_hl launches for c now --
+ * 0 none (unsupported), 1 the 256 x 256 tile kernel, 2 the row-window kernel. */
 int dcn_conv_wgrad_hl_eligible(const dcn_conv_desc* c);
+int dcn_conv_wgrad_hl_kind(const dcn_conv_desc* c);
 size_t dcn_conv_wgrad_workspace_hl(const dcn_conv_desc* c);
 int dcn_conv_wgrad_hl(const dcn_conv_desc* c, const void* x_hl, const float* x_absmax, const void* dout_hl,
                       const float* dout_absmax, float* dw, void* slabs, void* stream);

@@ -552,6 +552,44 @@ wgrad_reduce_kernel(const float* __restrict__ slab, float* __restrict__ dw, int6
     reinterpret_cast<float4*>(dw)[i] = a;
 }
 
+// The same sum for MANY splits of a SMALL tensor (the narrow layers' weight gradients: 64 x 576 values in 250 slabs -- one
+// work-item per float4 walking 250 slabs four loads at a time took 30 us, three times the GEMM it completes): 16 float4 columns x
+// 16 split lanes per workgroup, lane sl sums the slabs sl, sl + 16, ... in order, the 16 lane sums are added in order 0..15.
+// Fixed order again (another one than the kernel above: a launch uses one or the other by its split count alone).
+__global__ void __launch_bounds__(256)
+wgrad_reduce_wide_kernel(const float* __restrict__ slab, float* __restrict__ dw, int64_t n4, int splits) {
+    __shared__ float4 part[16][16];
+    const int c = threadIdx.x & 15, sl = threadIdx.x >> 4;
+    const int64_t i = (int64_t)blockIdx.x * 16 + c;
+    float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (i < n4) {
+        const float4* src = reinterpret_cast<const float4*>(slab) + i;
+        int s = sl;
+        for (; s + 48 < splits; s += 64) {
+            const float4 b0 = src[(int64_t)s * n4], b1 = src[(int64_t)(s + 16) * n4], b2 = src[(int64_t)(s + 32) * n4],
+                         b3 = src[(int64_t)(s + 48) * n4];
+            a.x += b0.x; a.y += b0.y; a.z += b0.z; a.w += b0.w;
+            a.x += b1.x; a.y += b1.y; a.z += b1.z; a.w += b1.w;
+            a.x += b2.x; a.y += b2.y; a.z += b2.z; a.w += b2.w;
+            a.x += b3.x; a.y += b3.y; a.z += b3.z; a.w += b3.w;
+        }
+        for (; s < splits; s += 16) {
+            const float4 b = src[(int64_t)s * n4];
+            a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+        }
+    }
+    part[sl][c] = a;
+    __syncthreads();
+    if (sl == 0 && i < n4) {
+#pragma unroll
+        for (int k = 1; k < 16; ++k) {
+            const float4 b = part[k][c];
+            a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+        }
+        reinterpret_cast<float4*>(dw)[i] = a;
+    }
+}
+
 // wt[c][tap][n] = w[n][tap][c]
 __global__ void __launch_bounds__(256)
 transpose_weight_kernel(const float* __restrict__ w, float* __restrict__ wt, int cout, int taps, int cin, int ldn) {
@@ -597,6 +635,10 @@ bool valid_desc(const dcn_conv_desc* c) {
 
 namespace dcnconv {
 void launch_wgrad_reduce(const float* slabs, float* dw, int64_t n4, int splits, hipStream_t st) {
+    if (splits >= 32) {   // (a count no launch of the wide layers reaches at eight images: their summation order stays what it was)
+        hipLaunchKernelGGL(wgrad_reduce_wide_kernel, dim3((unsigned)dcn::ceil_div64(n4, 16)), dim3(256), 0, st, slabs, dw, n4, splits);
+        return;
+    }
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)dcn::ceil_div64(n4, 256)), dim3(256), 0, st, slabs, dw, n4,
                        splits);
 }

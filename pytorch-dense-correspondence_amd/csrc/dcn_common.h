@@ -11,6 +11,7 @@
 #ifndef DCN_WAIT_VMCNT
 #define DCN_WAIT_VMCNT(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
 #define DCN_WAIT_LGKMCNT0() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
+#define DCN_OPAQUE_INT(v) asm volatile("" : "+v"(v))   // the optimiser forgets what it knew about v (no loop-invariant hoisting)
 #endif
 
 namespace dcn {

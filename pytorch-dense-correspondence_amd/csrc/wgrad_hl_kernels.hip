@@ -317,11 +317,271 @@ int wgrad_hl_splits(const dcn_conv_desc* c, int* stages_per_split) {
     return dcn::ceil_div(nstages, sps);
 }
 
+
+// ------------------------------------------------------------------------------------------------------------------------
+// Row-window kernel ("hlr") of the NARROW 3 x 3 layers (64 / 128 channels: ResNet layers 1 and 2), whose 64 x 576 / 128 x 1152
+// weight gradients are a fraction of one 256 x 256 tile above.  One workgroup owns 64 output channels x ALL nine taps x 64 input
+// channels -- 18 16 x 16 accumulator tiles per wavefront, the whole reduction in registers -- and walks a range of STAGES = 32
+// consecutive output pixels of ONE image row.  Per stage LDS holds the 32 dy pixels (64 channels) and three row WINDOWS of x
+// (rows y - 1, y, y + 1; x0 - 1 .. x0 + 32; the tile's 64 channels): filter tap (r, s) reads window r at pixel offset s, so an
+// input pixel enters LDS 3.2 times per launch instead of 9 (what bounds the gather form on these layers is the L2 -> LDS traffic
+// and the per-tap operand split, not the matrix pipe: 108 - 160 TF), and every border case is a per-lane out-of-range LDS-DMA
+// offset (zeros) because stages never straddle an image row.  Wavefront (nh = wv & 1, cq = wv >> 1): dy blocks 2 nh, 2 nh + 1 x
+// taps 0..8 x input block cq: 2 dy fragments and 9 shifted x fragments per stage -- 44 transposing reads for 54 MFMAs.  Same hl32
+// lines, same 32-byte-unit swizzle key(pixel) = (pixel & 3) | ((pixel >> 3) & 1) << 2 as above (a 32-lane read touches two runs of
+// four consecutive pixel rows eight apart WHATEVER the tap shift: eight distinct keys); two stage buffers, all wavefronts in
+// step (DMA of stage s + 1 | wait stage s | barrier | 9 taps, fragments two taps ahead | barrier).
+// (64 x 64)-channel tiles x pixel ranges fill the chip; slabs summed by the fixed-order reduce kernels: bit-reproducible.
+// Measured (profiles/r5q_wgrad_hlr.txt, slab reduce included): layer 1 at eight images 101.7 -> 52.4 us, at two 37.0 -> 26.5 us.
+constexpr int RW_WP = 34;                 // window pixels: 32 + 2 (dilation 1, padding 1)
+constexpr int RW_DY_BYTES = 32 * 256;     // [32 pixels][2 chunk lines]
+
+template <int CB> struct RwGeom {
+    static constexpr int kPitch = 256 * CB;                                  // bytes per window pixel (cin = 64 CB)
+    static constexpr int kXInstr = (3 * RW_WP * kPitch + 8191) / 8192;        // LDS-DMA instructions per wavefront (1 KB each)
+    static constexpr int kXBytes = kXInstr * 8192;
+    static constexpr int kStageBytes = RW_DY_BYTES + kXBytes;
+};
+
+struct WgradHlr {
+    const void* xh;
+    const void* dh;
+    float* slab;               // [splits][cout][K]
+    const float* x_absmax;
+    const float* d_absmax;
+    unsigned x_bytes, d_bytes;
+    int hin, win, cin, cout, ldo, K, nstages, segs, splits, stages_per_split, ntiles_n, ntiles_c;
+    FastDiv div_segs, div_h;
+};
+
+template <int CB>
+__global__ void __launch_bounds__(512, 1)
+conv_wgrad_hlr_kernel(WgradHlr p) {
+    using G = RwGeom<CB>;
+    constexpr int E = G::kXInstr, PITCH = G::kPitch;
+    __shared__ __attribute__((aligned(16))) unsigned char lds[2 * G::kStageBytes];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int nh = wv & 1, cq = wv >> 1;
+    const int tiles = p.ntiles_n * p.ntiles_c;
+    const int bid = xcd_remap(blockIdx.x, tiles * p.splits);
+    const int split = bid / tiles, tile = bid - split * tiles;
+    const int tn_ = tile / p.ntiles_c, tc_ = tile - tn_ * p.ntiles_c;
+    const int n0 = tn_ * 64, c0 = tc_ * 64 * CB;
+    const int s_begin = split * p.stages_per_split;
+    const int s_end = min(p.nstages, s_begin + p.stages_per_split);
+    const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.xh), 0, (int)p.x_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_d = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.dh), 0, (int)p.d_bytes, 0x00020000);
+    auto key_of = [](int pixel) { return (pixel & 3) | (((pixel >> 3) & 1) << 2); };
+
+    // ---- LDS-DMA pieces of this lane (lane constants).  One instruction fills 1 KB of LDS, lane l its 16-byte slot l.
+    // dy: wavefront wv -> stage pixels 4 wv .. 4 wv + 3 (256 B each); x: instruction k = wv + 8 e -> bytes [1024 k, 1024 k + 1024)
+    // of the window image [3][RW_WP][PITCH].  PHYSICAL 16-byte slot ps of a pixel holds half (ps & 1) of physical 32-byte unit
+    // ps >> 1 = logical unit (ps >> 1) ^ key(pixel): unit u -> chunk line u >> 2, plane (u >> 1) & 1, 16-channel half u & 1.
+    auto unit_src = [](int u, int ps) { return (u >> 2) * 128 + ((u >> 1) & 1) * 64 + (u & 1) * 32 + (ps & 1) * 16; };
+    const int dpix = 4 * wv + (lane >> 4);
+    const int dsrc = (n0 / 32) * 128 + unit_src(((lane & 15) >> 1) ^ key_of(dpix), lane & 15);
+    int xinfo[E];   // source bytes inside the pixel | window pixel q << 16 | (window r + 1) << 24  (r + 1 = 0: past the image: zeros)
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+        const int byte = (wv + 8 * e) * 1024 + lane * 16;
+        const int row = byte / PITCH, ps = (byte - row * PITCH) >> 4;
+        const int r = row / RW_WP, q = row - r * RW_WP;
+        xinfo[e] = unit_src((ps >> 1) ^ key_of(q), ps) | (q << 16) | ((row < 3 * RW_WP ? r + 1 : 0) << 24);
+    }
+    const int ldo4 = p.ldo * 4, cin4 = p.cin * 4;
+    auto issue_stage = [&](int t, int buf) {   // stage t -> (image row id = img * H + y, segment)
+        const int rowid = fdiv(t, p.div_segs), x0 = (t - rowid * p.segs) * 32;
+        const int img = fdiv(rowid, p.div_h), y = rowid - img * p.hin;
+        unsigned char* base = lds + buf * G::kStageBytes;
+        const int vd = (x0 + dpix < p.win) ? (rowid * p.win + x0 + dpix) * ldo4 + dsrc : kOob;
+        glds16(rs_d, base + wv * 1024, vd, 0);
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+            const int r1 = xinfo[e] >> 24, q = (xinfo[e] >> 16) & 255, src = xinfo[e] & 0xffff;
+            const int yy = y + r1 - 2, xx = x0 - 1 + q;
+            const bool ok = (r1 > 0) & ((unsigned)yy < (unsigned)p.hin) & ((unsigned)xx < (unsigned)p.win);
+            const int vx = ok ? ((rowid + r1 - 2) * p.win + xx) * cin4 + c0 * 4 + src : kOob;
+            glds16(rs_x, base + RW_DY_BYTES + (wv + 8 * e) * 1024, vx, 0);
+        }
+    };
+
+    // ---- fragments.  Lane (gq = lane >> 4, s16 = lane & 15) supplies pixel row 8 gq + 4 h + (s16 >> 2) (+ the tap's column shift for
+    // x), channels 4 (s16 & 3) .. + 3 of a 16-channel block, and receives pixels 8 gq + 4 h .. + 3 of channel s16 (see the header)
+    const int gq = lane >> 4, s16 = lane & 15, rq = s16 >> 2;
+    const int sub = (s16 & 3) * 8;
+    // logical unit of (16-channel block b of the pixel, plane): chunk line b >> 1, half b & 1 -- as a byte offset (x 32)
+    auto unit32 = [](int b, int pl) { return ((((b >> 1) * 2 + pl) * 2) + (b & 1)) * 32; };
+    // Byte offsets of the lane's reads.  The fields of an offset do not overlap -- pixel row x pitch (bits >= 8), swizzled unit
+    // (bits 5-7, + bit 8 at cin = 128), 8-byte run (bits 3-4) -- and the blocks / planes one wavefront reads differ in unit bits 0-1
+    // only (dy: block i, plane pl of blocks 2 nh, 2 nh + 1 = unit 4 nh + 2 pl + i; x: 4 cq + 2 pl + c, or 4 (cq >> 1) + 2 pl + (cq & 1)
+    // at cin = 64): ONE base per (column shift, read) and an XOR with (block * 32 | plane * 64) per read; window row, second read
+    // and stage buffer are additive constants (the instruction's immediate offset).  The column shift can carry into bit 3 of
+    // the pixel: the key is per (shift, read).
+    const int abase = (8 * gq + rq) * 256 + sub + (unit32(2 * nh, 0) ^ ((rq | ((gq & 1) << 2)) * 32));   // second read: + 4 * 256
+    int bbase[3][2];
+#pragma unroll
+    for (int sft = 0; sft < 3; ++sft)
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int q = 8 * gq + rq + sft + 4 * h;
+            bbase[sft][h] = q * PITCH + sub + (unit32(CB * cq, 0) ^ (key_of(q) * 32));
+        }
+    typedef short s8v __attribute__((ext_vector_type(8)));
+    auto frag2 = [&](const unsigned char* q0, const unsigned char* q1) {
+        const s4v lo = lds_tr4(q0), hi = lds_tr4(q1);
+        const s8v v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        return __builtin_bit_cast(h8, v);
+    };
+    f32x4_t acc[2][9][CB];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int t = 0; t < 9; ++t)
+#pragma unroll
+            for (int c = 0; c < CB; ++c) acc[i][t][c] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    h8 fa[2][2];        // dy: [block][plane]
+    constexpr int AH = CB == 1 ? 2 : 1;   // taps read ahead of the MFMAs (6 MFMAs per tap at cin = 64 do not cover an LDS read)
+    h8 fb[AH + 1][CB][2];   // x of one tap, a ring of AH + 1: [slot][block][plane]
+    // (the bases of the stage at hand, re-materialised per stage behind an opaque barrier: the optimiser would otherwise keep all
+    // 80 / 152 loop-invariant addresses of a stage in registers -- spills at cin = 128 -- or recompute them in full per read)
+    int va = 0, vb[3][2] = {};
+    auto read_a = [&]() {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int pl = 0; pl < 2; ++pl) {
+                const unsigned char* q = lds + (va ^ (i * 32 | pl * 64));
+                fa[i][pl] = frag2(q, q + 4 * 256);
+            }
+    };
+    auto read_b = [&](int tap, int slot) {
+        const int r = tap / 3, sft = tap - 3 * r;
+        const int woff = RW_DY_BYTES + r * RW_WP * PITCH;
+#pragma unroll
+        for (int c = 0; c < CB; ++c)
+#pragma unroll
+            for (int pl = 0; pl < 2; ++pl)
+                fb[slot][c][pl] = frag2(lds + (vb[sft][0] ^ (c * 32 | pl * 64)) + woff, lds + (vb[sft][1] ^ (c * 32 | pl * 64)) + woff);
+    };
+    auto mfma_tap = [&](int tap, int slot) {
+#pragma unroll
+        for (int pt = 0; pt < 3; ++pt)
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int c = 0; c < CB; ++c)
+                    acc[i][tap][c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(pt == 0 ? fa[i][1] : fa[i][0],
+                                                                            pt == 1 ? fb[slot][c][1] : fb[slot][c][0],
+                                                                            acc[i][tap][c], 0, 0, 0);
+    };
+    if (s_begin < s_end) issue_stage(s_begin, 0);
+    for (int t = s_begin; t < s_end; ++t) {
+        const int buf = (t - s_begin) & 1;
+        // (the other buffer was last read in stage t - 1, behind that iteration's closing barrier)
+        if (t + 1 < s_end) {
+            issue_stage(t + 1, buf ^ 1);
+            __builtin_amdgcn_sched_barrier(0);
+            static_assert((CB == 1 && E + 1 == 5) || (CB == 2 && E + 1 == 8), "counted vmcnt below");   // (CB = 2: 128 input channels per workgroup, 144 accumulator registers -- measured slower than two 64-channel tiles (twice the slab bytes per launch); not instantiated)
+            if constexpr (CB == 1) DCN_WAIT_VMCNT(5); else DCN_WAIT_VMCNT(8);   // all but the E + 1 instructions just issued
+        } else {
+            __builtin_amdgcn_sched_barrier(0);
+            DCN_WAIT_VMCNT(0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        va = abase + buf * G::kStageBytes;
+        DCN_OPAQUE_INT(va);
+#pragma unroll
+        for (int sft = 0; sft < 3; ++sft)
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                vb[sft][h] = bbase[sft][h] + buf * G::kStageBytes;
+                DCN_OPAQUE_INT(vb[sft][h]);
+            }
+        read_a();
+#pragma unroll
+        for (int tap = 0; tap < AH; ++tap) read_b(tap, tap);
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {   // (fenced: AH taps' fragments ahead, no more -- 144 accumulator registers at cin = 128)
+            if (tap + AH < 9) read_b(tap + AH, (tap + AH) % (AH + 1));
+            __builtin_amdgcn_sched_barrier(0);
+            mfma_tap(tap, tap % (AH + 1));
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        DCN_WAIT_LGKMCNT0();
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    // C fragment of a 16 x 16 tile: row 4 (lane >> 4) + r <-> output channel, column lane & 15 <-> input channel of the tap
+    const float inv = 1.f / ((p.d_absmax ? pow2_scale(*p.d_absmax) : 1.f) * (p.x_absmax ? pow2_scale(*p.x_absmax) : 1.f));
+    float* out = p.slab + (int64_t)split * p.cout * p.K;
+    const int fc = lane & 15, fq4 = 4 * (lane >> 4);
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+            for (int c = 0; c < CB; ++c) {
+                const int kc = tap * p.cin + c0 + (CB * cq + c) * 16 + fc;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int n = n0 + (2 * nh + i) * 16 + fq4 + r;
+                    out[(int64_t)n * p.K + kc] = acc[i][tap][c][r] * inv;
+                }
+            }
+}
+
+// which convolutions: the 3 x 3, stride-1, dilation-1 ones with 64 or 128 input channels and whole 64-channel output tiles
+bool wgrad_hlr_supported(const dcn_conv_desc* c) {
+    if (!c || c->n < 1 || c->hin < 1 || c->win < 1 || c->kh != 3 || c->kw != 3 || c->dil != 1 || c->pad != 1) return false;
+    if (c->stride != 1 || c->hin != c->hout || c->win != c->wout || c->ldc != c->cout) return false;
+    if ((c->cin % 64) != 0 || (c->cout % 64) != 0) return false;
+    const int64_t xb = (int64_t)c->n * c->hin * c->win * c->cin * 4, db = (int64_t)c->n * c->hout * c->wout * c->ldc * 4;
+    return xb <= ((int64_t)1 << 31) - 1 && db <= ((int64_t)1 << 31) - 1;
+}
+int wgrad_hlr_stages(const dcn_conv_desc* c) { return c->n * c->hout * dcn::ceil_div(c->wout, 32); }
+// stage ranges: one round of workgroups (64-channel tiles x splits <= 256), every split at least two stages
+int wgrad_hlr_splits(const dcn_conv_desc* c, int* stages_per_split) {
+    const int nstages = wgrad_hlr_stages(c), tiles = (c->cout / 64) * (c->cin / 64);
+    int s = std::max(1, std::min(std::max(256 / tiles, 1), nstages / 2));
+    if (const int v = dcn::tuning().wgrad_splits) { if (v >= 1 && v <= nstages) s = v; }
+    const int sps = dcn::ceil_div(nstages, s);
+    *stages_per_split = sps;
+    return dcn::ceil_div(nstages, sps);
+}
+// the row-window kernel takes the launch (instead of the 256 x 256 tile kernel above / the fp32-operand kernel)
+bool use_hlr(const dcn_conv_desc* c) {
+    const int v = dcn::tuning().wgrad_hlr;
+    if (v == 0 || !wgrad_hlr_supported(c)) return false;
+    if (v == 2) return true;
+    return (c->cout % 256) != 0 && (int64_t)c->n * c->hout * c->wout >= (dcn::tuning().wgrad_hlr_min_m > 0 ? dcn::tuning().wgrad_hlr_min_m : 16384);
+}
+int launch_wgrad_hlr(const dcn_conv_desc* c, const void* x_hl, const float* x_absmax, const void* dout_hl,
+                     const float* dout_absmax, float* dw, void* slabs, hipStream_t st) {
+    WgradHlr p;
+    p.xh = x_hl; p.dh = dout_hl; p.x_absmax = x_absmax; p.d_absmax = dout_absmax;
+    p.x_bytes = (unsigned)((int64_t)c->n * c->hin * c->win * c->cin * 4);
+    p.d_bytes = (unsigned)((int64_t)c->n * c->hout * c->wout * c->ldc * 4);
+    p.hin = c->hin; p.win = c->win; p.cin = c->cin; p.cout = c->cout; p.ldo = c->ldc; p.K = 9 * c->cin;
+    p.segs = dcn::ceil_div(c->wout, 32); p.nstages = wgrad_hlr_stages(c);
+    p.splits = wgrad_hlr_splits(c, &p.stages_per_split);
+    p.ntiles_n = c->cout / 64; p.ntiles_c = c->cin / 64;
+    p.div_segs = make_fastdiv(p.segs); p.div_h = make_fastdiv(c->hin);
+    p.slab = p.splits == 1 ? dw : (float*)slabs;
+    hipLaunchKernelGGL(conv_wgrad_hlr_kernel<1>, dim3(p.ntiles_n * p.ntiles_c * p.splits), dim3(512), 0, st, p);
+    if (p.splits > 1) launch_wgrad_reduce((const float*)slabs, dw, (int64_t)c->cout * p.K / 4, p.splits, st);
+    return dcn::check_launch();
+}
 }  // namespace
 
 // Which convolutions' weight gradients take the hl32 kernel: whole 256-channel output tiles, enough K columns and pixels.
 extern "C" int dcn_conv_wgrad_hl_eligible(const dcn_conv_desc* c) {
-    if (!wgrad_hl_supported(c) || dcn::tuning().wgrad_hl == 0) return 0;
+    if (dcn::tuning().wgrad_hl == 0) return 0;
+    if (use_hlr(c)) return 1;                    // the narrow 3 x 3 layers: row-window kernel
+    if (!wgrad_hl_supported(c)) return 0;
     if (dcn::tuning().wgrad_hl == 2) return 1;   // (tests: every supported convolution)
     // (round 3 asked for M >= 16384: at two images the step lost 0.5 % -- with the main stream's GEMMs on 38-76 tiles the
     // fp32-operand kernel's launches ran for free on the idle CUs.  Round 5: the small-tile forward / dgrad kernel fills the
@@ -332,11 +592,17 @@ extern "C" int dcn_conv_wgrad_hl_eligible(const dcn_conv_desc* c) {
     return ((c->cout % 256) == 0 && c->kh * c->kw * c->cin >= 1024 && (int64_t)c->n * c->hout * c->wout >= min_m) ? 1 : 0;
 }
 
+extern "C" int dcn_conv_wgrad_hl_kind(const dcn_conv_desc* c) { return use_hlr(c) ? 2 : (wgrad_hl_supported(c) ? 1 : 0); }
+
 extern "C" size_t dcn_conv_wgrad_workspace_hl(const dcn_conv_desc* c) {
-    if (!wgrad_hl_supported(c)) return 0;
+    // (the larger of the two kernels' slabs wherever both support the convolution: a plan sized under one setting of
+    // DCN_WGRAD_HLR stays valid under another)
+    size_t bytes = 0;
     int sps;
-    const int splits = wgrad_hl_splits(c, &sps);
-    return (size_t)splits * c->cout * c->kh * c->kw * c->cin * sizeof(float);
+    if (wgrad_hlr_supported(c)) bytes = (size_t)wgrad_hlr_splits(c, &sps) * c->cout * 9 * c->cin * sizeof(float);
+    if (wgrad_hl_supported(c))
+        bytes = std::max(bytes, (size_t)wgrad_hl_splits(c, &sps) * c->cout * c->kh * c->kw * c->cin * sizeof(float));
+    return bytes;
 }
 
 // x_hl: hl32 image of the convolution's input [n, hin, win, cin], scaled by pow2_scale(*x_absmax); dout_hl: hl32 image of
@@ -345,6 +611,7 @@ extern "C" size_t dcn_conv_wgrad_workspace_hl(const dcn_conv_desc* c) {
 extern "C" int dcn_conv_wgrad_hl(const dcn_conv_desc* c, const void* x_hl, const float* x_absmax, const void* dout_hl,
                                  const float* dout_absmax, float* dw, void* slabs, void* stream) {
     if (!x_hl || !dout_hl || !dw || !slabs) return DCN_E_INVALID;
+    if (use_hlr(c)) return launch_wgrad_hlr(c, x_hl, x_absmax, dout_hl, dout_absmax, dw, slabs, (hipStream_t)stream);
     if (!wgrad_hl_supported(c)) return DCN_E_UNSUPPORTED;
     WgradHl p;
     p.xh = x_hl; p.dh = dout_hl; p.x_absmax = x_absmax; p.d_absmax = dout_absmax;

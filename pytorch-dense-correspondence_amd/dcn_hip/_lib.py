@@ -151,6 +151,7 @@ SYMBOLS = {
     "dcn_split_weights_checked_f16": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                               c_float, c_void_p, c_void_p]),
     "dcn_conv_wgrad_hl_eligible": (c_int, [ctypes.POINTER(ConvDesc)]),
+    "dcn_conv_wgrad_hl_kind": (c_int, [ctypes.POINTER(ConvDesc)]),
     "dcn_conv_wgrad_workspace_hl": (c_size_t, [ctypes.POINTER(ConvDesc)]),
     "dcn_conv_wgrad_hl": (c_int, [ctypes.POINTER(ConvDesc), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "dcn_conv_hl_eligible": (c_int, [ctypes.POINTER(ConvDesc), c_int]),

@@ -470,6 +470,7 @@ static inline hipemu_s4 hipemu_ds_read_tr16_b64(const void* p) {
 #define __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, lp, sz, vo, so, a, b) hipemu_buffer_load_lds(rs, (void*)(lp), sz, vo, so)
 #define DCN_WAIT_VMCNT(n) hipemu_wait_vmcnt(n)
 #define DCN_WAIT_LGKMCNT0() ((void)0)
+#define DCN_OPAQUE_INT(v) ((void)(v))
 #define __builtin_amdgcn_s_barrier() ::hipemu::block_barrier()
 #define __builtin_amdgcn_s_setprio(x) ((void)0)
 #define __builtin_amdgcn_sched_barrier(x) ((void)0)

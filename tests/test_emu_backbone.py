@@ -2,6 +2,7 @@
 against the oracle on narrow networks.  The oracle itself is float32, so the yard-stick is a float64 copy of
 it: the engine must be as close to the float64 truth as the float32 oracle is (x3 + 1e-5)."""
 import copy
+import ctypes
 
 import pytest
 import torch
@@ -293,10 +294,13 @@ def test_grouped_pair_forward_equals_two_forward_calls(arch, bw, shape):
     assert rel_err(y1, o(xs)) < 2e-5 and rel_err(y2, o(xs * 0.5)) < 2e-5
 
 
-@pytest.mark.parametrize("arch,bw,shape,groups,producers", [
-    ("Resnet18_8s", 32, (1, 32, 40), 1, 1), ("Resnet18_8s", 32, (1, 32, 40), 1, 0), ("Resnet50_8s", 32, (1, 32, 32), 1, 1),
-    ("Resnet18_8s", 32, (2, 128, 128), 2, 1)])
-def test_wide_layers_through_the_hl32_path(arch, bw, shape, groups, producers, dcn_env, conv_mode):
+@pytest.mark.parametrize("arch,bw,shape,groups,producers,hlr", [
+    ("Resnet18_8s", 32, (1, 32, 40), 1, 1, 1), ("Resnet18_8s", 32, (1, 32, 40), 1, 0, 1), ("Resnet50_8s", 32, (1, 32, 32), 1, 1, 1),
+    ("Resnet18_8s", 32, (2, 128, 128), 2, 1, 1),
+    # DCN_WGRAD_HLR=2: the 3 x 3 / dilation-1 layers with 64 (base width 32: layer 2) or 128 (base width 64) input channels
+    # take the row-window weight-gradient kernel -- saved hl32 images of THEIR inputs, the max-pool output's among them
+    ("Resnet18_8s", 32, (1, 32, 40), 1, 1, 2), ("Resnet18_8s", 64, (1, 32, 40), 1, 1, 2), ("Resnet18_8s", 32, (2, 128, 128), 2, 0, 2)])
+def test_wide_layers_through_the_hl32_path(arch, bw, shape, groups, producers, hlr, dcn_env, conv_mode):
     """DCN_GEMM_HL=2: every convolution the pre-split (hl32) LDS-DMA kernel supports takes it (forward and dgrad, engine
     workspace, weight images per call), DCN_WGRAD_HL=2: every weight gradient the hl32 wgrad kernel supports (saved hl32 images
     of the activations, hl32 images of the gradients from the batch-norm backward passes).  Forward: against the engine's own fp32-operand kernels and the float64 oracle.
@@ -323,9 +327,15 @@ def test_wide_layers_through_the_hl32_path(arch, bw, shape, groups, producers, d
             return torch.cat(net.forward_pair(x[:N // 2], x[N // 2:]))
         return net(x)
     from dcn_hip import backbone as _bb
-    dcn_env(DCN_GEMM_HL=2, DCN_WGRAD_HL=2, DCN_HL_PRODUCERS=producers)
+    dcn_env(DCN_GEMM_HL=2, DCN_WGRAD_HL=2, DCN_HL_PRODUCERS=producers, DCN_WGRAD_HLR=hlr)
     _bb._PLANS.clear()                     # (plans reserve the saved hl32 images when they are built: after the switches are set)
     y = fwd(m)
+    if hlr == 2:   # the plan's convolutions that take the row-window kernel: at least the stride-1 3 x 3 ones of one layer
+        from dcn_hip import _lib as L
+        ch = 64 if bw == 32 else 128
+        for hh_, ww_, c_ in ((H // 8, W // 8, ch),) + (((H // 4, W // 4, 64),) if bw == 64 else ()):
+            d = L.ConvDesc(N, hh_, ww_, c_, hh_, ww_, c_, 3, 3, 1, 1, 1, c_, 0)
+            assert L.get().dcn_conv_wgrad_hl_kind(ctypes.byref(d)) == 2
     dcn_env(DCN_GEMM_HL=0, DCN_WGRAD_HL=2, DCN_HL_PRODUCERS=producers)
     y2, y3 = fwd(m2), fwd(m3)
     if groups == 1:

@@ -517,6 +517,30 @@ def test_conv_hlx_schedule_and_counter_switches(L, case, switch, dma, dcn_env, m
     kernel_checks.check_conv_hl(L, "cpu", n, h, w, cin, cout, k, dil, set_env=dcn_env, scale_x=sx, seed=len(str(case)), hlx=hlx)
 
 
+WGRAD_HLR_CASES = [
+    # n, h, w, cin, cout, k, dil, forced splits   (row-window kernel of the narrow 3 x 3 layers: DCN_WGRAD_HLR=2)
+    (1, 3, 40, 64, 64, 3, 1, None),      # cin = 64: two segments per row (32 + 8 pixels), image borders on every side of every stage
+    (2, 4, 33, 128, 128, 3, 1, "3"),     # cin = 128 (two input blocks per wavefront), two 64-channel tiles, three stage ranges over two images
+    (1, 2, 20, 64, 192, 3, 1, "1"),      # rows shorter than a stage, three tiles, ONE range: the kernel writes dw itself (no slabs)
+    (1, 5, 64, 128, 64, 3, 1, "5"),      # whole segments only (no ragged one), five ranges of two stages
+    (2, 20, 32, 64, 64, 3, 1, "40"),     # 40 ranges of ONE stage: the slabs are summed by the many-splits reduce kernel (>= 32)
+]
+
+
+@pytest.mark.parametrize("dma", ["late", "early"])
+@pytest.mark.parametrize("case", WGRAD_HLR_CASES, ids=[str(c) for c in WGRAD_HLR_CASES])
+def test_wgrad_hl32_row_window_kernel(L, case, dma, dcn_env, monkeypatch):
+    """conv_wgrad_hlr_kernel (wgrad_hl_kernels.hip): 64 output channels x nine taps x all input channels per workgroup, three
+    row windows of x per 32-pixel stage -- against float64 autograd and the fp32-operand kernel, both LDS-DMA landing modes."""
+    import kernel_checks
+    monkeypatch.setenv("HIPEMU_LDS_DMA", dma)
+    n, h, w, cin, cout, k, dil, splits = case
+    dcn_env(DCN_WGRAD_HLR=2)
+    d = L.ConvDesc(n, h, w, cin, h, w, cout, k, k, 1, dil * (k - 1) // 2, dil, cout, 0)
+    assert L.get().dcn_conv_wgrad_hl_kind(ctypes.byref(d)) == 2
+    kernel_checks.check_wgrad_hl(L, "cpu", n, h, w, cin, cout, k, dil, set_env=dcn_env, splits=splits, seed=len(str(case)))
+
+
 WGRAD_HL_CASES = [
     # n, h, w, cin, cout, k, dil, forced splits
     (1, 3, 40, 32, 64, 3, 1, None),      # one ragged tile (64 of 256 output channels, K = 288 of 2 x 256), 120 pixels = 4 stages

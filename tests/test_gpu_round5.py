@@ -112,3 +112,31 @@ def test_tile_choice_of_the_small_batch_launches(L, dcn_env):
     d = L.ConvDesc(8, 60, 80, 256, 60, 80, 256, 3, 3, 1, 2, 2, 256, 0)       # layer 3 at 8 images: 192-row tiles (200) or 160 x 256 (240)
     info = (ctypes.c_int * 6)()
     assert lib.dcn_conv_hl_shape_info(ctypes.byref(d), 0, info) == 0 and info[0] in (160, 192) and info[4] * info[5] >= 200
+
+
+WGRAD_HLR = [
+    # n, h, w, cin, cout, k, dil, forced splits, DCN_WGRAD_HLR
+    (1, 3, 40, 64, 64, 3, 1, None, 2),        # the CPU suite's small cases
+    (2, 4, 33, 128, 128, 3, 1, "3", 2),
+    (1, 2, 20, 64, 192, 3, 1, "1", 2),
+    (8, 120, 160, 64, 64, 3, 1, None, 1),     # layer 1 of config 2: one 64-channel tile, 256 stage ranges
+    (8, 60, 80, 128, 128, 3, 1, None, 1),     # layer 2: rows of 80 pixels = 2.5 stages (the third half empty), two tiles x 128 ranges
+    (2, 120, 160, 64, 64, 3, 1, None, 1),     # config 1 (B = 1)
+    (4, 120, 160, 128, 128, 3, 1, None, 1),   # ResNet50-8s layer-2 3 x 3 at 1280 x 960 (config 5)
+]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", WGRAD_HLR, ids=[str(c) for c in WGRAD_HLR])
+def test_wgrad_hl32_row_window_kernel(L, case, dcn_env):
+    """conv_wgrad_hlr_kernel (wgrad_hl_kernels.hip) on the hardware: against float64 autograd, the fp32-operand kernel, and itself
+    (bit-reproducible) -- kernel_checks.check_wgrad_hl; the layer shapes take it by default."""
+    n, h, w, cin, cout, k, dil, splits, hlr = case
+    dcn_env(DCN_WGRAD_HLR=hlr)
+    d = L.ConvDesc(n, h, w, cin, h, w, cout, k, k, 1, dil * (k - 1) // 2, dil, cout, 0)
+    assert L.get().dcn_conv_wgrad_hl_kind(ctypes.byref(d)) == 2
+    assert L.get().dcn_conv_wgrad_hl_eligible(ctypes.byref(d)) == 1
+    for rep in range(2):
+        res = kernel_checks.check_wgrad_hl(L, "cuda", n, h, w, cin, cout, k, dil, set_env=dcn_env, splits=splits,
+                                           seed=len(str(case)) + rep)
+    print(case, res)

@@ -147,7 +147,7 @@ def main():
                     return rc | lib.dcn_conv_wgrad_hl(ctypes.byref(d), _lib.ptr(xw_hl), _lib.ptr(axw), _lib.ptr(dyw_hl), _lib.ptr(amax),
                                                      _lib.ptr(dw), _lib.ptr(slab_hl), st)
                 calls["wgrad"] = wgrad_hl
-                name = name + " [hl wgrad]"
+                name = name + (" [hlr wgrad]" if lib.dcn_conv_wgrad_hl_kind(ctypes.byref(d)) == 2 else " [hl wgrad]")
             if hl_f or hl_d:
                 P, I = ctypes.c_void_p, ctypes.c_int
                 arr = lambda ty, v: (ty * 1)(v)
