@@ -41,8 +41,10 @@
 //   DCN_HLX_COUNTERS        0: the arrival words of the small-tile kernel's K splits live in the caller's scratch and are cleared by
 //                           a fill launch in front of every split launch (default 1: a library-owned clean buffer per stream)
 //   DCN_WGRAD_HLR           0: the 64 / 128-channel 3 x 3 layers' weight gradients stay on the fp32-operand kernel; 1 (default): on the
-//                           row-window hl32 kernel (conv_wgrad_hlr_kernel) from DCN_WGRAD_HLR_MIN_M output pixels (default 16384);
+//                           row-window hl32 kernel (conv_wgrad_hlr_kernel) from about eight 32-pixel stages per workgroup (four images at 640 x 480), or
+//                           from DCN_WGRAD_HLR_MIN_M output pixels when that is set;
 //                           2: every convolution that kernel supports (tests)
+//   DCN_WGRAD_HLR_PAIRS     0: the row-window kernel's single-row form (stage = one image row x 32 pixels) instead of the row-pair one
 //   DCN_WGRAD_HL_MIN_M      output pixels from which the weight gradients of the wide layers take the hl32 kernel (default 4096)
 //   DCN_HL_PRODUCERS        0: hl32 activation / gradient images are made by stand-alone split passes instead of by the
 //                           batch-norm apply kernels that produce the tensors
@@ -93,6 +95,7 @@ struct Tuning {
     int wgrad_hl = 1;            // wide layers' weight gradients on the pre-split (hl32) LDS-DMA kernel
     int wgrad_hlr = 1;           // see DCN_WGRAD_HLR above
     int wgrad_hlr_min_m = 0;     // 0: the default of use_hlr (wgrad_hl_kernels.hip)
+    int wgrad_hlr_pairs = 1;     // see DCN_WGRAD_HLR_PAIRS above
     int hl_producers = 1;        // hl32 images written by the producing batch-norm passes (0: stand-alone split passes)
     int hl_only_mid = 1;         // mid-block activations whose two readers (next conv, its wgrad) take the hl32 image: no fp32 copy (0: keep it)
     int stem_pool_fused = 1;     // the stem's batch norm + ReLU applied inside the max-pool pass (0: an apply pass of its own)

@@ -63,6 +63,7 @@ void read_env(Tuning& t) {
     if (const char* e = getenv("DCN_WGRAD_HL_MIN_M")) t.wgrad_hl_min_m = atoi(e);
     if (const char* e = getenv("DCN_WGRAD_HLR")) t.wgrad_hlr = atoi(e);
     if (const char* e = getenv("DCN_WGRAD_HLR_MIN_M")) t.wgrad_hlr_min_m = atoi(e);
+    if (const char* e = getenv("DCN_WGRAD_HLR_PAIRS")) t.wgrad_hlr_pairs = atoi(e);
     if (const char* e = getenv("DCN_HL_PRODUCERS")) t.hl_producers = atoi(e) != 0;
     if (const char* e = getenv("DCN_BN_REVERSE")) t.bn_reverse = atoi(e);
     if (const char* e = getenv("DCN_BN_NT")) t.bn_nt = atoi(e);

@@ -332,7 +332,8 @@ int wgrad_hl_splits(const dcn_conv_desc* c, int* stages_per_split) {
 // four consecutive pixel rows eight apart WHATEVER the tap shift: eight distinct keys); two stage buffers, all wavefronts in
 // step (DMA of stage s + 1 | wait stage s | barrier | 9 taps, fragments two taps ahead | barrier).
 // (64 x 64)-channel tiles x pixel ranges fill the chip; slabs summed by the fixed-order reduce kernels: bit-reproducible.
-// Measured (profiles/r5q_wgrad_hlr.txt, slab reduce included): layer 1 at eight images 101.7 -> 52.4 us, at two 37.0 -> 26.5 us.
+// Measured (profiles/r5r_wgrad_hlr_64ch_tiles.txt, slab reduce included): layer 1 at eight images 103.2 -> 52.9 us, layer 2 72.0 -> 58.0 us;
+// the step: config 2 +1.9 %, its two-call form +1.6 %, config 5 (ResNet50, 1280 x 960) +3.6 % (profiles/r5s_ab_wgrad_hlr.txt, r5t_*).
 constexpr int RW_WP = 34;                 // window pixels: 32 + 2 (dilation 1, padding 1)
 constexpr int RW_DY_BYTES = 32 * 256;     // [32 pixels][2 chunk lines]
 
@@ -534,7 +535,199 @@ conv_wgrad_hlr_kernel(WgradHlr p) {
             }
 }
 
-// which convolutions: the 3 x 3, stride-1, dilation-1 ones with 64 or 128 input channels and whole 64-channel output tiles
+
+// ---- ROW-PAIR form of the same kernel (default).  The single-row form above is bound by its transposing LDS reads (44 reads per 54
+// MFMAs and wavefront: 180 KB per stage against 1728 matrix-pipe cycles; measured 4000 cycles per stage): here a stage is TWO image
+// rows (y, y + 1) x 32 pixels, the two wavefront groups (wv >> 2) take one row each -- FOUR x windows (rows y - 1 .. y + 2) serve
+// both, group g reads windows g .. g + 2 -- and a wavefront (cq = wv & 3) owns ALL four dy blocks x nine taps x input block cq:
+// 36 accumulator tiles (144 registers), 16 + 36 reads for 108 MFMAs.  An input pixel now enters LDS 2.1 times per launch.  The
+// groups' accumulators (sums over different pixels of the same 64 x 576 tile) are added through LDS at the end, group 1 into
+// group 0, in two passes of 18 tiles; group 0 writes the slab.  Measured (profiles/r5u_wgrad_hlr_row_pairs.txt): layer 1 at eight
+// images 52.1 -> 48.6 us, layer 2 57.8 -> 51.7 us -- of which about 18 us are the launch pair's fixed part (256 slabs of 147 KB
+// written and summed: 26 us at two images, 33 us at four).
+constexpr int RP_DY_BYTES = 2 * 32 * 256;                  // [2 rows][32 pixels][2 chunk lines]
+constexpr int RP_XINSTR = 5;                               // LDS-DMA instructions per wavefront for [4][RW_WP][256 B] = 34 KB (40 KB held)
+constexpr int RP_STAGE = RP_DY_BYTES + RP_XINSTR * 8192;   // 56 KB
+
+__global__ void __launch_bounds__(512, 1)
+conv_wgrad_hlrp_kernel(WgradHlr p) {
+    constexpr int E = RP_XINSTR, PITCH = 256;
+    __shared__ __attribute__((aligned(16))) unsigned char lds[2 * RP_STAGE];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int grp = wv >> 2, cq = wv & 3;
+    const int tiles = p.ntiles_n * p.ntiles_c;
+    const int bid = xcd_remap(blockIdx.x, tiles * p.splits);
+    const int split = bid / tiles, tile = bid - split * tiles;
+    const int tn_ = tile / p.ntiles_c, tc_ = tile - tn_ * p.ntiles_c;
+    const int n0 = tn_ * 64, c0 = tc_ * 64;
+    const int s_begin = split * p.stages_per_split;
+    const int s_end = min(p.nstages, s_begin + p.stages_per_split);
+    const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.xh), 0, (int)p.x_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_d = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.dh), 0, (int)p.d_bytes, 0x00020000);
+    auto key_of = [](int pixel) { return (pixel & 3) | (((pixel >> 3) & 1) << 2); };
+    auto unit_src = [](int u, int ps) { return (u >> 2) * 128 + ((u >> 1) & 1) * 64 + (u & 1) * 32 + (ps & 1) * 16; };
+    // ---- LDS-DMA pieces (see the single-row kernel).  dy: instruction wv + 8 e = pixels 4 wv .. + 3 of row y + e; x: instruction
+    // wv + 8 e = bytes [1024 (wv + 8 e), + 1024) of the window image [4][RW_WP][256 B]
+    const int dpix = 4 * wv + (lane >> 4);
+    const int dsrc = (n0 / 32) * 128 + unit_src(((lane & 15) >> 1) ^ key_of(dpix), lane & 15);
+    int xinfo[E];   // source bytes inside the pixel | window pixel q << 16 | (window r + 1) << 24  (0: past the image: zeros)
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+        const int byte = (wv + 8 * e) * 1024 + lane * 16;
+        const int row = byte / PITCH, ps = (byte - row * PITCH) >> 4;
+        const int r = row / RW_WP, q = row - r * RW_WP;
+        xinfo[e] = unit_src((ps >> 1) ^ key_of(q), ps) | (q << 16) | ((row < 4 * RW_WP ? r + 1 : 0) << 24);
+    }
+    const int ldo4 = p.ldo * 4, cin4 = p.cin * 4;
+    auto issue_stage = [&](int t, int buf) {   // stage t -> (row pair id = img * ceil(H / 2) + y / 2, segment)
+        const int pairid = fdiv(t, p.div_segs), x0 = (t - pairid * p.segs) * 32;
+        const int img = fdiv(pairid, p.div_h), y = 2 * (pairid - img * p.div_h.d);
+        const int rowid = img * p.hin + y;
+        unsigned char* base = lds + buf * RP_STAGE;
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            const int vd = ((x0 + dpix < p.win) & (y + e < p.hin)) ? ((rowid + e) * p.win + x0 + dpix) * ldo4 + dsrc : kOob;
+            glds16(rs_d, base + (wv + 8 * e) * 1024, vd, 0);
+        }
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+            const int r1 = xinfo[e] >> 24, q = (xinfo[e] >> 16) & 255, src = xinfo[e] & 0xffff;
+            const int yy = y + r1 - 2, xx = x0 - 1 + q;
+            const bool ok = (r1 > 0) & ((unsigned)yy < (unsigned)p.hin) & ((unsigned)xx < (unsigned)p.win);
+            const int vx = ok ? ((rowid + r1 - 2) * p.win + xx) * cin4 + c0 * 4 + src : kOob;
+            glds16(rs_x, base + RP_DY_BYTES + (wv + 8 * e) * 1024, vx, 0);
+        }
+    };
+    // ---- fragments (byte offsets as in the single-row kernel: one base per (column shift, read), XOR (block, plane) bits per read)
+    const int gq = lane >> 4, s16 = lane & 15, rq = s16 >> 2;
+    const int sub = (s16 & 3) * 8;
+    const int abase = grp * 8192 + (8 * gq + rq) * 256 + sub + ((rq | ((gq & 1) << 2)) * 32);   // second read: + 4 * 256
+    auto unit32 = [](int b, int pl) { return ((((b >> 1) * 2 + pl) * 2) + (b & 1)) * 32; };
+    int bbase[3][2];
+#pragma unroll
+    for (int sft = 0; sft < 3; ++sft)
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int q = 8 * gq + rq + sft + 4 * h;
+            bbase[sft][h] = RP_DY_BYTES + grp * RW_WP * PITCH + q * PITCH + sub + (unit32(cq, 0) ^ (key_of(q) * 32));
+        }
+    typedef short s8v __attribute__((ext_vector_type(8)));
+    auto frag2 = [&](const unsigned char* q0, const unsigned char* q1) {
+        const s4v lo = lds_tr4(q0), hi = lds_tr4(q1);
+        const s8v v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        return __builtin_bit_cast(h8, v);
+    };
+    f32x4_t acc[4][9];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int t = 0; t < 9; ++t) acc[i][t] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    h8 fa[4][2];       // dy: [block][plane]
+    h8 fb[2][2];       // x of one tap, double-buffered: [slot][plane]
+    int va = 0, vb[3][2] = {};
+    auto read_a = [&]() {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int pl = 0; pl < 2; ++pl) {
+                const unsigned char* q = lds + (va ^ unit32(i, pl));
+                fa[i][pl] = frag2(q, q + 4 * 256);
+            }
+    };
+    auto read_b = [&](int tap, int slot) {
+        const int r = tap / 3, sft = tap - 3 * r;
+#pragma unroll
+        for (int pl = 0; pl < 2; ++pl)
+            fb[slot][pl] = frag2(lds + (vb[sft][0] ^ (pl * 64)) + r * RW_WP * PITCH, lds + (vb[sft][1] ^ (pl * 64)) + r * RW_WP * PITCH);
+    };
+    auto mfma_tap = [&](int tap, int slot) {
+#pragma unroll
+        for (int pt = 0; pt < 3; ++pt)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                acc[i][tap] = __builtin_amdgcn_mfma_f32_16x16x32_f16(pt == 0 ? fa[i][1] : fa[i][0], pt == 1 ? fb[slot][1] : fb[slot][0],
+                                                                     acc[i][tap], 0, 0, 0);
+    };
+    if (s_begin < s_end) issue_stage(s_begin, 0);
+    for (int t = s_begin; t < s_end; ++t) {
+        const int buf = (t - s_begin) & 1;
+        if (t + 1 < s_end) {
+            issue_stage(t + 1, buf ^ 1);
+            __builtin_amdgcn_sched_barrier(0);
+            static_assert(E + 2 == 7, "counted vmcnt below");
+            DCN_WAIT_VMCNT(7);   // all but the E + 2 instructions just issued
+        } else {
+            __builtin_amdgcn_sched_barrier(0);
+            DCN_WAIT_VMCNT(0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        va = abase + buf * RP_STAGE;
+        DCN_OPAQUE_INT(va);
+#pragma unroll
+        for (int sft = 0; sft < 3; ++sft)
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                vb[sft][h] = bbase[sft][h] + buf * RP_STAGE;
+                DCN_OPAQUE_INT(vb[sft][h]);
+            }
+        read_a();
+        read_b(0, 0);
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {   // (fenced: one tap's fragments ahead -- 144 accumulator registers)
+            if (tap + 1 < 9) read_b(tap + 1, (tap + 1) & 1);
+            __builtin_amdgcn_sched_barrier(0);
+            mfma_tap(tap, tap & 1);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        DCN_WAIT_LGKMCNT0();
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    // ---- group 1's sums into group 0's, two passes of 18 tiles through LDS ([wavefront cq][tile][lane] float4: 72 KB)
+    float4* xch = reinterpret_cast<float4*>(lds);
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+        if (grp == 1) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int tap = 0; tap < 9; ++tap) {
+                    const f32x4_t v = acc[2 * half + i][tap];
+                    xch[(cq * 18 + i * 9 + tap) * 64 + lane] = make_float4(v[0], v[1], v[2], v[3]);
+                }
+        }
+        __syncthreads();
+        if (grp == 0) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int tap = 0; tap < 9; ++tap) {
+                    const float4 v = xch[(cq * 18 + i * 9 + tap) * 64 + lane];
+                    acc[2 * half + i][tap][0] += v.x; acc[2 * half + i][tap][1] += v.y;
+                    acc[2 * half + i][tap][2] += v.z; acc[2 * half + i][tap][3] += v.w;
+                }
+        }
+        __syncthreads();
+    }
+    if (grp != 0) return;
+    const float inv = 1.f / ((p.d_absmax ? pow2_scale(*p.d_absmax) : 1.f) * (p.x_absmax ? pow2_scale(*p.x_absmax) : 1.f));
+    float* out = p.slab + (int64_t)split * p.cout * p.K;
+    const int fc = lane & 15, fq4 = 4 * (lane >> 4);
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            const int kc = tap * p.cin + c0 + cq * 16 + fc;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) out[(int64_t)(n0 + i * 16 + fq4 + r) * p.K + kc] = acc[i][tap][r] * inv;
+        }
+}
+
+// which convolutions: the 3 x 3, stride-1, dilation-1 ones with whole 64-channel input and output tiles
 bool wgrad_hlr_supported(const dcn_conv_desc* c) {
     if (!c || c->n < 1 || c->hin < 1 || c->win < 1 || c->kh != 3 || c->kw != 3 || c->dil != 1 || c->pad != 1) return false;
     if (c->stride != 1 || c->hin != c->hout || c->win != c->wout || c->ldc != c->cout) return false;
@@ -542,7 +735,11 @@ bool wgrad_hlr_supported(const dcn_conv_desc* c) {
     const int64_t xb = (int64_t)c->n * c->hin * c->win * c->cin * 4, db = (int64_t)c->n * c->hout * c->wout * c->ldc * 4;
     return xb <= ((int64_t)1 << 31) - 1 && db <= ((int64_t)1 << 31) - 1;
 }
-int wgrad_hlr_stages(const dcn_conv_desc* c) { return c->n * c->hout * dcn::ceil_div(c->wout, 32); }
+bool hlr_pairs() { return dcn::tuning().wgrad_hlr_pairs != 0; }
+// stages: (image row | row pair) x 32-pixel segment
+int wgrad_hlr_stages(const dcn_conv_desc* c) {
+    return c->n * (hlr_pairs() ? dcn::ceil_div(c->hout, 2) : c->hout) * dcn::ceil_div(c->wout, 32);
+}
 // stage ranges: one round of workgroups (64-channel tiles x splits <= 256), every split at least two stages
 int wgrad_hlr_splits(const dcn_conv_desc* c, int* stages_per_split) {
     const int nstages = wgrad_hlr_stages(c), tiles = (c->cout / 64) * (c->cin / 64);
@@ -557,7 +754,12 @@ bool use_hlr(const dcn_conv_desc* c) {
     const int v = dcn::tuning().wgrad_hlr;
     if (v == 0 || !wgrad_hlr_supported(c)) return false;
     if (v == 2) return true;
-    return (c->cout % 256) != 0 && (int64_t)c->n * c->hout * c->wout >= (dcn::tuning().wgrad_hlr_min_m > 0 ? dcn::tuning().wgrad_hlr_min_m : 16384);
+    if ((c->cout % 256) == 0) return false;   // (the 256 x 256 tile kernel's layers)
+    if (dcn::tuning().wgrad_hlr_min_m > 0) return (int64_t)c->n * c->hout * c->wout >= dcn::tuning().wgrad_hlr_min_m;
+    // from about eight stages per workgroup: at two images (layer 1: 4.7 stages on each of 256 workgroups) every launch is still
+    // faster than the fp32-operand kernel's (26.7 vs 37.2 us, 30.6 vs 39.2 us) but the STEP is not (-0.7 %: the old kernel's few
+    // workgroups ran beside the main stream's GEMMs, these take the whole chip) -- profiles/r5s_ab_wgrad_hlr.txt
+    return (int64_t)c->n * c->hout * dcn::ceil_div(c->wout, 32) * (c->cout / 64) * (c->cin / 64) >= 2048;
 }
 int launch_wgrad_hlr(const dcn_conv_desc* c, const void* x_hl, const float* x_absmax, const void* dout_hl,
                      const float* dout_absmax, float* dw, void* slabs, hipStream_t st) {
@@ -569,9 +771,10 @@ int launch_wgrad_hlr(const dcn_conv_desc* c, const void* x_hl, const float* x_ab
     p.segs = dcn::ceil_div(c->wout, 32); p.nstages = wgrad_hlr_stages(c);
     p.splits = wgrad_hlr_splits(c, &p.stages_per_split);
     p.ntiles_n = c->cout / 64; p.ntiles_c = c->cin / 64;
-    p.div_segs = make_fastdiv(p.segs); p.div_h = make_fastdiv(c->hin);
+    p.div_segs = make_fastdiv(p.segs); p.div_h = make_fastdiv(hlr_pairs() ? dcn::ceil_div(c->hin, 2) : c->hin);
     p.slab = p.splits == 1 ? dw : (float*)slabs;
-    hipLaunchKernelGGL(conv_wgrad_hlr_kernel<1>, dim3(p.ntiles_n * p.ntiles_c * p.splits), dim3(512), 0, st, p);
+    if (hlr_pairs()) hipLaunchKernelGGL(conv_wgrad_hlrp_kernel, dim3(p.ntiles_n * p.ntiles_c * p.splits), dim3(512), 0, st, p);
+    else hipLaunchKernelGGL(conv_wgrad_hlr_kernel<1>, dim3(p.ntiles_n * p.ntiles_c * p.splits), dim3(512), 0, st, p);
     if (p.splits > 1) launch_wgrad_reduce((const float*)slabs, dw, (int64_t)c->cout * p.K / 4, p.splits, st);
     return dcn::check_launch();
 }

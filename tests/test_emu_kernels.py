@@ -527,11 +527,15 @@ WGRAD_HLR_CASES = [
 ]
 
 
+@pytest.mark.parametrize("pairs", [1, 0])
 @pytest.mark.parametrize("dma", ["late", "early"])
 @pytest.mark.parametrize("case", WGRAD_HLR_CASES, ids=[str(c) for c in WGRAD_HLR_CASES])
-def test_wgrad_hl32_row_window_kernel(L, case, dma, dcn_env, monkeypatch):
-    """conv_wgrad_hlr_kernel (wgrad_hl_kernels.hip): 64 output channels x nine taps x all input channels per workgroup, three
-    row windows of x per 32-pixel stage -- against float64 autograd and the fp32-operand kernel, both LDS-DMA landing modes."""
+def test_wgrad_hl32_row_window_kernel(L, case, dma, pairs, dcn_env, monkeypatch):
+    """conv_wgrad_hlrp_kernel / conv_wgrad_hlr_kernel (wgrad_hl_kernels.hip): 64 output channels x nine taps x 64 input channels
+    per workgroup, row windows of x per 32-pixel stage (row pairs: two image rows per stage, one per wavefront group, sums joined
+    through LDS; DCN_WGRAD_HLR_PAIRS=0: one row) -- against float64 autograd and the fp32-operand kernel, both LDS-DMA landing
+    modes; odd image heights leave the last pair's second row empty."""
+    monkeypatch.setenv("DCN_WGRAD_HLR_PAIRS", str(pairs))
     import kernel_checks
     monkeypatch.setenv("HIPEMU_LDS_DMA", dma)
     n, h, w, cin, cout, k, dil, splits = case

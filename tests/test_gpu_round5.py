@@ -121,18 +121,23 @@ WGRAD_HLR = [
     (1, 2, 20, 64, 192, 3, 1, "1", 2),
     (8, 120, 160, 64, 64, 3, 1, None, 1),     # layer 1 of config 2: one 64-channel tile, 256 stage ranges
     (8, 60, 80, 128, 128, 3, 1, None, 1),     # layer 2: rows of 80 pixels = 2.5 stages (the third half empty), two tiles x 128 ranges
-    (2, 120, 160, 64, 64, 3, 1, None, 1),     # config 1 (B = 1)
+    (2, 120, 160, 64, 64, 3, 1, None, 2),     # config 1 (B = 1): not by default (the step does not gain), forced
     (4, 120, 160, 128, 128, 3, 1, None, 1),   # ResNet50-8s layer-2 3 x 3 at 1280 x 960 (config 5)
+    (1, 5, 64, 128, 64, 3, 1, "5", 2),        # odd height: the last row pair's second row is empty
 ]
 
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("case", WGRAD_HLR, ids=[str(c) for c in WGRAD_HLR])
-def test_wgrad_hl32_row_window_kernel(L, case, dcn_env):
-    """conv_wgrad_hlr_kernel (wgrad_hl_kernels.hip) on the hardware: against float64 autograd, the fp32-operand kernel, and itself
-    (bit-reproducible) -- kernel_checks.check_wgrad_hl; the layer shapes take it by default."""
+@pytest.mark.parametrize("pairs", [1, 0])
+def test_wgrad_hl32_row_window_kernel(L, case, pairs, dcn_env):
+    """conv_wgrad_hlrp_kernel (row pairs, the default) / conv_wgrad_hlr_kernel (wgrad_hl_kernels.hip) on the hardware: against float64
+    autograd, the fp32-operand kernel, and itself (bit-reproducible) -- kernel_checks.check_wgrad_hl; the layer shapes take it by
+    default."""
     n, h, w, cin, cout, k, dil, splits, hlr = case
-    dcn_env(DCN_WGRAD_HLR=hlr)
+    if pairs == 0 and n * h * w > 200000:
+        pytest.skip("single-row form: the small cases and one layer shape")
+    dcn_env(DCN_WGRAD_HLR=hlr, DCN_WGRAD_HLR_PAIRS=pairs)
     d = L.ConvDesc(n, h, w, cin, h, w, cout, k, k, 1, dil * (k - 1) // 2, dil, cout, 0)
     assert L.get().dcn_conv_wgrad_hl_kind(ctypes.byref(d)) == 2
     assert L.get().dcn_conv_wgrad_hl_eligible(ctypes.byref(d)) == 1

@@ -30,7 +30,7 @@ for s in $steps; do
     dist1)     # the RCCL path with ONE rank (nobody to talk to: what the collective machinery costs a step)
                timeout 300 python bench.py --force-dist --no-variants --cpu-baseline-steps 0 --profile-steps 0 --steps 20 --warmup 5 2>/dev/null | tail -1 > gpurun_out/${tag}_bench_force_dist_1rank.json; python -c "import json; d=json.loads(open('gpurun_out/${tag}_bench_force_dist_1rank.json').read()); print('force-dist, 1 rank: %.1f images/s  %.2f ms/step  %s' % (d['value'], d['ms_per_step'], {k: d.get(k) for k in ('allreduce_ms','communication') if k in d}))" ;;
     hlr)       # row-window weight-gradient kernel of the narrow 3 x 3 layers against the fp32-operand kernel, N = 8 and N = 2
-               for nn in ${HLR_N:-8 2}; do for v in 1 0; do echo "--- DCN_WGRAD_HLR=$v DCN_WGRAD_HLR_MIN_M=1, N = $nn" | tee -a gpurun_out/${tag}_wgrad_hlr.txt
+               for nn in ${HLR_N:-8 2}; do for v in ${HLR_V:-1 0}; do echo "--- DCN_WGRAD_HLR=$v DCN_WGRAD_HLR_MIN_M=1 DCN_WGRAD_HLR_PAIRS=${DCN_WGRAD_HLR_PAIRS:-default}, N = $nn" | tee -a gpurun_out/${tag}_wgrad_hlr.txt
                  timeout 200 env DCN_WGRAD_HLR=$v DCN_WGRAD_HLR_MIN_M=1 python tools/conv_bench.py --mode hl --n $nn --only "3x3 " --kinds wgrad --x-direct --reps 20 2>&1 | grep -v "Warn\|amdgpu.ids" | grep "layer1\|layer2 3x3" | cut -c1-200 | tee -a gpurun_out/${tag}_wgrad_hlr.txt; done; done ;;
     *)         bash tools/gpu_r4_session.sh $tag $s ;;
   esac
