@@ -537,7 +537,9 @@ def main():
                     "launches_per_step": hn / args.profile_steps, "avg_launch_us": 1e3 * hms / hn,
                     "algorithmic_gflop_per_launch": hfl / hn / 1e9, "kernel_ms_per_step": hms / args.profile_steps,
                     "traffic": traffic_hl},
-                "conv_wgrad": {"achieved": (wfl / (wms * 1e-3) / 1e12) if wms > 0 else None,
+                "conv_wgrad": {"kernel": "weight gradients: conv_wgrad_hl_kernel (256 x 256 tiles, wide layers), conv_wgrad_hlrp_kernel (row-window "
+                                         "kernel, 64 / 128-channel 3 x 3 layers), conv_wgrad_f16_kernel (the others), slab reduce launches included",
+                               "achieved": (wfl / (wms * 1e-3) / 1e12) if wms > 0 else None,
                                "frac": (wfl / (wms * 1e-3) / 1e12 / peak) if wms > 0 else None,
                                "launches_per_step": wn / args.profile_steps,
                                "avg_launch_us": (1e3 * wms / wn) if wn else None,
