@@ -737,12 +737,12 @@ bool wgrad_hlr_supported(const dcn_conv_desc* c) {
 }
 bool hlr_pairs() { return dcn::tuning().wgrad_hlr_pairs != 0; }
 // stages: (image row | row pair) x 32-pixel segment
-int wgrad_hlr_stages(const dcn_conv_desc* c) {
-    return c->n * (hlr_pairs() ? dcn::ceil_div(c->hout, 2) : c->hout) * dcn::ceil_div(c->wout, 32);
+int wgrad_hlr_stages(const dcn_conv_desc* c, bool pairs) {
+    return c->n * (pairs ? dcn::ceil_div(c->hout, 2) : c->hout) * dcn::ceil_div(c->wout, 32);
 }
 // stage ranges: one round of workgroups (64-channel tiles x splits <= 256), every split at least two stages
-int wgrad_hlr_splits(const dcn_conv_desc* c, int* stages_per_split) {
-    const int nstages = wgrad_hlr_stages(c), tiles = (c->cout / 64) * (c->cin / 64);
+int wgrad_hlr_splits(const dcn_conv_desc* c, int* stages_per_split, bool pairs) {
+    const int nstages = wgrad_hlr_stages(c, pairs), tiles = (c->cout / 64) * (c->cin / 64);
     int s = std::max(1, std::min(std::max(256 / tiles, 1), nstages / 2));
     if (const int v = dcn::tuning().wgrad_splits) { if (v >= 1 && v <= nstages) s = v; }
     const int sps = dcn::ceil_div(nstages, s);
@@ -768,8 +768,8 @@ int launch_wgrad_hlr(const dcn_conv_desc* c, const void* x_hl, const float* x_ab
     p.x_bytes = (unsigned)((int64_t)c->n * c->hin * c->win * c->cin * 4);
     p.d_bytes = (unsigned)((int64_t)c->n * c->hout * c->wout * c->ldc * 4);
     p.hin = c->hin; p.win = c->win; p.cin = c->cin; p.cout = c->cout; p.ldo = c->ldc; p.K = 9 * c->cin;
-    p.segs = dcn::ceil_div(c->wout, 32); p.nstages = wgrad_hlr_stages(c);
-    p.splits = wgrad_hlr_splits(c, &p.stages_per_split);
+    p.segs = dcn::ceil_div(c->wout, 32); p.nstages = wgrad_hlr_stages(c, hlr_pairs());
+    p.splits = wgrad_hlr_splits(c, &p.stages_per_split, hlr_pairs());
     p.ntiles_n = c->cout / 64; p.ntiles_c = c->cin / 64;
     p.div_segs = make_fastdiv(p.segs); p.div_h = make_fastdiv(hlr_pairs() ? dcn::ceil_div(c->hin, 2) : c->hin);
     p.slab = p.splits == 1 ? dw : (float*)slabs;
@@ -802,7 +802,8 @@ extern "C" size_t dcn_conv_wgrad_workspace_hl(const dcn_conv_desc* c) {
     // DCN_WGRAD_HLR stays valid under another)
     size_t bytes = 0;
     int sps;
-    if (wgrad_hlr_supported(c)) bytes = (size_t)wgrad_hlr_splits(c, &sps) * c->cout * 9 * c->cin * sizeof(float);
+    if (wgrad_hlr_supported(c))   // (either form of the row-window kernel: DCN_WGRAD_HLR_PAIRS may change after a plan was sized)
+        bytes = (size_t)std::max(wgrad_hlr_splits(c, &sps, true), wgrad_hlr_splits(c, &sps, false)) * c->cout * 9 * c->cin * sizeof(float);
     if (wgrad_hl_supported(c))
         bytes = std::max(bytes, (size_t)wgrad_hl_splits(c, &sps) * c->cout * c->kh * c->kw * c->cin * sizeof(float));
     return bytes;
