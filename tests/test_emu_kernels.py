@@ -545,6 +545,34 @@ def test_wgrad_hl32_row_window_kernel(L, case, dma, pairs, dcn_env, monkeypatch)
     kernel_checks.check_wgrad_hl(L, "cpu", n, h, w, cin, cout, k, dil, set_env=dcn_env, splits=splits, seed=len(str(case)))
 
 
+def test_wgrad_hl32_kernel_choice(L, dcn_env):
+    """Which weight-gradient kernel dcn_conv_wgrad_hl launches (dcn_conv_wgrad_hl_kind / _eligible; host logic only): the row-window
+    kernel for the 64 / 128-channel 3 x 3 stride-1 dilation-1 layers from four images at 640 x 480, the 256 x 256 tile kernel for
+    whole 256-channel output tiles, neither for the rest (strided, 1 x 1, dilated narrow layers stay on the fp32-operand kernel)."""
+    lib = L.get()
+    dcn_env(DCN_WGRAD_HLR=1)
+
+    def kind(n, h, w, cin, cout, k, stride=1, dil=1):
+        pad = dil * (k - 1) // 2
+        d = L.ConvDesc(n, h, w, cin, (h + 2 * pad - dil * (k - 1) - 1) // stride + 1, (w + 2 * pad - dil * (k - 1) - 1) // stride + 1,
+                       cout, k, k, stride, pad, dil, cout, 0)
+        return lib.dcn_conv_wgrad_hl_kind(ctypes.byref(d)), lib.dcn_conv_wgrad_hl_eligible(ctypes.byref(d))
+    assert kind(8, 120, 160, 64, 64, 3) == (2, 1)          # layer 1 of config 2
+    assert kind(8, 60, 80, 128, 128, 3) == (2, 1)          # layer 2
+    assert kind(4, 120, 160, 64, 64, 3) == (2, 1)          # the two-call pattern: four images per call
+    assert kind(4, 240, 320, 64, 64, 3) == (2, 1)          # ResNet50-8s at 1280 x 960 (config 5)
+    assert kind(2, 120, 160, 64, 64, 3) == (1, 0)          # config 1: too few stages per workgroup -- fp32-operand kernel
+    assert kind(8, 60, 80, 128, 256, 3, dil=2) == (1, 1)   # layer3.0.conv1: whole 256-channel tiles -- tile kernel
+    assert kind(8, 60, 80, 256, 256, 3, dil=2) == (1, 1)
+    assert kind(8, 120, 160, 64, 128, 3, stride=2)[1] == 0   # strided
+    assert kind(8, 120, 160, 64, 64, 1)[1] == 0              # 1 x 1
+    assert kind(8, 60, 80, 128, 128, 3, dil=2)[1] == 0       # dilated narrow layer
+    dcn_env(DCN_WGRAD_HLR=0)
+    assert kind(8, 120, 160, 64, 64, 3) == (1, 0)
+    dcn_env(DCN_WGRAD_HLR=2)
+    assert kind(1, 8, 20, 64, 64, 3) == (2, 1) and kind(8, 60, 80, 128, 256, 3) == (2, 1)
+
+
 WGRAD_HL_CASES = [
     # n, h, w, cin, cout, k, dil, forced splits
     (1, 3, 40, 32, 64, 3, 1, None),      # one ragged tile (64 of 256 output channels, K = 288 of 2 x 256), 120 pixels = 4 stages
