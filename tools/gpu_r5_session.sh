@@ -21,7 +21,7 @@ for s in $steps; do
                timeout 400 python tools/conv_bench.py --mode hl --n ${CONV_N:-2} --x-direct --reps 30 --relu-x 2>&1 | grep -v "Warn\|amdgpu.ids" | cut -c1-170 | tee gpurun_out/${tag}_conv_per_layer_n${CONV_N:-2}.txt ;;
     sq)        # SQ counters of the hl32 kernels at N = 8 (two --pmc passes, each with --kernel-trace only)
                i=0; for pass in "SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES GRBM_GUI_ACTIVE SQ_WAIT_INST_ANY SQ_WAIT_ANY" "SQ_WAVE_CYCLES SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT"; do i=$((i+1))
-                 (cd /tmp && timeout 300 rocprofv3 --kernel-trace --pmc $pass --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/${tag}_sq_$i -- python $GRAFT_REPO_ROOT/tools/conv_bench.py --mode hl --n 8 --kinds fwd,dgrad,wgrad --x-direct --no-split --only "3x3 d" --reps 5 --relu-x > $GRAFT_REPO_ROOT/gpurun_out/${tag}_sq_$i.log 2>&1); done
+                 (cd /tmp && timeout 300 rocprofv3 --kernel-trace --pmc $pass --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/${tag}_sq_$i -- python $GRAFT_REPO_ROOT/tools/conv_bench.py --mode hl --n 8 --kinds ${SQ_KINDS:-fwd,dgrad,wgrad} --x-direct --no-split --only "${SQ_ONLY:-3x3 d}" --reps 5 --relu-x > $GRAFT_REPO_ROOT/gpurun_out/${tag}_sq_$i.log 2>&1); done
                python tools/sq_summary.py gpurun_out/${tag}_hl_sq_counters.txt "rocprofv3 --kernel-trace --pmc <two passes> -- python tools/conv_bench.py --mode hl --n 8 --kinds fwd,dgrad,wgrad --x-direct --no-split --only '3x3 d' --reps 5 --relu-x" gpurun_out/${tag}_sq_1 gpurun_out/${tag}_sq_2; cat gpurun_out/${tag}_hl_sq_counters.txt | cut -c1-120 ;;
     fp32all)   # the exact-fp32 MFMA arithmetic beside every split-fp16 row of the results table
                for w in config1 config2 config3 config4 config5; do for sep in "" "--separate-forwards"; do
