@@ -1,0 +1,5 @@
+"""``dense_correspondence.correspondence_tools``: the device pair generator here, everything else (augmentation, plotter, the CPU
+sampler) from the reference's directory of the same package."""
+from dcn_hip._dropin import merge_package_path as _merge
+
+__path__ = _merge(__path__, __name__)   # the reference's modules of this package stay importable next to these (dcn_hip/_dropin.py)

@@ -1,13 +1,22 @@
 """MI355X mirror of the two sampling functions of
 ``dense_correspondence/correspondence_tools/correspondence_finder.py``, same names and
 argument meaning, for DEVICE-resident inputs: the reference runs them on the CPU in a 5-worker loader
-(``device='CPU'``, :22-27), which cannot feed hundreds of images per second.  There is no CPU path here -- keep using the
-reference's own module for that; a missing HIP library or a CPU tensor raises.
+(``device='CPU'``, :22-27), which cannot feed hundreds of images per second.  There is no CPU path here: a CPU request
+(``device='CPU'``, or host tensors handed to ``create_non_correspondences``) and every other name of the reference's module
+go to the reference's own ``correspondence_finder`` when it is importable behind this source root (dcn_hip/_dropin.py) --
+its ``SpartanDataset`` keeps sampling on the CPU exactly as before -- and raise otherwise.
 """
 import numpy as np
 import torch
 
 from dcn_hip import pairgen as _pg
+from dcn_hip._dropin import reference_sibling as _reference_sibling
+
+_ref = _reference_sibling(__name__, __file__)
+
+
+def __getattr__(name):
+    return _ref.attr(name)
 
 
 def get_default_K_matrix():
@@ -35,7 +44,12 @@ def batch_find_pixel_correspondences(img_a_depth, img_a_pose, img_b_depth, img_b
     or ``(None, None)`` when nothing survives.  ``uv_a``: optional ``(u, v)`` tensors of candidate pixels (the reference
     only accepts one pixel there; here any number)."""
     if device != 'GPU':
-        raise ValueError("this module only implements device='GPU'; the CPU sampler is the reference's own")
+        ref = _ref.get()
+        if ref is None:
+            raise ValueError("this module only implements device='GPU'; the CPU sampler is the reference's own (%s)"
+                             % _ref.why_not())
+        return ref.batch_find_pixel_correspondences(img_a_depth, img_a_pose, img_b_depth, img_b_pose, uv_a=uv_a,
+                                                    num_attempts=num_attempts, device=device, img_a_mask=img_a_mask, K=K)
     dev = torch.device("cuda")
     da, db = _device_depth(img_a_depth, dev), _device_depth(img_b_depth, dev)
     h, w = int(da.shape[0]), int(da.shape[1])
@@ -67,6 +81,10 @@ def create_non_correspondences(uv_b_matches, img_b_shape, num_non_matches_per_ma
     follows is a no-op for in-range samples.  The observable result -- the plain samples -- is what is returned.)"""
     if uv_b_matches is None:
         return None
+    if torch.is_tensor(uv_b_matches[0]) and not uv_b_matches[0].is_cuda and _ref.get() is not None:
+        # host tensors: the reference's CPU loader calling its own sampler (spartan_dataset_masked.py:672-695)
+        return _ref.get().create_non_correspondences(uv_b_matches, img_b_shape,
+                                                     num_non_matches_per_match=num_non_matches_per_match, img_b_mask=img_b_mask)
     h, w = int(img_b_shape[0]), int(img_b_shape[1])
     num_matches = len(uv_b_matches[0])
     n = num_matches * num_non_matches_per_match

@@ -9,7 +9,9 @@ Same names, arguments, file names and file contents (one ``[H, W, D]`` float32 `
 see csrc/backbone_engine.hip) instead of one forward per image, and the device -> host copy of a batch overlaps the next
 batch's forward.  ``dataset`` is duck-typed: ``get_pose_data(scene_name)``, ``rgb_image_to_tensor(rgb)`` and either
 ``get_rgb_image_from_scene_name_and_idx(scene_name, idx)`` or ``get_rgbd_mask_pose(scene_name, idx)`` -- the reference's
-``SpartanDataset`` (dataset loading itself is out of this package's scope)."""
+``SpartanDataset`` (dataset loading itself is out of this package's scope).  Every other name of the reference's module
+(``PandaDataFrameWrapper`` ..., evaluation.py:34) is handed on to it when it is importable behind this source root
+(dcn_hip/_dropin.py)."""
 import os
 import shutil
 import time
@@ -18,6 +20,13 @@ import numpy as np
 import torch
 
 import dense_correspondence_manipulation.utils.utils as utils
+from dcn_hip._dropin import reference_sibling as _reference_sibling
+
+_ref = _reference_sibling(__name__, __file__)
+
+
+def __getattr__(name):
+    return _ref.attr(name)
 
 PADDED_STRING_WIDTH = 6   # SpartanDataset.PADDED_STRING_WIDTH (spartan_dataset_masked.py:41)
 
