@@ -62,6 +62,9 @@ WORKLOADS = {
                     desc="BASELINE configs[4] per-GPU share: B=2 pairs 1280x960 D=32 Resnet50_8s, masked / background "
                          "non-match sampling (2500 matches x 2 masked + 2 background non-matches)"),
     "tiny": dict(B=1, H=96, W=128, D=3, Pm=500, Pk=250, Pg=250, backbone="Resnet34_8s", desc="smoke-size workload"),
+    # --dry-run-cpu only: a Resnet18_8s of base width 8 at 64 x 64 (what the host-emulated kernels step through in seconds)
+    "dryrun": dict(B=2, H=64, W=64, D=3, Pm=60, Pk=30, Pg=30, backbone="DryRunNet", base_width=8,
+                   desc="DRY RUN: B=2 pairs 64x64 D=3 Resnet18_8s of base width 8, host-emulated kernels"),
 }
 F16_MFMA_PEAK_TFLOPS = 2516.6   # v_mfma_f32_32x32x16_f16: 1024 FLOP/clk/SIMD x 1024 SIMDs x 2.4 GHz ("~2.5 PF dense")
 F16X3_PEAK_TFLOPS = F16_MFMA_PEAK_TFLOPS / 3.0
@@ -231,12 +234,51 @@ def pairgen_bench(args):
     print(json.dumps(out), flush=True)
 
 
-def respawn_under_torchrun(n):
+class _HostEvent(object):
+    """--dry-run-cpu: torch.cuda.Event stand-in (host clock)."""
+
+    def __init__(self, enable_timing=True):
+        self.t = None
+
+    def record(self, stream=None):
+        self.t = time.perf_counter()
+
+    def elapsed_time(self, other):
+        return 1e3 * (other.t - self.t)
+
+
+def enter_cpu_dry_run(args):
+    """`--dry-run-cpu`: NOT a measurement.  The whole bench choreography -- respawn under torch.distributed.run, rendezvous,
+    per-rank jobs, bucketed gradient all-reduce, barriers, max-over-ranks timing, the weak- / strong-scaling legs, the JSON
+    line -- on a box without a GPU: host-emulated kernels (tests/hostemu, the same kernel sources compiled for the host), the
+    `gloo` backend, a narrow network.  It exists so that the multi-GPU control flow, which the authoring container cannot run
+    on RCCL, is executed by the CPU test-suite (tests/test_bench_dry_run.py); every number it prints is meaningless."""
+    sys.path.insert(0, os.path.join(ROOT, "tests", "hostemu"))
+    import build_emu
+    from dcn_hip import _lib
+    _lib.load(build_emu.build())
+    import pytorch_segmentation_detection.models.resnet_dilated as rd
+
+    class DryRunNet(rd.Resnet18_8s):
+        def __init__(self, num_classes):
+            super(DryRunNet, self).__init__(num_classes=num_classes, base_width=8)
+    DryRunNet.arch, DryRunNet.attr = rd.Resnet18_8s.arch, rd.Resnet18_8s.attr
+    rd.DryRunNet = DryRunNet
+    torch.cuda.synchronize = lambda *a, **k: None
+    torch.cuda.empty_cache = lambda *a, **k: None
+    torch.cuda.Event = _HostEvent
+    args.workload = "dryrun"
+    args.cpu_baseline_steps = 0
+    args.hip_graph = False
+    args.conv_mode = "f16x3"
+
+
+def respawn_under_torchrun(n, dry_run_cpu=False):
     """`python bench.py --gpus N` with no torch.distributed.run around it: start the N ranks ourselves (one process per
     GPU, RCCL over xGMI) and relay rank 0's JSON line."""
     import socket
     import subprocess
-    if not torch.cuda.is_available() or torch.cuda.device_count() < n:
+    if not dry_run_cpu and (not torch.cuda.is_available() or torch.cuda.device_count() < n):
         raise SystemExit("bench.py --gpus %d: only %d GPU(s) visible on this node" %
                          (n, torch.cuda.device_count() if torch.cuda.is_available() else 0))
     sock = socket.socket()
@@ -270,7 +312,11 @@ class Job(object):
         dcn.to(dev)
         broadcast_module(dcn)
         self.pcl = pcl = PixelwiseContrastiveLoss(image_shape=dcn.image_shape, config=LOSS_CONFIG)
-        self.grads = grads = FlatGradients(dcn, bucketed=False if args.monolithic_allreduce else None)
+        # --force-dist with ONE rank: the bucketed schedule anyway, its all-reduces issued over the one-rank RCCL group, so that
+        # a single GPU runs the communication-stream path the 8-GPU job runs (communication.bucketed_steps > 0)
+        one_rank_dist = use_dist and (not dist.is_initialized() or dist.get_world_size() == 1)
+        self.bucketed_default = False if args.monolithic_allreduce else (True if one_rank_dist else None)
+        self.grads = grads = FlatGradients(dcn, bucketed=self.bucketed_default, single_rank_collectives=one_rank_dist)
         self.opt = opt = grads.attach((torch.optim.Adam if args.torch_adam else Adam)(
             dcn.parameters(), lr=1.0e-4, weight_decay=1.0e-4))   # training.py:133-145
         img_a, img_b, lists = make_batch(B, H, W, wl["Pm"], wl["Pk"], wl["Pg"], seed=1 + rank, masked=wl.get("masked", False))
@@ -386,32 +432,42 @@ def main():
     ap.add_argument("--force-dist", action="store_true", help="initialise RCCL even with one rank (smoke-tests the collective path)")
     ap.add_argument("--monolithic-allreduce", action="store_true",
                     help="ONE all-reduce after backward instead of the bucketed, overlapped schedule")
+    ap.add_argument("--dry-run-cpu", action="store_true",
+                    help="NOT a measurement: run the bench's control flow (respawn, rendezvous, bucketed all-reduce, barriers, "
+                         "scaling legs, JSON line) on CPU with host-emulated kernels and gloo -- see enter_cpu_dry_run")
     ap.add_argument("--no-variants", action="store_true", help="skip the extra measurements (fp32-MFMA mode, config 4 on one "
                                                                 "GPU, strong-scaling point) that ride on the JSON line")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
-        respawn_under_torchrun(args.gpus)   # does not return
+        respawn_under_torchrun(args.gpus, args.dry_run_cpu)   # does not return
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs an MI355X: the dense-correspondence hot path has no CPU fallback")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    if args.dry_run_cpu:
+        enter_cpu_dry_run(args)
+        dev = torch.device("cpu")
+    else:
+        if not torch.cuda.is_available():
+            raise SystemExit("bench.py needs an MI355X: the dense-correspondence hot path has no CPU fallback")
+        torch.cuda.set_device(local_rank)
+        dev = torch.device("cuda", local_rank)
     use_dist = world > 1 or args.force_dist
     rccl = None
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if args.dry_run_cpu:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
         dist.barrier()
         import ctypes
         ctypes.CDLL(None).fflush(None)  # RCCL's version banner sits in the C stdio buffer: emit it now, not after the JSON line
         rccl = {"backend": dist.get_backend(), "ranks": dist.get_world_size(),
-                "nccl_version": ".".join(str(v) for v in torch.cuda.nccl.version())}
+                "nccl_version": None if args.dry_run_cpu else ".".join(str(v) for v in torch.cuda.nccl.version())}
 
     if args.workload is None:
         args.workload = "config2" if world == 1 else "config4"
@@ -423,7 +479,7 @@ def main():
     bb.set_conv_mode(args.conv_mode)
     from dense_correspondence.loss_functions import loss_composer
     info = _lib.library_info()
-    assert not info["hostemu"], "bench.py must run the gfx950 library"
+    assert args.dry_run_cpu or not info["hostemu"], "bench.py must run the gfx950 library"
 
     wl = dict(WORKLOADS[args.workload])
     if args.batch:
@@ -467,7 +523,7 @@ def main():
         grads.bucketed = False
         nocomm, _ = job.timed(2, max(4, args.steps // 2), args.warmup + args.steps, use_dist)
         job.comm = True
-        grads.bucketed = False if args.monolithic_allreduce else None
+        grads.bucketed = job.bucketed_default
         broadcast = __import__("dcn_hip.distributed", fromlist=["broadcast_module"]).broadcast_module
         broadcast(dcn)   # the un-synchronised steps let the replicas drift: re-align before anything else is measured
         comm = {"allreduce_ms": ar_ms, "allreduce_bytes": grads.flat.numel() * 4,
@@ -477,14 +533,16 @@ def main():
                 "backward has produced it (dcn_plan_stream_wait_grad_bucket)",
                 "ms_per_step_without_allreduce": 1e3 * nocomm / max(4, args.steps // 2),
                 "allreduce_exposed_ms": 1e3 * elapsed / args.steps - 1e3 * nocomm / max(4, args.steps // 2),
-                "bucketed_steps": grads.stats["bucketed_steps"], "monolithic_steps": grads.stats["monolithic_steps"]}
+                "bucketed_steps": grads.stats["bucketed_steps"], "monolithic_steps": grads.stats["monolithic_steps"],
+                "bucket_collectives": grads.stats["bucket_collectives"]}
         comm.update(rccl)
 
     # ---- roofline of the dominant kernel: extra steps, every conv_gemm / conv_wgrad launch bracketed by HIP events
     def measure_roofline(job_, conv_mode, first_it):
         wl_, B_ = job_.wl, job_.B
-        plan = bb.get_plan(wl_["backbone"], 64, B_, wl_["H"], wl_["W"], wl_["D"]) if job_.separate else \
-            bb.get_plan(wl_["backbone"], 64, 2 * B_, wl_["H"], wl_["W"], wl_["D"], 2)
+        arch_ = "Resnet18_8s" if wl_["backbone"] == "DryRunNet" else wl_["backbone"]
+        plan = bb.get_plan(arch_, wl_.get("base_width", 64), B_, wl_["H"], wl_["W"], wl_["D"]) if job_.separate else \
+            bb.get_plan(arch_, wl_.get("base_width", 64), 2 * B_, wl_["H"], wl_["W"], wl_["D"], 2)
         plan.profile_begin()
         for it in range(args.profile_steps):
             job_.step(first_it + it, eager=True)   # the engine's per-launch events do not exist inside a graph
@@ -663,7 +721,7 @@ def main():
     # ---- the same loss measurement at BASELINE configs[2]'s list sizes (B = 32 pairs, D = 16, 10 000 + 50 000 + 50 000
     # pixel pairs each: the only config where the gather moves enough bytes to talk about HBM bandwidth), on
     # random descriptor maps resident in HBM
-    if loss_roof is not None and world == 1 and not args.no_variants and args.workload != "config3":
+    if loss_roof is not None and world == 1 and not args.no_variants and args.workload != "config3" and not args.dry_run_cpu:
         from dcn_hip.loss import PairLists
         c3 = WORKLOADS["config3"]
         B3, D3, HW3 = c3["B"], c3["D"], c3["H"] * c3["W"]
@@ -703,7 +761,7 @@ def main():
     # configs[3]'s per-GPU share on ONE GPU (the 1-GPU point of the weak-scaling curve the multi-GPU runs trace), and for
     # N > 1 the fixed-global-batch-64 strong-scaling point
     variants = {}
-    short = max(5, args.steps // 2)
+    short = max(5, args.steps // 2) if not args.dry_run_cpu else 2
 
     def summarize(job_, sec, steps_, extra=None):
         d = {"value": 2 * job_.B * world * steps_ / sec, "unit": "images/s", "ms_per_step": 1e3 * sec / steps_, "steps": steps_,
@@ -775,8 +833,8 @@ def main():
             job.comm = True
             grads.bucketed = saved_mode
             __import__("dcn_hip.distributed", fromlist=["broadcast_module"]).broadcast_module(dcn)
-        if world > 1 and 64 % world == 0 and args.workload == "config4" and not args.batch:
-            Bs = 64 // world
+        if world > 1 and 64 % world == 0 and args.workload in ("config4", "dryrun") and not args.batch:
+            Bs = (4 if args.dry_run_cpu else 64) // world
             if Bs == B:
                 variants["strong_scaling_global64"] = summarize(job, elapsed, args.steps, {"note": "same as the headline at this N"})
             else:
@@ -791,13 +849,14 @@ def main():
         images_per_step = 2 * B * world
         ms_per_step = 1e3 * elapsed / args.steps
         out = {"metric": "training images/sec, 640x480 D=3 ResNet34-8s" if args.workload in ("config1", "config2", "config4")
-               else "training images/sec (%s)" % args.workload,
+               else ("training images/sec (%s)" % args.workload if not args.dry_run_cpu else "DRY RUN -- not a measurement"),
                "value": images_per_step * args.steps / elapsed, "unit": "images/s", "n_gpus": world,
                "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
                "scaling": "weak", "vs_baseline": None, "host_enqueue_ms_per_step": host_enqueue_ms,
                "host_enqueue_idle_gpu_ms_per_step": getattr(job, "host_enqueue_idle_ms", None),
                "host_enqueue_ms_per_rank": host_enqueue_per_rank, "host_usable_cpus": usable_cpus(),
-               "dtype": "f32 (f16x3 products)" if args.conv_mode == "f16x3" else "f32", "data": "synthetic",
+               "dtype": "f32 (f16x3 products)" if args.conv_mode == "f16x3" else "f32",
+               "data": "synthetic" if not args.dry_run_cpu else "DRY RUN on CPU (host-emulated kernels, gloo): NOT a measurement",
                "arithmetic": ("fp32 tensors and accumulation; convolution products as 3 fp16 MFMAs on exact hi/lo operand "
                               "splits (~22 mantissa bits per operand; parity with the fp32 reference at 1e-4, tests/test_gpu_parity.py)"
                               if args.conv_mode == "f16x3" else "fp32 MFMA"),
@@ -816,7 +875,8 @@ def main():
                                                      else "the multi-GPU lines run config4 (B = 8 pairs) per rank: their N = 1 point is "
                                                           "variants.config4_one_gpu, not `value`") if world == 1 else
                           "variants.weak_scaling.one_gpu_same_box (rank 0 alone on the same per-rank workload)",
-                          "train_gflop_per_image": 3 * bb.get_plan(wl["backbone"], 64, B, H, W, D).forward_flops / B / 1e9},
+                          "train_gflop_per_image": 3 * bb.get_plan("Resnet18_8s" if args.dry_run_cpu else wl["backbone"],
+                                                                   wl.get("base_width", 64), B, H, W, D).forward_flops / B / 1e9},
                "roofline": roofline, "roofline_elementwise": roofline_elementwise, "breakdown": headline_breakdown,
                "roofline_loss_gather": loss_roof, "variants": variants,
                "allreduce_ms": comm["allreduce_ms"] if comm else None, "communication": comm}
@@ -824,6 +884,42 @@ def main():
             out["cpu_baseline"] = cpu_baseline(wl, args.cpu_baseline_steps, 1)
         else:
             out["cpu_baseline"] = None
+        # ---- the comparisons that matter, flat and LAST on the line (a reader that keeps the contract keys and the tail of a
+        # 14 KB line sees them; `variants` above has the detail): scalars only, short keys
+        def pick(d, *path):
+            for k in path:
+                if not isinstance(d, dict) or d.get(k) is None:
+                    return None
+                d = d[k]
+            return round(d, 4) if isinstance(d, float) else d
+        summary = {"images_per_s": round(out["value"], 2), "ms_per_step": round(ms_per_step, 3),
+                   "frac_gemm_fwd_dgrad": pick(roofline, "frac"), "frac_hl_kernel": pick(roofline, "hl_kernel", "frac"),
+                   "frac_wgrad": pick(roofline, "conv_wgrad", "frac"), "wgrad_launches_per_step": pick(roofline, "conv_wgrad", "launches_per_step"),
+                   "frac_elementwise_hbm": pick(roofline_elementwise, "frac"),
+                   "elementwise_ms": pick(roofline_elementwise, "kernel_ms_per_step"),
+                   "bn_finalize_launches": pick(roofline_elementwise, "bn_finalize", "launches_per_step"),
+                   "bn_finalize_ms": pick(roofline_elementwise, "bn_finalize", "kernel_ms_per_step"),
+                   "frac_loss_gather_hbm": pick(loss_roof, "frac"),
+                   "frac_loss_gather_pairs_config3_sizes": pick(loss_roof, "at_config3_list_sizes", "frac_pairs_only"),
+                   "engine_launches_per_step": pick(headline_breakdown, "engine_launches_per_step"),
+                   "host_enqueue_idle_gpu_ms": pick(out, "host_enqueue_idle_gpu_ms_per_step")}
+        for key, short_name in (("fp32_mfma", "exact_fp32"), ("separate_forwards", "separate_forwards"), ("config1_one_gpu", "config1_pair"),
+                                ("config1_separate_forwards", "config1_separate_forwards"), ("config3_one_gpu", "config3"),
+                                ("config4_one_gpu", "config4"), ("config5_one_gpu", "config5")):
+            v = variants.get(key)
+            if v:
+                summary[short_name] = {"images_per_s": round(v["value"], 2), "ms_per_step": round(v["ms_per_step"], 3),
+                                       "frac": pick(v, "roofline", "frac"),
+                                       "host_idle_ms": pick(v, "breakdown", "host_enqueue_idle_gpu_ms_per_step")}
+        if comm:
+            summary["communication"] = {k: pick(comm, k) for k in ("allreduce_ms", "allreduce_exposed_ms", "bucketed_steps",
+                                                                   "bucket_collectives", "monolithic_steps", "ranks")}
+        # the driver's parser keeps the scalars of `roofline` and `config`: the two numbers asked for most often ride there too
+        if roofline is not None:
+            roofline["frac_wgrad"], roofline["frac_elementwise_hbm"] = summary["frac_wgrad"], summary["frac_elementwise_hbm"]
+        out["config"]["exact_fp32_images_per_s"] = pick(summary, "exact_fp32", "images_per_s")
+        out["config"]["separate_forwards_images_per_s"] = pick(summary, "separate_forwards", "images_per_s")
+        out["summary"] = summary
         print(json.dumps(out), flush=True)
     if use_dist:
         dist.barrier()

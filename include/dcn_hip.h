@@ -52,6 +52,11 @@ const char* dcn_version(void);
  * while another thread is inside the library. */
 void dcn_reload_env(void);
 
+/* The ONE exception to "the library allocates no device memory": a 64 KB buffer of arrival words per (device, stream) that
+ * ever ran a K-split launch of the small-tile gather-GEMM (csrc/conv_hlx_kernels.hip; never while the stream is being
+ * captured).  This call frees them all; the caller has synchronised those streams.  The Python binding registers it atexit. */
+void dcn_release_pooled_buffers(void);
+
 /* =====================================================================================================
  * 1. Pixelwise contrastive loss  (kernel K9)
  *
@@ -190,6 +195,11 @@ int dcn_plan_create(const char* arch, int base_width, int n, int h, int w, int d
  * Larger launches fill the 256 CUs better at small batch.  DCN_E_UNSUPPORTED if a group's rows are not tile-aligned. */
 int dcn_plan_create_grouped(const char* arch, int base_width, int n, int groups, int h, int w, int d, dcn_plan** out);
 void dcn_plan_destroy(dcn_plan* plan);
+/* A training-mode forward call leaves a small host-side record keyed by its `saved` pointer (what the matching backward call
+ * must agree with).  dcn_plan_forget_saved drops it when the caller releases that arena without (or after) differentiating
+ * it -- returns how many records were dropped; dcn_plan_num_forward_records counts the records a plan holds. */
+int dcn_plan_forget_saved(dcn_plan* plan, const void* saved);
+int dcn_plan_num_forward_records(const dcn_plan* plan);
 
 /* How the plan's convolutions multiply.  Both modes take and return fp32 tensors and accumulate in fp32.
  *   DCN_CONV_FP32  : fp32 MFMA (v_mfma_f32_32x32x2_f32), 157 TFLOP/s peak.

@@ -117,9 +117,10 @@ struct dcn_plan {
         bool wt_saved = false;                    // the backward pass's weight images are in the saved arena (s_wht / s_wlt / s_whlt)
         std::vector<unsigned char> hl_t_written;  // ... per convolution: its transposed hl32 image among them
     };
-    // newest last; one per forward call awaiting its backward.  A record is a few hundred bytes and is replaced by the next
-    // forward call that fills the same arena; the bound only keeps a process that never calls backward from growing without
-    // limit (round 5: was 8 -- five image pairs forwarded separately and differentiated by one backward() exceed that)
+    // newest last; one per forward call awaiting its backward.  A record is a few hundred bytes; it is replaced by the next
+    // forward call that fills the same arena and dropped when the caller says the arena is gone (dcn_plan_forget_saved: the
+    // Python binding ties that to the arena tensor's lifetime).  The bound only keeps a C caller that never does either from
+    // growing without limit (round 5: was 8 -- five image pairs forwarded separately and differentiated by one backward() exceed that)
     static constexpr size_t kMaxFwdRecords = 4096;
     std::vector<FwdRecord> fwd_records;
     // backward pass, split-fp16 mode: the weight-gradient GEMMs run on a second, low-priority stream next to the
@@ -773,6 +774,21 @@ extern "C" int dcn_plan_create_grouped(const char* arch, int base_width, int n, 
     *out = p;
     return DCN_OK;
 }
+// The caller has released the saved arena at this address (or will overwrite it with something else): the plan drops what it
+// remembered about the forward call that filled it.  Returns the number of records dropped (0: none was held).
+extern "C" int dcn_plan_forget_saved(dcn_plan* plan, const void* saved) {
+    if (!plan) return DCN_E_INVALID;
+    int n = 0;
+    for (size_t i = 0; i < plan->fwd_records.size();)
+        if (plan->fwd_records[i].saved == saved) { plan->fwd_records.erase(plan->fwd_records.begin() + i); ++n; }
+        else ++i;
+    return n;
+}
+
+extern "C" int dcn_plan_num_forward_records(const dcn_plan* plan) {
+    return plan ? (int)plan->fwd_records.size() : DCN_E_INVALID;
+}
+
 extern "C" void dcn_plan_destroy(dcn_plan* plan) {
     if (!plan) return;
     for (hipEvent_t e : plan->prof_ev) hipEventDestroy(e);

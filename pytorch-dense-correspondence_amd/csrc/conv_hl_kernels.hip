@@ -468,57 +468,62 @@ __device__ __forceinline__ void gemm_segment_hl(const GemmConv& p, unsigned char
     for (int tb = 0; tb < 2 * MT; ++tb)
 #pragma unroll
         for (int cb = 0; cb < 4; ++cb) acc[tb][cb] *= inv;
-    if (k0 == 0 && k1 == nk) {
-        gemm_epilogue16<2 * MT, 4, BM, 256>(p, acc, mt, nt, grp, grp * GR, wn * 64, reinterpret_cast<float*>(lds));
-        return;
-    }
-    // ---- stream-K partial: parked device-coherently, completed by the last contributor inside the launch
-    // (conv_f16_kernels.hip, gemm_segment_f16: same protocol; slot layout [wavefront][row block][column block][lane] float4)
-    constexpr int TM = MT;
-    const __amdgpu_buffer_rsrc_t rs_p = __builtin_amdgcn_make_buffer_rsrc(p.sk_partial, 0, (int)p.sk_bytes, 0x00020000);
-    constexpr int kSc1 = 16;
-    constexpr int kPieces = 2 * MT * 4;   // float4 pieces per lane
-    const int lane_off = (wv * (kPieces * 64) + lane) * 16;
-    {
-        const int so = (int)((slot - p.sk_partial) * 4);
+    // ONE instance of the epilogue for whole tiles and completed stream-K tiles alike (two inlined copies cost the 256-row
+    // stream-K instantiation 416 bytes of scratch per lane)
+    bool complete = k0 == 0 && k1 == nk;
+    int rel = 0;
+    if (!complete) {
+        // ---- stream-K partial: parked device-coherently, completed by the last contributor inside the launch
+        // (conv_f16_kernels.hip, gemm_segment_f16: same protocol; slot layout [wavefront][row block][column block][lane] float4)
+        constexpr int TM = MT;
+        const __amdgpu_buffer_rsrc_t rs_p = __builtin_amdgcn_make_buffer_rsrc(p.sk_partial, 0, (int)p.sk_bytes, 0x00020000);
+        constexpr int kSc1 = 16;
+        constexpr int kPieces = 2 * MT * 4;   // float4 pieces per lane
+        const int lane_off = (wv * (kPieces * 64) + lane) * 16;
+        {
+            const int so = (int)((slot - p.sk_partial) * 4);
 #pragma unroll
-        for (int pc = 0; pc < kPieces; ++pc)
-            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, acc[pc >> 2][pc & 3]), rs_p, lane_off + pc * 1024, so, kSc1);
-    }
-    const int rel = tile - p.sk_dp;
-    const int ua = rel * nk, ub = ua + nk - 1;
-    const int ga = ua / p.sk_units, gb = ub / p.sk_units;
-    __builtin_amdgcn_s_waitcnt(0x0F70);                // vmcnt(0): this work-item's partial has been written through
-    __syncthreads();
-    int* s_last = reinterpret_cast<int*>(lds + 2 * kHlStage - 16);   // (inside the one LDS array: see the header)
-    if (tid == 0) *s_last = sk_arrive_is_last(p.sk_count + rel, p.sk_id, gb - ga + 1) ? 1 : 0;
-    __syncthreads();
-    if (*s_last) {
-#pragma unroll
-        for (int tb = 0; tb < 2 * MT; ++tb)
-#pragma unroll
-            for (int cb = 0; cb < 4; ++cb) acc[tb][cb] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-        // (each contributor's partial in batches of 16 (12) loads of 16 B issued back to back, then added: left to itself the
-        // compiler waits for every 4 loads -- device-coherent round trips on the critical path of the launch)
-        constexpr int kBatch = TM == 4 ? 16 : (TM == 3 ? 12 : 10);
-        static_assert(kPieces % kBatch == 0, "whole batches");
-        for (int g = ga; g <= gb; ++g) {               // fixed order, own partial included: deterministic
-            const int first_tile = (g * p.sk_units) / nk;
-            const int so = (2 * g + (first_tile == rel ? 0 : 1)) * (BM * 256 * 4);
-#pragma unroll
-            for (int b0 = 0; b0 < kPieces; b0 += kBatch) {
-                u32x4 t[kBatch];
-#pragma unroll
-                for (int j = 0; j < kBatch; ++j) t[j] = __builtin_amdgcn_raw_buffer_load_b128(rs_p, lane_off + (b0 + j) * 1024, so, kSc1);
-                __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int j = 0; j < kBatch; ++j) acc[(b0 + j) >> 2][(b0 + j) & 3] += __builtin_bit_cast(f32x4_t, t[j]);
-                __builtin_amdgcn_sched_barrier(0);
-            }
+            for (int pc = 0; pc < kPieces; ++pc)
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, acc[pc >> 2][pc & 3]), rs_p, lane_off + pc * 1024, so, kSc1);
         }
-        __syncthreads();                               // (s_last has been read by everyone: the epilogue reuses the array)
+        rel = tile - p.sk_dp;
+        const int ua = rel * nk, ub = ua + nk - 1;
+        const int ga = ua / p.sk_units, gb = ub / p.sk_units;
+        __builtin_amdgcn_s_waitcnt(0x0F70);                // vmcnt(0): this work-item's partial has been written through
+        __syncthreads();
+        int* s_last = reinterpret_cast<int*>(lds + 2 * kHlStage - 16);   // (inside the one LDS array: see the header)
+        if (tid == 0) *s_last = sk_arrive_is_last(p.sk_count + rel, p.sk_id, gb - ga + 1) ? 1 : 0;
+        __syncthreads();
+        complete = *s_last != 0;
+        if (complete) {
+#pragma unroll
+            for (int tb = 0; tb < 2 * MT; ++tb)
+#pragma unroll
+                for (int cb = 0; cb < 4; ++cb) acc[tb][cb] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+            // (each contributor's partial in batches of loads of 16 B issued back to back, then added: left to itself the
+            // compiler waits for every 4 loads -- device-coherent round trips on the critical path of the launch)
+            constexpr int kBatch = TM == 4 ? 16 : (TM == 3 ? 12 : 10);
+            static_assert(kPieces % kBatch == 0, "whole batches");
+            for (int g = ga; g <= gb; ++g) {               // fixed order, own partial included: deterministic
+                const int first_tile = (g * p.sk_units) / nk;
+                const int so = (2 * g + (first_tile == rel ? 0 : 1)) * (BM * 256 * 4);
+#pragma unroll
+                for (int b0 = 0; b0 < kPieces; b0 += kBatch) {
+                    u32x4 t[kBatch];
+#pragma unroll
+                    for (int j = 0; j < kBatch; ++j) t[j] = __builtin_amdgcn_raw_buffer_load_b128(rs_p, lane_off + (b0 + j) * 1024, so, kSc1);
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int j = 0; j < kBatch; ++j) acc[(b0 + j) >> 2][(b0 + j) & 3] += __builtin_bit_cast(f32x4_t, t[j]);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+            __syncthreads();                               // (s_last has been read by everyone: the epilogue reuses the array)
+        }
+    }
+    if (complete) {
         gemm_epilogue16<2 * MT, 4, BM, 256>(p, acc, mt, nt, grp, grp * GR, wn * 64, reinterpret_cast<float*>(lds));
-        if (tid == 0) atomicExch(p.sk_count + rel, 0ull);
+        if (!(k0 == 0 && k1 == nk) && tid == 0) atomicExch(p.sk_count + rel, 0ull);
     }
 }
 
@@ -531,22 +536,31 @@ conv_gemm_hl_kernel(GemmConv p) {
         gemm_segment_hl<TR, MT>(p, lds, xcd_remap(blockIdx.x, p.mtiles * p.ntiles), 0, nk, nk, nullptr);
     } else {
         // hybrid schedule (as conv_gemm_f16_kernel): whole rounds of tiles data-parallel, then ONE stream-K pass that splits
-        // the K stages of the leftover tiles evenly
+        // the K stages of the leftover tiles evenly.  ONE call site for both kinds of work item: two inlined copies of the
+        // segment (round 5) cost the 256-row instantiation 416 bytes of scratch per lane in its epilogues.
         const int g = xcd_remap(blockIdx.x, gridDim.x);
-        for (int tile = g; tile < p.sk_dp; tile += gridDim.x) {
-            gemm_segment_hl<TR, MT>(p, lds, tile, 0, nk, nk, nullptr);
-            __syncthreads();
-        }
+        int tile = g;
         int u = p.sk_dp * nk + g * p.sk_units;
         const int total = p.mtiles * p.ntiles * nk;
         const int u_end = min(total, u + p.sk_units);
-        bool first = true;
-        while (u < u_end) {
-            const int tile = fdiv(u, p.div_nk), k0 = u - tile * nk;
-            const int k1 = min(nk, k0 + (u_end - u));
-            gemm_segment_hl<TR, MT>(p, lds, tile, k0, k1, nk, p.sk_partial + (int64_t)(2 * g + (first ? 0 : 1)) * (64 * MT * 256));
-            u += k1 - k0;
-            first = false;
+        int parked = 0;                                    // partials this workgroup has parked (at most two: slots 2 g, 2 g + 1)
+        for (;;) {
+            int t, k0, k1;
+            float* slot = nullptr;
+            if (tile < p.sk_dp) {
+                t = tile; k0 = 0; k1 = nk;
+                tile += gridDim.x;
+            } else if (u < u_end) {
+                t = fdiv(u, p.div_nk);
+                k0 = u - t * nk;
+                k1 = min(nk, k0 + (u_end - u));
+                slot = p.sk_partial + (int64_t)(2 * g + parked) * (64 * MT * 256);
+                u += k1 - k0;
+                parked = 1;
+            } else {
+                break;
+            }
+            gemm_segment_hl<TR, MT>(p, lds, t, k0, k1, nk, slot);
             __syncthreads();
         }
     }
@@ -681,6 +695,9 @@ void launch_gemm_hl_rows(const GemmConv& p, bool sk, dim3 grid, hipStream_t st) 
 }
 
 int launch_gemm_hl(GemmConv& p, int group_rows, void* workspace, hipStream_t st) {
+    // (gemm_epilogue16 -- this kernel's and the small-tile kernel's epilogue -- has no ReLU, no abs-max output and no
+    // backward-statistics partials: a caller that asks for one of them must not get a silently different result)
+    if (p.relu || p.out_absmax || p.bnb_partial) return DCN_E_UNSUPPORTED;
     p.sshift = 0;
     p.div_hw = make_fastdiv(p.hd * p.wd);
     p.div_w = make_fastdiv(p.wd);

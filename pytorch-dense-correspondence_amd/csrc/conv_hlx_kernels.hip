@@ -457,27 +457,54 @@ HlxShape hlx_shape(int M, int cd, int K, int group_rows, int taps, int cs) {
 // is being captured into a graph (no allocation then), for more tiles than the buffer holds, or with DCN_HLX_COUNTERS=0:
 // the launch then uses the words behind the partials in the caller's scratch, cleared by a fill launch.
 constexpr int kPoolWords = 8192;
+struct CounterPool {
+    std::mutex mu;
+    std::unordered_map<unsigned long long, unsigned long long*> map;
+};
+CounterPool& counter_pool() {
+    static CounterPool* pool = new CounterPool;   // (never destroyed: no hipFree from a static destructor after the runtime is gone;
+    return *pool;                                  //  dcn_release_pooled_buffers frees the device buffers on request)
+}
 unsigned long long* pooled_counters(hipStream_t st, int tiles) {
     if (tiles > kPoolWords || dcn::tuning().hlx_counters == 0) return nullptr;
-    static std::mutex mu;
-    static std::unordered_map<unsigned long long, unsigned long long*> pool;
+    // A launch that is being CAPTURED never gets the pooled words, not even those a previous eager launch on the same stream
+    // created: the graph would carry the pointer, and a replay on another stream concurrent with eager split launches on this
+    // one would share the per-tile words.  Captured launches keep their words in the caller's scratch behind a fill node.
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(st, &cs) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    if (cs != hipStreamCaptureStatusNone) return nullptr;
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess) return nullptr;
     const unsigned long long key = ((unsigned long long)(uintptr_t)st << 8) ^ (unsigned long long)(dev & 0xff);
-    std::lock_guard<std::mutex> lock(mu);
-    auto it = pool.find(key);
-    if (it != pool.end()) return it->second;
-    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
-    if (hipStreamIsCapturing(st, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) return nullptr;
+    CounterPool& pool = counter_pool();
+    std::lock_guard<std::mutex> lock(pool.mu);
+    auto it = pool.map.find(key);
+    if (it != pool.map.end()) return it->second;
     void* ptr = nullptr;
     if (hipMalloc(&ptr, kPoolWords * sizeof(unsigned long long)) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
-    if (hipMemset(ptr, 0, kPoolWords * sizeof(unsigned long long)) != hipSuccess) { (void)hipFree(ptr); (void)hipGetLastError(); return nullptr; }
-    pool[key] = (unsigned long long*)ptr;
+    // zeroed ON THE LAUNCHING STREAM: a null-stream memset has no ordering with a non-blocking stream's launches
+    if (hipMemsetAsync(ptr, 0, kPoolWords * sizeof(unsigned long long), st) != hipSuccess) { (void)hipFree(ptr); (void)hipGetLastError(); return nullptr; }
+    pool.map[key] = (unsigned long long*)ptr;
     return (unsigned long long*)ptr;
 }
 
+}  // namespace dcnconv
+
+// Frees the library-owned arrival-word buffers (one 64 KB buffer per (device, stream) that ever ran a K-split launch).  The
+// caller has synchronised the streams that used them; the next split launch allocates afresh.
+extern "C" void dcn_release_pooled_buffers(void) {
+    dcnconv::CounterPool& pool = dcnconv::counter_pool();
+    std::lock_guard<std::mutex> lock(pool.mu);
+    for (auto& kv : pool.map)
+        if (hipFree(kv.second) != hipSuccess) (void)hipGetLastError();
+    pool.map.clear();
+}
+
+namespace dcnconv {
+
 int launch_gemm_hlx(GemmConv& p, const HlxShape& g, void* workspace, hipStream_t st) {
     if (!g.ok || (g.splits > 1 && !workspace)) return DCN_E_INVALID;
+    if (p.relu || p.out_absmax || p.bnb_partial) return DCN_E_UNSUPPORTED;   // (not in gemm_epilogue16, see launch_gemm_hl)
     p.sshift = 0;
     p.div_hw = make_fastdiv(p.hd * p.wd);
     p.div_w = make_fastdiv(p.wd);

@@ -729,9 +729,11 @@ conv_wgrad_hlrp_kernel(WgradHlr p) {
 
 // which convolutions: the 3 x 3, stride-1, dilation-1 ones with whole 64-channel input and output tiles
 bool wgrad_hlr_supported(const dcn_conv_desc* c) {
-    if (!c || c->n < 1 || c->hin < 1 || c->win < 1 || c->kh != 3 || c->kw != 3 || c->dil != 1 || c->pad != 1) return false;
+    if (!c || c->n < 1 || c->hin < 1 || c->win < 1 || c->hout < 1 || c->wout < 1 || c->kh != 3 || c->kw != 3 || c->dil != 1 ||
+        c->pad != 1) return false;
     if (c->stride != 1 || c->hin != c->hout || c->win != c->wout || c->ldc != c->cout) return false;
-    if ((c->cin % 64) != 0 || (c->cout % 64) != 0) return false;
+    // (whole 64-channel tiles, at least one each way: a zero channel count passes `% 64` and divides by zero tiles below)
+    if (c->cin < 64 || c->cout < 64 || (c->cin % 64) != 0 || (c->cout % 64) != 0) return false;
     const int64_t xb = (int64_t)c->n * c->hin * c->win * c->cin * 4, db = (int64_t)c->n * c->hout * c->wout * c->ldc * 4;
     return xb <= ((int64_t)1 << 31) - 1 && db <= ((int64_t)1 << 31) - 1;
 }

@@ -1,4 +1,5 @@
 """ctypes loader for libdcn_hip.so.  Declares every symbol of include/dcn_hip.h."""
+import atexit
 import ctypes
 import os
 
@@ -33,6 +34,7 @@ SYMBOLS = {
     # name: (restype, argtypes)
     "dcn_version": (c_char_p, []),
     "dcn_reload_env": (None, []),
+    "dcn_release_pooled_buffers": (None, []),
     "dcn_plan_num_activation_slots": (c_int, [c_void_p]),
     "dcn_plan_fused_bn_backward": (c_int, [c_void_p]),
     "dcn_plan_activation_absmax_offset": (c_size_t, [c_void_p]),
@@ -63,6 +65,8 @@ SYMBOLS = {
     "dcn_fill_bytes": (c_int, [c_void_p, c_int, c_size_t, c_void_p]),
     "dcn_plan_create": (c_int, [c_char_p, c_int, c_int, c_int, c_int, c_int, ctypes.POINTER(c_void_p)]),
     "dcn_plan_destroy": (None, [c_void_p]),
+    "dcn_plan_forget_saved": (c_int, [c_void_p, c_void_p]),
+    "dcn_plan_num_forward_records": (c_int, [c_void_p]),
     "dcn_plan_num_params": (c_int, [c_void_p]),
     "dcn_plan_num_bn": (c_int, [c_void_p]),
     "dcn_plan_param_info": (c_int, [c_void_p, c_int, c_char_p, c_int, ctypes.POINTER(c_int64), ctypes.POINTER(c_int)]),
@@ -190,6 +194,7 @@ def load(path=None):
     ver = lib.dcn_version().decode()
     for hook in _reset_hooks:
         hook()
+    atexit.register(lib.dcn_release_pooled_buffers)   # (the per-stream arrival-word buffers, csrc/conv_hlx_kernels.hip)
     _lib = lib
     _info.update(path=p, version=ver, hostemu=("hostemu" in ver))
     return _lib

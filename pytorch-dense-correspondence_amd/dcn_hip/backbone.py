@@ -5,6 +5,7 @@ kernels; this file allocates buffers with the PyTorch caching allocator, builds 
 C ABI takes and hooks the two C calls into ``torch.autograd``.
 """
 import ctypes
+import weakref
 
 import torch
 
@@ -78,6 +79,10 @@ class Plan(object):
     def stream_wait_grad_bucket(self, k, stream_ptr):
         """Make the stream wait until every gradient of bucket k of the LAST backward pass has been computed."""
         _lib.check(_lib.get().dcn_plan_stream_wait_grad_bucket(self.handle, k, stream_ptr), "dcn_plan_stream_wait_grad_bucket")
+
+    def num_forward_records(self):
+        """Forward calls whose saved arena is still alive (one small host-side record each in the engine)."""
+        return int(_lib.get().dcn_plan_num_forward_records(self.handle))
 
     def fused_bn_backward(self):
         """Batch norms of the last backward call whose reduction ran in a dgrad epilogue (0 in fp32 mode / DCN_BN_BWD_FUSED=0)."""
@@ -170,6 +175,13 @@ def _arena(nbytes, dev):
     return torch.empty(nbytes, dtype=torch.uint8, device=dev)
 
 
+def _forget_saved(plan_ref, lib, ptr):
+    """Finalizer of a saved arena: the plan's record of the forward call that filled it dies with the tensor."""
+    plan = plan_ref()
+    if plan is not None and _lib._lib is lib:     # (the plan and the library it was made by are still alive)
+        lib.dcn_plan_forget_saved(plan.handle, ptr)
+
+
 class _BackboneFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, image, image_b, plan, bn_running, training, normalize, momentum, eps, *params):
@@ -202,6 +214,8 @@ class _BackboneFn(torch.autograd.Function):
                                           int(bool(training)), int(bool(normalize)), _lib.ptr(desc), _lib.ptr(saved),
                                           _lib.ptr(ws), _lib.stream_ptr())
         _lib.check(rc, "dcn_backbone_forward")
+        if training:   # the engine keyed a record of this call by the arena's address: tie it to the arena's lifetime
+            weakref.finalize(saved, _forget_saved, weakref.ref(plan), lib, saved.data_ptr()).atexit = False
         ctx.plan = plan
         # the n + 1 range scalars are COPIED out (a small device-to-device copy, no sync): views would keep the whole saved
         # arena of this call alive on the long-lived plan -- two arenas per forward, and one pinned for ever after an

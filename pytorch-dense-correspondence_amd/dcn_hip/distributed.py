@@ -24,7 +24,7 @@ import torch.distributed as dist
 class FlatGradients(object):
     """Owns the flat gradient buffer of ``module`` and averages it across ranks."""
 
-    def __init__(self, module, process_group=None, bucketed=None):
+    def __init__(self, module, process_group=None, bucketed=None, single_rank_collectives=False):
         self.params = [p for p in module.parameters() if p.requires_grad]
         if not self.params:
             raise ValueError("module has no trainable parameters")
@@ -38,6 +38,9 @@ class FlatGradients(object):
         self.flat = torch.zeros(offsets[-1], dtype=torch.float32, device=dev)
         self.group = process_group
         self.bucketed = bucketed        # None: decide per step (distributed initialised, world > 1)
+        # True: issue the collectives even when the group has ONE rank (an all-reduce over one rank is the identity) -- the
+        # way to run the communication-stream / RCCL path of the bucketed schedule on a single GPU (bench.py --force-dist)
+        self.single_rank_collectives = bool(single_rank_collectives)
         self._views = []
         for p, off in zip(self.params, offsets):
             self._views.append(self._view_for(p, off))
@@ -49,7 +52,7 @@ class FlatGradients(object):
         self._comm_stream = None
         self._bucket_step = False       # this step's gradients were reduced bucket by bucket during backward
         self._detached = False
-        self.stats = {"bucketed_steps": 0, "monolithic_steps": 0, "reinstalled_views": 0}
+        self.stats = {"bucketed_steps": 0, "monolithic_steps": 0, "reinstalled_views": 0, "bucket_collectives": 0}
 
     def _view_for(self, p, off):
         chunk = self.flat[off:off + p.numel()]
@@ -120,6 +123,9 @@ class FlatGradients(object):
             return False    # (inside a hipGraph capture the collectives stay outside the graph: monolithic)
         return self._world() > 1 or bool(self.bucketed)
 
+    def _collective(self, world):
+        return world > 1 or (self.single_rank_collectives and dist.is_available() and dist.is_initialized())
+
     def accumulate_and_reduce_buckets(self, plan, engine_flat):
         """Called by the backbone's backward once all its launches are enqueued.  For every bucket, in completion order:
         wait for the engine's grad-ready event on the communication stream, average the ENGINE's slice over the ranks
@@ -137,16 +143,20 @@ class FlatGradients(object):
                 plan.stream_wait_grad_bucket(k, _lib.c_void_p(comm.cuda_stream))
                 with torch.cuda.stream(comm):
                     src = engine_flat[lo:hi]
-                    if world > 1:
-                        src.div_(world)
+                    if self._collective(world):
+                        if world > 1:
+                            src.div_(world)
                         dist.all_reduce(src, op=dist.ReduceOp.SUM, group=self.group)   # enqueued; `comm` is ordered behind it
+                        self.stats["bucket_collectives"] += 1
                     self.flat[lo:hi].add_(src)
         else:   # host-emulation tests (gloo): same slices, same order, synchronously
             for lo, hi in plan.grad_buckets:
                 src = engine_flat[lo:hi]
-                if world > 1:
-                    src.div_(world)
+                if self._collective(world):
+                    if world > 1:
+                        src.div_(world)
                     dist.all_reduce(src, op=dist.ReduceOp.SUM, group=self.group)
+                    self.stats["bucket_collectives"] += 1
                 self.flat[lo:hi].add_(src)
         self._bucket_step = True
         self.stats["bucketed_steps"] += 1
@@ -165,10 +175,11 @@ class FlatGradients(object):
             return None
         self.ensure_views()
         world = self._world()
-        if world == 1:
+        if not self._collective(world):
             return None
         self.stats["monolithic_steps"] += 1
-        self.flat.div_(world)
+        if world > 1:
+            self.flat.div_(world)
         return dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=self.group, async_op=async_op)
 
 

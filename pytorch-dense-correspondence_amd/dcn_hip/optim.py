@@ -116,8 +116,9 @@ class Adam(torch.optim.Optimizer):
                 (t, items), = by_step.items()
                 if len(items) == len(group["params"]):
                     self._fast = getattr(self, "_fast", {})
-                    self._fast[gi] = {"t": t, "items": items, "cols": cols, "numel": numel,
-                                      "ptrs": [tuple(x.data_ptr() for x in it) for it in items],
+                    # (pointers and shapes only for the gradients: the cache must not keep last step's gradient tensors alive)
+                    self._fast[gi] = {"t": t, "items": [(it[0], None, it[2], it[3]) for it in items], "cols": cols,
+                                      "numel": numel, "ptrs": [tuple(x.data_ptr() for x in it) for it in items],
                                       "steps": [self.state[it[0]]["step"] for it in items]}
         return loss
 
@@ -137,8 +138,11 @@ class Adam(torch.optim.Optimizer):
         for p, it, ptr, st in zip(params, items, fast["ptrs"], fast["steps"]):
             g = p.grad
             state = self.state.get(p)
-            if (p is not it[0] or g is None or g is not it[1] and (g.data_ptr() != ptr[1] or g.stride() != p.stride() or g.dtype != p.dtype)
-                    or state is None or state.get("exp_avg") is not it[2] or state.get("exp_avg_sq") is not it[3]
+            # (pointer, strides and dtype of the gradient are compared on EVERY call: the same tensor object may have been
+            # re-pointed -- `p.grad.data = ...`, `set_`, a bucket view reassigned -- and the cached tables hold addresses)
+            if (p is not it[0] or g is None or g.data_ptr() != ptr[1] or g.stride() != p.stride() or g.dtype != p.dtype
+                    or g.is_sparse or state is None or state.get("exp_avg") is not it[2] or state.get("exp_avg_sq") is not it[3]
+                    or it[2].data_ptr() != ptr[2] or it[3].data_ptr() != ptr[3]
                     or state.get("step") is not st or p.data_ptr() != ptr[0]):
                 self._fast.pop(gi, None)
                 return False

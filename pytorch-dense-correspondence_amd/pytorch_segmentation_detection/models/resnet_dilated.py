@@ -135,7 +135,11 @@ class _DilatedResnet8s(nn.Module):
         tab = self.__dict__.get("_table_cache")
         if tab is not None:
             ok = True
-            for owner, name, t in tab[0]:
+            for parent, child, mod in tab[5]:      # every module on the way to an owner is still the one registered there
+                if parent._modules.get(child) is not mod:   # (a replaced submodule keeps ITS tensors: the slots alone would pass)
+                    ok = False
+                    break
+            for owner, name, t in (tab[0] if ok else ()):
                 if owner._parameters.get(name) is not t:
                     ok = False
                     break
@@ -148,19 +152,30 @@ class _DilatedResnet8s(nn.Module):
                 return tab[2], tab[3], tab[4]
         trunk = getattr(self, self.attr)
         slots_p, slots_b, params, running, tracked = [], [], [], [], []
+        links, seen = [(self, self.attr, trunk)], set()
+
+        def chain(dotted):                      # registers the (parent, child name, child) edges from the trunk to `dotted`
+            node = trunk
+            for part in dotted.split(".") if dotted else ():
+                nxt = node._modules[part]
+                if (id(node), part) not in seen:
+                    seen.add((id(node), part))
+                    links.append((node, part, nxt))
+                node = nxt
+            return node
         for n in self._param_names:
             owner_name, _, leaf = n.rpartition(".")
-            owner = trunk.get_submodule(owner_name) if owner_name else trunk
+            owner = chain(owner_name)
             t = owner._parameters[leaf]
             slots_p.append((owner, leaf, t))
             params.append(t)
         for n in self._bn_names:
-            node = trunk.get_submodule(n)
+            node = chain(n)
             for leaf in ("running_mean", "running_var", "num_batches_tracked"):
                 slots_b.append((node, leaf, node._buffers[leaf]))
             running += [node.running_mean, node.running_var]
             tracked.append(node.num_batches_tracked)
-        self.__dict__["_table_cache"] = (slots_p, slots_b, params, running, tracked)
+        self.__dict__["_table_cache"] = (slots_p, slots_b, params, running, tracked, links)
         return params, running, tracked
 
     def forward(self, x, normalize=False, groups=1, x_b=None):
