@@ -155,6 +155,18 @@ int dcn_contrastive_loss_backward_saved(int num_pairs, int64_t hw, int d, const 
                                         const int64_t* offsets_host, const int64_t* offsets_dev, const dcn_loss_config* cfg,
                                         const int32_t* hard_neg, const float* grad_loss, const float* pair_records,
                                         int prefilled, float* grad_a, float* grad_b, void* stream);
+
+/* The same backward pass with BIT-REPRODUCIBLE gradient maps: every contribution is accumulated as 64-bit fixed point under a
+ * per-image-pair power-of-two scale with integer atomics (order-independent), then converted once.  `workspace`:
+ * dcn_loss_exact_workspace_bytes(num_pairs, hw, d) bytes (two int64 maps the size of the gradient maps x 2 + a word per pair).
+ * grad_a / grad_b are written in full.  DCN_E_UNSUPPORTED when an image pair has >= 2^22 pixel pairs (use the float path).
+ * Replaces the index_add_ backward of pixelwise_contrastive_loss.py:154-165,192-210 like the call above. */
+size_t dcn_loss_exact_workspace_bytes(int num_pairs, int64_t hw, int d);
+int dcn_contrastive_loss_backward_saved_exact(int num_pairs, int64_t hw, int d, const int64_t* idx_a, const int64_t* idx_b,
+                                              const int64_t* offsets_host, const int64_t* offsets_dev,
+                                              const dcn_loss_config* cfg, const int32_t* hard_neg, const float* grad_loss,
+                                              const float* pair_records, void* workspace, float* grad_a, float* grad_b,
+                                              void* stream);
 /* Stream-ordered fill of n bytes (n % 4 == 0) with a byte value, as a kernel (an ordinary node under hipGraph capture). */
 int dcn_fill_bytes(void* p, int byte_value, size_t n, void* stream);
 

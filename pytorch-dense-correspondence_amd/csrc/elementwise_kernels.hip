@@ -119,16 +119,40 @@ bn_finalize_kernel(const float* __restrict__ partial, int tiles, int groups, int
     __shared__ float s_bound[4];
     const int cl = threadIdx.x & 3, part = threadIdx.x >> 2, wv = threadIdx.x >> 6;
     const int c = blockIdx.x * 4 + cl;
-    float bound = 0.f;
+    // (round 6) what the four finishing work-items need besides the partials -- the affine parameters, the running statistics,
+    // the bound words -- is requested NOW, in the shadow of the partial loads, instead of behind the reduction: the kernel is a
+    // chain of dependent memory round trips (8 us for a few KB), 36 of them per forward pass with nothing else on the GPU
+    const bool lead = threadIdx.x < 4 && c < C;
+    const float pre_gamma = lead ? gamma[c] : 0.f, pre_beta = lead ? beta[c] : 0.f;
+    const float pre_rm = (lead && running_mean) ? running_mean[c] : 0.f, pre_rv = (lead && running_mean) ? running_var[c] : 0.f;
+    const float pre_res = (threadIdx.x == 0 && res_bound) ? *res_bound : 0.f;
+    const unsigned pre_bound = (threadIdx.x == 0 && out_bound && training) ? __atomic_load_n(reinterpret_cast<unsigned*>(out_bound), __ATOMIC_RELAXED) : 0u;
+    float bound = 0.f, rm_cur = pre_rm, rv_cur = pre_rv;
     for (int g = 0; g < groups; ++g) {
         double a = 0.0, b = 0.0;
         float mx = 0.f;
         if (training && c < C) {
-#pragma unroll 4
-            for (int t = g * tiles + part; t < (g + 1) * tiles; t += 64) {
-                a += (double)partial[((int64_t)t * 3 + 0) * C + c];
-                b += (double)partial[((int64_t)t * 3 + 1) * C + c];
-                mx = fmaxf(mx, partial[((int64_t)t * 3 + 2) * C + c]);
+            // (round 6) the partial rows of this work-item eight at a time as straight-line loads (a row past the end re-reads
+            // the last one and is not added), then added in the order they always were: the `#pragma unroll 4` loop ran its
+            // first (tiles / 64) mod 4 iterations one memory round trip each -- three of them for 200 tiles
+            const int t_end = (g + 1) * tiles;
+            for (int t0 = g * tiles + part; t0 < t_end; t0 += 64 * 8) {
+                float bs[8], bq[8], bm[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int t = min(t0 + 64 * u, t_end - 1);
+                    bs[u] = partial[((int64_t)t * 3 + 0) * C + c];
+                    bq[u] = partial[((int64_t)t * 3 + 1) * C + c];
+                    bm[u] = partial[((int64_t)t * 3 + 2) * C + c];
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    if (t0 + 64 * u < t_end) {
+                        a += (double)bs[u];
+                        b += (double)bq[u];
+                        mx = fmaxf(mx, bm[u]);
+                    }
+                }
             }
         }
         a = part_tree_sum(a);
@@ -138,6 +162,11 @@ bn_finalize_kernel(const float* __restrict__ partial, int tiles, int groups, int
         if ((threadIdx.x & 63) < 4) { s_sum[wv][cl] = a; s_sq[wv][cl] = b; s_mx[wv][cl] = mx; }
         __syncthreads();
         if (threadIdx.x >= 4 || c >= C) continue;
+        if (g == 0) {   // (the prefetched words become visible to the optimiser HERE: no conversion of them hoisted above the partial loads)
+            DCN_OPAQUE_INT(rm_cur); DCN_OPAQUE_INT(rv_cur);
+        }
+        float gam = pre_gamma, bet = pre_beta;
+        DCN_OPAQUE_INT(gam); DCN_OPAQUE_INT(bet);
         double mean, var;
         if (training) {
             a = (s_sum[0][cl] + s_sum[1][cl]) + (s_sum[2][cl] + s_sum[3][cl]);
@@ -146,17 +175,21 @@ bn_finalize_kernel(const float* __restrict__ partial, int tiles, int groups, int
             var = b / count - mean * mean;
             if (var < 0.0) var = 0.0;
             if (running_mean) {
+                // (a second group of the same call -- forward_pair -- updates what group 0 has just stored: two consecutive
+                // nn.BatchNorm2d calls; the value is carried in a register)
                 const double unbiased = count > 1.0 ? var * count / (count - 1.0) : var;
-                running_mean[c] = (float)((1.0 - momentum) * (double)running_mean[c] + momentum * mean);
-                running_var[c] = (float)((1.0 - momentum) * (double)running_var[c] + momentum * unbiased);
+                rm_cur = (float)((1.0 - momentum) * (double)rm_cur + momentum * mean);
+                rv_cur = (float)((1.0 - momentum) * (double)rv_cur + momentum * unbiased);
+                running_mean[c] = rm_cur;
+                running_var[c] = rv_cur;
             }
         } else {
-            mean = (double)running_mean[c];
-            var = (double)running_var[c];
+            mean = (double)rm_cur;
+            var = (double)rv_cur;
         }
         const float invstd = (float)(1.0 / sqrt(var + (double)eps));
-        const float sc = gamma[c] * invstd;
-        const float sh = beta[c] - (float)mean * sc;
+        const float sc = gam * invstd;
+        const float sh = bet - (float)mean * sc;
         scale[g * gstride + c] = sc;
         shift[g * gstride + c] = sh;
         if (save_mean) { save_mean[g * gstride + c] = (float)mean; save_invstd[g * gstride + c] = invstd; }
@@ -171,9 +204,9 @@ bn_finalize_kernel(const float* __restrict__ partial, int tiles, int groups, int
         if (threadIdx.x < 4) s_bound[threadIdx.x] = c < C ? bound : 0.f;
         __syncthreads();
         if (threadIdx.x == 0) {
-            const float m = fmaxf(fmaxf(s_bound[0], s_bound[1]), fmaxf(s_bound[2], s_bound[3])) + (res_bound ? *res_bound : 0.f);
+            const float m = fmaxf(fmaxf(s_bound[0], s_bound[1]), fmaxf(s_bound[2], s_bound[3])) + pre_res;
             const unsigned bits = __float_as_uint(m);
-            if (m > 0.f && bits > __atomic_load_n(reinterpret_cast<unsigned*>(out_bound), __ATOMIC_RELAXED))
+            if (m > 0.f && bits > pre_bound)   // (a stale word only costs a redundant atomicMax)
                 atomicMax(reinterpret_cast<unsigned*>(out_bound), bits);
         }
     }
@@ -339,19 +372,36 @@ bn_bwd_finalize_kernel(const float* __restrict__ partial, int chunks, int groups
     const int cl = threadIdx.x & 3, part = threadIdx.x >> 2, wv = threadIdx.x >> 6;
     const int c = blockIdx.x * 4 + cl;
     const bool lead = threadIdx.x < 4 && c < C;
+    // (round 6: requested in the shadow of the partial loads, see bn_finalize_kernel; at most two groups)
+    const float pre_gamma = lead ? gamma[c] : 0.f;
+    const float pre_is0 = lead ? invstd[c] : 0.f, pre_is1 = (lead && groups > 1) ? invstd[gstride + c] : 0.f;
+    const unsigned pre_bound = (threadIdx.x == 0 && absmax) ? __atomic_load_n(reinterpret_cast<unsigned*>(absmax), __ATOMIC_RELAXED) : 0u;
     double tot_a = 0.0, tot_b = 0.0;
     float bound = 0.f;
     for (int g = 0; g < groups; ++g) {
         double a = 0.0, b = 0.0;
         float mg = 0.f, mx = 0.f;
         if (c < C) {
-#pragma unroll 4
-            for (int t = g * chunks + part; t < (g + 1) * chunks; t += 64) {
-                const float4 s4 = reinterpret_cast<const float4*>(partial)[(int64_t)t * C + c];
-                a += (double)s4.x;
-                b += (double)s4.y;
-                mg = fmaxf(mg, s4.z);
-                mx = fmaxf(mx, s4.w);
+            // (round 6) the partial rows of this work-item EIGHT loads at a time, then added in the order they always were: the
+            // compiler had turned the `#pragma unroll 4` loop into load | wait | add | load | wait ... -- five dependent memory
+            // round trips for the five chunks a work-item owns at eight images: that WAS the kernel's 8 us
+            const int t_end = (g + 1) * chunks;
+            for (int t0 = g * chunks + part; t0 < t_end; t0 += 64 * 8) {
+                float4 buf[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int t = min(t0 + 64 * u, t_end - 1);   // (straight-line loads: a row past the end re-reads the last one ...)
+                    buf[u] = reinterpret_cast<const float4*>(partial)[(int64_t)t * C + c];
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    if (t0 + 64 * u < t_end) {                  // (... and is not added)
+                        a += (double)buf[u].x;
+                        b += (double)buf[u].y;
+                        mg = fmaxf(mg, buf[u].z);
+                        mx = fmaxf(mx, buf[u].w);
+                    }
+                }
             }
         }
         a = part_tree_sum(a);
@@ -366,7 +416,9 @@ bn_bwd_finalize_kernel(const float* __restrict__ partial, int chunks, int groups
             b = (s_b[0][cl] + s_b[1][cl]) + (s_b[2][cl] + s_b[3][cl]);
             mg = fmaxf(fmaxf(s_mg[0][cl], s_mg[1][cl]), fmaxf(s_mg[2][cl], s_mg[3][cl]));
             mx = fmaxf(fmaxf(s_mx[0][cl], s_mx[1][cl]), fmaxf(s_mx[2][cl], s_mx[3][cl]));
-            const float c1 = gamma[c] * invstd[g * gstride + c], c2 = (float)(a / count), c3 = (float)(b / count);
+            float is_g = g == 0 ? pre_is0 : (g == 1 ? pre_is1 : invstd[g * gstride + c]), gam = pre_gamma;
+            DCN_OPAQUE_INT(is_g); DCN_OPAQUE_INT(gam);
+            const float c1 = gam * is_g, c2 = (float)(a / count), c3 = (float)(b / count);
             float* k = k123 + (int64_t)g * 3 * C;
             k[c] = c1;
             k[C + c] = c2;
@@ -385,7 +437,7 @@ bn_bwd_finalize_kernel(const float* __restrict__ partial, int chunks, int groups
         bound = fmaxf(bound, __shfl_xor(bound, 2));
         if (threadIdx.x == 0) {
             const unsigned bits = __float_as_uint(bound);
-            if (bound > 0.f && bits > __atomic_load_n(reinterpret_cast<unsigned*>(absmax), __ATOMIC_RELAXED))
+            if (bound > 0.f && bits > pre_bound)   // (a stale word only costs a redundant atomicMax)
                 atomicMax(reinterpret_cast<unsigned*>(absmax), bits);
         }
     }

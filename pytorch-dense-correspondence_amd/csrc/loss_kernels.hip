@@ -447,6 +447,133 @@ loss_bwd_saved_kernel(int64_t hw, int D, int num_pairs, const int64_t* __restric
     }
 }
 
+// ---- the same backward pass, ORDER-INDEPENDENT (round 6): every contribution v is converted to 64-bit fixed point under a
+// per-image-pair power-of-two scale and accumulated with INTEGER atomics -- integer addition is associative, so the dense
+// gradient maps carry the same bits whatever order the hardware retires the atomics in (the fp32 atomics above make the loss
+// backward the one kernel of a training step that is not run-to-run reproducible).  Three launches behind the zero-fill of
+// the int64 maps:
+//   1. loss_bwd_vmax_kernel:        vmax[p] = max |v| over all contributions of pair p (same expression as the scatter);
+//   2. loss_bwd_saved_exact_kernel: q = rint(v * 2^e_p), e_p = 40 - exponent(vmax[p]):  |q| <= 2^40, and a pair has fewer than
+//                                   2^22 contributions (checked by the launcher), so no sum can leave 63 bits; the rounding of a
+//                                   contribution is 2^-40 of the largest one -- 16 bits below fp32's own resolution;
+//   3. loss_exact_convert_kernel:   grad = (float)(acc * 2^-e_p)  (an exact double product, ONE rounding).
+// A non-finite contribution makes vmax non-finite: the pair's maps are then filled with NaN, as the float path would make them
+// wherever the value lands.
+__device__ __forceinline__ double exact_scale(float vmax) {      // 2^e with vmax * 2^e in [2^39, 2^40); 0: nothing to add
+    if (!(vmax > 0.f) || !(vmax < __builtin_huge_valf())) return 0.0;
+    int x;
+    (void)frexpf(vmax, &x);                                      // vmax = m 2^x, m in [0.5, 1)
+    return ldexp(1.0, 40 - x);
+}
+
+template <int LP, bool SINGLE>
+__global__ void __launch_bounds__(kThreads)
+loss_bwd_vmax_kernel(int D, int num_pairs, const int64_t* __restrict__ offsets, dcn_loss_config cfg,
+                     const int* __restrict__ hard_neg, const float* __restrict__ grad_loss, const float* __restrict__ rec_d,
+                     const float* __restrict__ rec_s, unsigned* __restrict__ vmax_bits) {
+    constexpr int GROUPS = kThreads / LP, PPB = GROUPS * kItems;
+    const int seg = blockIdx.y, p = seg >> 2, t = seg & 3;
+    const int64_t beg = offsets[seg], len = offsets[seg + 1] - beg;
+    const int64_t chunk0 = (int64_t)blockIdx.x * PPB;
+    if (chunk0 >= len) return;
+    const int grp = threadIdx.x / LP, sub = threadIdx.x % LP;
+    int64_t lens[4];
+    int h[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { lens[k] = offsets[4 * p + k + 1] - offsets[4 * p + k]; h[k] = hard_neg[4 * p + k]; }
+    const PairScales sc = pair_scales(cfg, h, lens);
+    float coef = t == DCN_LIST_MATCH ? sc.match_coef : (t == DCN_LIST_BLIND ? sc.blind_coef : sc.nonmatch_coef);
+    if (coef == 0.f) return;
+    coef *= grad_loss[0] / (float)num_pairs;
+    float m = 0.f;
+    bool bad = false;
+#pragma unroll
+    for (int it = 0; it < kItems; ++it) {
+        const int64_t j = chunk0 + (int64_t)it * GROUPS + grp;
+        if (j >= len) continue;
+        const float sf = rec_s[beg + j];
+        if (sf == 0.f) continue;
+        const float g = sf * coef;
+        for (int c = sub; c < (SINGLE ? (sub < D ? sub + 1 : 0) : D); c += LP) {
+            const float v = fabsf(g * rec_d[(beg + j) * D + c]);
+            bad |= !(v == v);                                    // (fmaxf drops a NaN)
+            m = fmaxf(m, v);
+        }
+    }
+    if (bad) m = __builtin_huge_valf();
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) m = fmaxf(m, __shfl_xor(m, o));
+    if ((threadIdx.x & 63) == 0 && m > 0.f) {
+        const unsigned bits = __float_as_uint(m);
+        if (bits > __atomic_load_n(vmax_bits + p, __ATOMIC_RELAXED)) atomicMax(vmax_bits + p, bits);
+    }
+}
+
+template <int LP, bool SINGLE>
+__global__ void __launch_bounds__(kThreads)
+loss_bwd_saved_exact_kernel(int64_t hw, int D, int num_pairs, const int64_t* __restrict__ idx_a,
+                            const int64_t* __restrict__ idx_b, const int64_t* __restrict__ offsets, dcn_loss_config cfg,
+                            const int* __restrict__ hard_neg, const float* __restrict__ grad_loss,
+                            const float* __restrict__ rec_d, const float* __restrict__ rec_s,
+                            const float* __restrict__ vmax, unsigned long long* __restrict__ accA,
+                            unsigned long long* __restrict__ accB) {
+    constexpr int GROUPS = kThreads / LP, PPB = GROUPS * kItems;
+    const int seg = blockIdx.y, p = seg >> 2, t = seg & 3;
+    const int64_t beg = offsets[seg], len = offsets[seg + 1] - beg;
+    const int64_t chunk0 = (int64_t)blockIdx.x * PPB;
+    if (chunk0 >= len) return;
+    const double scale = exact_scale(vmax[p]);
+    if (scale == 0.0) return;                                    // nothing to add, or a non-finite pair (the convert pass writes NaN)
+    const int grp = threadIdx.x / LP, sub = threadIdx.x % LP;
+    int64_t lens[4];
+    int h[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { lens[k] = offsets[4 * p + k + 1] - offsets[4 * p + k]; h[k] = hard_neg[4 * p + k]; }
+    const PairScales sc = pair_scales(cfg, h, lens);
+    float coef = t == DCN_LIST_MATCH ? sc.match_coef : (t == DCN_LIST_BLIND ? sc.blind_coef : sc.nonmatch_coef);
+    if (coef == 0.f) return;
+    coef *= grad_loss[0] / (float)num_pairs;
+    unsigned long long* gAp = accA + (int64_t)p * hw * D;
+    unsigned long long* gBp = accB + (int64_t)p * hw * D;
+#pragma unroll
+    for (int it = 0; it < kItems; ++it) {
+        const int64_t j = chunk0 + (int64_t)it * GROUPS + grp;
+        if (j >= len) continue;
+        const float sf = rec_s[beg + j];
+        if (sf == 0.f) continue;
+        const int64_t ia = idx_a[beg + j], ib = idx_b[beg + j];
+        const float g = sf * coef;
+        for (int c = sub; c < (SINGLE ? (sub < D ? sub + 1 : 0) : D); c += LP) {
+            const float v = g * rec_d[(beg + j) * D + c];
+            const long long q = __double2ll_rn((double)v * scale);       // |q| <= 2^40; exact product, one rounding
+            if (q != 0) {
+                atomicAdd(gAp + ia * D + c, (unsigned long long)q);       // (two's complement: adding -q is adding 2^64 - q)
+                atomicAdd(gBp + ib * D + c, (unsigned long long)(-q));
+            }
+        }
+    }
+}
+
+// grad[i] = acc[i] * 2^-e of its image pair; maps: [2][num_pairs][per_pair] (A maps, then B maps)
+__global__ void __launch_bounds__(256)
+loss_exact_convert_kernel(const long long* __restrict__ acc, const float* __restrict__ vmax, float* __restrict__ grad_a,
+                          float* __restrict__ grad_b, int64_t per_pair, int num_pairs) {
+    const int64_t total = 2 * (int64_t)num_pairs * per_pair;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int64_t m = i / per_pair;                           // map index: [0, P) of A, [P, 2P) of B
+        const int p = (int)(m >= num_pairs ? m - num_pairs : m);
+        const float vm = vmax[p];
+        float out;
+        if (!(vm < __builtin_huge_valf())) out = __builtin_nanf("");       // a non-finite contribution somewhere in this pair
+        else {
+            const double scale = exact_scale(vm);
+            out = scale == 0.0 ? 0.f : (float)((double)acc[i] / scale);    // (division by a power of two: exact)
+        }
+        float* dst = m >= num_pairs ? grad_b + (i - (int64_t)num_pairs * per_pair) : grad_a + i;
+        *dst = out;
+    }
+}
+
 // workgroups per list for descriptor dimension d (d <= 0: the worst case over all d, for workspace sizing)
 int chunks_for(int64_t max_list_len, int d) {
     const int ppb = pairs_per_block(d > 0 ? lanes_per_pair(d) : 32);
@@ -723,6 +850,64 @@ extern "C" int dcn_contrastive_loss_backward_saved(int num_pairs, int64_t hw, in
             break;
     }
 #undef DCN_LAUNCH_BWDS
+    return dcn::check_launch();
+}
+
+// Workspace of the order-independent backward: the two int64 accumulation maps + one abs-max word per image pair.
+extern "C" size_t dcn_loss_exact_workspace_bytes(int num_pairs, int64_t hw, int d) {
+    if (num_pairs < 1 || hw < 1 || d < 1) return 0;
+    return (size_t)2 * num_pairs * (size_t)hw * d * sizeof(long long) + (((size_t)num_pairs * 4 + 255) / 256) * 256;
+}
+
+// dcn_contrastive_loss_backward_saved with bit-reproducible gradient maps (64-bit fixed-point accumulation under a per-pair
+// power-of-two scale; see loss_bwd_saved_exact_kernel).  grad_a / grad_b are written in full (no zero-fill needed).
+// DCN_E_UNSUPPORTED when an image pair has 2^22 pixel pairs or more (the headroom of the 63-bit sums): use the float path.
+extern "C" int dcn_contrastive_loss_backward_saved_exact(int num_pairs, int64_t hw, int d, const int64_t* idx_a,
+                                                         const int64_t* idx_b, const int64_t* offsets_host,
+                                                         const int64_t* offsets_dev, const dcn_loss_config* cfg,
+                                                         const int32_t* hard_neg, const float* grad_loss,
+                                                         const float* pair_records, void* workspace, float* grad_a,
+                                                         float* grad_b, void* stream) {
+    if (!offsets_host || !offsets_dev || !cfg || !hard_neg || !grad_loss || !pair_records || !workspace || !grad_a || !grad_b ||
+        num_pairs < 1 || hw < 1 || d < 1)
+        return DCN_E_INVALID;
+    for (int p = 0; p < num_pairs; ++p)
+        if (offsets_host[4 * p + 4] - offsets_host[4 * p] >= ((int64_t)1 << 22)) return DCN_E_UNSUPPORTED;
+    hipStream_t st = (hipStream_t)stream;
+    const size_t per_pair = (size_t)hw * d, map_bytes = (size_t)num_pairs * per_pair * sizeof(long long);
+    unsigned long long* accA = (unsigned long long*)workspace;
+    unsigned long long* accB = accA + (size_t)num_pairs * per_pair;
+    float* vmax = (float*)((char*)workspace + 2 * map_bytes);
+    if (dcn::fill_bytes_async(workspace, 0, dcn_loss_exact_workspace_bytes(num_pairs, hw, d), st) != DCN_OK) return DCN_E_LAUNCH;
+    const int64_t ml = max_len(offsets_host, num_pairs);
+    if (ml > 0) {
+        if (!idx_a || !idx_b) return DCN_E_INVALID;
+        const int64_t total = offsets_host[4 * num_pairs];
+        const float* rec_d = pair_records;
+        const float* rec_s = pair_records + (size_t)total * d;
+        const dim3 grid(chunks_for(ml, d), 4 * num_pairs), block(kThreads);
+#define DCN_LAUNCH_BWDX(LP, SINGLE)                                                                                          \
+        do {                                                                                                                  \
+            hipLaunchKernelGGL((loss_bwd_vmax_kernel<LP, SINGLE>), grid, block, 0, st, d, num_pairs, offsets_dev, *cfg,       \
+                               (const int*)hard_neg, grad_loss, rec_d, rec_s, (unsigned*)vmax);                              \
+            hipLaunchKernelGGL((loss_bwd_saved_exact_kernel<LP, SINGLE>), grid, block, 0, st, hw, d, num_pairs, idx_a, idx_b, \
+                               offsets_dev, *cfg, (const int*)hard_neg, grad_loss, rec_d, rec_s, (const float*)vmax, accA, accB); \
+        } while (0)
+        switch (lanes_per_pair(d)) {
+            case 4: DCN_LAUNCH_BWDX(4, true); break;
+            case 8: DCN_LAUNCH_BWDX(8, true); break;
+            case 16: DCN_LAUNCH_BWDX(16, true); break;
+            default:
+                if (d <= 32) DCN_LAUNCH_BWDX(32, true);
+                else DCN_LAUNCH_BWDX(32, false);
+                break;
+        }
+#undef DCN_LAUNCH_BWDX
+    }
+    const int64_t total_elems = 2 * (int64_t)num_pairs * (int64_t)per_pair;
+    const unsigned blocks = (unsigned)std::min<int64_t>(dcn::ceil_div64(total_elems, 256), 256 * 16);
+    hipLaunchKernelGGL(loss_exact_convert_kernel, dim3(blocks), dim3(256), 0, st, (const long long*)workspace, (const float*)vmax,
+                       grad_a, grad_b, (int64_t)per_pair, num_pairs);
     return dcn::check_launch();
 }
 

@@ -62,6 +62,10 @@ SYMBOLS = {
     "dcn_contrastive_loss_backward_saved": (c_int, [c_int, c_int64, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
                                                     ctypes.POINTER(LossConfig), c_void_p, c_void_p, c_void_p, c_int, c_void_p,
                                                     c_void_p, c_void_p]),
+    "dcn_loss_exact_workspace_bytes": (c_size_t, [c_int, c_int64, c_int]),
+    "dcn_contrastive_loss_backward_saved_exact": (c_int, [c_int, c_int64, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
+                                                          ctypes.POINTER(LossConfig), c_void_p, c_void_p, c_void_p, c_void_p,
+                                                          c_void_p, c_void_p, c_void_p]),
     "dcn_fill_bytes": (c_int, [c_void_p, c_int, c_size_t, c_void_p]),
     "dcn_plan_create": (c_int, [c_char_p, c_int, c_int, c_int, c_int, c_int, ctypes.POINTER(c_void_p)]),
     "dcn_plan_destroy": (None, [c_void_p]),

@@ -94,6 +94,14 @@ def make_config(margins, image_width, match_loss_weight=1.0, non_match_loss_weig
 # (backward kernel 462 -> 418 us, forward 259 -> 279 us); the early zero-fill competes with the forward gather for HBM and
 # buys nothing (897 us alone, 910 us with records) while its two cross-stream waits cost ~13 us on a 41-us call at configs[1]'s
 # sizes: off by default.
+# Round 6: the backward scatter with INTEGER atomics on 64-bit fixed point (csrc/loss_kernels.hip, loss_bwd_saved_exact_kernel):
+# order-independent, so the gradient maps -- and with them the whole training step -- are bit-reproducible run to run.  Costs
+# two int64 maps (twice the bytes of the fp32 gradient maps) and a conversion pass: the default wherever that workspace stays
+# below EXACT_BACKWARD_MAX_BYTES (BASELINE configs 1 / 2 / 4: 15 - 118 MB); above it (configs 3 / 5: 2.5 / 1.3 GB) the fp32
+# atomics.  DCN_LOSS_EXACT=1 / 0 forces either.
+import os as _os
+EXACT_BACKWARD = {"1": True, "0": False}.get(_os.environ.get("DCN_LOSS_EXACT", ""), None)   # None: by workspace size
+EXACT_BACKWARD_MAX_BYTES = 256 << 20
 SAVE_PAIR_RECORDS = True   # forward keeps per-pair (difference, factor) records, backward reads them instead of gathering again
 PREFILL_GRADIENTS = False  # the dense gradient maps zero-filled on a side stream while the forward kernels run
 _fill_streams = {}
@@ -199,6 +207,18 @@ class _ContrastiveLossFn(torch.autograd.Function):
             else:
                 g2 = torch.empty((2, P, HW, D), dtype=torch.float32, device=hard.device)
             gl = grad_loss.reshape(1).to(torch.float32).contiguous()
+            exact_bytes = int(lib.dcn_loss_exact_workspace_bytes(P, HW, D))
+            per_pair_max = max(lists.offsets_host[4 * p + 4] - lists.offsets_host[4 * p] for p in range(lists.num_pairs))
+            exact = (EXACT_BACKWARD if EXACT_BACKWARD is not None else exact_bytes <= EXACT_BACKWARD_MAX_BYTES) and \
+                per_pair_max < (1 << 22) and not prefilled
+            if exact:
+                ws = torch.empty(exact_bytes, dtype=torch.uint8, device=hard.device)
+                rc = lib.dcn_contrastive_loss_backward_saved_exact(
+                    P, HW, D, _lib.ptr(lists.idx_a), _lib.ptr(lists.idx_b), ctypes.cast(lists._off_c, ctypes.c_void_p),
+                    _lib.ptr(lists.offsets_dev), ctypes.byref(cfg), _lib.ptr(hard), _lib.ptr(gl), _lib.ptr(ctx.records),
+                    _lib.ptr(ws), _lib.ptr(g2[0]), _lib.ptr(g2[1]), _lib.stream_ptr())
+                _lib.check(rc, "dcn_contrastive_loss_backward_saved_exact")
+                return g2[0], g2[1], None, None, None
             rc = lib.dcn_contrastive_loss_backward_saved(
                 P, HW, D, _lib.ptr(lists.idx_a), _lib.ptr(lists.idx_b), ctypes.cast(lists._off_c, ctypes.c_void_p),
                 _lib.ptr(lists.offsets_dev), ctypes.byref(cfg), _lib.ptr(hard), _lib.ptr(gl), _lib.ptr(ctx.records), prefilled,

@@ -285,6 +285,7 @@ static inline void hipemu_atomic_store(float* p, float v) {
 #define __hip_atomic_store(p, v, order, scope) hipemu_atomic_store(p, v)
 #define __builtin_amdgcn_s_sleep(n) std::this_thread::yield()
 static inline unsigned __float_as_uint(float f) { unsigned u; memcpy(&u, &f, 4); return u; }
+static inline long long __double2ll_rn(double x) { return llrint(x); }   // (default rounding mode: to nearest even, as v_cvt does)
 static inline float __uint_as_float(unsigned u) { float f; memcpy(&f, &u, 4); return f; }
 #define unsafeAtomicAdd atomicAdd
 static inline unsigned __umulhi(unsigned a, unsigned b) { return (unsigned)(((unsigned long long)a * b) >> 32); }

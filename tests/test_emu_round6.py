@@ -102,3 +102,85 @@ def test_forward_records_die_with_their_arena():
         net(x)
     gc.collect()
     assert plan.num_forward_records() == base
+
+
+# ---- order-independent loss backward (64-bit fixed-point accumulation) ----------------------------------------------------
+
+def _loss_grads(A, B, lists8, cfg_dict, H, W, exact, D=None):
+    """gradient maps of the composed loss for ONE image pair through the product's get_loss, with the exact / float backward"""
+    from dcn_hip import loss as K
+    from dense_correspondence.loss_functions import loss_composer
+    from dense_correspondence.loss_functions.pixelwise_contrastive_loss import PixelwiseContrastiveLoss
+    old = K.EXACT_BACKWARD
+    K.EXACT_BACKWARD = exact
+    try:
+        a = A.clone().requires_grad_(True)
+        b = B.clone().requires_grad_(True)
+        pcl = PixelwiseContrastiveLoss([H, W], cfg_dict)
+        out = loss_composer.get_loss(pcl, torch.tensor([0]), a, b, *lists8)
+        out[0].backward()
+        return a.grad.clone(), b.grad.clone()
+    finally:
+        K.EXACT_BACKWARD = old
+
+
+def test_exact_loss_backward_matches_the_reference_goldens_and_is_order_independent():
+    import glob
+    import os
+    from helpers import lists_from_golden, load_golden_loss
+    for name in ("within_d3", "within_d16", "within_margins", "within_blind"):
+        z, cfg = load_golden_loss(os.path.join(os.path.dirname(__file__), "golden", "loss_ref_%s.npz" % name))
+        A, B = torch.tensor(z["A"]), torch.tensor(z["B"])
+        H, W = int(z["H"]), int(z["W"])
+        lists = lists_from_golden(z)
+        ga, gb = _loss_grads(A, B, lists, cfg, H, W, exact=True)
+        assert rel_err(ga, z["gradA"]) < 1e-5 and rel_err(gb, z["gradB"]) < 1e-5          # the reference's own gradients
+        fa, fb = _loss_grads(A, B, lists, cfg, H, W, exact=False)
+        assert rel_err(ga, fa) < 1e-6 and rel_err(gb, fb) < 1e-6
+        # the same multiset of pixel pairs in another order: other lanes, other workgroups, another order of the atomics
+        g = torch.Generator().manual_seed(5)
+        shuffled = []
+        for t in range(4):
+            a_, b_ = lists[2 * t], lists[2 * t + 1]
+            if a_.numel() > 1:
+                perm = torch.randperm(a_.numel(), generator=g)
+                a_, b_ = a_[perm], b_[perm]
+            shuffled += [a_, b_]
+        ga2, gb2 = _loss_grads(A, B, tuple(shuffled), cfg, H, W, exact=True)
+        assert torch.equal(ga, ga2) and torch.equal(gb, gb2), name
+
+
+def test_exact_loss_backward_with_every_pair_on_one_pixel_and_non_finite_input():
+    from oracle import synth
+    H, W, D = 16, 24, 3
+    g = torch.Generator().manual_seed(2)
+    A = (torch.rand(1, H * W, D, generator=g) * 2 - 1) * 0.3
+    B = (torch.rand(1, H * W, D, generator=g) * 2 - 1) * 0.3
+    n = 3000
+    ma = torch.full((n,), 7, dtype=torch.int64)                 # 3000 contributions to ONE pixel of A
+    mb = torch.randint(0, H * W, (n,), generator=g)
+    ka, kb = torch.randint(0, H * W, (n,), generator=g), torch.full((n,), 11, dtype=torch.int64)
+    empty = torch.tensor([-1])
+    lists = (ma, mb, ka, kb, ka.clone(), kb.clone(), empty, empty)
+    ga, gb = _loss_grads(A, B, lists, synth.LOSS_CONFIG, H, W, exact=True)
+    # float64 reference of the accumulated gradient (loss_numpy-style, via torch double autograd on the oracle)
+    from oracle import loss_oracle
+    a64, b64 = A.double().requires_grad_(True), B.double().requires_grad_(True)
+    pcl = loss_oracle.PixelwiseContrastiveLoss([H, W], synth.LOSS_CONFIG)
+    loss_oracle.get_loss(pcl, torch.tensor([0]), a64, b64, *lists)[0].backward()
+    assert rel_err(ga, a64.grad) < 2e-6 and rel_err(gb, b64.grad) < 2e-6
+    perm = torch.randperm(n, generator=g)
+    lists2 = (ma[perm], mb[perm], ka.flip(0), kb.flip(0), ka.clone(), kb.clone(), empty, empty)
+    ga2, gb2 = _loss_grads(A, B, lists2, synth.LOSS_CONFIG, H, W, exact=True)
+    assert torch.equal(ga, ga2) and torch.equal(gb, gb2)
+    # a NaN descriptor that a pair reads poisons that image pair's maps (the float path puts the NaN where it lands)
+    A2 = A.clone()
+    A2[0, 7, 1] = float("nan")
+    ga3, _ = _loss_grads(A2, B, lists, synth.LOSS_CONFIG, H, W, exact=True)
+    assert torch.isnan(ga3).any()
+    # no pixel pairs at all: zero maps
+    none = (empty,) * 8
+    from dcn_hip import loss as K
+    from dcn_hip.loss import PairLists
+    pl = PairLists.from_lists([none], torch.device("cpu"), hw=H * W)
+    assert pl.total == 0
