@@ -554,23 +554,33 @@ loss_bwd_saved_exact_kernel(int64_t hw, int D, int num_pairs, const int64_t* __r
     }
 }
 
-// grad[i] = acc[i] * 2^-e of its image pair; maps: [2][num_pairs][per_pair] (A maps, then B maps)
+// grad = acc * 2^-e of the map's image pair; maps: [2][num_pairs][per_pair] (A maps, then B maps).  grid = (x, 2 * num_pairs):
+// one map per blockIdx.y, so the scale is formed once per work-item; two elements (16 B in, 8 B out) per work-item and trip.
 __global__ void __launch_bounds__(256)
 loss_exact_convert_kernel(const long long* __restrict__ acc, const float* __restrict__ vmax, float* __restrict__ grad_a,
                           float* __restrict__ grad_b, int64_t per_pair, int num_pairs) {
-    const int64_t total = 2 * (int64_t)num_pairs * per_pair;
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
-        const int64_t m = i / per_pair;                           // map index: [0, P) of A, [P, 2P) of B
-        const int p = (int)(m >= num_pairs ? m - num_pairs : m);
-        const float vm = vmax[p];
-        float out;
-        if (!(vm < __builtin_huge_valf())) out = __builtin_nanf("");       // a non-finite contribution somewhere in this pair
-        else {
-            const double scale = exact_scale(vm);
-            out = scale == 0.0 ? 0.f : (float)((double)acc[i] / scale);    // (division by a power of two: exact)
+    const int m = blockIdx.y;                                     // map index: [0, P) of A, [P, 2P) of B
+    const int p = m >= num_pairs ? m - num_pairs : m;
+    const float vm = vmax[p];
+    const bool bad = !(vm < __builtin_huge_valf());               // a non-finite contribution somewhere in this pair
+    const double scale = exact_scale(vm);
+    const double inv = scale == 0.0 ? 0.0 : 1.0 / scale;          // (a power of two: exact)
+    const long long* src = acc + (int64_t)m * per_pair;
+    float* dst = (m >= num_pairs ? grad_b : grad_a) + (int64_t)p * per_pair;
+    const float nanv = __builtin_nanf("");
+    if ((per_pair & 1) == 0) {
+        typedef long long ll2 __attribute__((ext_vector_type(2)));
+        const int64_t n2 = per_pair >> 1;
+        for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n2; i += (int64_t)gridDim.x * 256) {
+            const ll2 q = reinterpret_cast<const ll2*>(src)[i];
+            float2 o;
+            o.x = bad ? nanv : (float)((double)q[0] * inv);
+            o.y = bad ? nanv : (float)((double)q[1] * inv);
+            reinterpret_cast<float2*>(dst)[i] = o;
         }
-        float* dst = m >= num_pairs ? grad_b + (i - (int64_t)num_pairs * per_pair) : grad_a + i;
-        *dst = out;
+    } else {
+        for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < per_pair; i += (int64_t)gridDim.x * 256)
+            dst[i] = bad ? nanv : (float)((double)src[i] * inv);
     }
 }
 
@@ -904,10 +914,10 @@ extern "C" int dcn_contrastive_loss_backward_saved_exact(int num_pairs, int64_t 
         }
 #undef DCN_LAUNCH_BWDX
     }
-    const int64_t total_elems = 2 * (int64_t)num_pairs * (int64_t)per_pair;
-    const unsigned blocks = (unsigned)std::min<int64_t>(dcn::ceil_div64(total_elems, 256), 256 * 16);
-    hipLaunchKernelGGL(loss_exact_convert_kernel, dim3(blocks), dim3(256), 0, st, (const long long*)workspace, (const float*)vmax,
-                       grad_a, grad_b, (int64_t)per_pair, num_pairs);
+    const unsigned bx = (unsigned)std::max<int64_t>(1, std::min<int64_t>(dcn::ceil_div64((int64_t)per_pair / 2 + 1, 256 * 4),
+                                                                         (256 * 16) / (2 * num_pairs) + 1));
+    hipLaunchKernelGGL(loss_exact_convert_kernel, dim3(bx, 2 * num_pairs), dim3(256), 0, st, (const long long*)workspace,
+                       (const float*)vmax, grad_a, grad_b, (int64_t)per_pair, num_pairs);
     return dcn::check_launch();
 }
 
