@@ -47,7 +47,7 @@ const char* dcn_version(void);
 /* The DCN_* environment overrides -- the full list with their meaning is the header comment of csrc/dcn_tuning.h:
  * DCN_CONV_MODE, DCN_BACKWARD_OVERLAP, DCN_GEMM_TILE_M, DCN_STEM8, DCN_GEMM_SK, DCN_GEMM_SK_MIN_GAIN,
  * DCN_GEMM_UNI, DCN_GEMM_SK_FIXUP, DCN_BN_BWD_FUSED, DCN_DEFER_RESIDUAL_ADD, DCN_WGRAD_TILE, DCN_WGRAD_DEEP, DCN_WGRAD_ROLES,
- * DCN_WGRAD_SPLITS, DCN_GEMM_HL, DCN_GEMM_HL_ROWS, DCN_WGRAD_HL, DCN_HL_PRODUCERS, DCN_HL_ONLY_MID, DCN_STEM_POOL_FUSED, DCN_BN_REVERSE, DCN_BN_NT, DCN_BN_REDUCE_WIDE, DCN_WSPLIT_OVERLAP -- are read ONCE, at the first call that needs them -- never on the
+ * DCN_WGRAD_SPLITS, DCN_GEMM_HL, DCN_HL_MIN_K, DCN_GEMM_HL_ROWS, DCN_WGRAD_HL, DCN_HL_PRODUCERS, DCN_HL_ONLY_MID, DCN_STEM_POOL_FUSED, DCN_BN_REVERSE, DCN_BN_NT, DCN_BN_REDUCE_WIDE, DCN_WSPLIT_OVERLAP -- are read ONCE, at the first call that needs them -- never on the
  * launch path.  dcn_reload_env re-reads them (tests / tuning scripts that change a variable in-process); not to be called
  * while another thread is inside the library. */
 void dcn_reload_env(void);

@@ -767,7 +767,9 @@ extern "C" int dcn_conv_hl_eligible(const dcn_conv_desc* c, int dgrad) {
     const int cs = dgrad ? c->ldc : c->cin, cd = dgrad ? c->cin : c->cout;
     const int64_t M = (int64_t)c->n * (dgrad ? c->hin * c->win : c->hout * c->wout);
     const int64_t K = (int64_t)c->kh * c->kw * cs;
-    if (!(cd >= 128 && K >= 512 && M >= 4096)) return 0;
+    // (round 6: K >= 128 instead of 512 -- the 1 x 1 convolutions fed by 128 - 511 channels: at eight images layer3 / layer4
+    // downsample forward 34.5 -> 26.9 / 67.5 -> 50.3 us, ResNet50-8s conv3 1 x 1 256 -> 1024 255.6 -> 195.1 us, profiles/r6e_*, r6f_*)
+    if (!(cd >= 128 && K >= std::min(512, dcn::tuning().hl_min_k) && M >= 4096)) return 0;
     const HlShape chosen = hl_shape_of(c, dgrad);
     // the small tiles (round 5): chosen by the cost model where the big ones leave CUs idle -- sub-round launches (B = 1, the
     // two-call pattern), layer 3 at 8 images; 128-channel destinations only when asked for (DCN_GEMM_HLX_NARROW)

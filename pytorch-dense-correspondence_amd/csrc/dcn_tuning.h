@@ -22,6 +22,10 @@
 //   DCN_GEMM_HL             0: the wide layers stay on the fp32-operand gather-GEMM (conv_f16_kernels.hip) instead of the
 //                           pre-split (hl32) LDS-DMA kernel (conv_hl_kernels.hip); 2: every convolution that kernel supports
 //                           takes it, whatever its size (tests)
+//   DCN_HL_MIN_K            reduction length (filter taps x source channels) from which a wide convolution's forward / dgrad and
+//                           weight gradient take the hl32 kernels (default 128; DCN_HL_MIN_K=1024 restores the thresholds up to round 5 -- 512 / 1024 --, which
+//                           kept the 1 x 1 convolutions fed by fewer than 512 / 1024 channels -- the downsample branches, the
+//                           bottleneck blocks' conv3 -- on the fp32-operand kernels: 1.3 - 2x slower there, profiles/r6e_*, r6f_*)
 //   DCN_GEMM_HL_ROWS        192 / 256 / 320: tile height of the hl32 gather-GEMM (default 0: whichever quantises better on the
 //                           256 CUs, hl_shape in conv_hl_kernels.hip); -320: as decided, but never 320 (the round-3 choice)
 //   DCN_GEMM_HLX            0: never the small-tile variants of the hl32 gather-GEMM (conv_hlx_kernels.hip: 160 x 256 / 160 x 128
@@ -82,6 +86,7 @@ struct Tuning {
     int wgrad_tile = 0;          // 0: unset
     int wgrad_deep = 4;
     int gemm_hl = 1;             // wide layers on the pre-split (hl32) LDS-DMA gather-GEMM
+    int hl_min_k = 128;          // see DCN_HL_MIN_K
     int gemm_hl_rows = 0;        // hl32 gather-GEMM tile height: 0 = by tile quantisation, 192 / 256 = forced
     int gemm_hlx = 1;            // small-tile variants of the hl32 gather-GEMM where hl_shape's cost model picks them
     int gemm_hlx_kg = 0;         // forced K groups per workgroup (0: as decided)

@@ -37,6 +37,7 @@ void read_env(Tuning& t) {
     if (const char* e = getenv("DCN_WGRAD_SPLITS")) t.wgrad_splits = atoi(e);
     if (const char* e = getenv("DCN_GEMM_HL")) t.gemm_hl = atoi(e);
     if (const char* e = getenv("DCN_GEMM_HL_ROWS")) t.gemm_hl_rows = atoi(e);
+    if (const char* e = getenv("DCN_HL_MIN_K")) { const int v = atoi(e); if (v >= 32) t.hl_min_k = v; }
     if (const char* e = getenv("DCN_GEMM_HLX")) {   // "0" / "1": off / on (as decided); "kg,splits": forced (0 = as decided)
         int a = 0, b = 0;
         if (strchr(e, ',')) {

@@ -278,7 +278,7 @@ def test_record_based_backward_equals_the_gathering_backward(path):
             assert rel_err(A.grad, first[0]) < 1e-6 and rel_err(B.grad, first[1]) < 1e-6
             grads[mode] = first + (out[0].detach().clone(),)
         finally:
-            K.SAVE_PAIR_RECORDS = K.PREFILL_GRADIENTS = True
+            K.SAVE_PAIR_RECORDS, K.PREFILL_GRADIENTS = True, False   # (the module's defaults)
     assert torch.equal(grads[False][2], grads[True][2])
     assert rel_err(grads[True][0], grads[False][0]) < 1e-6 and rel_err(grads[True][1], grads[False][1]) < 1e-6
 
@@ -303,7 +303,7 @@ def test_record_based_backward_large_descriptors_and_no_grad_path():
             loss.backward()
             res[mode] = (loss.detach().clone(), A.grad.clone(), B.grad.clone())
         finally:
-            K.SAVE_PAIR_RECORDS = K.PREFILL_GRADIENTS = True
+            K.SAVE_PAIR_RECORDS, K.PREFILL_GRADIENTS = True, False   # (the module's defaults)
     assert torch.equal(res[False][0], res[True][0])
     assert rel_err(res[True][1], res[False][1]) < 1e-6 and rel_err(res[True][2], res[False][2]) < 1e-6
     with torch.no_grad():
