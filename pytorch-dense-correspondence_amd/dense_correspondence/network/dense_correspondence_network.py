@@ -175,8 +175,15 @@ class DenseCorrespondenceNetwork(nn.Module):
         return [u, v]
 
     def load_training_dataset(self):
-        raise NotImplementedError("dataset loading (SpartanDataset) is outside the MI355X hot path; "
-                                  "use the reference's dataset package")
+        # :333-345 -- with the reference's own dataset package importable behind this source root (dcn_hip/_dropin.py) this is
+        # the reference's behaviour; the placeholder SpartanDataset of this root cannot load anything and says so
+        from dense_correspondence.dataset.spartan_dataset_masked import SpartanDataset
+        if not hasattr(SpartanDataset, "get_within_scene_data"):
+            raise NotImplementedError("dataset loading (SpartanDataset) is outside the MI355X hot path: put the reference's "
+                                      "source roots behind this one on sys.path (INTEGRATION.md) to use its dataset package")
+        network_params_folder = utils.convert_to_absolute_path(self.path_to_network_params_folder)
+        config = utils.getDictFromYamlFilename(os.path.join(network_params_folder, 'dataset.yaml'))
+        return SpartanDataset(config_expanded=config)
 
     # ---- construction (:360-485)
     @staticmethod
