@@ -184,3 +184,20 @@ def test_exact_loss_backward_with_every_pair_on_one_pixel_and_non_finite_input()
     from dcn_hip.loss import PairLists
     pl = PairLists.from_lists([none], torch.device("cpu"), hw=H * W)
     assert pl.total == 0
+
+
+def test_hl32_eligibility_from_reduction_length_128(dcn_env):
+    """Round 6: the 1 x 1 convolutions fed by 128 - 1023 channels (downsample branches, bottleneck conv3) take the hl32 kernels;
+    DCN_HL_MIN_K=1024 restores the thresholds of round 5 (forward / dgrad from K = 512, weight gradient from K = 1024)."""
+    from dcn_hip import _lib as L
+    lib = L.get()
+    down4 = L.ConvDesc(8, 60, 80, 256, 60, 80, 512, 1, 1, 1, 0, 1, 512, 0)      # layer4 downsample 1 x 1 256 -> 512
+    down3 = L.ConvDesc(8, 60, 80, 128, 60, 80, 256, 1, 1, 1, 0, 1, 256, 0)      # layer3 downsample 1 x 1 128 -> 256
+    conv3 = L.ConvDesc(4, 120, 160, 256, 120, 160, 1024, 1, 1, 1, 0, 1, 1024, 0)  # ResNet50-8s layer3 conv3
+    wide = L.ConvDesc(8, 60, 80, 512, 60, 80, 512, 3, 3, 1, 4, 4, 512, 0)
+    for d in (down4, down3, conv3):
+        assert lib.dcn_conv_hl_eligible(ctypes.byref(d), 0) == 1 and lib.dcn_conv_wgrad_hl_eligible(ctypes.byref(d)) == 1
+    dcn_env(DCN_HL_MIN_K=1024)
+    for d in (down4, down3, conv3):
+        assert lib.dcn_conv_hl_eligible(ctypes.byref(d), 0) == 0 and lib.dcn_conv_wgrad_hl_eligible(ctypes.byref(d)) == 0
+    assert lib.dcn_conv_hl_eligible(ctypes.byref(wide), 0) == 1 and lib.dcn_conv_wgrad_hl_eligible(ctypes.byref(wide)) == 1
