@@ -712,23 +712,7 @@ def main():
         npairs = pair_lists.total
         pair_bytes = (16 * D + 16) * npairs              # 2 descriptor reads + 2 int64 indices + 2 gradient accumulations
         fill_bytes = 2 * B * H * W * D * 4               # zero-fill of the two dense gradient maps
-        # the same call with the fp32-atomics backward (DCN_LOSS_EXACT=0): what the order-independent default costs here
-        from dcn_hip import loss as _K
-        _old_exact, _K.EXACT_BACKWARD = _K.EXACT_BACKWARD, False
-        try:
-            for _ in range(3):
-                loss_fwd_bwd(da, db, pair_lists, pcl)
-            e0.record()
-            for _ in range(reps):
-                loss_fwd_bwd(da, db, pair_lists, pcl)
-            e1.record()
-            torch.cuda.synchronize()
-            ms_float = e0.elapsed_time(e1) / reps
-        finally:
-            _K.EXACT_BACKWARD = _old_exact
         loss_roof = {"bound": "hbm", "kernel": "loss_fwd_kernel + loss_finalize_kernel + loss_mean_kernel + order-independent backward (int64 fill, loss_bwd_vmax / _saved_exact / _exact_convert_kernel; fp32 atomics where the int64 maps would exceed 256 MB)",
-                     "us_per_call_fp32_atomics_backward": 1e3 * ms_float,
-                     "frac_fp32_atomics_backward": (pair_bytes + fill_bytes) / (ms_float * 1e-3) / 1e9 / 8000.0,
                      "achieved": (pair_bytes + fill_bytes) / (ms * 1e-3) / 1e9, "peak": 8000.0, "unit": "GB/s",
                      "frac": (pair_bytes + fill_bytes) / (ms * 1e-3) / 1e9 / 8000.0, "us_per_call": 1e3 * ms,
                      "pixel_pairs": npairs, "algorithmic_bytes": {"pairs": pair_bytes, "zero_fill": fill_bytes},
