@@ -881,6 +881,7 @@ extern "C" int dcn_contrastive_loss_backward_saved_exact(int num_pairs, int64_t 
     if (!offsets_host || !offsets_dev || !cfg || !hard_neg || !grad_loss || !pair_records || !workspace || !grad_a || !grad_b ||
         num_pairs < 1 || hw < 1 || d < 1)
         return DCN_E_INVALID;
+    if (num_pairs > 16383) return DCN_E_UNSUPPORTED;                  // (grid.y of the scatter / conversion launches: 4 / 2 per pair)
     for (int p = 0; p < num_pairs; ++p)
         if (offsets_host[4 * p + 4] - offsets_host[4 * p] >= ((int64_t)1 << 22)) return DCN_E_UNSUPPORTED;
     hipStream_t st = (hipStream_t)stream;

@@ -210,7 +210,7 @@ class _ContrastiveLossFn(torch.autograd.Function):
             exact_bytes = int(lib.dcn_loss_exact_workspace_bytes(P, HW, D))
             per_pair_max = max(lists.offsets_host[4 * p + 4] - lists.offsets_host[4 * p] for p in range(lists.num_pairs))
             exact = (EXACT_BACKWARD if EXACT_BACKWARD is not None else exact_bytes <= EXACT_BACKWARD_MAX_BYTES) and \
-                per_pair_max < (1 << 22)     # (maps zero-filled ahead of time, PREFILL_GRADIENTS, are simply overwritten)
+                per_pair_max < (1 << 22) and P <= 16383     # (maps zero-filled ahead of time, PREFILL_GRADIENTS, are simply overwritten)
             if exact:
                 ws = torch.empty(exact_bytes, dtype=torch.uint8, device=hard.device)
                 rc = lib.dcn_contrastive_loss_backward_saved_exact(
