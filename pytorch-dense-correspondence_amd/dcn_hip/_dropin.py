@@ -137,8 +137,12 @@ class reference_sibling(object):
                 self._why = "no module %s on the reference's side of the package path" % self._fullname
                 return None
             private = self._fullname + "__reference"
-            spec2 = importlib.util.spec_from_file_location(private, spec.origin, loader=type(spec.loader)(private, spec.origin))
-            mod = importlib.util.module_from_spec(spec2)
+            try:   # (the same kind of loader under the private name: a source-file loader or a subclass of one, e.g. a converting one)
+                spec2 = importlib.util.spec_from_file_location(private, spec.origin, loader=type(spec.loader)(private, spec.origin))
+                mod = importlib.util.module_from_spec(spec2)
+            except Exception as e:
+                self._why = "%s cannot be loaded under a private name (%s: %s)" % (spec.origin, type(e).__name__, e)
+                return None
             mod.__package__ = self._fullname.rpartition(".")[0]      # its relative / sibling imports resolve as usual
             sys.modules[private] = mod
             try:

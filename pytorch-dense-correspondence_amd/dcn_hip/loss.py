@@ -5,6 +5,7 @@ PyTorch caching allocator and wires ``torch.autograd``.  Reference semantics:
 dense_correspondence/loss_functions/pixelwise_contrastive_loss.py and loss_composer.py.
 """
 import ctypes
+import os as _os
 
 import torch
 
@@ -99,7 +100,6 @@ def make_config(margins, image_width, match_loss_weight=1.0, non_match_loss_weig
 # two int64 maps (twice the bytes of the fp32 gradient maps) and a conversion pass: the default wherever that workspace stays
 # below EXACT_BACKWARD_MAX_BYTES (BASELINE configs 1 / 2 / 4: 15 - 118 MB); above it (configs 3 / 5: 2.5 / 1.3 GB) the fp32
 # atomics.  DCN_LOSS_EXACT=1 / 0 forces either.
-import os as _os
 EXACT_BACKWARD = {"1": True, "0": False}.get(_os.environ.get("DCN_LOSS_EXACT", ""), None)   # None: by workspace size
 EXACT_BACKWARD_MAX_BYTES = 256 << 20
 SAVE_PAIR_RECORDS = True   # forward keeps per-pair (difference, factor) records, backward reads them instead of gathering again
